@@ -1,0 +1,113 @@
+"""ctypes binding of libdyolo.so (C-ABI declared in include/dyolo.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C drone-yolo_amd/csrc`` into
+``drone-yolo_amd/lib/libdyolo.so``.  There is no fallback: if the library is missing, or a call
+returns a non-zero status, this module raises — the product path never silently degrades to a
+CPU or eager-PyTorch implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdyolo.so")
+
+DY_BF16, DY_F16, DY_F32 = 0, 1, 2
+DY_ACT_NONE, DY_ACT_SILU = 0, 1
+DY_MAX_LEVELS = 8
+
+_vp, _i32, _f32, _i64 = C.c_void_p, C.c_int32, C.c_float, C.c_int64
+
+
+class ConvDesc(C.Structure):
+    """Mirror of ``dy_conv_desc`` (include/dyolo.h)."""
+
+    _fields_ = [
+        ("x", _vp), ("w", _vp), ("bias", _vp), ("residual", _vp), ("y", _vp),
+        ("batch", _i32), ("h", _i32), ("w_in", _i32), ("cin", _i32), ("ld_x", _i32),
+        ("ho", _i32), ("wo", _i32), ("cout", _i32), ("ld_y", _i32), ("ld_res", _i32),
+        ("ksize", _i32), ("stride", _i32), ("pad", _i32),
+        ("groups", _i32), ("act", _i32), ("dtype", _i32), ("out_f32", _i32),
+        ("k_pad", _i32), ("cout_pad", _i32), ("up2x", _i32),
+        ("x2", _vp), ("ld_x2", _i32), ("cin_split", _i32),
+    ]  # fmt: skip
+
+
+class DecodeDesc(C.Structure):
+    """Mirror of ``dy_decode_desc``."""
+
+    _fields_ = [
+        ("level", _vp * DY_MAX_LEVELS),
+        ("h", _i32 * DY_MAX_LEVELS), ("w", _i32 * DY_MAX_LEVELS), ("ld", _i32 * DY_MAX_LEVELS),
+        ("stride", _f32 * DY_MAX_LEVELS),
+        ("n_levels", _i32), ("batch", _i32), ("nc", _i32), ("reg_max", _i32),
+        ("out", _vp),
+    ]  # fmt: skip
+
+
+class NmsDesc(C.Structure):
+    """Mirror of ``dy_nms_desc``."""
+
+    _fields_ = [
+        ("pred", _vp),
+        ("batch", _i32), ("nc", _i32), ("n_extra", _i32), ("anchors", _i32),
+        ("conf_thres", _f32), ("iou_thres", _f32),
+        ("max_det", _i32), ("max_nms", _i32),
+        ("max_wh", _f32), ("agnostic", _i32),
+        ("classes_mask", _vp),
+        ("out", _vp), ("out_count", _vp), ("out_index", _vp),
+        ("workspace", _vp), ("workspace_bytes", _i64),
+    ]  # fmt: skip
+
+
+# name -> (restype, argtypes); every symbol include/dyolo.h declares must appear here
+# (tests/test_cabi.py checks both directions).
+SIGNATURES = {
+    "dy_version": (_i32, []),
+    "dy_last_error_string": (C.c_char_p, []),
+    "dy_dtype_size": (_i32, [_i32]),
+    "dy_conv_k_pad": (_i32, [_i32, _i32, _i32]),
+    "dy_conv_cout_pad": (_i32, [_i32]),
+    "dy_conv2d_nhwc": (_i32, [C.POINTER(ConvDesc), _vp]),
+    "dy_nchw_f32_to_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "dy_nhwc_to_nchw_f32": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "dy_upsample2x_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "dy_copy_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "dy_sppf_maxpool3": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "dy_detect_decode": (_i32, [C.POINTER(DecodeDesc), _vp]),
+    "dy_nms_workspace_bytes": (_i64, [_i32, _i32]),
+    "dy_nms": (_i32, [C.POINTER(NmsDesc), _vp]),
+    "dy_scale_boxes": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
+}
+
+_lib = None
+
+
+class DyoloError(RuntimeError):
+    """A libdyolo call returned a non-zero ``dy_status``."""
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the library; raise loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: the HIP extension has not been built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C drone-yolo_amd/csrc`. "
+                "There is no CPU / eager fallback for this path."
+            )
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "libdyolo") -> None:
+    if rc != 0:
+        msg = lib().dy_last_error_string()
+        raise DyoloError(f"{what} failed with status {rc}: {msg.decode() if msg else ''}")

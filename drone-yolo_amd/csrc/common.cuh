@@ -1,0 +1,107 @@
+// Shared device/host helpers for libdyolo (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "dyolo.h"
+
+namespace dy {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // one 16-byte chunk
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+
+constexpr int kWave = 64;
+
+// ---- element traits -----------------------------------------------------------
+// EPC = elements per 16-byte chunk.  A "k-group" is 4 chunks (the K extent one
+// lane-quarter layout of a 16x16 MFMA covers): 32 k for bf16/f16, 16 k for f32.
+template <typename T> struct Elem;
+
+template <> struct Elem<bf16_t> {
+  static constexpr int EPC = 8;
+  static __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
+                                                   0, 0);
+  }
+  static __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+  static __device__ __forceinline__ bf16_t from_f32(float v) { return (bf16_t)v; }
+};
+
+template <> struct Elem<f16_t> {
+  static constexpr int EPC = 8;
+  static __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
+                                                  0);
+  }
+  static __device__ __forceinline__ float to_f32(f16_t v) { return (float)v; }
+  static __device__ __forceinline__ f16_t from_f32(float v) { return (f16_t)v; }
+};
+
+template <> struct Elem<float> {
+  static constexpr int EPC = 4;
+  // Lane-quarter q holds k = 4q..4q+3 of the 16-k group in its chunk; instruction j
+  // consumes element j of every quarter, so A and B agree on the (q, j) -> k map.
+  static __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
+    f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], c, 0, 0, 0);
+    return c;
+  }
+  static __device__ __forceinline__ float to_f32(float v) { return v; }
+  static __device__ __forceinline__ float from_f32(float v) { return v; }
+};
+
+// Unpack / pack one 16-byte chunk to fp32 lanes.
+template <typename T> struct Chunk {
+  static constexpr int EPC = Elem<T>::EPC;
+  static __device__ __forceinline__ void unpack(u32x4 v, float (&f)[EPC]) {
+    typedef __attribute__((ext_vector_type(EPC))) T vec_t;
+    vec_t t = __builtin_bit_cast(vec_t, v);
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) f[i] = Elem<T>::to_f32(t[i]);
+  }
+  static __device__ __forceinline__ u32x4 pack(const float (&f)[EPC]) {
+    typedef __attribute__((ext_vector_type(EPC))) T vec_t;
+    vec_t t;
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) t[i] = Elem<T>::from_f32(f[i]);
+    return __builtin_bit_cast(u32x4, t);
+  }
+};
+
+__device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ u32x4 zero_chunk() { return u32x4{0u, 0u, 0u, 0u}; }
+
+// XCD-aware block remap (guide T1, bijective form): blocks b and b+8 share an XCD's
+// L2, so hand every XCD a contiguous range of logical tile ids.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+  const unsigned q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, i = bid >> 3;
+  const unsigned base = (xcd < r) ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+  return base + i;
+}
+
+// ---- host-side error plumbing ----------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define DY_REQUIRE(cond, code, ...)   \
+  do {                                \
+    if (!(cond)) {                    \
+      ::dy::set_error(__VA_ARGS__);   \
+      return (code);                  \
+    }                                 \
+  } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace dy

@@ -1,0 +1,228 @@
+// Bandwidth-bound layout kernels: input layout conversion, 2x nearest upsample, strided
+// NHWC copy and the SPPF triple max-pool.  All move 16-byte chunks per lane (guide G13).
+#include "common.cuh"
+
+namespace dy {
+
+// ---- fp32 NCHW -> NHWC(T), zero-padded channels ---------------------------------------------
+// One thread per pixel: plane reads are coalesced across lanes, the write is one or
+// more 16-byte chunks per lane (c_pad * sizeof(T) bytes, contiguous across lanes when
+// ld_dst == c_pad).  Reference: engine/predictor.py:118-136 (dtype cast of a tensor source).
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int n,
+                                                           int c, int hw, int c_pad, int ld) {
+  constexpr int EPC = Elem<T>::EPC;
+  const long long total = (long long)n * hw;
+  for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (long long)gridDim.x * 256) {
+    const int img = (int)(pix / hw);
+    const int p = (int)(pix - (long long)img * hw);
+    const float* s = src + (size_t)img * c * hw + p;
+    T* d = dst + (size_t)pix * ld;
+    for (int c0 = 0; c0 < c_pad; c0 += EPC) {
+      float f[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) f[e] = (c0 + e < c) ? s[(size_t)(c0 + e) * hw] : 0.f;
+      *reinterpret_cast<u32x4*>(d + c0) = Chunk<T>::pack(f);
+    }
+  }
+}
+
+// ---- NHWC(T) -> fp32 NCHW ---------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int n,
+                                                           int c, int hw, int ld) {
+  const long long total = (long long)n * c * hw;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int p = (int)(i % hw);
+    const long long t = i / hw;
+    const int ch = (int)(t % c);
+    const int img = (int)(t / c);
+    dst[i] = Elem<T>::to_f32(src[((size_t)img * hw + p) * ld + ch]);
+  }
+}
+
+// ---- 2x nearest upsample / strided copy (chunk granular) -------------------------------------
+template <bool UP>
+__global__ __launch_bounds__(256) void copy_chunks_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int n,
+                                                          int ho, int wo, int cchunks, int lds_chunks,
+                                                          int ldd_chunks) {
+  // src dims are (ho/2, wo/2) when UP else (ho, wo); pitches are in 16-byte chunks.
+  const long long total = (long long)n * ho * wo * cchunks;
+  const int hs = UP ? ho / 2 : ho, ws = UP ? wo / 2 : wo;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cc = (int)(i % cchunks);
+    long long t = i / cchunks;
+    const int x = (int)(t % wo);
+    t /= wo;
+    const int y = (int)(t % ho);
+    const int img = (int)(t / ho);
+    const int ys = UP ? (y >> 1) : y, xs = UP ? (x >> 1) : x;
+    const size_t so = ((size_t)(img * hs + ys) * ws + xs) * (size_t)lds_chunks + cc;
+    const size_t d_o = ((size_t)(img * ho + y) * wo + x) * (size_t)ldd_chunks + cc;
+    dst[d_o] = src[so];
+  }
+}
+
+// ---- SPPF: three chained k x k stride-1 max pools (block.py:185-191) ----------------------------
+// One workgroup per (image, 16-byte channel chunk): the whole h x w map of that chunk
+// sits in LDS; each pass is a separable row-max then column-max over a (2*(k/2)+1) window
+// clipped at the border (MaxPool2d pads with -inf, i.e. ignores out-of-range taps).
+template <typename T>
+__device__ __forceinline__ u32x4 chunk_max(u32x4 a, u32x4 b) {
+  constexpr int EPC = Elem<T>::EPC;
+  float fa[EPC], fb[EPC];
+  Chunk<T>::unpack(a, fa);
+  Chunk<T>::unpack(b, fb);
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) fa[e] = fmaxf(fa[e], fb[e]);
+  return Chunk<T>::pack(fa);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sppf_maxpool3_kernel(const T* __restrict__ x, T* __restrict__ y1,
+                                                            T* __restrict__ y2, T* __restrict__ y3, int h, int w,
+                                                            int cchunks, int ld, int r) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  constexpr int EPC = Elem<T>::EPC;
+  const int hw = h * w;
+  u32x4* cur = reinterpret_cast<u32x4*>(dyn_smem);
+  u32x4* tmp = cur + hw;
+  u32x4* nxt = tmp + hw;
+  const int img = blockIdx.x / cchunks;
+  const int cc = blockIdx.x - img * cchunks;
+  const size_t base = (size_t)img * hw * ld + (size_t)cc * EPC;
+  for (int p = threadIdx.x; p < hw; p += 256) cur[p] = *reinterpret_cast<const u32x4*>(x + base + (size_t)p * ld);
+  __syncthreads();
+  T* outs[3] = {y1, y2, y3};
+#pragma unroll 1
+  for (int pass = 0; pass < 3; ++pass) {
+    for (int p = threadIdx.x; p < hw; p += 256) {
+      const int yy = p / w, xx = p - yy * w;
+      const int x0 = xx - r < 0 ? 0 : xx - r, x1 = xx + r >= w ? w - 1 : xx + r;
+      u32x4 m = cur[yy * w + x0];
+      for (int q = x0 + 1; q <= x1; ++q) m = chunk_max<T>(m, cur[yy * w + q]);
+      tmp[p] = m;
+    }
+    __syncthreads();
+    T* o = outs[pass];
+    for (int p = threadIdx.x; p < hw; p += 256) {
+      const int yy = p / w, xx = p - yy * w;
+      const int y0 = yy - r < 0 ? 0 : yy - r, y1e = yy + r >= h ? h - 1 : yy + r;
+      u32x4 m = tmp[y0 * w + xx];
+      for (int q = y0 + 1; q <= y1e; ++q) m = chunk_max<T>(m, tmp[q * w + xx]);
+      nxt[p] = m;
+      *reinterpret_cast<u32x4*>(o + base + (size_t)p * ld) = m;
+    }
+    __syncthreads();
+    u32x4* t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+}
+
+static inline int grid_for(long long items) {
+  long long b = (items + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 2048 * 4 ? 2048 * 4 : b));
+}
+
+}  // namespace dy
+
+using namespace dy;
+
+extern "C" int32_t dy_nchw_f32_to_nhwc(const float* src, void* dst, int32_t n, int32_t c, int32_t h, int32_t w,
+                                       int32_t c_pad, int32_t ld_dst, int32_t dtype, dy_stream_t stream) {
+  const int es = dy_dtype_size(dtype);
+  DY_REQUIRE(src && dst && es, DY_ERR_INVALID_ARG, "dy_nchw_f32_to_nhwc: null pointer or bad dtype");
+  DY_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0, DY_ERR_INVALID_ARG, "dy_nchw_f32_to_nhwc: bad dims");
+  const int epc = 16 / es;
+  DY_REQUIRE(c_pad >= c && c_pad % epc == 0 && ld_dst >= c_pad && (ld_dst * es) % 16 == 0 && aligned16(dst),
+             DY_ERR_INVALID_ARG, "dy_nchw_f32_to_nhwc: c_pad/ld_dst must be multiples of %d elements, dst 16B aligned", epc);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int grid = grid_for((long long)n * h * w);
+  if (dtype == DY_BF16)
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, src, (bf16_t*)dst, n, c, h * w, c_pad, ld_dst);
+  else if (dtype == DY_F16)
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<f16_t>), dim3(grid), dim3(256), 0, st, src, (f16_t*)dst, n, c, h * w, c_pad, ld_dst);
+  else
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), dim3(grid), dim3(256), 0, st, src, (float*)dst, n, c, h * w, c_pad, ld_dst);
+  return check_launch("nchw_to_nhwc_kernel");
+}
+
+extern "C" int32_t dy_nhwc_to_nchw_f32(const void* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w,
+                                       int32_t ld_src, int32_t src_dtype, dy_stream_t stream) {
+  const int es = dy_dtype_size(src_dtype);
+  DY_REQUIRE(src && dst && es, DY_ERR_INVALID_ARG, "dy_nhwc_to_nchw_f32: null pointer or bad dtype");
+  DY_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0 && ld_src >= c, DY_ERR_INVALID_ARG, "dy_nhwc_to_nchw_f32: bad dims");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int grid = grid_for((long long)n * c * h * w);
+  if (src_dtype == DY_BF16)
+    hipLaunchKernelGGL((nhwc_to_nchw_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, dst, n, c, h * w, ld_src);
+  else if (src_dtype == DY_F16)
+    hipLaunchKernelGGL((nhwc_to_nchw_kernel<f16_t>), dim3(grid), dim3(256), 0, st, (const f16_t*)src, dst, n, c, h * w, ld_src);
+  else
+    hipLaunchKernelGGL((nhwc_to_nchw_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)src, dst, n, c, h * w, ld_src);
+  return check_launch("nhwc_to_nchw_kernel");
+}
+
+static int32_t copy_common(bool up, const void* src, void* dst, int32_t n, int32_t h, int32_t w, int32_t c,
+                           int32_t ld_src, int32_t ld_dst, int32_t dtype, dy_stream_t stream, const char* who) {
+  const int es = dy_dtype_size(dtype);
+  DY_REQUIRE(src && dst && es, DY_ERR_INVALID_ARG, "%s: null pointer or bad dtype", who);
+  const int epc = 16 / es;
+  DY_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && c % epc == 0, DY_ERR_INVALID_ARG, "%s: c must be a multiple of %d", who, epc);
+  DY_REQUIRE(ld_src >= c && ld_dst >= c && ld_src % epc == 0 && ld_dst % epc == 0 && aligned16(src) && aligned16(dst),
+             DY_ERR_INVALID_ARG, "%s: views must be 16-byte aligned", who);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int ho = up ? 2 * h : h, wo = up ? 2 * w : w;
+  const int grid = grid_for((long long)n * ho * wo * (c / epc));
+  if (up)
+    hipLaunchKernelGGL((copy_chunks_kernel<true>), dim3(grid), dim3(256), 0, st, (const u32x4*)src, (u32x4*)dst, n, ho, wo,
+                       c / epc, ld_src / epc, ld_dst / epc);
+  else
+    hipLaunchKernelGGL((copy_chunks_kernel<false>), dim3(grid), dim3(256), 0, st, (const u32x4*)src, (u32x4*)dst, n, ho, wo,
+                       c / epc, ld_src / epc, ld_dst / epc);
+  return check_launch(who);
+}
+
+extern "C" int32_t dy_upsample2x_nhwc(const void* src, void* dst, int32_t n, int32_t h, int32_t w, int32_t c,
+                                      int32_t ld_src, int32_t ld_dst, int32_t dtype, dy_stream_t stream) {
+  return copy_common(true, src, dst, n, h, w, c, ld_src, ld_dst, dtype, stream, "dy_upsample2x_nhwc");
+}
+
+extern "C" int32_t dy_copy_nhwc(const void* src, void* dst, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ld_src,
+                                int32_t ld_dst, int32_t dtype, dy_stream_t stream) {
+  return copy_common(false, src, dst, n, h, w, c, ld_src, ld_dst, dtype, stream, "dy_copy_nhwc");
+}
+
+extern "C" int32_t dy_sppf_maxpool3(const void* x, void* y1, void* y2, void* y3, int32_t n, int32_t h, int32_t w,
+                                    int32_t c, int32_t ld, int32_t k, int32_t dtype, dy_stream_t stream) {
+  const int es = dy_dtype_size(dtype);
+  DY_REQUIRE(x && y1 && y2 && y3 && es, DY_ERR_INVALID_ARG, "dy_sppf_maxpool3: null pointer or bad dtype");
+  const int epc = 16 / es;
+  DY_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && c % epc == 0 && ld >= c && ld % epc == 0, DY_ERR_INVALID_ARG,
+             "dy_sppf_maxpool3: c/ld must be multiples of %d", epc);
+  DY_REQUIRE(k >= 1 && (k & 1), DY_ERR_INVALID_ARG, "dy_sppf_maxpool3: k must be odd");
+  DY_REQUIRE(aligned16(x) && aligned16(y1) && aligned16(y2) && aligned16(y3), DY_ERR_INVALID_ARG,
+             "dy_sppf_maxpool3: views must be 16-byte aligned");
+  DY_REQUIRE((long long)h * w <= 3072, DY_ERR_UNSUPPORTED, "dy_sppf_maxpool3: h*w=%d exceeds the LDS-resident limit 3072", h * w);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t smem = (size_t)h * w * 16 * 3;
+  const int cchunks = c / epc;
+  const dim3 grid((unsigned)(n * cchunks));
+#define DY_SPPF_LAUNCH(T)                                                                                          \
+  do {                                                                                                              \
+    if (smem > 48 * 1024)                                                                                           \
+      (void)hipFuncSetAttribute((const void*)sppf_maxpool3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                (int)smem);                                                                         \
+    hipLaunchKernelGGL((sppf_maxpool3_kernel<T>), grid, dim3(256), smem, st, (const T*)x, (T*)y1, (T*)y2, (T*)y3, h, \
+                       w, cchunks, ld, k / 2);                                                                      \
+  } while (0)
+  if (dtype == DY_BF16)
+    DY_SPPF_LAUNCH(bf16_t);
+  else if (dtype == DY_F16)
+    DY_SPPF_LAUNCH(f16_t);
+  else
+    DY_SPPF_LAUNCH(float);
+#undef DY_SPPF_LAUNCH
+  return check_launch("sppf_maxpool3_kernel");
+}

@@ -1,0 +1,115 @@
+"""``YOLO`` / ``Model`` user API (reference: ultralytics/engine/model.py:29-1177,
+ultralytics/models/yolo/model.py:11-59) for the detection task on the MI355X path."""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import List, Union
+
+import torch
+import torch.nn as nn
+
+from ..nn.tasks import DetectionModel, yaml_model_load
+from ..utils import LOGGER
+from .predictor import DetectionPredictor
+from .results import Results
+
+
+class Model(nn.Module):
+    """Same constructor and call surface as the reference ``Model`` (engine/model.py:82-87, 501-560, 744-817)."""
+
+    def __init__(self, model: Union[str, Path] = "yolov8s-p2-repvgg.yaml", task: str = None, verbose: bool = False) -> None:
+        super().__init__()
+        self.predictor = None
+        self.model = None
+        self.trainer = None
+        self.ckpt = None
+        self.cfg = None
+        self.ckpt_path = None
+        self.overrides = {}
+        self.task = task or "detect"
+        if self.task != "detect":
+            raise NotImplementedError(f"task '{self.task}': only 'detect' is on the accelerated path")
+        model = str(model).strip()
+        if Path(model).suffix in {".yaml", ".yml"}:
+            self._new(model, verbose=verbose)
+        elif Path(model).suffix == ".pt":
+            self._load(model)
+        else:
+            raise NotImplementedError(f"'{model}': give a model YAML (*.yaml) or a state-dict checkpoint (*.pt); "
+                                      "weight-name downloads need network access and are out of scope")
+        self.model_name = model
+
+    def _new(self, cfg: str, task=None, model=None, verbose=False) -> None:
+        """Build from a YAML — reference engine/model.py:231-264."""
+        cfg_dict = yaml_model_load(cfg)
+        self.cfg = cfg
+        self.model = (model or DetectionModel)(cfg_dict, verbose=verbose)
+        self.overrides["model"] = self.cfg
+        self.overrides["task"] = self.task
+
+    def _load(self, weights: str, task=None) -> None:
+        """Load {'yaml': cfg dict, 'model': state_dict} checkpoints written by ``save``.
+
+        The reference's checkpoints pickle whole ``ultralytics`` module graphs (tasks.py:786-926);
+        reading those is SURVEY §8(f) rank 4 and not built yet.
+        """
+        ckpt = torch.load(weights, map_location="cpu", weights_only=True)
+        if not (isinstance(ckpt, dict) and "yaml" in ckpt and "model" in ckpt):
+            raise NotImplementedError("only checkpoints written by Model.save() are supported for now")
+        self.model = DetectionModel(ckpt["yaml"], verbose=False)
+        self.model.load_state_dict(ckpt["model"])
+        self.ckpt, self.ckpt_path = ckpt, weights
+        self.overrides["model"] = weights
+
+    def save(self, filename: Union[str, Path] = "saved_model.pt") -> None:
+        yaml_d = {k: v for k, v in self.model.yaml.items()}
+        torch.save({"yaml": yaml_d, "model": self.model.state_dict()}, filename)
+
+    def __call__(self, source=None, stream: bool = False, **kwargs):
+        return self.predict(source, stream, **kwargs)
+
+    def predict(self, source=None, stream: bool = False, predictor=None, **kwargs) -> List[Results]:
+        """Reference engine/model.py:501-560: predictor created on first use, conf defaults to 0.25."""
+        if source is None:
+            raise ValueError("'source' is missing; the device path takes a BCHW float tensor in [0, 1]")
+        args = {**self.overrides, "conf": 0.25, **kwargs}
+        args.pop("model", None), args.pop("task", None), args.pop("mode", None)
+        if self.predictor is None or getattr(self, "_pred_args", None) != args:
+            self.predictor = (predictor or DetectionPredictor)(self.model, overrides=args)
+            self._pred_args = args
+        return self.predictor(source, stream=stream)
+
+    def train(self, trainer=None, **kwargs):
+        """Reference engine/model.py:744-817. The device training step (conv dgrad/wgrad, BN batch stats,
+        TaskAlignedAssigner + v8DetectionLoss, RCCL gradient all-reduce) is SURVEY §8 a28-a36 and not built yet."""
+        raise NotImplementedError("train(): the HIP training path is not built yet; no eager-PyTorch fallback exists")
+
+    def fuse(self):
+        self.model.fuse()
+        return self
+
+    def info(self, detailed: bool = False, verbose: bool = True):
+        return self.model.info(detailed=detailed, verbose=verbose)
+
+    @property
+    def names(self):
+        return self.model.names
+
+    @property
+    def device(self):
+        return next(self.model.parameters()).device
+
+    def to(self, device):
+        self.model.to(device)
+        return self
+
+
+class YOLO(Model):
+    """``YOLO(model, task=None, verbose=False)`` — reference models/yolo/model.py:11-23."""
+
+    def __init__(self, model="yolov8s-p2-repvgg.yaml", task=None, verbose=False):
+        super().__init__(model=model, task=task, verbose=verbose)
+
+    @property
+    def task_map(self):
+        return {"detect": {"model": DetectionModel, "predictor": DetectionPredictor}}

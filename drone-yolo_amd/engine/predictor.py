@@ -1,0 +1,158 @@
+"""Inference loop of the detection path on the device.
+
+Reference: ``BasePredictor`` (ultralytics/engine/predictor.py:118-323: preprocess, inference,
+stream_inference, setup_model) and ``DetectionPredictor`` (models/yolo/detect/predict.py:23-73:
+postprocess = NMS + scale_boxes + Results).  MI355X-first differences:
+
+* one pass = input layout/dtype conversion -> 80-odd conv launches -> decode -> NMS -> box rescale,
+  all libdyolo kernels on one HIP stream, recorded once per input shape as a ``LaunchPlan`` and
+  replayed (optionally from a hipGraph) afterwards — no per-image Python loop, no host syncs
+  inside the pass (the reference syncs at every boolean index of ops.py:266-330).
+* results stay on the device as padded (N, max_det, 6) + counts; ``Results`` are materialised with
+  one device->host transfer of the counts.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from .. import hip_ops as H
+from ..utils import LOGGER, ops
+from ..utils.torch_utils import select_device
+from .results import Results
+
+_DTYPE_NAMES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "half": torch.float16,
+                "float16": torch.float16, "fp32": torch.float32, "float32": torch.float32}
+
+
+def resolve_dtype(dtype=None, half: bool = False) -> torch.dtype:
+    if isinstance(dtype, torch.dtype):
+        return dtype
+    if dtype is None:
+        return torch.float16 if half else torch.bfloat16
+    try:
+        return _DTYPE_NAMES[str(dtype).lower()]
+    except KeyError:
+        raise ValueError(f"unknown dtype '{dtype}', expected one of {sorted(_DTYPE_NAMES)}") from None
+
+
+class CompiledForward:
+    """A recorded forward for one (batch, H, W): its launch plan, static buffers and optional hipGraph."""
+
+    def __init__(self):
+        self.plan = H.LaunchPlan()
+        self.pred: Optional[torch.Tensor] = None  # decoded (N, 4+nc, A) fp32
+        self.nms: Optional[H.NmsBuffers] = None
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.static_in: Optional[torch.Tensor] = None
+
+
+class DetectionPredictor:
+    """Device-resident predictor (reference predictor.py:64-323, detect/predict.py:8-73)."""
+
+    def __init__(self, model, overrides: Optional[dict] = None):
+        a = dict(conf=0.25, iou=0.7, max_det=300, classes=None, agnostic_nms=False, half=False, dtype=None, device="",
+                 verbose=False, graph=False, max_nms=30000, max_wh=7680)
+        a.update(overrides or {})
+        self.args = a
+        self.device = select_device(a["device"])
+        self.dtype = resolve_dtype(a["dtype"], a["half"])
+        self.model = model.to(self.device).eval()
+        self.model.requires_grad_(False)
+        self._compiled: Dict[Tuple, CompiledForward] = {}
+        self._classes_mask = None
+        if a["classes"] is not None:
+            m = torch.zeros(self.model.yaml["nc"], dtype=torch.uint8)
+            m[torch.as_tensor(list(a["classes"]), dtype=torch.long)] = 1
+            self._classes_mask = m.to(self.device)
+
+    # ---- stages (names follow the reference) -------------------------------------------------------
+    def preprocess(self, im) -> torch.Tensor:
+        """Tensor source: BCHW float in [0,1], moved to the device (predictor.py:118-136; tensors are not /255)."""
+        if not isinstance(im, torch.Tensor):
+            raise NotImplementedError("only torch.Tensor (BCHW, float, [0,1]) sources are built on the device path; "
+                                      "LetterBox for image files/arrays is SURVEY §8(f) rank 2")
+        if im.dim() == 3:
+            im = im[None]
+        if im.shape[1] != self.model.yaml.get("ch", 3):
+            raise ValueError(f"expected {self.model.yaml.get('ch', 3)} input channels, got {im.shape[1]}")
+        s = int(self.model.stride.max())
+        if im.shape[2] % s or im.shape[3] % s:
+            raise ValueError(f"tensor source must have H, W divisible by the model stride {s} (loaders.py:516-584)")
+        return im.to(self.device, torch.float32, non_blocking=True).contiguous()
+
+    def _record(self, im: torch.Tensor) -> CompiledForward:
+        cf = CompiledForward()
+        a = self.args
+        n, _, h, w = im.shape
+        params = torch.tensor([[1.0, 0.0, 0.0, float(w), float(h)]] * n, dtype=torch.float32, device=self.device)
+        with H.record(cf.plan):
+            x = H.to_nhwc(im, self.dtype, mark_input=True)
+            y, _ = self.model._predict_once(x)
+            cf.pred = y
+            cf.nms = H.nms(y, float(a["conf"]), float(a["iou"]), max_det=int(a["max_det"]), max_nms=int(a["max_nms"]),
+                           max_wh=float(a["max_wh"]), agnostic=bool(a["agnostic_nms"]), nc=self.model.yaml["nc"],
+                           classes_mask=self._classes_mask)
+            # construct_result: scale_boxes(img.shape[2:], boxes, orig.shape) — tensor sources are their own
+            # original image, so gain 1 / pad 0 and the clip to (h, w) remain (detect/predict.py:59-73)
+            H.scale_boxes_(cf.nms, params)
+        cf.plan.keep.append(params)
+        return cf
+
+    def forward_device(self, im: torch.Tensor) -> CompiledForward:
+        """Run one batch; outputs stay on the device in the returned object's ``nms`` buffers."""
+        key = (tuple(im.shape), self.dtype)
+        cf = self._compiled.get(key)
+        if cf is None:
+            cf = self._compiled[key] = self._record(im)  # recording also executes the launches
+            if self.args["graph"]:
+                self._capture(cf, im)
+            return cf
+        if cf.graph is not None:
+            if im.data_ptr() != cf.static_in.data_ptr():
+                cf.static_in.copy_(im, non_blocking=True)
+            cf.graph.replay()
+        else:
+            cf.plan.rebind_input(im.data_ptr())
+            cf.plan.replay(torch.cuda.current_stream().cuda_stream)
+        return cf
+
+    def _capture(self, cf: CompiledForward, im: torch.Tensor) -> None:
+        """Capture the recorded launches into a hipGraph (replay cost ~10 us instead of ~100 launches)."""
+        cf.static_in = im.clone()
+        cf.plan.rebind_input(cf.static_in.data_ptr())
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            cf.plan.replay(torch.cuda.current_stream().cuda_stream)
+        cf.graph = g
+
+    def static_input(self, shape) -> Optional[torch.Tensor]:
+        cf = self._compiled.get((tuple(shape), self.dtype))
+        return None if cf is None else cf.static_in
+
+    def postprocess(self, cf: CompiledForward, im: torch.Tensor, paths=None) -> List[Results]:
+        counts = cf.nms.count.tolist()  # the pass's only device->host synchronisation
+        names = self.model.names
+        out = []
+        for i, k in enumerate(counts):
+            out.append(Results(im[i], paths[i] if paths else f"image{i}.jpg", names, boxes=cf.nms.out[i, :k].clone(),
+                               orig_shape=im.shape[2:]))
+        return out
+
+    def __call__(self, source, stream: bool = False):
+        prof = [ops.Profile(device=self.device) for _ in range(3)]
+        with prof[0]:
+            im = self.preprocess(source)
+        with prof[1]:
+            cf = self.forward_device(im)
+        with prof[2]:
+            results = self.postprocess(cf, im)
+        n = max(len(results), 1)
+        for r in results:
+            r.speed = {"preprocess": prof[0].dt * 1e3 / n, "inference": prof[1].dt * 1e3 / n,
+                       "postprocess": prof[2].dt * 1e3 / n}
+        if self.args["verbose"]:
+            LOGGER.info(f"{len(results)} images: " + ", ".join(f"{len(r)} boxes" for r in results))
+        return iter(results) if stream else results

@@ -1,0 +1,336 @@
+"""Tensor-level wrappers over the libdyolo C-ABI.
+
+Activations are torch tensors that are *logically* (N, C, H, W) — the shape the reference's
+modules exchange (nn/tasks.py:148-154) — but live in NHWC memory: ``stride(1) == 1`` and
+``stride(3)`` is the pixel pitch ``ld``.  A channel slice ``buf[:, c0:c1]`` of such a tensor is a
+valid view for every kernel, which is how Concat / chunk are done without copies.
+
+PyTorch is used here for device memory and streams only; every arithmetic op on the hot path
+is a libdyolo kernel.  A ``LaunchPlan`` records the (function, arguments) list of a forward so
+later forwards with the same shapes replay the launches without re-running the Python modules.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import DY_ACT_NONE, DY_ACT_SILU, ConvDesc, DecodeDesc, NmsDesc, check, lib
+
+_DTYPES = {torch.bfloat16: _lib.DY_BF16, torch.float16: _lib.DY_F16, torch.float32: _lib.DY_F32}
+
+
+def dy_dtype(dt: torch.dtype) -> int:
+    try:
+        return _DTYPES[dt]
+    except KeyError:
+        raise TypeError(f"unsupported activation dtype {dt}; use bfloat16, float16 or float32") from None
+
+
+def elems_per_chunk(dt: torch.dtype) -> int:
+    return 16 // torch.empty((), dtype=dt).element_size()
+
+
+def require_device(t: torch.Tensor, what: str = "tensor") -> None:
+    """The hot path is HIP only: refuse CPU tensors loudly instead of falling back."""
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what} is on '{t.device}': the Drone-YOLO hot path runs on an MI355X (HIP) device only; "
+            "there is no CPU fallback in this package."
+        )
+
+
+def alloc_nhwc(n: int, c: int, h: int, w: int, dtype: torch.dtype, device, ld: Optional[int] = None) -> torch.Tensor:
+    """Logical (n,c,h,w) tensor in NHWC memory with pixel pitch ``ld`` (default c)."""
+    ld = c if ld is None else ld
+    buf = torch.empty((n, h, w, ld), dtype=dtype, device=device)
+    return buf.permute(0, 3, 1, 2)[:, :c]
+
+
+def view_params(t: torch.Tensor) -> Tuple[int, int]:
+    """(data_ptr, ld) of an NHWC view; raises if ``t`` is not one."""
+    if t.dim() != 4:
+        raise ValueError(f"expected a 4-D (N,C,H,W) tensor, got shape {tuple(t.shape)}")
+    n, c, h, w = t.shape
+    sn, sc, sh, sw = t.stride()
+    ld = sw if w > 1 else (sh if h > 1 else (sn if n > 1 else c))
+    ok = (c == 1 or sc == 1) and (w == 1 or sw == ld) and (h == 1 or sh == w * ld) and (n == 1 or sn == h * w * ld)
+    if not ok or ld < c:
+        raise ValueError(
+            f"tensor of shape {tuple(t.shape)} / strides {t.stride()} is not an NHWC view; "
+            "use hip_ops.to_nhwc() or torch.channels_last"
+        )
+    return t.data_ptr(), ld
+
+
+# ---- launch plan ------------------------------------------------------------------------------
+
+
+class LaunchPlan:
+    """Recorded kernel launches of one forward: list of (cfunc, args) + the buffers they use."""
+
+    def __init__(self):
+        self.ops: List[Tuple[object, tuple, bool]] = []  # (cfunc, args-without-stream, by_desc)
+        self.keep: List[object] = []  # tensors / descriptors that must outlive the plan
+        self.input_slot: Optional[Tuple[int, int]] = None  # (op index, arg index) of the user input pointer
+        self.outputs = None
+
+    def replay(self, stream: int) -> None:
+        for fn, args, _ in self.ops:
+            rc = fn(*args, stream)
+            if rc:
+                check(rc, fn.__name__)
+
+    def rebind_input(self, ptr: int) -> None:
+        i, j = self.input_slot
+        fn, args, d = self.ops[i]
+        args = list(args)
+        args[j] = ptr
+        self.ops[i] = (fn, tuple(args), d)
+
+
+_recording: Optional[LaunchPlan] = None
+
+
+class record:
+    """Context manager: launches issued inside are also appended to ``plan``."""
+
+    def __init__(self, plan: LaunchPlan):
+        self.plan = plan
+
+    def __enter__(self):
+        global _recording
+        if _recording is not None:
+            raise RuntimeError("nested LaunchPlan recording")
+        _recording = self.plan
+        return self.plan
+
+    def __exit__(self, *exc):
+        global _recording
+        _recording = None
+        return False
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _launch(fn, args: tuple, keep: Sequence[object] = ()) -> None:
+    rc = fn(*args, _stream())
+    if rc:
+        check(rc, fn.__name__)
+    if _recording is not None:
+        _recording.ops.append((fn, args, False))
+        _recording.keep.extend(keep)
+
+
+# ---- convolution --------------------------------------------------------------------------------
+
+
+class PackedConv:
+    """Folded + packed weights of one convolution in the layout ``dy_conv2d_nhwc`` expects.
+
+    ``weight``: (cout, cin/groups, k, k) fp32 with BatchNorm / RepVGG branches already folded,
+    ``bias``: (cout,) fp32.  Packing = (cout, k, k, cin) row-major, rows padded to k_pad, rows
+    count padded to cout_pad with zeros (include/dyolo.h).
+    """
+
+    def __init__(self, weight: torch.Tensor, bias: torch.Tensor, stride: int, pad: int, groups: int, act: bool,
+                 dtype: torch.dtype, device):
+        L = lib()
+        cout, cin_g, k, k2 = weight.shape
+        assert k == k2, "square kernels only"
+        self.cout, self.cin, self.k, self.stride, self.pad, self.groups = cout, cin_g * groups, k, stride, pad, groups
+        self.act = DY_ACT_SILU if act else DY_ACT_NONE
+        self.dtype = dtype
+        w = weight.detach().to(torch.float32).permute(0, 2, 3, 1).reshape(cout, k * k * cin_g)
+        if groups == 1:
+            self.k_pad = L.dy_conv_k_pad(self.cin, k, dy_dtype(dtype))
+            self.cout_pad = L.dy_conv_cout_pad(cout)
+            wp = torch.zeros((self.cout_pad, self.k_pad), dtype=torch.float32)
+            wp[:cout, : w.shape[1]] = w
+            bp = torch.zeros((self.cout_pad,), dtype=torch.float32)
+            bp[:cout] = bias.detach().to(torch.float32)
+        else:
+            self.k_pad, self.cout_pad = w.shape[1], cout
+            wp, bp = w, bias.detach().to(torch.float32)
+        self.w = wp.to(dtype).contiguous().to(device)
+        self.b = bp.contiguous().to(device)
+
+
+def conv_out_hw(h: int, w: int, k: int, s: int, p: int) -> Tuple[int, int]:
+    return (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+
+
+def conv2d(x: torch.Tensor, pc: PackedConv, out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+           out_f32: bool = False, up2x: bool = False, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(conv(x) + bias) (+ residual) through ``dy_conv2d_nhwc``.
+
+    ``x2``: optional second input whose channels follow x's (Concat folded into the gather);
+    ``up2x``: x is consumed through a fused 2x nearest upsample.
+    """
+    require_device(x, "conv2d input")
+    if x.dtype != pc.dtype:
+        raise TypeError(f"conv2d: input dtype {x.dtype} != packed weight dtype {pc.dtype}")
+    n, c1, hb, wb = x.shape
+    h, w = (2 * hb, 2 * wb) if up2x else (hb, wb)
+    cin = c1 + (x2.shape[1] if x2 is not None else 0)
+    if cin != pc.cin:
+        raise ValueError(f"conv2d: input has {cin} channels, weights expect {pc.cin}")
+    ho, wo = conv_out_hw(h, w, pc.k, pc.stride, pc.pad)
+    odt = torch.float32 if out_f32 else x.dtype
+    if out is None:
+        out = alloc_nhwc(n, pc.cout, ho, wo, odt, x.device)
+    elif tuple(out.shape) != (n, pc.cout, ho, wo) or out.dtype != odt:
+        raise ValueError(f"conv2d: out has shape {tuple(out.shape)}/{out.dtype}, expected {(n, pc.cout, ho, wo)}/{odt}")
+    xp, ldx = view_params(x)
+    yp, ldy = view_params(out)
+    d = ConvDesc()
+    d.x, d.w, d.bias, d.y = xp, pc.w.data_ptr(), pc.b.data_ptr(), yp
+    d.batch, d.h, d.w_in, d.cin, d.ld_x = n, h, w, cin, ldx
+    d.ho, d.wo, d.cout, d.ld_y = ho, wo, pc.cout, ldy
+    d.ksize, d.stride, d.pad, d.groups = pc.k, pc.stride, pc.pad, pc.groups
+    d.act, d.dtype, d.out_f32 = pc.act, dy_dtype(x.dtype), int(out_f32)
+    d.k_pad, d.cout_pad, d.up2x = pc.k_pad, pc.cout_pad, int(up2x)
+    if residual is not None:
+        if tuple(residual.shape) != tuple(out.shape) or residual.dtype != x.dtype:
+            raise ValueError("conv2d: residual must match the output shape and the input dtype")
+        d.residual, d.ld_res = view_params(residual)
+    if x2 is not None:
+        if tuple(x2.shape[2:]) != (h, w) or x2.shape[0] != n or x2.dtype != x.dtype:
+            raise ValueError("conv2d: x2 must have the (upsampled) spatial size and dtype of x")
+        d.x2, d.ld_x2 = view_params(x2)
+        d.cin_split = c1
+    _launch(lib().dy_conv2d_nhwc, (C.byref(d),), keep=(d, x, out, residual, x2, pc))
+    return out
+
+
+# ---- layout ops -------------------------------------------------------------------------------------
+
+
+def to_nhwc(src: torch.Tensor, dtype: torch.dtype, c_pad: Optional[int] = None, out: Optional[torch.Tensor] = None,
+            mark_input: bool = False) -> torch.Tensor:
+    """fp32 NCHW (contiguous) -> NHWC view of ``dtype`` with channels zero-padded to ``c_pad``."""
+    require_device(src, "input")
+    if src.dtype != torch.float32 or not src.is_contiguous():
+        raise ValueError("to_nhwc expects a contiguous fp32 NCHW tensor")
+    n, c, h, w = src.shape
+    epc = elems_per_chunk(dtype)
+    c_pad = c_pad or (c + epc - 1) // epc * epc
+    if out is None:
+        out = alloc_nhwc(n, c_pad, h, w, dtype, src.device)
+    op, ld = view_params(out)
+    args = (src.data_ptr(), op, n, c, h, w, c_pad, ld, dy_dtype(dtype))
+    _launch(lib().dy_nchw_f32_to_nhwc, args, keep=(out,))
+    if mark_input and _recording is not None:
+        _recording.input_slot = (len(_recording.ops) - 1, 0)
+    return out
+
+
+def to_nchw_f32(x: torch.Tensor) -> torch.Tensor:
+    """NHWC view -> contiguous fp32 NCHW tensor (module-level parity checks, user hand-back)."""
+    require_device(x)
+    n, c, h, w = x.shape
+    xp, ld = view_params(x)
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    _launch(lib().dy_nhwc_to_nchw_f32, (xp, out.data_ptr(), n, c, h, w, ld, dy_dtype(x.dtype)), keep=(x, out))
+    return out
+
+
+def upsample2x(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    require_device(x)
+    n, c, h, w = x.shape
+    if out is None:
+        out = alloc_nhwc(n, c, 2 * h, 2 * w, x.dtype, x.device)
+    xp, lds = view_params(x)
+    op, ldd = view_params(out)
+    _launch(lib().dy_upsample2x_nhwc, (xp, op, n, h, w, c, lds, ldd, dy_dtype(x.dtype)), keep=(x, out))
+    return out
+
+
+def copy_nhwc(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    require_device(x)
+    n, c, h, w = x.shape
+    xp, lds = view_params(x)
+    op, ldd = view_params(out)
+    _launch(lib().dy_copy_nhwc, (xp, op, n, h, w, c, lds, ldd, dy_dtype(x.dtype)), keep=(x, out))
+    return out
+
+
+def sppf_maxpool3(x: torch.Tensor, y1: torch.Tensor, y2: torch.Tensor, y3: torch.Tensor, k: int) -> None:
+    require_device(x)
+    n, c, h, w = x.shape
+    xp, ld = view_params(x)
+    ptrs = []
+    for y in (y1, y2, y3):
+        p, l2 = view_params(y)
+        if l2 != ld or tuple(y.shape) != tuple(x.shape):
+            raise ValueError("sppf_maxpool3: outputs must be slices of the same buffer as x")
+        ptrs.append(p)
+    _launch(lib().dy_sppf_maxpool3, (xp, *ptrs, n, h, w, c, ld, k, dy_dtype(x.dtype)), keep=(x, y1, y2, y3))
+
+
+# ---- detect decode + NMS --------------------------------------------------------------------------
+
+
+def detect_decode(levels: Sequence[torch.Tensor], strides: Sequence[float], nc: int, reg_max: int,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """levels[i]: fp32 NHWC view (N, 4*reg_max+nc, H_i, W_i) -> (N, 4+nc, A) fp32."""
+    n = levels[0].shape[0]
+    d = DecodeDesc()
+    A = 0
+    for i, t in enumerate(levels):
+        require_device(t)
+        if t.dtype != torch.float32 or t.shape[1] != 4 * reg_max + nc:
+            raise ValueError("detect_decode: levels must be fp32 with 4*reg_max+nc channels")
+        p, ld = view_params(t)
+        d.level[i], d.h[i], d.w[i], d.ld[i], d.stride[i] = p, t.shape[2], t.shape[3], ld, float(strides[i])
+        A += t.shape[2] * t.shape[3]
+    d.n_levels, d.batch, d.nc, d.reg_max = len(levels), n, nc, reg_max
+    if out is None:
+        out = torch.empty((n, 4 + nc, A), dtype=torch.float32, device=levels[0].device)
+    d.out = out.data_ptr()
+    _launch(lib().dy_detect_decode, (C.byref(d),), keep=(d, out, *levels))
+    return out
+
+
+class NmsBuffers:
+    """Persistent outputs + workspace of ``dy_nms`` for one (batch, anchors, max_det)."""
+
+    def __init__(self, batch: int, anchors: int, max_det: int, device):
+        self.batch, self.anchors, self.max_det = batch, anchors, max_det
+        nbytes = lib().dy_nms_workspace_bytes(batch, anchors)
+        self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        self.out = torch.empty((batch, max_det, 6), dtype=torch.float32, device=device)
+        self.count = torch.empty((batch,), dtype=torch.int32, device=device)
+        self.index = torch.empty((batch, max_det), dtype=torch.int32, device=device)
+
+
+def nms(pred: torch.Tensor, conf_thres: float, iou_thres: float, max_det: int = 300, max_nms: int = 30000,
+        max_wh: float = 7680.0, agnostic: bool = False, nc: int = 0, classes_mask: Optional[torch.Tensor] = None,
+        bufs: Optional[NmsBuffers] = None) -> NmsBuffers:
+    """Batched NMS on (N, 4+nc(+nm), A) fp32 predictions; results stay on the device."""
+    require_device(pred, "prediction")
+    if pred.dtype != torch.float32 or not pred.is_contiguous() or pred.dim() != 3:
+        raise ValueError("nms expects a contiguous fp32 (N, 4+nc, A) tensor")
+    n, ch, A = pred.shape
+    nc = nc or ch - 4
+    if bufs is None or (bufs.batch, bufs.anchors, bufs.max_det) != (n, A, max_det):
+        bufs = NmsBuffers(n, A, max_det, pred.device)
+    d = NmsDesc()
+    d.pred, d.batch, d.nc, d.n_extra, d.anchors = pred.data_ptr(), n, nc, ch - 4 - nc, A
+    d.conf_thres, d.iou_thres, d.max_det, d.max_nms = conf_thres, iou_thres, max_det, max_nms
+    d.max_wh, d.agnostic = max_wh, int(agnostic)
+    d.classes_mask = classes_mask.data_ptr() if classes_mask is not None else None
+    d.out, d.out_count, d.out_index = bufs.out.data_ptr(), bufs.count.data_ptr(), bufs.index.data_ptr()
+    d.workspace, d.workspace_bytes = bufs.workspace.data_ptr(), bufs.workspace.numel()
+    _launch(lib().dy_nms, (C.byref(d),), keep=(d, pred, bufs, classes_mask))
+    return bufs
+
+
+def scale_boxes_(bufs: NmsBuffers, params: torch.Tensor) -> None:
+    """In-place scale_boxes + clip_boxes of the kept rows; params: device fp32 (N,5)."""
+    _launch(lib().dy_scale_boxes, (bufs.out.data_ptr(), bufs.count.data_ptr(), params.data_ptr(), bufs.batch, bufs.max_det),
+            keep=(bufs, params))

@@ -1,0 +1,315 @@
+"""Model graph: YAML -> modules -> executor (reference: ultralytics/nn/tasks.py).
+
+``yaml_model_load`` (:1093-1124), ``guess_model_scale`` (:1127-1141), ``parse_model`` (:929-1090),
+``BaseModel`` (:95-295) and ``DetectionModel`` (:299-345) keep the reference's names and
+arguments.  What differs is MI355X-first:
+
+* ``RepVGGBlock`` is a first-class base module here.  In the reference it is exported
+  (nn/modules/__init__.py:62) but missing from ``parse_model``'s globals and ``base_modules``
+  (tasks.py:12-66, 954-991), so the shipped YAML cannot be built from scratch there.
+* the executor plans Concat by construction: a layer whose output feeds a Concat writes into its
+  channel slice of that Concat's buffer (``out=``), and Upsample+Concat in front of a C2f are
+  folded into the C2f.cv1 gather (dual-source + 2x-nearest addressing in ``dy_conv2d_nhwc``).
+* strides are derived from the graph instead of a CPU forward on zeros (tasks.py:324-337): the
+  product path has no CPU forward.
+* a forward is recorded once per input shape as a ``LaunchPlan`` and replayed afterwards.
+"""
+from __future__ import annotations
+
+import ast
+import contextlib
+import math
+import re
+from copy import deepcopy
+from pathlib import Path
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+import yaml
+
+from .. import hip_ops as H
+from ..utils import LOGGER
+from ..utils.ops import make_divisible
+from ..utils.torch_utils import initialize_weights
+from .modules import SPPF, Bottleneck, C2f, Concat, Conv, Detect, DWConv, RepVGGBlock, Upsample
+
+CFG_DIR = Path(__file__).resolve().parents[1] / "cfg"
+
+_MODULES = {
+    "Conv": Conv, "DWConv": DWConv, "RepVGGBlock": RepVGGBlock, "C2f": C2f, "SPPF": SPPF, "Bottleneck": Bottleneck,
+    "Concat": Concat, "Detect": Detect, "nn.Upsample": Upsample,
+}  # fmt: skip
+_BASE_MODULES = frozenset({Conv, DWConv, RepVGGBlock, C2f, SPPF, Bottleneck})
+_REPEAT_MODULES = frozenset({C2f})
+
+
+def guess_model_scale(model_path) -> str:
+    """'yolov8s-p2-repvgg.yaml' -> 's' (reference tasks.py:1127-1141)."""
+    with contextlib.suppress(AttributeError):
+        return re.search(r"yolo[v]?\d+([nslmx])", Path(model_path).stem).group(1)
+    return ""
+
+
+def yaml_model_load(path) -> dict:
+    """Load a model YAML; the scale letter in the file name selects ``scales[...]`` (tasks.py:1093-1124)."""
+    path = Path(path)
+    unified = re.sub(r"(\d+)([nslmx])(.+)?$", r"\1\3", str(path))  # yolov8s-p2.yaml -> yolov8-p2.yaml
+    for cand in (Path(unified), path, CFG_DIR / "models" / "v8" / Path(unified).name, CFG_DIR / "models" / "v8" / path.name):
+        if cand.is_file():
+            with open(cand, errors="ignore", encoding="utf-8") as f:
+                d = yaml.safe_load(f)
+            d["scale"] = guess_model_scale(path)
+            d["yaml_file"] = str(path)
+            return d
+    raise FileNotFoundError(f"model YAML '{path}' not found (also looked in {CFG_DIR / 'models' / 'v8'})")
+
+
+def parse_model(d: dict, ch: int, verbose: bool = True):
+    """YAML dict -> (nn.Sequential of layers, save list); same walk as reference tasks.py:929-1090."""
+    legacy = True  # v8 YAMLs: Detect keeps the two-3x3 class branch (tasks.py:934,1062)
+    max_channels = float("inf")
+    nc, act, scales = (d.get(x) for x in ("nc", "activation", "scales"))
+    depth, width = (d.get(x, 1.0) for x in ("depth_multiple", "width_multiple"))
+    if scales:
+        scale = d.get("scale")
+        if not scale:
+            scale = tuple(scales.keys())[0]
+            LOGGER.warning(f"WARNING no model scale passed. Assuming scale='{scale}'.")
+        depth, width, max_channels = scales[scale]
+    if act:
+        raise NotImplementedError("custom 'activation:' in the YAML is not supported: the conv epilogue builds SiLU only")
+    if verbose:
+        LOGGER.info(f"\n{'':>3}{'from':>20}{'n':>3}{'params':>10}  {'module':<45}{'arguments':<30}")
+    ch = [ch]
+    layers, save, c2 = [], [], ch[-1]
+    for i, (f, n, mname, args) in enumerate(d["backbone"] + d["head"]):
+        if mname not in _MODULES:
+            raise NotImplementedError(f"module '{mname}' (layer {i}) is not on the Drone-YOLO detection path")
+        m = _MODULES[mname]
+        args = list(args)
+        for j, a in enumerate(args):
+            if isinstance(a, str):
+                with contextlib.suppress(ValueError, SyntaxError):
+                    args[j] = nc if a == "nc" else ast.literal_eval(a)
+        n = n_ = max(round(n * depth), 1) if n > 1 else n
+        if m in _BASE_MODULES:
+            c1, c2 = ch[f], args[0]
+            if c2 != nc:
+                c2 = make_divisible(min(c2, max_channels) * width, 8)
+            args = [c1, c2, *args[1:]]
+            if m in _REPEAT_MODULES:
+                args.insert(2, n)
+                n = 1
+        elif m is Concat:
+            c2 = sum(ch[x] for x in f)
+        elif m is Detect:
+            args.append([ch[x] for x in f])
+            m.legacy = legacy
+        else:
+            c2 = ch[f]
+        m_ = nn.Sequential(*(m(*args) for _ in range(n))) if n > 1 else m(*args)
+        t = mname
+        m_.np = sum(x.numel() for x in m_.parameters())
+        m_.i, m_.f, m_.type = i, f, t
+        if verbose:
+            LOGGER.info(f"{i:>3}{str(f):>20}{n_:>3}{m_.np:10.0f}  {t:<45}{str(args):<30}")
+        save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)
+        layers.append(m_)
+        if i == 0:
+            ch = []
+        ch.append(c2)
+    return nn.Sequential(*layers), sorted(save)
+
+
+def _layer_stride(m: nn.Module) -> float:
+    """Spatial scale factor of one top-level layer (input size / output size)."""
+    if isinstance(m, nn.Sequential):
+        return math.prod(_layer_stride(x) for x in m)
+    if isinstance(m, Conv):
+        return float(m.conv.stride[0])
+    if isinstance(m, RepVGGBlock):
+        return float(m.stride)
+    if isinstance(m, Upsample):
+        return 1.0 / float(m.scale_factor)
+    return 1.0
+
+
+class BaseModel(nn.Module):
+    """Sequential executor with a skip list — reference tasks.py:95-295."""
+
+    def forward(self, x, *args, **kwargs):
+        if isinstance(x, dict):
+            return self.loss(x, *args, **kwargs)
+        return self.predict(x, *args, **kwargs)
+
+    def predict(self, x, profile=False, visualize=False, augment=False, embed=None):
+        if profile or visualize or augment or embed:
+            raise NotImplementedError("profile/visualize/augment/embed are outside the accelerated path")
+        return self._predict_once(x)
+
+    # ---- graph planning ---------------------------------------------------------------------------
+    def _plan_graph(self) -> None:
+        """Decide, per layer, where its output lives (Concat by construction) and which
+        Upsample/Concat pairs are folded into the consuming C2f."""
+        layers = list(self.model)
+        self._srcs = {m.i: [(m.i - 1) if s == -1 else (m.i + s if s < 0 else s) for s in
+                            ([m.f] if isinstance(m.f, int) else list(m.f))] for m in layers}
+        consumers: Dict[int, List[int]] = {i: [] for i in range(len(layers))}
+        for i, srcs in self._srcs.items():
+            for s in srcs:
+                if i > 0:
+                    consumers[s].append(i)
+        self._virtual: Dict[int, tuple] = {}  # concat layer index -> (lowres_src, skip_src) folded into next C2f
+        self._skip: set = set()  # layers that launch nothing (folded Upsample / Concat)
+        self._place: Dict[int, tuple] = {}  # producer layer -> (concat layer, channel offset)
+        fold = getattr(self, "fold_concat", True)
+        for m in layers:
+            if not isinstance(m, Concat):
+                continue
+            src = self._srcs[m.i]
+            nxt = layers[m.i + 1] if m.i + 1 < len(layers) else None
+            up = layers[src[0]]
+            if (fold and len(src) == 2 and isinstance(up, Upsample) and consumers[up.i] == [m.i]
+                    and isinstance(nxt, C2f) and consumers[m.i] == [nxt.i] and self._srcs[nxt.i] == [m.i]):
+                self._virtual[m.i] = (self._srcs[up.i][0], src[1])
+                self._skip.update((up.i, m.i))
+                continue
+            off = 0
+            for s in src:
+                c = self._out_ch[s]
+                n_cat = sum(1 for k in consumers[s] if isinstance(layers[k], Concat) and k not in self._virtual)
+                if s not in self._place and n_cat == 1 and not isinstance(layers[s], (Concat, Detect, nn.Sequential)):
+                    self._place[s] = (m.i, off)
+                off += c
+
+    def _predict_once(self, x):
+        """Run every layer; ``x`` is an NHWC-view tensor (see hip_ops)."""
+        if not hasattr(self, "_place"):
+            self._plan_graph()
+        y: List[Optional[torch.Tensor]] = []
+        cat_bufs: Dict[int, torch.Tensor] = {}
+        for m in self.model:
+            i = m.i
+            if i in self._skip:
+                y.append(None)
+                continue
+            src = self._srcs[i]
+            kw = {}
+            if isinstance(m, C2f) and src[0] in self._virtual:
+                lo, skip = self._virtual[src[0]]
+                xin, kw = y[lo], {"x2": y[skip], "up2x": True}
+            elif isinstance(m.f, int):
+                xin = x if (i == 0) else y[src[0]]
+            else:
+                xin = [y[j] for j in src]
+            if i in self._place:
+                ci, off = self._place[i]
+                if ci not in cat_bufs:
+                    n = x.shape[0]
+                    h, w = self._out_hw(ci, x.shape[2], x.shape[3])
+                    cat_bufs[ci] = H.alloc_nhwc(n, self._out_ch[ci], h, w, x.dtype, x.device)
+                kw["out"] = cat_bufs[ci][:, off : off + self._out_ch[i]]
+            if isinstance(m, Concat) and i in cat_bufs:
+                kw["out"] = cat_bufs[i]
+            out = m(xin, **kw)
+            y.append(out)
+        return y[-1]
+
+    def _out_hw(self, i: int, h: int, w: int):
+        s = self._cum_stride[i]
+        return int(round(h / s)), int(round(w / s))
+
+    def fuse(self, verbose=True):
+        """Reference tasks.py:193-221 folds Conv+BN in place; here folding happens when weights are
+        packed for the device, so this only drops stale packs and reports."""
+        for m in self.modules():
+            if hasattr(m, "invalidate_packed"):
+                m.invalidate_packed()
+        return self
+
+    def is_fused(self, thresh=10):
+        return True
+
+    def info(self, detailed=False, verbose=True, imgsz=640):
+        n_p = sum(p.numel() for p in self.parameters())
+        n_l = len(list(self.modules()))
+        if verbose:
+            LOGGER.info(f"{Path(self.yaml.get('yaml_file', 'model')).stem} summary: {n_l} modules, {n_p:,} parameters")
+        return n_l, n_p
+
+    def load(self, weights, verbose=True):
+        """Load a state dict (or a module) with matching keys/shapes — reference tasks.py:265-278."""
+        sd = weights.state_dict() if isinstance(weights, nn.Module) else (weights.get("model", weights) if isinstance(
+            weights, dict) else weights)
+        if isinstance(sd, nn.Module):
+            sd = sd.float().state_dict()
+        own = self.state_dict()
+        ok = {k: v for k, v in sd.items() if k in own and own[k].shape == v.shape}
+        self.load_state_dict(ok, strict=False)
+        if verbose:
+            LOGGER.info(f"Transferred {len(ok)}/{len(own)} items from pretrained weights")
+
+    def loss(self, batch, preds=None):
+        raise NotImplementedError("v8DetectionLoss / training step: not built yet on the HIP path (SURVEY §8 a28-a35)")
+
+
+class DetectionModel(BaseModel):
+    """YOLO detection model — reference tasks.py:299-345."""
+
+    def __init__(self, cfg="yolov8s-p2-repvgg.yaml", ch=3, nc=None, verbose=True):
+        super().__init__()
+        self.yaml = cfg if isinstance(cfg, dict) else yaml_model_load(cfg)
+        ch = self.yaml["ch"] = self.yaml.get("ch", ch)
+        if nc and nc != self.yaml["nc"]:
+            if verbose:
+                LOGGER.info(f"Overriding model.yaml nc={self.yaml['nc']} with nc={nc}")
+            self.yaml["nc"] = nc
+        self.model, self.save = parse_model(deepcopy(self.yaml), ch=ch, verbose=verbose)
+        self.names = {i: f"{i}" for i in range(self.yaml["nc"])}
+        self.inplace = self.yaml.get("inplace", True)
+        self.end2end = False
+
+        # per-layer channels and cumulative stride (replaces the zeros(1,ch,256,256) probe, tasks.py:324-337)
+        self._out_ch: Dict[int, int] = {}
+        self._cum_stride: Dict[int, float] = {}
+        for m in self.model:
+            src = [m.f] if isinstance(m.f, int) else list(m.f)
+            src = [(m.i - 1) if s == -1 else (m.i + s if s < 0 else s) for s in src]
+            s_in = 1.0 if m.i == 0 else self._cum_stride[src[0]]
+            self._cum_stride[m.i] = s_in * _layer_stride(m)
+            if isinstance(m, Concat):
+                self._out_ch[m.i] = sum(self._out_ch[s] for s in src)
+            elif isinstance(m, (Upsample,)):
+                self._out_ch[m.i] = self._out_ch[src[0]]
+            elif isinstance(m, Detect):
+                self._out_ch[m.i] = m.no
+            else:
+                last = m[-1] if isinstance(m, nn.Sequential) else m
+                self._out_ch[m.i] = _module_out_channels(last)
+        det = self.model[-1]
+        if isinstance(det, Detect):
+            src = [(det.i + s if s < 0 else s) for s in det.f]
+            det.stride = torch.tensor([self._cum_stride[s] for s in src])
+            self.stride = det.stride
+            det.bias_init()
+        else:
+            self.stride = torch.Tensor([32])
+        initialize_weights(self)
+        if verbose:
+            self.info()
+
+    def init_criterion(self):
+        raise NotImplementedError("v8DetectionLoss is not built yet on the HIP path")
+
+
+def _module_out_channels(m: nn.Module) -> int:
+    if isinstance(m, Conv):
+        return m.conv.out_channels
+    if isinstance(m, RepVGGBlock):
+        return (m.rbr_reparam if hasattr(m, "rbr_reparam") else m.rbr_dense.conv).out_channels
+    if isinstance(m, (C2f, SPPF)):
+        return m.cv2.conv.out_channels
+    if isinstance(m, Bottleneck):
+        return m.cv2.conv.out_channels
+    raise TypeError(f"cannot infer output channels of {type(m).__name__}")

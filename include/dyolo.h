@@ -1,0 +1,196 @@
+/*
+ * dyolo.h — C-ABI of libdyolo.so, the MI355X (gfx950) device library for the
+ * Drone-YOLO detection hot path.
+ *
+ * The reference (ultralytics fork, /root/reference) has no FFI boundary of its
+ * own: its seam is Python nn.Modules looked up by name (nn/tasks.py:1012-1018)
+ * that call torch ATen ops.  Every entry point below replaces the torch call
+ * sites named in its comment; the Python host mirror (drone-yolo_amd/nn/...,
+ * utils/ops.py) binds them with ctypes exactly as INTEGRATION.md shows.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types, no C++ types.
+ *   - all pointers are DEVICE pointers unless a comment says "host".
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*),
+ *     re-entrant, never allocates or frees, never synchronises.
+ *   - return value: DY_OK (0) or a negative dy_status; the message for the
+ *     last failure on the calling thread is dy_last_error_string().
+ *   - activations are NHWC ("channels last"): element (n,h,w,c) of a view lives
+ *     at base + ((n*H + h)*W + w)*ld + c, where ld >= C is the pixel pitch in
+ *     ELEMENTS.  A channel slice of a wider buffer is therefore just another
+ *     (base, ld) pair: Concat / chunk are done by construction, not by copies
+ *     (reference: nn/modules/conv.py:323-333, block.py:237-242).
+ *   - dtype of activations/weights: DY_BF16, DY_F16 or DY_F32.  Accumulation,
+ *     bias, SiLU and residual adds are always fp32.
+ */
+#ifndef DYOLO_H_
+#define DYOLO_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DYOLO_VERSION_MAJOR 0
+#define DYOLO_VERSION_MINOR 1
+
+typedef void* dy_stream_t; /* hipStream_t */
+
+typedef enum dy_status {
+  DY_OK = 0,
+  DY_ERR_INVALID_ARG = -1,   /* null pointer, bad size, misaligned view */
+  DY_ERR_UNSUPPORTED = -2,   /* shape / dtype combination not built */
+  DY_ERR_LAUNCH = -3,        /* hipLaunchKernel / HIP runtime error */
+  DY_ERR_WORKSPACE = -4      /* workspace too small */
+} dy_status;
+
+typedef enum dy_dtype { DY_BF16 = 0, DY_F16 = 1, DY_F32 = 2 } dy_dtype;
+typedef enum dy_act { DY_ACT_NONE = 0, DY_ACT_SILU = 1 } dy_act;
+
+/* ---- library -------------------------------------------------------------- */
+
+/* (major << 16) | minor. */
+int32_t dy_version(void);
+/* Message of the last error raised on this thread ("" if none). Host string. */
+const char* dy_last_error_string(void);
+/* Size in bytes of one element of `dtype` (2, 2, 4) or 0 if unknown. */
+int32_t dy_dtype_size(int32_t dtype);
+
+/* ---- convolution ----------------------------------------------------------
+ * Replaces: Conv.forward / forward_fuse = SiLU(BN(conv2d(x))) (nn/modules/conv.py:37-55),
+ * RepVGGBlock.forward after get_equivalent_kernel_bias folding (nn/modules/block.py:1421-1490),
+ * Bottleneck.forward's residual add (block.py:348-350), the plain nn.Conv2d 1x1 heads
+ * of Detect (nn/modules/head.py:43-57) and DWConv (conv.py:102-107, groups > 1).
+ *
+ * y[n,ho,wo,co] = act( sum_{r,q,c} x[n, ho*stride - pad + r, wo*stride - pad + q, c]
+ *                                   * w[co][(r*ksize + q)*cin + c]  + bias[co] ) (+ residual)
+ *
+ * Weights are PACKED by the caller:  row co holds the K = ksize*ksize*cin taps in
+ * (r, q, c) order, rows are k_pad elements apart, k_pad = dy_conv_k_pad(...), rows
+ * co >= cout up to cout_pad = dy_conv_cout_pad(cout) and columns k >= K must be ZERO.
+ * BatchNorm (eps, running stats) and RepVGG branches are folded into w/bias by the
+ * caller (utils/torch_utils.py:242-269 is the folding rule).
+ * bias: fp32[cout_pad].  residual (optional, same dtype as x) is added AFTER the
+ * activation.  Requirements: cin % (16/elem_size) == 0, ld_* and view bases aligned
+ * to 16 bytes (vector path) — unaligned OUTPUT views fall back to scalar stores.
+ */
+typedef struct dy_conv_desc {
+  const void* x;         /* input view base */
+  const void* w;         /* packed weights [cout_pad][k_pad] */
+  const float* bias;     /* [cout_pad] fp32 */
+  const void* residual;  /* optional view (n,ho,wo,cout), pitch ld_res; NULL = none */
+  void* y;               /* output view base */
+  int32_t batch, h, w_in, cin, ld_x;
+  int32_t ho, wo, cout, ld_y, ld_res;
+  int32_t ksize, stride, pad;
+  int32_t groups;        /* 1 = dense (MFMA path); >1 = grouped/depthwise direct kernel:
+                            w is then [cout][ksize*ksize*(cin/groups)] unpadded */
+  int32_t act;           /* dy_act */
+  int32_t dtype;         /* dy_dtype of x, w, residual */
+  int32_t out_f32;       /* 1: y is fp32 regardless of dtype (Detect logits) */
+  int32_t k_pad, cout_pad;
+  int32_t up2x;          /* 1: x is read through a fused 2x nearest upsample
+                            (nn.Upsample(None,2,'nearest') folded into this conv's gather):
+                            h,w_in are the UPSAMPLED dims, the buffer holds (h/2, w_in/2) */
+  /* Optional second source = Concat folded into the gather (conv.py:323-333): input
+   * channels [0,cin_split) are read from x (through up2x if set), channels
+   * [cin_split,cin) from x2 (never upsampled), pitch ld_x2.  x2 = NULL: single source. */
+  const void* x2;
+  int32_t ld_x2, cin_split;
+} dy_conv_desc;
+
+int32_t dy_conv_k_pad(int32_t cin, int32_t ksize, int32_t dtype);
+int32_t dy_conv_cout_pad(int32_t cout);
+int32_t dy_conv2d_nhwc(const dy_conv_desc* d, dy_stream_t stream);
+
+/* ---- layout / copy ops ------------------------------------------------------ */
+
+/* Replaces: predictor preprocess `.half()/.float()` + the NCHW->device layout step
+ * (engine/predictor.py:118-136).  src: fp32 NCHW (n,c,h,w) contiguous.  dst: NHWC
+ * view of `dtype`, pitch ld_dst, channels [c, c_pad) are written as zero. */
+int32_t dy_nchw_f32_to_nhwc(const float* src, void* dst, int32_t n, int32_t c, int32_t h, int32_t w,
+                            int32_t c_pad, int32_t ld_dst, int32_t dtype, dy_stream_t stream);
+
+/* Inverse, for handing activations back to NCHW callers: src NHWC view -> fp32 NCHW. */
+int32_t dy_nhwc_to_nchw_f32(const void* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w,
+                            int32_t ld_src, int32_t src_dtype, dy_stream_t stream);
+
+/* Replaces: nn.Upsample(None, 2, 'nearest') feeding Concat (yolov8-p2-repvgg.yaml:30,34,38).
+ * src (n,h,w,c) pitch ld_src -> dst (n,2h,2w,c) pitch ld_dst (typically a channel
+ * slice of the Concat buffer). c % (16/elem_size) == 0. */
+int32_t dy_upsample2x_nhwc(const void* src, void* dst, int32_t n, int32_t h, int32_t w, int32_t c,
+                           int32_t ld_src, int32_t ld_dst, int32_t dtype, dy_stream_t stream);
+
+/* Strided NHWC copy (Concat fallback when a producer could not write in place;
+ * conv.py:323-333). */
+int32_t dy_copy_nhwc(const void* src, void* dst, int32_t n, int32_t h, int32_t w, int32_t c,
+                     int32_t ld_src, int32_t ld_dst, int32_t dtype, dy_stream_t stream);
+
+/* Replaces: SPPF's three chained MaxPool2d(k,1,k//2) (nn/modules/block.py:185-191).
+ * x: (n,h,w,c) pitch ld.  y1,y2,y3: pooled once/twice/thrice, same pitch ld (the
+ * channel slices of the SPPF concat buffer).  k odd, (k/2)*3 halo; h*w*16B*3 must
+ * fit LDS (h*w <= 3072). */
+int32_t dy_sppf_maxpool3(const void* x, void* y1, void* y2, void* y3, int32_t n, int32_t h, int32_t w,
+                         int32_t c, int32_t ld, int32_t k, int32_t dtype, dy_stream_t stream);
+
+/* ---- Detect decode ------------------------------------------------------------
+ * Replaces: Detect._inference (nn/modules/head.py:100-131) = DFL (block.py:58-76) +
+ * make_anchors (utils/tal.py:333-345) + dist2bbox xywh (tal.py:348-357) * stride +
+ * sigmoid(cls), concatenated to (batch, 4+nc, A).
+ * Per level l the raw head output is an fp32 NHWC view (n, h_l, w_l, 4*reg_max + nc)
+ * with pitch ld_l: channels [0,4*reg_max) are the box bins, the next nc the class logits.
+ * out: fp32 (batch, 4+nc, A) contiguous, A = sum_l h_l*w_l, levels in order. */
+#define DY_MAX_LEVELS 8
+typedef struct dy_decode_desc {
+  const float* level[DY_MAX_LEVELS];
+  int32_t h[DY_MAX_LEVELS], w[DY_MAX_LEVELS], ld[DY_MAX_LEVELS];
+  float stride[DY_MAX_LEVELS];
+  int32_t n_levels, batch, nc, reg_max;
+  float* out;
+} dy_decode_desc;
+int32_t dy_detect_decode(const dy_decode_desc* d, dy_stream_t stream);
+
+/* ---- NMS --------------------------------------------------------------------
+ * Replaces: ops.non_max_suppression single-label path (utils/ops.py:181-332)
+ * including torchvision.ops.nms (called at ops.py:312): candidates = anchors
+ * whose best class score > conf_thres; xywh -> xyxy; if more than max_nms keep the
+ * max_nms best; boxes offset by cls*max_wh unless agnostic; greedy NMS in
+ * descending score order (ties: lower anchor index first), suppress when
+ * IoU > iou_thres; first max_det survivors are emitted.
+ * pred: fp32 (batch, 4+nc(+nm), A) contiguous (the decode output).
+ * classes_mask: optional host-independent DEVICE array of nc bytes (1 = keep class) or NULL.
+ * out: fp32 (batch, max_det, 6): x1,y1,x2,y2,conf,cls; rows >= count are zero.
+ * out_count: int32 (batch).  out_index: optional int32 (batch, max_det) anchor index of
+ * every kept row (for parity tests / mask gathers) or NULL.
+ * workspace: dy_nms_workspace_bytes(batch, A) bytes, 16-byte aligned.
+ */
+typedef struct dy_nms_desc {
+  const float* pred;
+  int32_t batch, nc, n_extra, anchors;
+  float conf_thres, iou_thres;
+  int32_t max_det, max_nms;
+  float max_wh;
+  int32_t agnostic;
+  const uint8_t* classes_mask;
+  float* out;
+  int32_t* out_count;
+  int32_t* out_index;
+  void* workspace;
+  int64_t workspace_bytes;
+} dy_nms_desc;
+int64_t dy_nms_workspace_bytes(int32_t batch, int32_t anchors);
+int32_t dy_nms(const dy_nms_desc* d, dy_stream_t stream);
+
+/* Replaces: ops.scale_boxes + ops.clip_boxes (utils/ops.py:92-127, 335-354) as applied by
+ * DetectionPredictor.construct_result (models/yolo/detect/predict.py:59-73) to the kept rows.
+ * boxes: fp32 (batch, max_det, 6), updated in place for rows < counts[b]:
+ *   x = clamp((x - pad_x) / gain, 0, clip_w),  y = clamp((y - pad_y) / gain, 0, clip_h).
+ * params: DEVICE fp32 (batch, 5) = gain, pad_x, pad_y, clip_w, clip_h per image. */
+int32_t dy_scale_boxes(float* boxes, const int32_t* counts, const float* params, int32_t batch,
+                       int32_t max_det, dy_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYOLO_H_ */

@@ -1,0 +1,385 @@
+"""ORACLE tooling — generates tests/golden/*.npz by IMPORTING THE REAL REFERENCE from /root/reference.
+
+Run in the build container only (the reference never travels to the GPU box):
+
+    python oracle/make_golden.py            # writes tests/golden/, prints the oracle-vs-reference check
+
+What it does
+  1. makes `import ultralytics` possible here: the container lacks `cv2` and `torchvision`, which the
+     reference imports at module scope (ultralytics/utils/__init__.py:23,53).  Two throw-away stub
+     modules are injected into sys.modules for the duration of this script (nothing is written into the
+     repo or the reference): `cv2` (attribute sink, never called on the hot path) and `torchvision`
+     whose `ops.nms` is the oracle's `nms_greedy` — so the reference's own `non_max_suppression` code
+     runs for real, but the NMS primitive under it is ours (parity unpinned at that boundary, see
+     oracle/drone_yolo_oracle.py).
+  2. builds the reference modules / models (RepVGGBlock via the work-around of SURVEY §8c: the shipped
+     parse_model cannot resolve 'RepVGGBlock', so the YAML is built with Conv in those slots and the four
+     layers are replaced by real `RepVGGBlock(c1, c2, 3, 2)` modules), loads seeded weights
+     (`seeded_state_dict`) and runs them on CPU in eval mode, fused like the predictor (AutoBackend
+     fuse=True).
+  3. checks the oracle restatement against those outputs (max-abs error printed, asserted <= 2e-5) and
+     stores inputs' seeds + reference outputs as small fixtures.
+"""
+from __future__ import annotations
+
+import importlib.metadata
+import os
+import sys
+import types
+from copy import deepcopy
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+REF = Path("/root/reference")
+OUT = ROOT / "tests" / "golden"
+sys.path.insert(0, str(ROOT))
+
+from oracle import drone_yolo_oracle as O  # noqa: E402
+
+
+# ---- 1. import the reference -----------------------------------------------------------------------------------
+def import_reference():
+    os.environ.setdefault("YOLO_CONFIG_DIR", "/tmp/dyolo_ref_cfg")
+    os.makedirs(os.environ["YOLO_CONFIG_DIR"], exist_ok=True)
+
+    class _Sink(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            return lambda *a, **k: None
+
+    cv2 = _Sink("cv2")
+    cv2.__version__ = "4.10.0"
+    cv2.IMREAD_COLOR = 1
+    sys.modules["cv2"] = cv2
+
+    tv = types.ModuleType("torchvision")
+    tv.__version__ = "0.25.0"
+    tv_ops = types.ModuleType("torchvision.ops")
+
+    def _nms(boxes, scores, iou_threshold):
+        return torch.from_numpy(O.nms_greedy(boxes.detach().cpu().numpy(), scores.detach().cpu().numpy(), iou_threshold))
+
+    tv_ops.nms = _nms
+    tv.ops = tv_ops
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.ops"] = tv_ops
+    _real_version = importlib.metadata.version
+    importlib.metadata.version = lambda name: "0.25.0" if name == "torchvision" else _real_version(name)
+    sys.path.insert(0, str(REF))
+    import ultralytics  # noqa: F401
+    from ultralytics.nn import tasks as rtasks
+    from ultralytics.nn.modules import block as rblock
+    from ultralytics.nn.modules import conv as rconv
+    from ultralytics.nn.modules import head as rhead
+    from ultralytics.utils import ops as rops
+    from ultralytics.utils import tal as rtal
+    from ultralytics.utils import torch_utils as rtu
+
+    return types.SimpleNamespace(tasks=rtasks, block=rblock, conv=rconv, head=rhead, ops=rops, tal=rtal, tu=rtu)
+
+
+def build_reference_model(R, yaml_name: str, scale: str, nc: int):
+    """DetectionModel of the reference for a RepVGG YAML (SURVEY §8c work-around)."""
+    import yaml as _yaml
+
+    d = _yaml.safe_load(open(REF / "ultralytics" / "cfg" / "models" / "v8" / yaml_name))
+    d["scale"] = scale
+    d["nc"] = nc
+    rep = [i for i, l in enumerate(d["backbone"] + d["head"]) if l[2] == "RepVGGBlock"]
+    d2 = deepcopy(d)
+    for l in d2["backbone"] + d2["head"]:
+        if l[2] == "RepVGGBlock":
+            l[2] = "Conv"
+    model = R.tasks.DetectionModel(d2, ch=3, nc=nc, verbose=False)
+    for i in rep:
+        old = model.model[i]
+        new = R.block.RepVGGBlock(old.conv.in_channels, old.conv.out_channels, 3, 2)
+        new.i, new.f, new.type, new.np = old.i, old.f, "ultralytics.nn.modules.block.RepVGGBlock", sum(p.numel() for p in new.parameters())
+        model.model[i] = new
+    R.tu.initialize_weights(model)
+    return model, d
+
+
+def our_yaml(name: str, scale: str, nc: int) -> dict:
+    import yaml as _yaml
+
+    d = _yaml.safe_load(open(ROOT / "drone-yolo_amd" / "cfg" / "models" / "v8" / name))
+    d["scale"], d["nc"] = scale, nc
+    return d
+
+
+def maxerr(a, b):
+    return float((a.double() - b.double()).abs().max()) if a.numel() else 0.0
+
+
+def rel_tol_check(name, got, ref, tol=2e-5):
+    e = maxerr(got, ref)
+    scale = max(1.0, float(ref.abs().max()))
+    print(f"  oracle vs reference  {name:<40s} max|err| {e:.3e}  (scale {scale:.2f})")
+    assert e <= tol * scale, f"{name}: oracle deviates from the reference by {e}"
+
+
+def tnp(t):
+    return t.detach().cpu().numpy()
+
+
+# ---- 2./3. per-operator vectors -----------------------------------------------------------------------------
+def per_op(R):
+    out = {}
+    g = torch.Generator().manual_seed(1234)
+
+    def rnd(*s):
+        return torch.randn(*s, generator=g)
+
+    def seed_module(m, seed):
+        sd = O.seeded_state_dict({k: v for k, v in m.state_dict().items()}, seed)
+        m.load_state_dict(sd)
+        R.tu.initialize_weights(m)
+        m.eval()
+        return {f"model.0.{k}": v for k, v in sd.items()}
+
+    with torch.no_grad():
+        # Conv 3x3 s2 (unfused module == oracle unfused == oracle fused)
+        m = R.conv.Conv(16, 32, 3, 2)
+        sd = seed_module(m, 11)
+        x = rnd(2, 16, 20, 24)
+        y = m(x)
+        rel_tol_check("Conv k3 s2 (BN unfused)", O.conv_block(x, sd, "model.0", 3, 2, fused=False), y)
+        rel_tol_check("Conv k3 s2 (BN fused)", O.conv_block(x, sd, "model.0", 3, 2, fused=True), y)
+        fc = R.tu.fuse_conv_and_bn(m.conv, m.bn)
+        wf, bf = O.fuse_conv_bn(sd["model.0.conv.weight"], sd, "model.0.bn")
+        rel_tol_check("fuse_conv_and_bn weight", wf, fc.weight)
+        rel_tol_check("fuse_conv_and_bn bias", bf, fc.bias)
+        out.update(conv_x=tnp(x), conv_y=tnp(y), conv_seed=11, conv_args=np.array([16, 32, 3, 2]))
+
+        m = R.conv.Conv(24, 16, 1, 1)
+        sd = seed_module(m, 12)
+        x = rnd(1, 24, 9, 7)
+        y = m(x)
+        rel_tol_check("Conv k1 s1", O.conv_block(x, sd, "model.0", 1, 1), y)
+        out.update(conv1_x=tnp(x), conv1_y=tnp(y), conv1_seed=12, conv1_args=np.array([24, 16, 1, 1]))
+
+        m = R.conv.DWConv(32, 16, 3, 2)
+        sd = seed_module(m, 13)
+        x = rnd(2, 32, 12, 12)
+        y = m(x)
+        rel_tol_check("DWConv k3 s2 g16", O.conv_block(x, sd, "model.0", 3, 2, g=16), y)
+        out.update(dw_x=tnp(x), dw_y=tnp(y), dw_seed=13, dw_args=np.array([32, 16, 3, 2]))
+
+        # RepVGGBlock stride 2 (the Drone-YOLO use) and stride 1 with identity branch
+        for tag, (c1, c2, s) in {"rep_s2": (16, 32, 2), "rep_id": (16, 16, 1)}.items():
+            m = R.block.RepVGGBlock(c1, c2, 3, s)
+            sd = seed_module(m, 21 if s == 2 else 22)
+            x = rnd(2, c1, 16, 12)
+            y = m(x)
+            rel_tol_check(f"RepVGGBlock 3-branch s{s}", O.repvgg_block(x, sd, "model.0", s, has_identity=(s == 1)), y)
+            k, b = O.repvgg_equivalent(sd, "model.0", has_identity=(s == 1), in_channels=c1)
+            if s == 2:  # the reference's own fold needs `np` for the identity branch (block.py:1466, not imported)
+                kr, br = m.get_equivalent_kernel_bias()
+                rel_tol_check("RepVGG get_equivalent_kernel_bias k", k, kr)
+                rel_tol_check("RepVGG get_equivalent_kernel_bias b", b, br)
+            rel_tol_check(f"RepVGGBlock folded s{s}", torch.nn.functional.silu(torch.nn.functional.conv2d(x, k, b, s, 1)), y, tol=1e-4)
+            out.update({f"{tag}_x": tnp(x), f"{tag}_y": tnp(y), f"{tag}_seed": 21 if s == 2 else 22, f"{tag}_args": np.array([c1, c2, 3, s])})
+
+        m = R.block.Bottleneck(16, 16, True, 1, k=((3, 3), (3, 3)), e=1.0)
+        sd = seed_module(m, 31)
+        x = rnd(2, 16, 10, 10)
+        y = m(x)
+        rel_tol_check("Bottleneck shortcut", O.bottleneck(x, sd, "model.0", True, True), y)
+        out.update(bott_x=tnp(x), bott_y=tnp(y), bott_seed=31)
+
+        for tag, (c1, c2, n, sc) in {"c2f_a": (32, 32, 2, True), "c2f_b": (48, 16, 1, False)}.items():
+            m = R.block.C2f(c1, c2, n, sc)
+            sd = seed_module(m, 41 if sc else 42)
+            x = rnd(2, c1, 12, 8)
+            y = m(x)
+            rel_tol_check(f"C2f n={n} shortcut={sc}", O.c2f(x, sd, "model.0", n, sc, True), y)
+            out.update({f"{tag}_x": tnp(x), f"{tag}_y": tnp(y), f"{tag}_seed": 41 if sc else 42, f"{tag}_args": np.array([c1, c2, n, int(sc)])})
+
+        m = R.block.SPPF(32, 32, 5)
+        sd = seed_module(m, 51)
+        x = rnd(2, 32, 20, 20)
+        y = m(x)
+        rel_tol_check("SPPF k5", O.sppf(x, sd, "model.0", 5, True), y)
+        out.update(sppf_x=tnp(x), sppf_y=tnp(y), sppf_seed=51)
+
+        # DFL, anchors, dist2bbox, box ops
+        m = R.block.DFL(16)
+        x = rnd(2, 64, 50) * 2
+        y = m(x)
+        rel_tol_check("DFL", O.dfl(x, 16), y)
+        out.update(dfl_x=tnp(x), dfl_y=tnp(y))
+        feats = [torch.zeros(1, 1, 6, 8), torch.zeros(1, 1, 3, 4)]
+        ap, st = R.tal.make_anchors(feats, [8, 16], 0.5)
+        oap, ost = O.make_anchors([(6, 8), (3, 4)], [8, 16], 0.5)
+        rel_tol_check("make_anchors points", oap, ap)
+        rel_tol_check("make_anchors strides", ost, st)
+        out.update(anchors_pts=tnp(ap), anchors_st=tnp(st))
+        dist = torch.rand(2, 4, 60, generator=g) * 6
+        y = R.tal.dist2bbox(dist, ap.transpose(0, 1).unsqueeze(0), xywh=True, dim=1)
+        rel_tol_check("dist2bbox xywh", O.dist2bbox(dist, oap.transpose(0, 1).unsqueeze(0), True, 1), y)
+        out.update(d2b_x=tnp(dist), d2b_y=tnp(y))
+        b = torch.rand(7, 4, generator=g) * 100
+        rel_tol_check("xywh2xyxy", O.xywh2xyxy(b), R.ops.xywh2xyxy(b))
+        out.update(xywh_x=tnp(b), xywh_y=tnp(R.ops.xywh2xyxy(b)))
+        bb = torch.tensor([[-5.0, 10, 700, 500], [30, 40, 50, 60], [600, 300, 650, 490]])
+        y = R.ops.scale_boxes((384, 640), bb.clone(), (480, 800))
+        rel_tol_check("scale_boxes letterboxed", O.scale_boxes((384, 640), bb.clone(), (480, 800)), y)
+        out.update(scale_x=tnp(bb), scale_y=tnp(y), scale_shapes=np.array([384, 640, 480, 800]))
+
+        # Detect head (legacy=True as parse_model sets for v8 YAMLs, tasks.py:934,1062)
+        R.head.Detect.legacy = True
+        m = R.head.Detect(nc=5, ch=(16, 32))
+        m.stride = torch.tensor([8.0, 16.0])
+        sd = seed_module(m, 61)
+        m.stride = torch.tensor([8.0, 16.0])
+        xs = [rnd(2, 16, 8, 6), rnd(2, 32, 4, 3)]
+        y, raw = m([t.clone() for t in xs])
+        ofe = O.detect_head(xs, sd, "model.0", 5, True)
+        for i in range(2):
+            rel_tol_check(f"Detect raw level {i}", ofe[i], raw[i])
+        rel_tol_check("Detect decode (_inference)", O.detect_decode(ofe, [8.0, 16.0], 5), y)
+        out.update(det_x0=tnp(xs[0]), det_x1=tnp(xs[1]), det_y=tnp(y), det_raw0=tnp(raw[0]), det_raw1=tnp(raw[1]), det_seed=61)
+        m.shape = None
+    np.savez_compressed(OUT / "per_op.npz", **out)
+
+
+# ---- NMS vectors: the reference's non_max_suppression code over our nms primitive -----------------------------
+def nms_cases(R):
+    g = torch.Generator().manual_seed(77)
+    cases = {}
+
+    def pred_from(boxes_xywh, scores):  # (n,4), (n,nc) -> (1, 4+nc, n)
+        return torch.cat((boxes_xywh, scores), 1).t().unsqueeze(0).contiguous()
+
+    # a) random crowd: 3 images, 400 anchors, 6 classes
+    n, nc = 400, 6
+    xy = torch.rand(3, n, 2, generator=g) * 300 + 20
+    wh = torch.rand(3, n, 2, generator=g) * 60 + 4
+    sc = torch.rand(3, n, nc, generator=g) ** 3
+    cases["crowd"] = (torch.cat((xy, wh, sc), 2).transpose(1, 2).contiguous(), dict(conf_thres=0.25, iou_thres=0.7))
+    # b) exact score ties + duplicates (stable order decides)
+    b = torch.tensor([[50.0, 50, 20, 20]] * 4 + [[52.0, 50, 20, 20]] * 2 + [[200.0, 200, 30, 30]] * 2)
+    s = torch.zeros(8, 3)
+    s[:, 1] = torch.tensor([0.9, 0.9, 0.5, 0.9, 0.9, 0.3, 0.6, 0.6])
+    cases["ties"] = (pred_from(b, s), dict(conf_thres=0.25, iou_thres=0.5))
+    # c) IoU exactly at the threshold: two unit-offset boxes with IoU = 1/3, thr = 1/3 -> not suppressed (strict >)
+    b = torch.tensor([[10.0, 10, 20, 20], [20.0, 10, 20, 20], [100.0, 100, 10, 10]])
+    s = torch.tensor([[0.8], [0.7], [0.6]])
+    cases["edge_iou"] = (pred_from(b, s), dict(conf_thres=0.25, iou_thres=1.0 / 3.0))
+    # d) more survivors than max_det, and class-offset separation of co-located boxes
+    k = 40
+    b = torch.stack((torch.arange(k) * 50.0 + 25, torch.full((k,), 30.0), torch.full((k,), 20.0), torch.full((k,), 20.0)), 1)
+    s = torch.zeros(k, 4)
+    s[torch.arange(k), torch.arange(k) % 4] = torch.linspace(0.95, 0.3, k)
+    b2 = torch.tensor([[400.0, 300, 40, 40]] * 4)
+    s2 = torch.eye(4) * torch.tensor([0.9, 0.8, 0.7, 0.6])
+    cases["max_det"] = (pred_from(torch.cat((b, b2)), torch.cat((s, s2))), dict(conf_thres=0.25, iou_thres=0.7, max_det=10))
+    cases["class_offset"] = (pred_from(torch.cat((b, b2)), torch.cat((s, s2))), dict(conf_thres=0.25, iou_thres=0.7))
+    cases["agnostic"] = (pred_from(torch.cat((b, b2)), torch.cat((s, s2))), dict(conf_thres=0.25, iou_thres=0.7, agnostic=True))
+    cases["classes"] = (pred_from(torch.cat((b, b2)), torch.cat((s, s2))), dict(conf_thres=0.25, iou_thres=0.7, classes=[1, 3]))
+    # e) image with nothing above conf next to a populated one
+    p = torch.cat((xy[:2, :50], wh[:2, :50], sc[:2, :50, :2]), 2).transpose(1, 2).contiguous().clone()
+    p[0, 4:] *= 0.1
+    cases["empty_image"] = (p, dict(conf_thres=0.25, iou_thres=0.7))
+    out = {}
+    for name, (pred, kw) in cases.items():
+        ref = R.ops.non_max_suppression(pred.clone(), **kw)
+        okw = dict(kw)
+        ours = O.non_max_suppression(pred.clone(), **okw)
+        for i, (a, b_) in enumerate(zip(ours, ref)):
+            assert a.shape == b_.shape and torch.equal(a, b_), f"nms case {name} image {i}: oracle != reference"
+        print(f"  oracle vs reference  nms/{name:<34s} identical ({[len(r) for r in ref]} boxes)")
+        out[f"{name}__pred"] = tnp(pred)
+        out[f"{name}__kw"] = np.array(repr(kw))
+        out[f"{name}__n"] = np.array([len(r) for r in ref])
+        out[f"{name}__out"] = np.concatenate([tnp(r) for r in ref], 0) if sum(len(r) for r in ref) else np.zeros((0, 6), np.float32)
+    np.savez_compressed(OUT / "nms.npz", **out)
+
+
+# ---- end-to-end models ------------------------------------------------------------------------------------------
+def tune_cls_bias(d, template, seed, x, target=0.02):
+    """Pick the class-branch bias so that ~2 % of anchors clear conf=0.25 (the stock bias_init
+    leaves none).  The chosen value is stored in the fixture so both sides use the same number."""
+    sd = O.seeded_state_dict(template, seed, cls_bias=0.0)
+    y, _ = O.forward(d, sd, x)
+    logits = torch.logit(y[:, 4:].amax(1).clamp(1e-6, 1 - 1e-6)).flatten()
+    q = torch.quantile(logits, 1 - target)
+    return round(float(math.log(0.25 / 0.75) - q), 3)
+
+
+def e2e(R):
+    out = {}
+    specs = [  # tag, yaml, scale, nc, (B,H,W), seed, store_full_y
+        ("n64", "yolov8-p2-repvgg.yaml", "n", 10, (2, 64, 64), 101, True),
+        ("n128", "yolov8-p2-repvgg.yaml", "n", 10, (2, 128, 96), 102, True),
+        ("sf_n64", "yolov8-p2-repvgg-sf.yaml", "n", 10, (1, 64, 64), 103, True),
+        ("s640", "yolov8-p2-repvgg.yaml", "s", 10, (1, 640, 640), 104, False),
+        ("v8n320", "yolov8.yaml", "n", 80, (1, 320, 320), 105, False),
+    ]
+    for tag, yname, scale, nc, (b, h, w), seed, full in specs:
+        torch.manual_seed(0)
+        if "repvgg" in yname:
+            model, _ = build_reference_model(R, yname, scale, nc)
+        else:
+            import yaml as _yaml
+
+            dd = _yaml.safe_load(open(REF / "ultralytics" / "cfg" / "models" / "v8" / yname))
+            dd["scale"], dd["nc"] = scale, nc
+            model = R.tasks.DetectionModel(dd, ch=3, nc=nc, verbose=False)
+        d = our_yaml(yname, scale, nc)
+        template = {k: v for k, v in model.state_dict().items()}
+        x = torch.rand(b, 3, h, w, generator=torch.Generator().manual_seed(seed))
+        bias = tune_cls_bias(d, template, seed, x)
+        sd = O.seeded_state_dict(template, seed, cls_bias=bias)
+        model.load_state_dict(sd)
+        R.tu.initialize_weights(model)
+        model.eval()
+        n_params = sum(p.numel() for p in model.parameters())
+        with torch.no_grad():
+            y_unf, raw_unf = model(x)  # as built (BN unfused)
+            model.fuse(verbose=False)  # what AutoBackend does for predict (autobackend.py:143-155)
+            y, raw = model(x)
+            oy, oraw = O.forward(d, sd, x, fused=True)
+            oy_u, _ = O.forward(d, sd, x, fused=False)
+        print(f"[{tag}] {yname} scale={scale} nc={nc} input={tuple(x.shape)} params={n_params} cls_bias={bias} A={y.shape[2]}")
+        rel_tol_check(f"{tag} decoded y (fused)", oy, y, tol=5e-5)
+        rel_tol_check(f"{tag} decoded y (unfused)", oy_u, y_unf, tol=5e-5)
+        for i in range(len(raw)):
+            rel_tol_check(f"{tag} raw level {i}", oraw[i], raw[i], tol=5e-5)
+        ref_det = R.ops.non_max_suppression(y.clone(), 0.25, 0.7, max_det=300, nc=nc)
+        our_det, our_idx = O.non_max_suppression(y.clone(), 0.25, 0.7, max_det=300, nc=nc, return_index=True)
+        for a, b_ in zip(our_det, ref_det):
+            assert torch.equal(a, b_), f"{tag}: oracle NMS rows differ from the reference's"
+        frac = float((y[:, 4:].amax(1) > 0.25).float().mean())
+        print(f"  candidates above conf: {frac * 100:.2f} %   kept: {[len(r) for r in ref_det]}")
+        out[f"{tag}__meta"] = np.array(repr(dict(yaml=yname, scale=scale, nc=nc, shape=(b, h, w), seed=seed, cls_bias=bias, params=n_params)))
+        out[f"{tag}__n"] = np.array([len(r) for r in ref_det])
+        out[f"{tag}__det"] = np.concatenate([tnp(r) for r in ref_det], 0)
+        out[f"{tag}__det_idx"] = np.concatenate([tnp(r) for r in our_idx], 0)
+        if full:
+            out[f"{tag}__y"] = tnp(y)
+        else:
+            out[f"{tag}__y_sub"] = tnp(y[:, :, ::37])
+            out[f"{tag}__y_sum"] = np.array([float(y.double().sum()), float(y.double().abs().sum()), float((y.double() ** 2).sum())])
+        out[f"{tag}__keys"] = np.array(sorted(template.keys()))
+        out[f"{tag}__shapes"] = np.array([repr(tuple(template[k].shape)) for k in sorted(template.keys())])
+    np.savez_compressed(OUT / "e2e.npz", **out)
+
+
+import math  # noqa: E402
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    OUT.mkdir(parents=True, exist_ok=True)
+    R = import_reference()
+    print("reference imported from", REF)
+    per_op(R)
+    nms_cases(R)
+    e2e(R)
+    for f in sorted(OUT.glob("*.npz")):
+        print(f"wrote {f.relative_to(ROOT)}  {f.stat().st_size / 1024:.1f} KiB")
