@@ -1,0 +1,67 @@
+"""CPU: libdyolo.so loads and exports exactly the symbols include/dyolo.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+from tests._util import ROOT
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "dyolo.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dy_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported_and_bound():
+    import drone_yolo_amd._lib as L
+
+    names = _declared()
+    assert len(names) >= 15
+    handle = L.lib()
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in dyolo.h but not exported by libdyolo.so"
+    assert sorted(L.SIGNATURES) == names, "ctypes SIGNATURES out of sync with include/dyolo.h"
+
+
+def test_host_only_entry_points():
+    import drone_yolo_amd._lib as L
+
+    h = L.lib()
+    assert h.dy_version() == (0 << 16) | 1
+    assert [h.dy_dtype_size(i) for i in (0, 1, 2, 7)] == [2, 2, 4, 0]
+    # bf16: 8 chunks x 8 elements per K-step
+    assert h.dy_conv_k_pad(64, 3, L.DY_BF16) == 576 and h.dy_conv_k_pad(32, 3, L.DY_BF16) == 320
+    assert h.dy_conv_k_pad(8, 3, L.DY_BF16) == 128 and h.dy_conv_k_pad(96, 1, L.DY_F32) == 96
+    assert [h.dy_conv_cout_pad(c) for c in (10, 64, 65, 512)] == [64, 64, 128, 512]
+    assert h.dy_nms_workspace_bytes(2, 34000) == 256 + 2 * 65536 * 8 + 136192
+    assert h.dy_last_error_string() is not None
+
+
+def test_descriptor_validation_without_gpu():
+    """Argument checks run before any HIP call, so they are testable on CPU."""
+    import drone_yolo_amd._lib as L
+
+    h = L.lib()
+    d = L.ConvDesc()
+    assert h.dy_conv2d_nhwc(ctypes.byref(d), None) == -1  # DY_ERR_INVALID_ARG: null pointers
+    assert b"null" in h.dy_last_error_string()
+    n = L.NmsDesc()
+    assert h.dy_nms(ctypes.byref(n), None) == -1
+    assert h.dy_conv2d_nhwc(None, None) == -1
+
+
+def test_struct_layout_matches_header():
+    """sizeof() of the ctypes mirrors must equal the C structs (checked against a tiny C program)."""
+    import subprocess
+    import tempfile
+
+    import drone_yolo_amd._lib as L
+
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "s.c")
+        open(src, "w").write('#include <stdio.h>\n#include "dyolo.h"\nint main(){printf("%zu %zu %zu\\n", '
+                             "sizeof(dy_conv_desc), sizeof(dy_decode_desc), sizeof(dy_nms_desc));return 0;}\n")
+        exe = os.path.join(td, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        sizes = [int(v) for v in subprocess.check_output([exe]).split()]
+    assert sizes == [ctypes.sizeof(L.ConvDesc), ctypes.sizeof(L.DecodeDesc), ctypes.sizeof(L.NmsDesc)]

@@ -1,0 +1,136 @@
+"""CPU: host-side logic of the package — YAML parsing, graph planning, weight folding/packing rules,
+sharding, and the guarantee that nothing silently falls back to CPU compute."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import drone_yolo_amd as D
+from drone_yolo_amd.nn import tasks
+from drone_yolo_amd.nn.modules import C2f, Concat, Conv, Detect, RepVGGBlock, Upsample
+from drone_yolo_amd.nn.modules.conv import fold_conv_bn
+from oracle import drone_yolo_oracle as O
+
+
+def test_yaml_scale_and_param_counts():
+    # parameter counts probed from the reference
+    for name, nc, params in (("yolov8n-p2-repvgg.yaml", 10, 2_972_360), ("yolov8s-p2-repvgg.yaml", 10, 10_815_576),
+                             ("yolov8s-p2-repvgg-sf.yaml", 10, 10_839_320), ("yolov8n.yaml", 80, 3_157_200)):
+        m = D.DetectionModel(name, nc=nc, verbose=False)
+        assert sum(p.numel() for p in m.parameters()) == params, name
+    m = D.DetectionModel("yolov8s-p2-repvgg.yaml", nc=10, verbose=False)
+    assert m.stride.tolist() == [4.0, 8.0, 16.0, 32.0]
+    assert isinstance(m.model[1], RepVGGBlock) and m.model[1].rbr_dense.conv.stride == (2, 2)
+    assert m.model[-1].legacy is True and m.model[-1].no == 74
+    # Detect.bias_init (head.py:133-144)
+    det = m.model[-1]
+    assert torch.allclose(det.cv2[0][-1].bias, torch.ones(64))
+    assert math.isclose(float(det.cv3[1][-1].bias[0]), math.log(5 / 10 / (640 / 8) ** 2), rel_tol=1e-6)
+    # BN constants (torch_utils.py:423-433)
+    assert m.model[0].bn.eps == 1e-3 and m.model[0].bn.momentum == 0.03
+
+
+def test_state_dict_keys_follow_reference_names():
+    m = D.DetectionModel("yolov8n-p2-repvgg.yaml", nc=10, verbose=False)
+    keys = set(m.state_dict())
+    for k in ("model.0.conv.weight", "model.0.bn.running_mean", "model.1.rbr_dense.conv.weight", "model.1.rbr_1x1.bn.running_var",
+              "model.2.m.0.cv1.conv.weight", "model.9.cv2.bn.bias", "model.28.cv2.0.0.conv.weight", "model.28.cv3.3.2.bias",
+              "model.28.dfl.conv.weight"):
+        assert k in keys, k
+    assert torch.equal(m.state_dict()["model.28.dfl.conv.weight"].flatten(), torch.arange(16.0))
+
+
+def test_graph_plan_folds_upsample_concat_and_places_producers():
+    m = D.DetectionModel("yolov8s-p2-repvgg.yaml", nc=10, verbose=False)
+    m._plan_graph()
+    assert m._virtual == {11: (9, 6), 14: (12, 4), 17: (15, 2)}
+    assert m._skip == {10, 11, 13, 14, 16, 17}
+    assert m._place == {19: (20, 0), 15: (20, 64), 22: (23, 0), 12: (23, 128), 25: (26, 0), 9: (26, 256)}
+    sf = D.DetectionModel("yolov8s-p2-repvgg-sf.yaml", nc=10, verbose=False)
+    sf._plan_graph()
+    assert 12 not in sf._virtual and sf._place[11] == (12, 0) and sf._place[6] == (12, 64) and sf._place[10] == (12, 320)
+
+
+def test_fold_rules_match_oracle():
+    torch.manual_seed(0)
+    c = Conv(8, 16, 3, 2)
+    sd = O.seeded_state_dict(c.state_dict(), 5)
+    c.load_state_dict(sd)
+    tasks.initialize_weights(c)
+    w, b = fold_conv_bn(c.conv.weight, None, c.bn)
+    wo, bo = O.fuse_conv_bn(sd["conv.weight"], {f"bn.{k[3:]}": v for k, v in sd.items() if k.startswith("bn.")}, "bn")
+    assert torch.allclose(w, wo, atol=1e-6) and torch.allclose(b, bo, atol=1e-6)
+    for (c1, c2, s) in ((8, 16, 2), (8, 8, 1)):
+        r = RepVGGBlock(c1, c2, 3, s)
+        sd = O.seeded_state_dict(r.state_dict(), 6)
+        r.load_state_dict(sd)
+        tasks.initialize_weights(r)
+        k, bb = r.get_equivalent_kernel_bias()
+        ko, bo = O.repvgg_equivalent({f"m.{k_}": v for k_, v in sd.items()}, "m", s == 1, c1)
+        assert torch.allclose(k, ko, atol=1e-6) and torch.allclose(bb, bo, atol=1e-6)
+        r.switch_to_deploy()
+        assert r.deploy and torch.allclose(r.rbr_reparam.weight, ko, atol=1e-6)
+
+
+def test_packed_weight_layout():
+    """Row co = (r, q, c)-ordered taps, zero padding to k_pad / cout_pad (include/dyolo.h)."""
+    from drone_yolo_amd import hip_ops as H
+
+    w = torch.arange(10 * 8 * 3 * 3, dtype=torch.float32).view(10, 8, 3, 3) / 100
+    pc = H.PackedConv(w, torch.arange(10.0), 1, 1, 1, True, torch.float32, "cpu")
+    assert tuple(pc.w.shape) == (64, 96) and pc.k_pad == 96 and pc.cout_pad == 64
+    assert pc.w[3, (1 * 3 + 2) * 8 + 5] == w[3, 5, 1, 2]
+    assert float(pc.w[10:].abs().sum()) == 0 and float(pc.w[:, 72:].abs().sum()) == 0
+    assert torch.equal(pc.b[:10], torch.arange(10.0)) and float(pc.b[10:].abs().sum()) == 0
+    pc16 = H.PackedConv(w, torch.zeros(10), 1, 1, 1, True, torch.bfloat16, "cpu")
+    assert tuple(pc16.w.shape) == (64, 128) and pc16.w.dtype == torch.bfloat16
+
+
+def test_no_cpu_fallback():
+    m = D.DetectionModel("yolov8n-p2-repvgg.yaml", nc=10, verbose=False).eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.model[0](torch.zeros(1, 8, 32, 32).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2))
+    from drone_yolo_amd.utils.torch_utils import select_device
+
+    with pytest.raises(RuntimeError):
+        select_device("cpu")
+    with pytest.raises(NotImplementedError):
+        D.YOLO("yolov8n-p2-repvgg.yaml").train(data="x.yaml")
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m.model[0](torch.zeros(1, 8, 8, 8))
+
+
+def test_view_params_and_alloc():
+    from drone_yolo_amd import hip_ops as H
+
+    t = H.alloc_nhwc(2, 24, 5, 7, torch.bfloat16, "cpu")
+    assert tuple(t.shape) == (2, 24, 5, 7) and t.stride() == (5 * 7 * 24, 1, 7 * 24, 24)
+    p, ld = H.view_params(t[:, 8:16])
+    assert ld == 24 and p == t.data_ptr() + 8 * 2
+    with pytest.raises(ValueError):
+        H.view_params(torch.zeros(2, 24, 5, 7))  # NCHW-contiguous is not an NHWC view
+    t2 = H.alloc_nhwc(1, 10, 4, 4, torch.float32, "cpu", ld=12)
+    assert H.view_params(t2)[1] == 12
+
+
+def test_shard_range_covers_batch():
+    from drone_yolo_amd.parallel import shard_range
+
+    for n in (1, 7, 8, 64, 65):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(e - s for s, e in spans) - min(e - s for s, e in spans) <= 1
+
+
+def test_ops_host_helpers():
+    from drone_yolo_amd.utils import ops
+
+    b = torch.tensor([[10.0, 20, 4, 6]])
+    assert torch.equal(ops.xywh2xyxy(b), torch.tensor([[8.0, 17, 12, 23]]))
+    assert ops.make_divisible(65, 8) == 72
+    bb = torch.tensor([[-5.0, 10, 700, 500], [30, 40, 50, 60]])
+    assert torch.allclose(ops.scale_boxes((384, 640), bb.clone(), (480, 800)), O.scale_boxes((384, 640), bb.clone(), (480, 800)))
