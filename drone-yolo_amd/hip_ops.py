@@ -138,8 +138,13 @@ class PackedConv:
     """
 
     def __init__(self, weight: torch.Tensor, bias: torch.Tensor, stride: int, pad: int, groups: int, act: bool,
-                 dtype: torch.dtype, device):
+                 dtype: torch.dtype, device, cin_pad: Optional[int] = None):
         L = lib()
+        if cin_pad is not None and cin_pad > weight.shape[1]:
+            # the input view carries zero-padded channels (the 3-channel image padded to one 16-byte chunk)
+            if groups != 1:
+                raise ValueError("cin_pad is only meaningful for dense convolutions")
+            weight = torch.nn.functional.pad(weight.detach().float(), (0, 0, 0, 0, 0, cin_pad - weight.shape[1]))
         cout, cin_g, k, k2 = weight.shape
         assert k == k2, "square kernels only"
         self.cout, self.cin, self.k, self.stride, self.pad, self.groups = cout, cin_g * groups, k, stride, pad, groups

@@ -181,12 +181,12 @@ class RepVGGBlock(_PackedMixin, nn.Module):
             self.deploy = True
             self.invalidate_packed()
 
-    def _pack(self, dtype, device) -> H.PackedConv:
+    def _pack(self, dtype, device, cin_pad=None) -> H.PackedConv:
         if hasattr(self, "rbr_reparam"):
             w, b = self.rbr_reparam.weight, self.rbr_reparam.bias
         else:
             w, b = self.get_equivalent_kernel_bias()
-        return H.PackedConv(w, b, self.stride, self.padding, self.groups, True, dtype, device)
+        return H.PackedConv(w, b, self.stride, self.padding, self.groups, True, dtype, device, cin_pad=cin_pad)
 
     def forward(self, inputs, out=None):
         _require_eval(self)

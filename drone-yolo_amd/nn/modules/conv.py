@@ -45,10 +45,13 @@ class _PackedMixin:
 
     def _packed_for(self, x: torch.Tensor) -> H.PackedConv:
         cache = self.__dict__.setdefault("_packed", {})
-        key = (x.dtype, x.device)
+        key = (x.dtype, x.device, x.shape[1])
         pc = cache.get(key)
         if pc is None:
             pc = cache[key] = self._pack(x.dtype, x.device)
+            if pc.groups == 1 and 0 < x.shape[1] - pc.cin < H.elems_per_chunk(x.dtype):
+                # zero-padded input channels (image input padded to one 16-byte chunk): pad the taps to match
+                pc = cache[key] = self._pack(x.dtype, x.device, cin_pad=x.shape[1])
         return pc
 
     def invalidate_packed(self) -> None:
@@ -90,11 +93,12 @@ class Conv(_PackedMixin, nn.Module):
         if not isinstance(self.act, (nn.SiLU, nn.Identity)):
             raise NotImplementedError("only SiLU / identity activations are built into the conv epilogue")
 
-    def _pack(self, dtype, device) -> H.PackedConv:
+    def _pack(self, dtype, device, cin_pad=None) -> H.PackedConv:
         w, b = fold_conv_bn(self.conv.weight, self.conv.bias, self.bn) if hasattr(self, "bn") else (
             self.conv.weight, self.conv.bias)
         c = self.conv
-        return H.PackedConv(w, b, c.stride[0], c.padding[0], c.groups, isinstance(self.act, nn.SiLU), dtype, device)
+        return H.PackedConv(w, b, c.stride[0], c.padding[0], c.groups, isinstance(self.act, nn.SiLU), dtype, device,
+                            cin_pad=cin_pad)
 
     def forward(self, x, out=None, residual=None, **kw):
         _require_eval(self)
@@ -113,8 +117,9 @@ class DWConv(Conv):
 class PlainConv2d(_PackedMixin, nn.Conv2d):
     """nn.Conv2d with bias and no activation (the last layer of each Detect branch, head.py:43-57)."""
 
-    def _pack(self, dtype, device) -> H.PackedConv:
-        return H.PackedConv(self.weight, self.bias, self.stride[0], self.padding[0], self.groups, False, dtype, device)
+    def _pack(self, dtype, device, cin_pad=None) -> H.PackedConv:
+        return H.PackedConv(self.weight, self.bias, self.stride[0], self.padding[0], self.groups, False, dtype, device,
+                            cin_pad=cin_pad)
 
     def forward(self, x, out=None, out_f32=False):
         return H.conv2d(x, self._packed_for(x), out=out, out_f32=out_f32)
