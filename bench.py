@@ -33,12 +33,23 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense, MI3
 HBM_PEAK_GBS = 8000.0
 
 
-def synthetic_state_dict(model, seed: int, cls_bias: float = -1.9):
-    """Random-init weights of the architecture (no checkpoints exist offline): conv ~ N(0, 2/fan_in) keeps
-    activations O(1) through the graph, BN near identity with non-trivial running stats, class-branch
-    bias raised so that ~2 % of the 34,000 anchors clear conf=0.25 (the stock bias_init leaves none,
-    which would make NMS trivially empty)."""
+def synthetic_state_dict(model, seed: int, cls_bias=None, bn_stats="file"):
+    """Random-init weights of the architecture (no checkpoints exist offline): conv ~ N(0, 2/fan_in), BN affine
+    near identity.  BatchNorm running statistics and the class-branch bias come from
+    bench_data/<model>_nc<nc>_seed<seed>_bn.npz, calibrated offline by oracle/calibrate_synthetic.py so that
+    activations stay O(1) through the graph and ~2 % of the 34,000 anchors clear conf=0.25 (random BN
+    statistics make the scores input independent, which would make NMS trivially empty or full)."""
+    import numpy as np
+
     g = torch.Generator().manual_seed(seed)
+    if bn_stats == "file":
+        name = os.path.splitext(os.path.basename(model.yaml.get("yaml_file", "model")))[0]
+        path = os.path.join(ROOT, "bench_data", f"{name}_nc{model.yaml['nc']}_seed{seed}_bn.npz")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} missing: run `python oracle/calibrate_synthetic.py --model {name}.yaml --seed {seed}`")
+        z = np.load(path)
+        bn_stats = {k: torch.from_numpy(z[k]) for k in z.files if not k.startswith("__")}
+        cls_bias = float(z["__cls_bias__"]) if cls_bias is None else cls_bias
     sd = {}
     for k, t in sorted(model.state_dict().items()):
         shape = tuple(t.shape)
@@ -47,9 +58,9 @@ def synthetic_state_dict(model, seed: int, cls_bias: float = -1.9):
         elif ".dfl." in k:
             sd[k] = t.clone()
         elif k.endswith("running_mean"):
-            sd[k] = torch.randn(shape, generator=g) * 0.1
+            sd[k] = bn_stats[k].clone() if bn_stats else torch.zeros(shape)
         elif k.endswith("running_var"):
-            sd[k] = torch.rand(shape, generator=g) * 0.5 + 0.75
+            sd[k] = bn_stats[k].clone() if bn_stats else torch.ones(shape)
         elif k.endswith("weight") and len(shape) == 1:
             sd[k] = torch.rand(shape, generator=g) * 0.4 + 0.8
         elif k.endswith("bias"):
@@ -58,7 +69,7 @@ def synthetic_state_dict(model, seed: int, cls_bias: float = -1.9):
             sd[k] = torch.randn(shape, generator=g) * math.sqrt(2.0 / (shape[1] * shape[2] * shape[3]))
     for k in sd:
         if ".cv3." in k and k.endswith(".2.bias"):
-            sd[k] = torch.full_like(sd[k], cls_bias) + torch.linspace(-0.3, 0.3, sd[k].numel())
+            sd[k] = torch.full_like(sd[k], float(cls_bias or 0.0)) + torch.linspace(-0.3, 0.3, sd[k].numel())
     return sd
 
 
