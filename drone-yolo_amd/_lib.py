@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdyolo.so")
 DY_BF16, DY_F16, DY_F32 = 0, 1, 2
 DY_ACT_NONE, DY_ACT_SILU = 0, 1
 DY_MAX_LEVELS = 8
+DY_WLAYOUT_ROWS, DY_WLAYOUT_HALO3X3 = 0, 1
 
 _vp, _i32, _f32, _i64 = C.c_void_p, C.c_int32, C.c_float, C.c_int64
 
@@ -30,7 +31,7 @@ class ConvDesc(C.Structure):
         ("ksize", _i32), ("stride", _i32), ("pad", _i32),
         ("groups", _i32), ("act", _i32), ("dtype", _i32), ("out_f32", _i32),
         ("k_pad", _i32), ("cout_pad", _i32), ("up2x", _i32),
-        ("x2", _vp), ("ld_x2", _i32), ("cin_split", _i32),
+        ("x2", _vp), ("ld_x2", _i32), ("cin_split", _i32), ("w_layout", _i32),
     ]  # fmt: skip
 
 

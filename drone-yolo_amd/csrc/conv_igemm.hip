@@ -333,6 +333,8 @@ static int launch_dtype(const ConvArgs& a, hipStream_t st) {
   return small ? launch_tile<T, 64, 16, OUTF32>(a, st) : launch_tile<T, 128, 16, OUTF32>(a, st);
 }
 
+int conv3x3_halo_dispatch(const dy_conv_desc* d, hipStream_t st);  // conv3x3_halo.hip
+
 }  // namespace dy
 
 using namespace dy;
@@ -394,6 +396,9 @@ extern "C" int32_t dy_conv2d_nhwc(const dy_conv_desc* d, dy_stream_t stream) {
   a.act = d->act;
   a.up2x = d->up2x ? 1 : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+
+  if (d->w_layout == DY_WLAYOUT_HALO3X3) return conv3x3_halo_dispatch(d, st);
+  DY_REQUIRE(d->w_layout == DY_WLAYOUT_ROWS, DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: unknown w_layout %d", d->w_layout);
 
   if (d->groups > 1) {
     DY_REQUIRE(d->cin % d->groups == 0 && d->cout % d->groups == 0, DY_ERR_INVALID_ARG,

@@ -120,33 +120,34 @@ __global__ __launch_bounds__(1024) void nms_suppress_kernel(const NmsArgs p) {
   int P2 = 1;
   while (P2 < n) P2 <<= 1;
   const bool in_lds = P2 <= p.SL;
-  u64* keys = in_lds ? skeys : gkeys;
-  if (n > 1) {
-    if (in_lds) {
-      for (int i = tid; i < P2; i += 1024) skeys[i] = i < n ? gkeys[i] : ~0ull;
-    } else {
-      for (int i = n + tid; i < P2; i += 1024) gkeys[i] = ~0ull;
-    }
-    __syncthreads();
+  // Bitonic sort, one compare-exchange pair per thread per pass.  The LDS and the global variant are
+  // separate loops on purpose: a pointer select between the two address spaces makes the compiler
+  // fall back to generic (flat) accesses, which were ~10x slower per pass.
+  auto bitonic = [&](auto* keys) {
     for (int k = 2; k <= P2; k <<= 1) {
       for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int i = tid; i < P2; i += 1024) {
-          const int ixj = i ^ j;
-          if (ixj > i) {
-            const u64 x = keys[i], y = keys[ixj];
-            const bool up = (i & k) == 0;
-            if ((x > y) == up) {
-              keys[i] = y;
-              keys[ixj] = x;
-            }
+        for (int t = tid; t < (P2 >> 1); t += 1024) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // element with bit j clear
+          const int ixj = i | j;
+          const u64 x = keys[i], y = keys[ixj];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) {
+            keys[i] = y;
+            keys[ixj] = x;
           }
         }
         __syncthreads();
       }
     }
-  } else if (n == 1 && in_lds) {
-    if (tid == 0) skeys[0] = gkeys[0];
+  };
+  if (in_lds) {
+    for (int i = tid; i < P2; i += 1024) skeys[i] = i < n ? gkeys[i] : ~0ull;
     __syncthreads();
+    if (n > 1) bitonic(skeys);
+  } else {
+    for (int i = n + tid; i < P2; i += 1024) gkeys[i] = ~0ull;
+    __syncthreads();
+    bitonic(gkeys);
   }
   if (tid >= 64) return;  // wave 0 runs the greedy scan
 
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(1024) void nms_suppress_kernel(const NmsArgs p) {
     float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, ox1 = 0.f, oy1 = 0.f, ox2 = 0.f, oy2 = 0.f, area = 0.f, score = 0.f;
     int anchor = 0, cls = 0;
     if (alive) {
-      const u64 key = keys[i];
+      const u64 key = in_lds ? skeys[i] : gkeys[i];
       anchor = (int)(unsigned)(key & 0xffffffffull);
       score = __uint_as_float(~(unsigned)(key >> 32));
       cls = (int)p.cls[(size_t)b * p.A + anchor];

@@ -138,7 +138,7 @@ class PackedConv:
     """
 
     def __init__(self, weight: torch.Tensor, bias: torch.Tensor, stride: int, pad: int, groups: int, act: bool,
-                 dtype: torch.dtype, device, cin_pad: Optional[int] = None):
+                 dtype: torch.dtype, device, cin_pad: Optional[int] = None, halo: Optional[bool] = None):
         L = lib()
         if cin_pad is not None and cin_pad > weight.shape[1]:
             # the input view carries zero-padded channels (the 3-channel image padded to one 16-byte chunk)
@@ -150,6 +150,23 @@ class PackedConv:
         self.cout, self.cin, self.k, self.stride, self.pad, self.groups = cout, cin_g * groups, k, stride, pad, groups
         self.act = DY_ACT_SILU if act else DY_ACT_NONE
         self.dtype = dtype
+        self.layout = _lib.DY_WLAYOUT_ROWS
+        if (halo is None or halo) and groups == 1 and k == 3 and pad == 1 and stride in (1, 2) and cout % 4 == 0 \
+                and self.cin >= 4 * elems_per_chunk(dtype) // 2:
+            # LDS-halo 3x3 kernel: MFMA-fragment-ordered weights (include/dyolo.h, DY_WLAYOUT_HALO3X3)
+            self.layout = _lib.DY_WLAYOUT_HALO3X3
+            e = elems_per_chunk(dtype)
+            kc, bn = 4 * e, (64 if cout > 32 else 32)
+            nt, nch = -(-cout // bn), -(-self.cin // kc)
+            wpad = torch.zeros((nt * bn, nch * kc, 3, 3), dtype=torch.float32)
+            wpad[:cout, : self.cin] = weight.detach().to(torch.float32).cpu()
+            wp = wpad.view(nt, bn // 16, 16, nch, 4, e, 3, 3).permute(0, 3, 6, 7, 1, 4, 2, 5).contiguous().view(-1)
+            self.k_pad, self.cout_pad = 0, L.dy_conv_cout_pad(cout)
+            bp = torch.zeros((self.cout_pad,), dtype=torch.float32)
+            bp[:cout] = bias.detach().to(torch.float32)
+            self.w = wp.to(dtype).contiguous().to(device)
+            self.b = bp.contiguous().to(device)
+            return
         w = weight.detach().to(torch.float32).permute(0, 2, 3, 1).reshape(cout, k * k * cin_g)
         if groups == 1:
             self.k_pad = L.dy_conv_k_pad(self.cin, k, dy_dtype(dtype))
@@ -198,7 +215,7 @@ def conv2d(x: torch.Tensor, pc: PackedConv, out: Optional[torch.Tensor] = None, 
     d.ho, d.wo, d.cout, d.ld_y = ho, wo, pc.cout, ldy
     d.ksize, d.stride, d.pad, d.groups = pc.k, pc.stride, pc.pad, pc.groups
     d.act, d.dtype, d.out_f32 = pc.act, dy_dtype(x.dtype), int(out_f32)
-    d.k_pad, d.cout_pad, d.up2x = pc.k_pad, pc.cout_pad, int(up2x)
+    d.k_pad, d.cout_pad, d.up2x, d.w_layout = pc.k_pad, pc.cout_pad, int(up2x), pc.layout
     if residual is not None:
         if tuple(residual.shape) != tuple(out.shape) or residual.dtype != x.dtype:
             raise ValueError("conv2d: residual must match the output shape and the input dtype")

@@ -47,6 +47,8 @@ typedef enum dy_status {
 
 typedef enum dy_dtype { DY_BF16 = 0, DY_F16 = 1, DY_F32 = 2 } dy_dtype;
 typedef enum dy_act { DY_ACT_NONE = 0, DY_ACT_SILU = 1 } dy_act;
+/* Packed weight layouts of dy_conv2d_nhwc (see dy_conv_desc.w_layout). */
+typedef enum dy_wlayout { DY_WLAYOUT_ROWS = 0, DY_WLAYOUT_HALO3X3 = 1 } dy_wlayout;
 
 /* ---- library -------------------------------------------------------------- */
 
@@ -98,6 +100,14 @@ typedef struct dy_conv_desc {
    * [cin_split,cin) from x2 (never upsampled), pitch ld_x2.  x2 = NULL: single source. */
   const void* x2;
   int32_t ld_x2, cin_split;
+  /* Weight layout.  DY_WLAYOUT_ROWS (0): the [cout_pad][k_pad] rows described above (any ksize/stride).
+   * DY_WLAYOUT_HALO3X3 (1): dense 3x3, pad 1, stride 1 or 2, single source, cout % 4 == 0 — selects the
+   * LDS-halo kernel.  Weights are then packed in MFMA-fragment order: with E = 16/elem_size,
+   * KC = 4*E channels per chunk, BN = (cout > 32 ? 64 : 32), NF = BN/16, the element
+   *   w[co = nt*BN + j*16 + lr][r][q][ci = c*KC + lq*E + e]
+   * lives at ((((nt*ceil(cin/KC) + c)*9 + (r*3+q))*NF + j)*64 + lq*16 + lr)*E + e, zero where co >= cout
+   * or ci >= cin.  k_pad / cout_pad are ignored; bias stays fp32[dy_conv_cout_pad(cout)]. */
+  int32_t w_layout;
 } dy_conv_desc;
 
 int32_t dy_conv_k_pad(int32_t cin, int32_t ksize, int32_t dtype);

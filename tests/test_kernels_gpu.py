@@ -56,6 +56,10 @@ CONV_CASES = [
     (64, 16, 3, 1, 8, 160, 160, False, "large M BN=16 no act"),
     (16, 24, 3, 1, 1, 12, 12, True, "n-scale odd cout"),
     (24, 48, 1, 1, 1, 12, 12, True, "cin=24"),
+    (48, 64, 3, 1, 2, 33, 37, True, "halo cin=48 odd dims"),
+    (128, 128, 3, 2, 2, 40, 40, True, "halo s2 deep"),
+    (64, 32, 3, 2, 1, 80, 80, True, "halo s2 BN=32"),
+    (64, 64, 3, 1, 40, 40, 40, True, "halo many tiles per block"),
 ]
 
 
@@ -120,7 +124,7 @@ def test_conv_dual_source_upsample_gather(dtype, device):
     check_close(back(y), ref, dtype, "dual-source up2x conv")
     # and a 3x3 through the upsample alone
     w3 = quantize(torch.randn(32, 64, 3, 3, generator=g) * 0.05, dtype)
-    pc3 = H.PackedConv(w3, torch.zeros(32), 1, 1, 1, False, dtype, device)
+    pc3 = H.PackedConv(w3, torch.zeros(32), 1, 1, 1, False, dtype, device, halo=False)
     y3 = H.conv2d(nhwc(a, dtype, device), pc3, up2x=True)
     torch.cuda.synchronize()
     check_close(back(y3), F.conv2d(F.interpolate(a, scale_factor=2.0, mode="nearest"), w3, None, 1, 1), dtype, "up2x 3x3 conv")
