@@ -1,29 +1,31 @@
-// 3x3 (pad 1, stride 1 or 2) NHWC convolution on CDNA4 MFMA: persistent workgroups, LDS halo tiles.
+// 3x3 (pad 1, stride 1 or 2) NHWC convolution on CDNA4 MFMA: persistent workgroups, LDS halo tiles,
+// weight-stationary when the weights fit.
 //
 // Why a second kernel: the generic implicit-GEMM kernel (conv_igemm.hip) re-gathers every input
 // pixel once per tap and spends ~8 VALU instructions of address arithmetic per MFMA.  Here a
-// workgroup owns a TH x 16 patch of output pixels x BN output channels and walks the input
-// channels in chunks of one MFMA k-group (32 bf16/f16 or 16 f32 channels = 64 bytes per pixel):
+// 512-thread workgroup (8 waves, two per SIMD so one wave's VALU epilogue overlaps the other's
+// MFMAs) owns a TH x 16 patch of output pixels x BN output channels and walks the input channels
+// in chunks of one MFMA k-group (32 bf16/f16 or 16 f32 channels = 64 bytes per pixel):
 //
-//   LDS stage = [ halo patch: ((TH-1)*S+3) x ((16-1)*S+3) pixels x 64 B ] + [ weights: 9 taps x BN x 64 B ]
-//
-//   - the halo patch is fetched ONCE per chunk (1.27x the output pixels for stride 1 instead of 9x);
-//     all nine taps read it at compile-time-constant pixel offsets;
-//   - weights are pre-packed by the host in MFMA-fragment order per (n-tile, chunk, tap), so staging
-//     them is a linear 16-byte-per-lane copy and every B fragment read is `stage + constant + lane*16`;
-//   - workgroups are persistent (grid = #CUs): a block walks its list of (tile, chunk) items with the
-//     loads of item i+1 in flight during the 144 MFMAs (per wave) of item i, one barrier per item,
-//     and no pipeline drain between tiles;
+//   - the halo patch ((TH-1)*S+3) x (15*S+3) pixels of one chunk is fetched ONCE (1.27x the output
+//     pixels for stride 1 instead of 9x) into an LDS image with an 80-byte pixel pitch: 16
+//     consecutive pixels then land on 16 distinct 16-byte bank slots (5 is odd), and every one of
+//     the nine taps reads it as `lane base + compile-time constant` — no address VALU in the loop;
+//   - weights are pre-packed by the host in MFMA-fragment order per (n-tile, chunk, tap), so
+//     staging them is a linear 16-byte-per-lane copy and a B fragment read is `base + const + lane*16`;
+//   - WS = true (weight stationary): the n-tile's whole weight set (nChunks x 9 x BN x 64 B, e.g.
+//     72 KB for 64->64) is loaded into LDS once per workgroup and only halo chunks stream
+//     (double buffered) — per-CU L2->LDS bandwidth (~25 B/clk) cannot feed both operands per item;
+//     WS = false streams (halo, weight) pairs per item for layers whose weights exceed LDS;
+//   - workgroups are persistent: a block walks its (tile, chunk) items with the loads of item i+1
+//     in flight during the MFMAs of item i, one barrier per item, no drain between tiles;
 //   - the MFMA is issued with the WEIGHT fragment as the A operand, so a lane ends up holding 4
 //     consecutive output channels of one pixel: the epilogue (bias, SiLU, residual) works on
 //     registers and stores 8 (bf16/f16) or 16 (f32) contiguous bytes per lane, no LDS round trip.
 //
-// Halo image swizzle: pixel p, 16-byte chunk c lives at p*64 + ((c ^ ((p>>2)&3)) << 4), which makes
-// the 16 consecutive pixels of a fragment row hit 16 distinct 16-byte slots of the 256-byte bank row,
-// and the staging writes of 8 consecutive lanes (2 pixels x 4 chunks) conflict free.
-//
 // Reference semantics: Conv / RepVGGBlock (folded) / Bottleneck residual, as conv_igemm.hip.
 #include "common.cuh"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace dy {
@@ -38,95 +40,138 @@ struct Conv3Args {
   int Ho, Wo, Cout, ldy, ldres;
   int act;
   int tilesX, tilesY, tilesN, nTiles, nChunks;
+  int dbg;  // ablation switches (DYOLO_DBG env): 1 skip global loads after the first item, 2 skip MFMAs,
+            // 4 skip epilogue, 8 skip LDS staging writes, 16 force the streaming (non-WS) variant
 };
 
-template <typename T, int S, int MF, int NF, bool OUTF32>
-__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const Conv3Args p) {
+constexpr int kHaloPixPitch = 80;  // bytes per halo pixel in LDS (64 data + 16 pad)
+
+template <typename T, int S, int MF, int NF, bool OUTF32, bool WS>
+__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
+  constexpr int NT = 512;
   constexpr int EPC = Elem<T>::EPC;
   constexpr int KCE = 4 * EPC;             // channels per chunk (one MFMA k-group)
-  constexpr int TH = 4 * MF, TW = 16;      // output patch of the workgroup; wave w owns rows [w*MF, (w+1)*MF)
+  constexpr int TH = 8 * MF, TW = 16;      // output patch of the workgroup; wave w owns rows [w*MF, (w+1)*MF)
   constexpr int HH = (TH - 1) * S + 3, HWD = (TW - 1) * S + 3;
   constexpr int NPIX = HH * HWD;
-  constexpr int A_BYTES = NPIX * 64;
-  constexpr int W_CHUNKS = 9 * NF * 64;    // 16-byte chunks of one weight stage
+  constexpr int PP = kHaloPixPitch;
+  constexpr int A_BYTES = (NPIX * PP + 15) / 16 * 16;
+  constexpr int W_CHUNKS = 9 * NF * 64;    // 16-byte chunks of one (n-tile, chunk) weight block
   constexpr int W_BYTES = W_CHUNKS * 16;
-  constexpr int STAGE = A_BYTES + W_BYTES;
-  constexpr int NA = (NPIX * 4 + 255) / 256;
-  constexpr int NW = (W_CHUNKS + 255) / 256;
+  constexpr int STAGE = WS ? A_BYTES : A_BYTES + W_BYTES;
+  constexpr int NA = (NPIX * 4 + NT - 1) / NT;
+  constexpr int NW = WS ? 1 : (W_CHUNKS + NT - 1) / NT;
   constexpr int BN = NF * 16;
   typedef typename std::conditional<OUTF32, float, T>::type OutT;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  // WS: [all weight chunks of this n-tile][stage 0][stage 1];  streaming: [stage 0][stage 1]
+  unsigned char* const stage0 = dyn_smem + (WS ? p.nChunks * W_BYTES : 0);
+  // bias (all n-tiles, fp32) lives behind the stages: epilogue reads must not be global loads, or their
+  // s_waitcnt vmcnt(0) would also drain the halo prefetch that is in flight
+  const float* const sbias = reinterpret_cast<const float*>(stage0 + 2 * STAGE);
+  // per-wave epilogue scratch (MF*16 pixels x BN channels of OutT, pixel pitch padded by 16 B): results are
+  // transposed through it so that global stores are whole pixel rows, 16 bytes per lane.  Row-strided
+  // 8-byte stores straight from the accumulator layout are store-issue bound (~580 cycles per wave store).
+  constexpr int EP_PITCH = BN * (int)sizeof(OutT) + 16;
+  constexpr int EP_BYTES = MF * 16 * EP_PITCH;
+  unsigned char* const escr = const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(sbias)) +
+                              ((WS ? BN : p.tilesN * BN) * 4) + (threadIdx.x >> 6) * EP_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane >> 4, lr = lane & 15;
   const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
   const u32x4* __restrict__ wg = reinterpret_cast<const u32x4*>(p.w);
+  const int G = (int)gridDim.x;
 
-  const int nItems = ((p.nTiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * p.nChunks;
+  const int myTiles = (p.nTiles - (int)blockIdx.x + G - 1) / G;
+  const int nItems = myTiles * p.nChunks;
   if (nItems <= 0) return;
 
-  // ---- loader state (runs one item ahead of the compute state) -----------------------------------
-  unsigned aoff[NA];       // element offset of this thread's halo slots for the loader's tile (~0u = outside)
-  int l_tile = -1, l_nt = 0;
-  u32x4 ra[NA], rw[NW];
-
-  auto decode_tile = [&](int tile, int& n, int& y0, int& x0, int& nt) {
-    nt = tile % p.tilesN;
-    int t = tile / p.tilesN;
-    const int tx = t % p.tilesX;
-    t /= p.tilesX;
-    const int ty = t % p.tilesY;
-    n = t / p.tilesY;
-    y0 = ty * TH;
-    x0 = tx * TW;
+  // tile id = ((n*tilesY + ty)*tilesX + tx)*tilesN + nt, this block visits blockIdx.x + k*G.
+  // Decode once, then advance by G with carries (no per-tile integer divisions).
+  struct TileIt {
+    int n, ty, tx, nt;
+  };
+  auto decode = [&](int tile) {
+    TileIt t;
+    t.nt = tile % p.tilesN;
+    int r = tile / p.tilesN;
+    t.tx = r % p.tilesX;
+    r /= p.tilesX;
+    t.ty = r % p.tilesY;
+    t.n = r / p.tilesY;
+    return t;
+  };
+  const TileIt step = decode(G);  // G as a mixed-radix number
+  auto advance = [&](TileIt& t) {
+    t.nt += step.nt;
+    int c = t.nt >= p.tilesN;
+    t.nt -= c ? p.tilesN : 0;
+    t.tx += step.tx + c;
+    c = t.tx >= p.tilesX;
+    t.tx -= c ? p.tilesX : 0;
+    t.ty += step.ty + c;
+    c = t.ty >= p.tilesY;
+    t.ty -= c ? p.tilesY : 0;
+    t.n += step.n + c;
   };
 
-  auto issue_loads = [&](int item) {
-    const int tile = (int)blockIdx.x + (item / p.nChunks) * (int)gridDim.x;
-    const int c = item % p.nChunks;
-    if (tile != l_tile) {
-      l_tile = tile;
-      int n, y0, x0;
-      decode_tile(tile, n, y0, x0, l_nt);
+  // ---- loader state (runs one item ahead of the compute state) -----------------------------------
+  TileIt lt = decode((int)blockIdx.x);
+  int l_chunk = 0;
+  unsigned aoff[NA];  // element offset of this thread's halo slots for the loader's tile (~0u = outside)
+  u32x4 ra[NA], rw[NW];
+
+  auto tile_offsets = [&]() {
 #pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        const int s = tid + 256 * i;
-        const int pix = s >> 2;
-        const int hy = pix / HWD, hx = pix - hy * HWD;
-        const int gy = y0 * S - 1 + hy, gx = x0 * S - 1 + hx;
-        const bool ok = (pix < NPIX) && ((unsigned)gy < (unsigned)p.H) && ((unsigned)gx < (unsigned)p.W);
-        aoff[i] = ok ? (unsigned)((n * p.H + gy) * p.W + gx) * (unsigned)p.ldx + (unsigned)((s & 3) * EPC) : ~0u;
-      }
+    for (int i = 0; i < NA; ++i) {
+      const int s = tid + NT * i;
+      const int pix = s >> 2;
+      const int hy = pix / HWD, hx = pix - hy * HWD;
+      const int gy = lt.ty * (TH * S) - 1 + hy, gx = lt.tx * (TW * S) - 1 + hx;
+      const bool ok = (pix < NPIX) && ((unsigned)gy < (unsigned)p.H) && ((unsigned)gx < (unsigned)p.W);
+      aoff[i] = ok ? (unsigned)((lt.n * p.H + gy) * p.W + gx) * (unsigned)p.ldx + (unsigned)((s & 3) * EPC) : ~0u;
     }
-    const int cbase = c * KCE;
+  };
+
+  auto issue_loads = [&]() {  // loads of (lt, l_chunk), then advance the loader
+    if (l_chunk == 0) tile_offsets();
+    const int cbase = l_chunk * KCE;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const bool ok = (aoff[i] != ~0u) && (cbase + (tid & 3) * EPC < p.Cin);
       ra[i] = ok ? *reinterpret_cast<const u32x4*>(xg + (size_t)aoff[i] + cbase) : zero_chunk();
     }
-    const u32x4* wsrc = wg + (size_t)(l_nt * p.nChunks + c) * W_CHUNKS;
+    if constexpr (!WS) {
+      const u32x4* wsrc = wg + (size_t)(lt.nt * p.nChunks + l_chunk) * W_CHUNKS;
 #pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const int s = tid + 256 * i;
-      if (W_CHUNKS % 256 == 0 || s < W_CHUNKS) rw[i] = wsrc[s];
+      for (int i = 0; i < NW; ++i) {
+        const int s = tid + NT * i;
+        if (W_CHUNKS % NT == 0 || s < W_CHUNKS) rw[i] = wsrc[s];
+      }
+    }
+    if (++l_chunk == p.nChunks) {
+      l_chunk = 0;
+      advance(lt);
     }
   };
 
   auto store_lds = [&](int stage) {
-    unsigned char* sa = dyn_smem + stage * STAGE;
-    unsigned char* sw = sa + A_BYTES;
+    unsigned char* sa = stage0 + stage * STAGE;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int s = tid + 256 * i;
+      const int s = tid + NT * i;
       const int pix = s >> 2, ch = s & 3;
-      if (NPIX * 4 % 256 == 0 || pix < NPIX)
-        *reinterpret_cast<u32x4*>(sa + pix * 64 + ((ch ^ ((pix >> 2) & 3)) << 4)) = ra[i];
+      if (NPIX * 4 % NT == 0 || pix < NPIX) *reinterpret_cast<u32x4*>(sa + pix * PP + ch * 16) = ra[i];
     }
+    if constexpr (!WS) {
+      unsigned char* sw = sa + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const int s = tid + 256 * i;
-      if (W_CHUNKS % 256 == 0 || s < W_CHUNKS) *reinterpret_cast<u32x4*>(sw + s * 16) = rw[i];
+      for (int i = 0; i < NW; ++i) {
+        const int s = tid + NT * i;
+        if (W_CHUNKS % NT == 0 || s < W_CHUNKS) *reinterpret_cast<u32x4*>(sw + s * 16) = rw[i];
+      }
     }
   };
 
@@ -138,19 +183,17 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const Conv3Args p) {
       for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
-  const int pix_lane = (wave * MF * S) * HWD + lr * S;  // halo pixel of (row wave*MF, col lr), tap (0,0)
-  auto compute = [&](int stage) {
-    const unsigned char* sa = dyn_smem + stage * STAGE;
-    const unsigned char* sw = sa + A_BYTES + lane * 16;
+  // byte offset of this lane's fragment element for tap (0,0), row i = 0 inside a halo stage
+  const int a_lane = ((wave * MF * S) * HWD + lr * S) * PP + lq * 16;
+  auto compute = [&](int stage, int chunk) {
+    const unsigned char* sa = stage0 + stage * STAGE + a_lane;
+    const unsigned char* sw = (WS ? dyn_smem + chunk * W_BYTES : stage0 + stage * STAGE + A_BYTES) + lane * 16;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int r = tap / 3, q = tap % 3;
       u32x4 a[MF], b[NF];
 #pragma unroll
-      for (int i = 0; i < MF; ++i) {
-        const int pix = pix_lane + (i * S + r) * HWD + q;
-        a[i] = *reinterpret_cast<const u32x4*>(sa + pix * 64 + ((lq ^ ((pix >> 2) & 3)) << 4));
-      }
+      for (int i = 0; i < MF; ++i) a[i] = *reinterpret_cast<const u32x4*>(sa + ((i * S + r) * HWD + q) * PP);
 #pragma unroll
       for (int j = 0; j < NF; ++j) b[j] = *reinterpret_cast<const u32x4*>(sw + (tap * NF + j) * 1024);
 #pragma unroll
@@ -163,20 +206,48 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const Conv3Args p) {
   // ---- epilogue from registers: lane holds couts (lq*4 .. +3) of pixel lr for every (i, j) ------------
   OutT* __restrict__ yg = reinterpret_cast<OutT*>(p.y);
   const T* __restrict__ rg = reinterpret_cast<const T*>(p.res);
-  auto epilogue = [&](int tile) {
-    int n, y0, x0, nt;
-    decode_tile(tile, n, y0, x0, nt);
-    const int xx = x0 + lr;
+  auto epilogue = [&](const TileIt& t) {
+    const int xx = t.tx * TW + lr;
+    const int co0 = t.nt * BN + lq * 4;
+    const int sb0 = WS ? t.nt * BN : 0;  // offset of the LDS bias window
+    size_t m[MF];
+    bool rowok[MF];
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
-      const int yy = y0 + wave * MF + i;
-      if (yy >= p.Ho || xx >= p.Wo) continue;
-      const size_t m = (size_t)(n * p.Ho + yy) * p.Wo + xx;
+      const int yy = t.ty * TH + wave * MF + i;
+      rowok[i] = yy < p.Ho && xx < p.Wo;
+      m[i] = (size_t)(t.n * p.Ho + (rowok[i] ? yy : 0)) * p.Wo + (rowok[i] ? xx : 0);
+    }
+    // all residual loads first (one wait for the lot), then the arithmetic
+    float rv[MF][NF][4];
+    if constexpr (!OUTF32) {
+      if (rg != nullptr) {
 #pragma unroll
-      for (int j = 0; j < NF; ++j) {
-        const int co = nt * BN + j * 16 + lq * 4;
-        if (co >= p.Cout) continue;
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + co);
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+          for (int j = 0; j < NF; ++j) {
+            const int co = co0 + j * 16;
+            const bool ok = rowok[i] && co < p.Cout;
+            const T* rp = rg + m[i] * (size_t)p.ldres + (ok ? co : 0);
+            if constexpr (sizeof(T) == 4) {
+              const f32x4 tt = ok ? *reinterpret_cast<const f32x4*>(rp) : f32x4{0.f, 0.f, 0.f, 0.f};
+              rv[i][j][0] = tt[0], rv[i][j][1] = tt[1], rv[i][j][2] = tt[2], rv[i][j][3] = tt[3];
+            } else {
+              typedef __attribute__((ext_vector_type(4))) T t4;
+              const u32x2 raw = ok ? *reinterpret_cast<const u32x2*>(rp) : u32x2{0u, 0u};
+              const t4 tt = __builtin_bit_cast(t4, raw);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) rv[i][j][e] = Elem<T>::to_f32(tt[e]);
+            }
+          }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+      const int co = co0 + j * 16;
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(sbias + co - sb0);  // zero beyond cout (padded buffer)
+#pragma unroll
+      for (int i = 0; i < MF; ++i) {
         float v[4] = {acc[i][j][0] + bb[0], acc[i][j][1] + bb[1], acc[i][j][2] + bb[2], acc[i][j][3] + bb[3]};
         if (p.act == DY_ACT_SILU) {
 #pragma unroll
@@ -184,82 +255,148 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const Conv3Args p) {
         }
         if constexpr (!OUTF32) {
           if (rg != nullptr) {
-            const T* rp = rg + m * (size_t)p.ldres + co;
-            if constexpr (sizeof(T) == 4) {
-              const f32x4 t = *reinterpret_cast<const f32x4*>(rp);
-              v[0] += t[0], v[1] += t[1], v[2] += t[2], v[3] += t[3];
-            } else {
-              typedef __attribute__((ext_vector_type(4))) T t4;
-              const t4 t = __builtin_bit_cast(t4, *reinterpret_cast<const u32x2*>(rp));
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += Elem<T>::to_f32(t[e]);
-            }
+            for (int e = 0; e < 4; ++e) v[e] += rv[i][j][e];
           }
         }
-        OutT* yp = yg + m * (size_t)p.ldy + co;
+        unsigned char* sp = escr + (i * 16 + lr) * EP_PITCH + (j * 16 + lq * 4) * (int)sizeof(OutT);
         if constexpr (OUTF32 || sizeof(T) == 4) {
-          *reinterpret_cast<f32x4*>(yp) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(sp) = f32x4{v[0], v[1], v[2], v[3]};
         } else {
           typedef __attribute__((ext_vector_type(4))) T t4;
           t4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f32(v[e]);
-          *reinterpret_cast<u32x2*>(yp) = __builtin_bit_cast(u32x2, o);
+          *reinterpret_cast<u32x2*>(sp) = __builtin_bit_cast(u32x2, o);
+        }
+      }
+    }
+    // read back as rows: CPR 16-byte chunks per pixel row, consecutive lanes cover consecutive chunks
+    constexpr int CPR = BN * (int)sizeof(OutT) / 16;
+    constexpr int VE = 16 / (int)sizeof(OutT);
+#pragma unroll
+    for (int k = 0; k < MF * 16 * CPR / 64; ++k) {
+      const int idx = k * 64 + lane;
+      const int pixl = idx / CPR, cc = idx - pixl * CPR;
+      const int i = pixl >> 4, px = pixl & 15;
+      const int yy = t.ty * TH + wave * MF + i, xo = t.tx * TW + px;
+      const int co = t.nt * BN + cc * VE;
+      const u32x4 val = *reinterpret_cast<const u32x4*>(escr + pixl * EP_PITCH + cc * 16);
+      if (yy < p.Ho && xo < p.Wo && co < p.Cout) {
+        OutT* yp = yg + ((size_t)(t.n * p.Ho + yy) * p.Wo + xo) * (size_t)p.ldy + co;
+        if (co + VE <= p.Cout) {
+          *reinterpret_cast<u32x4*>(yp) = val;
+        } else {  // ragged channel tail (cout % 4 == 0 is guaranteed): 8-byte halves
+          const u32x2 lo = u32x2{val[0], val[1]};
+          *reinterpret_cast<u32x2*>(yp) = lo;
         }
       }
     }
   };
 
-  // ---- item pipeline: one barrier per (tile, chunk) item -----------------------------------------------
-  issue_loads(0);
+  // ---- prologue ------------------------------------------------------------------------------------------
+  if constexpr (WS) {  // the block's n-tile is constant (host makes gridDim a multiple of tilesN)
+    const u32x4* wsrc = wg + (size_t)lt.nt * p.nChunks * W_CHUNKS;
+    const int total = p.nChunks * W_CHUNKS;
+    for (int s = tid; s < total; s += NT) *reinterpret_cast<u32x4*>(dyn_smem + s * 16) = wsrc[s];
+  }
+  {
+    float* sb = const_cast<float*>(sbias);
+    // WS blocks stay on one n-tile and keep only its BN biases; streaming blocks keep all of them.
+    // (tilesN * BN <= dy_conv_cout_pad(cout): the bias buffer is zero padded)
+    const int nb = WS ? BN : p.tilesN * BN, b0 = WS ? lt.nt * BN : 0;
+    for (int s = tid; s < nb; s += NT) sb[s] = p.bias[b0 + s];
+  }
+  TileIt ct = lt;  // compute-side tile
+  issue_loads();
   store_lds(0);
   zero_acc();
   __syncthreads();
+
+  // ---- item pipeline: one barrier per (tile, chunk) item -----------------------------------------------
+  int c_chunk = 0;
   for (int it = 0; it < nItems; ++it) {
     const bool more = (it + 1) < nItems;
-    if (more) issue_loads(it + 1);
-    compute(it & 1);
-    if ((it + 1) % p.nChunks == 0) {  // last chunk of a tile
-      epilogue((int)blockIdx.x + (it / p.nChunks) * (int)gridDim.x);
+    if (more && !(p.dbg & 1)) issue_loads();
+    if (!(p.dbg & 2)) compute(it & 1, c_chunk);
+    // staging writes first: their vmcnt(0) then waits for the prefetch alone, not for epilogue traffic
+    if (more && !(p.dbg & 8)) store_lds((it + 1) & 1);
+    if (++c_chunk == p.nChunks) {  // last chunk of a tile
+      c_chunk = 0;
+      if (!(p.dbg & 4)) epilogue(ct);
       zero_acc();
+      advance(ct);
     }
-    if (more) store_lds((it + 1) & 1);
     __syncthreads();
   }
 }
 
+template <typename T, int S, int MF, int NF>
+struct HaloGeom {
+  static constexpr int TH = 8 * MF, TW = 16;
+  static constexpr int NPIX = ((TH - 1) * S + 3) * ((TW - 1) * S + 3);
+  static constexpr int A_BYTES = (NPIX * kHaloPixPitch + 15) / 16 * 16;
+  static constexpr int W_BYTES = 9 * NF * 1024;
+};
+
+constexpr int kLdsBudget = 160 * 1024;
+
+// LDS bytes of one workgroup; *ws tells whether the weight-stationary layout fits.
+template <typename T, int S, int MF, int NF, bool OUTF32>
+static int halo_smem(const Conv3Args& a, bool* ws) {
+  typedef HaloGeom<T, S, MF, NF> Gm;
+  const int tilesN = (a.Cout + NF * 16 - 1) / (NF * 16);
+  const int ep_bytes = 8 * MF * 16 * (NF * 16 * (int)(OUTF32 ? 4 : sizeof(T)) + 16);
+  const int smem_ws = a.nChunks * Gm::W_BYTES + 2 * Gm::A_BYTES + NF * 16 * 4 + ep_bytes;
+  const int smem_st = 2 * (Gm::A_BYTES + Gm::W_BYTES) + tilesN * NF * 16 * 4 + ep_bytes;
+  *ws = smem_ws <= kLdsBudget && !(a.dbg & 16);
+  return *ws ? smem_ws : smem_st;
+}
+
 template <typename T, int S, int MF, int NF, bool OUTF32>
 static int launch_halo(const Conv3Args& a, int batch, hipStream_t st) {
-  constexpr int TH = 4 * MF, TW = 16;
-  constexpr int HH = (TH - 1) * S + 3, HWD = (TW - 1) * S + 3;
-  constexpr int STAGE = HH * HWD * 64 + 9 * NF * 1024;
+  typedef HaloGeom<T, S, MF, NF> Gm;
   Conv3Args p = a;
-  p.tilesX = (p.Wo + TW - 1) / TW;
-  p.tilesY = (p.Ho + TH - 1) / TH;
+  p.tilesX = (p.Wo + Gm::TW - 1) / Gm::TW;
+  p.tilesY = (p.Ho + Gm::TH - 1) / Gm::TH;
   p.tilesN = (p.Cout + NF * 16 - 1) / (NF * 16);
   p.nTiles = batch * p.tilesY * p.tilesX * p.tilesN;
-  const int smem = 2 * STAGE;
-  const int per_cu = (160 * 1024) / smem;  // LDS-limited residency
-  int grid = 256 * (per_cu < 1 ? 1 : per_cu);
+  bool ws = false;
+  const int smem = halo_smem<T, S, MF, NF, OUTF32>(p, &ws);
+  DY_REQUIRE(smem <= kLdsBudget, DY_ERR_UNSUPPORTED,
+             "dy_conv2d_nhwc: HALO3X3 stride-%d tile needs %d B of LDS (> %d); pack this layer with DY_WLAYOUT_ROWS", S, smem, kLdsBudget);
+  const int per_cu = kLdsBudget / smem >= 2 ? 2 : 1;  // 512-thread blocks: at most 2 are useful per CU
+  int grid = 256 * per_cu;
   if (grid > p.nTiles) grid = p.nTiles;
-  auto kern = conv3x3_halo_kernel<T, S, MF, NF, OUTF32>;
-  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, st, p);
+  if (ws && grid > p.tilesN) grid -= grid % p.tilesN;  // keep every block on one n-tile
+  if (ws) {
+    auto kern = conv3x3_halo_kernel<T, S, MF, NF, OUTF32, true>;
+    static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
+    (void)once;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, st, p);
+  } else {
+    auto kern = conv3x3_halo_kernel<T, S, MF, NF, OUTF32, false>;
+    static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
+    (void)once;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, st, p);
+  }
   return check_launch("conv3x3_halo_kernel");
 }
 
 template <typename T, bool OUTF32>
 static int launch_halo_dtype(const Conv3Args& a, int batch, int stride, hipStream_t st) {
   const bool nf4 = a.Cout > 32;
-  // TH = 16 (MF 4) when the map is tall enough and there are plenty of tiles; else TH = 8
+  // TH = 16 (MF 2) when the map is tall enough, there are plenty of tiles and the tile fits LDS; else TH = 8
   const long long tiles16 = (long long)batch * ((a.Ho + 15) / 16) * ((a.Wo + 15) / 16) * ((a.Cout + (nf4 ? 63 : 31)) / (nf4 ? 64 : 32));
-  const bool big = stride == 1 && a.Ho >= 16 && tiles16 >= 256;
+  bool ws = false;
+  bool big = stride == 1 && a.Ho >= 16 && tiles16 >= 256;
+  if (big) big = (nf4 ? halo_smem<T, 1, 2, 4, OUTF32>(a, &ws) : halo_smem<T, 1, 2, 2, OUTF32>(a, &ws)) <= kLdsBudget;
   if (stride == 1) {
-    if (nf4) return big ? launch_halo<T, 1, 4, 4, OUTF32>(a, batch, st) : launch_halo<T, 1, 2, 4, OUTF32>(a, batch, st);
-    return big ? launch_halo<T, 1, 4, 2, OUTF32>(a, batch, st) : launch_halo<T, 1, 2, 2, OUTF32>(a, batch, st);
+    if (nf4) return big ? launch_halo<T, 1, 2, 4, OUTF32>(a, batch, st) : launch_halo<T, 1, 1, 4, OUTF32>(a, batch, st);
+    return big ? launch_halo<T, 1, 2, 2, OUTF32>(a, batch, st) : launch_halo<T, 1, 1, 2, OUTF32>(a, batch, st);
   }
-  if (nf4) return launch_halo<T, 2, 2, 4, OUTF32>(a, batch, st);
-  return launch_halo<T, 2, 2, 2, OUTF32>(a, batch, st);
+  if (nf4) return launch_halo<T, 2, 1, 4, OUTF32>(a, batch, st);
+  return launch_halo<T, 2, 1, 2, OUTF32>(a, batch, st);
 }
 
 // Entry used by dy_conv2d_nhwc when d->w_layout == DY_WLAYOUT_HALO3X3.
@@ -271,8 +408,7 @@ int conv3x3_halo_dispatch(const dy_conv_desc* d, hipStream_t st) {
   DY_REQUIRE(d->cin % epc == 0 && d->cout % 4 == 0, DY_ERR_UNSUPPORTED, "dy_conv2d_nhwc: HALO3X3 needs cin %% %d == 0, cout %% 4 == 0", epc);
   DY_REQUIRE(aligned16(d->x) && (d->ld_x * es) % 16 == 0 && aligned16(d->w) && aligned16(d->bias) && aligned16(d->y), DY_ERR_INVALID_ARG,
              "dy_conv2d_nhwc: views must be 16-byte aligned");
-  const int oes = d->out_f32 ? 4 : es;
-  DY_REQUIRE((d->ld_y * oes) % (4 * oes) == 0, DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: ld_y must be a multiple of 4 elements");
+  DY_REQUIRE((d->ld_y * (d->out_f32 ? 4 : es)) % 16 == 0, DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: output pitch must be a multiple of 16 bytes");
   DY_REQUIRE(!d->residual || (aligned16(d->residual) && d->ld_res % 4 == 0), DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: residual view misaligned");
   DY_REQUIRE((long long)d->batch * d->h * d->w_in * d->ld_x < (1ll << 32), DY_ERR_UNSUPPORTED, "dy_conv2d_nhwc: input view exceeds 2^32 elements");
   Conv3Args a{};
@@ -292,6 +428,10 @@ int conv3x3_halo_dispatch(const dy_conv_desc* d, hipStream_t st) {
   a.ldres = d->ld_res;
   a.act = d->act;
   a.nChunks = (d->cin + 4 * epc - 1) / (4 * epc);
+  {
+    static const int dbg = getenv("DYOLO_DBG") ? atoi(getenv("DYOLO_DBG")) : 0;
+    a.dbg = dbg;
+  }
   switch (d->dtype) {
     case DY_BF16:
       return d->out_f32 ? launch_halo_dtype<bf16_t, true>(a, d->batch, d->stride, st) : launch_halo_dtype<bf16_t, false>(a, d->batch, d->stride, st);

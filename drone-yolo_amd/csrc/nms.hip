@@ -300,7 +300,8 @@ extern "C" int32_t dy_nms(const dy_nms_desc* d, dy_stream_t stream) {
   int rc = check_launch("nms_filter_kernel");
   if (rc != DY_OK) return rc;
   const size_t smem = (size_t)a.SL * 8 + align_up((size_t)d->max_det * 5 * 4, 16);
-  (void)hipFuncSetAttribute((const void*)nms_suppress_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  static const hipError_t attr_once = hipFuncSetAttribute((const void*)nms_suppress_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)attr_once;
   hipLaunchKernelGGL(nms_suppress_kernel, dim3((unsigned)d->batch), dim3(1024), smem, st, a);
   return check_launch("nms_suppress_kernel");
 }

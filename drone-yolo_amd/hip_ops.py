@@ -151,8 +151,10 @@ class PackedConv:
         self.act = DY_ACT_SILU if act else DY_ACT_NONE
         self.dtype = dtype
         self.layout = _lib.DY_WLAYOUT_ROWS
-        if (halo is None or halo) and groups == 1 and k == 3 and pad == 1 and stride in (1, 2) and cout % 4 == 0 \
-                and self.cin >= 4 * elems_per_chunk(dtype) // 2:
+        # stride-2 halo tiles are 17x33 pixels (2 x 45 KB of LDS): only a weight set of <= 36 KB fits beside them
+        s2_fits = self.cin <= 4 * elems_per_chunk(dtype) and cout > 32 or self.cin <= 8 * elems_per_chunk(dtype) and cout <= 32
+        if (halo is None or halo) and groups == 1 and k == 3 and pad == 1 and (stride == 1 or (stride == 2 and s2_fits)) \
+                and cout % 4 == 0 and self.cin >= 4 * elems_per_chunk(dtype) // 2:
             # LDS-halo 3x3 kernel: MFMA-fragment-ordered weights (include/dyolo.h, DY_WLAYOUT_HALO3X3)
             self.layout = _lib.DY_WLAYOUT_HALO3X3
             e = elems_per_chunk(dtype)

@@ -1,0 +1,34 @@
+"""Micro-benchmark of dy_conv2d_nhwc on single layer shapes (GPU box).
+usage: python tools/bench_conv.py [--halo 0|1] [--batch B] [shape ...]   shape = cin,cout,k,s,H"""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from drone_yolo_amd import hip_ops as H
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--halo", type=int, default=1)
+ap.add_argument("--batch", type=int, default=16)
+ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("shapes", nargs="*", default=["64,64,3,1,160", "32,32,3,1,160", "64,64,3,1,80", "128,128,3,1,40", "256,256,3,1,20",
+                                               "512,64,3,1,20", "64,128,3,2,160", "96,64,1,1,160", "768,512,1,1,20", "384,256,1,1,40"])
+a = ap.parse_args()
+dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[a.dtype]
+dev = torch.device("cuda", 0)
+for sh in a.shapes:
+    cin, cout, k, s, hh = (int(v) for v in sh.split(","))
+    x = torch.randn(a.batch, hh, hh, cin, device=dev).to(dt).permute(0, 3, 1, 2)
+    w = torch.randn(cout, cin, k, k) * (2.0 / (cin * k * k)) ** 0.5
+    pc = H.PackedConv(w, torch.zeros(cout), s, k // 2, 1, True, dt, dev, halo=bool(a.halo))
+    y = H.conv2d(x, pc)
+    torch.cuda.synchronize()
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.record()
+    for _ in range(a.iters):
+        H.conv2d(x, pc, out=y)
+    en.record()
+    torch.cuda.synchronize()
+    us = st.elapsed_time(en) / a.iters * 1e3
+    fl = 2.0 * a.batch * y.shape[2] * y.shape[3] * cout * cin * k * k
+    by = (x.numel() + y.numel()) * x.element_size()
+    print(f"{sh:<18s} B={a.batch} halo={a.halo} dbg={os.environ.get('DYOLO_DBG', '0')}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s  {by / us / 1e3:7.0f} GB/s(act)")
