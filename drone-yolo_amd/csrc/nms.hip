@@ -191,9 +191,10 @@ __global__ __launch_bounds__(1024) void nms_suppress_kernel(const NmsArgs p) {
     }
     u64 am = __ballot(alive);
     while (am != 0ull) {
-      const int t = __ffsll((long long)am) - 1;  // best surviving candidate of the chunk
-      const float tx1 = __shfl(ox1, t), ty1 = __shfl(oy1, t), tx2 = __shfl(ox2, t), ty2 = __shfl(oy2, t);
-      const float tar = __shfl(area, t);
+      const int t = __ffsll((long long)am) - 1;  // best surviving candidate of the chunk (wave-uniform)
+      // t is uniform, so broadcast its box with v_readlane (SGPR result) rather than LDS-routed shuffles
+      auto bcast = [&](float v) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), t)); };
+      const float tx1 = bcast(ox1), ty1 = bcast(oy1), tx2 = bcast(ox2), ty2 = bcast(oy2), tar = bcast(area);
       if (lane == t) {
         kx1[nk] = ox1;
         ky1[nk] = oy1;

@@ -142,8 +142,16 @@ def test_end_to_end_against_reference_vectors(tag, dtype, device):
         assert box_err < 2e-2 and cls_err < 1e-4, (box_err, cls_err)
         assert counts == [int(v) for v in g[f"{tag}__n"]]
         for i, c in enumerate(counts):
-            assert np.array_equal(cf.nms.index[i, :c].cpu().numpy(), exp_idx[i]), f"{tag} image {i}: kept indices differ"
-            assert np.array_equal(cf.nms.out[i, :c, 5].cpu().numpy(), exp_rows[i][:, 5]), f"{tag} image {i}: classes differ"
+            got_idx, got_cls = cf.nms.index[i, :c].cpu().numpy(), cf.nms.out[i, :c, 5].cpu().numpy()
+            # identical kept SET and identical class per kept anchor (bit-exact integer outputs) ...
+            assert sorted(got_idx.tolist()) == sorted(exp_idx[i].tolist()), f"{tag} image {i}: kept anchor sets differ"
+            cls_of = {int(a): int(k) for a, k in zip(exp_idx[i], exp_rows[i][:, 5])}
+            assert all(cls_of[int(a)] == int(k) for a, k in zip(got_idx, got_cls)), f"{tag} image {i}: classes differ"
+            # ... in identical order, except that two detections whose reference scores are closer than fp32
+            # round-off of the network (a few 1e-7) may swap places
+            score_of = {int(a): float(sc) for a, sc in zip(exp_idx[i], exp_rows[i][:, 4])}
+            for k in np.nonzero(got_idx != exp_idx[i])[0]:
+                assert abs(score_of[int(got_idx[k])] - float(exp_rows[i][k, 4])) < 2e-6, f"{tag} image {i}: order differs at rank {k}"
         assert iou_min >= 0.999, iou_min
     else:
         # reduced-precision storage: scores near conf / near-ties may flip; demand that the bulk agrees
