@@ -143,7 +143,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("DYOLO_BENCH_BATCH", 32)), help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("DYOLO_BENCH_BATCH", 128)), help="images per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--model", default="yolov8s-p2-repvgg.yaml")
     ap.add_argument("--no-graph", action="store_true", help="replay the launch plan from Python instead of a hipGraph")
@@ -190,8 +190,16 @@ def main():
         nbytes = sum(w[2] for w in work)
         tconv = sum(times.values())
         peak = MFMA_PEAK_TFLOPS[a.dtype]
-        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (all launches of one pass)", "achieved": round(flops / tconv / 1e12, 2),
-                "peak": peak, "unit": "TFLOP/s", "frac": round(flops / tconv / 1e12 / peak, 4), "traffic": None,
+        traffic = None  # HBM bytes of the conv launches of one pass, from the committed PMC summary (same batch only)
+        tfile = os.path.join(ROOT, "profiles", "r01_traffic_b128.json")
+        if os.path.exists(tfile):
+            tj = json.load(open(tfile))
+            if tj.get("batch") == a.batch and a.dtype == "bf16":
+                traffic = round(tj["families"]["conv"]["hbm_bytes_per_step"] / 1e9, 3)
+        roof = {"bound": "mfma", "kernel": "conv family: conv3x3_halo_kernel + conv_igemm_kernel (all launches of one pass)",
+                "achieved": round(flops / tconv / 1e12, 2),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(flops / tconv / 1e12 / peak, 4), "traffic": traffic,
+                "traffic_unit": "GB of HBM traffic per pass (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic_b128.json)",
                 "launches": len(work), "flops_per_image": round(flops / a.batch / 1e9, 3), "conv_ms_per_step": round(tconv * 1e3, 3),
                 "hbm_view": {"algorithmic_GB_per_step": round(nbytes / 1e9, 4), "achieved_GBs": round(nbytes / tconv / 1e9, 1),
                              "peak_GBs": HBM_PEAK_GBS, "frac": round(nbytes / tconv / 1e9 / HBM_PEAK_GBS, 4)}}
