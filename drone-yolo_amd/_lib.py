@@ -44,6 +44,7 @@ class DecodeDesc(C.Structure):
         ("stride", _f32 * DY_MAX_LEVELS),
         ("n_levels", _i32), ("batch", _i32), ("nc", _i32), ("reg_max", _i32),
         ("out", _vp),
+        ("nms_workspace", _vp), ("nms_workspace_bytes", _i64), ("conf_thres", _f32), ("classes_mask", _vp),
     ]  # fmt: skip
 
 
@@ -58,7 +59,7 @@ class NmsDesc(C.Structure):
         ("max_wh", _f32), ("agnostic", _i32),
         ("classes_mask", _vp),
         ("out", _vp), ("out_count", _vp), ("out_index", _vp),
-        ("workspace", _vp), ("workspace_bytes", _i64),
+        ("workspace", _vp), ("workspace_bytes", _i64), ("prefiltered", _i32),
     ]  # fmt: skip
 
 

@@ -23,6 +23,7 @@
 // area = (x2-x1)*(y2-y1); inter = max(0,xx2-xx1)*max(0,yy2-yy1);
 // suppress iff inter / (area_i + area_j - inter) > iou_thres.
 #include "common.cuh"
+#include "nms_ws.h"
 
 #pragma clang fp contract(off)
 
@@ -239,12 +240,8 @@ __global__ __launch_bounds__(256) void scale_boxes_kernel(float* __restrict__ bo
   o[3] = fminf(fmaxf((o[3] - py) / gain, 0.f), ch);
 }
 
-static inline int next_pow2(int v) {
-  int p = 1;
-  while (p < v) p <<= 1;
-  return p;
-}
-static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int next_pow2(int v) { return nms_next_pow2(v); }
+static inline size_t align_up(size_t v, size_t a) { return nms_align_up(v, a); }
 
 }  // namespace dy
 
@@ -252,8 +249,7 @@ using namespace dy;
 
 extern "C" int64_t dy_nms_workspace_bytes(int32_t batch, int32_t anchors) {
   if (batch <= 0 || anchors <= 0) return -1;
-  const size_t P = (size_t)next_pow2(anchors);
-  return (int64_t)(align_up((size_t)batch * 4, 256) + (size_t)batch * P * 8 + align_up((size_t)batch * anchors * 2, 256));
+  return (int64_t)nms_ws_bytes(batch, anchors);
 }
 
 extern "C" int32_t dy_nms(const dy_nms_desc* d, dy_stream_t stream) {
@@ -285,21 +281,22 @@ extern "C" int32_t dy_nms(const dy_nms_desc* d, dy_stream_t stream) {
   a.out = d->out;
   a.out_count = d->out_count;
   a.out_index = d->out_index;
-  a.P = next_pow2(d->anchors);
-  unsigned char* ws = reinterpret_cast<unsigned char*>(d->workspace);
-  a.counts = reinterpret_cast<int*>(ws);
-  const size_t off_keys = align_up((size_t)d->batch * 4, 256);
-  a.keys = reinterpret_cast<u64*>(ws + off_keys);
-  a.cls = reinterpret_cast<unsigned short*>(ws + off_keys + (size_t)d->batch * a.P * 8);
+  const NmsWs w = nms_ws_layout(d->workspace, d->batch, d->anchors);
+  a.P = w.P;
+  a.counts = w.counts;
+  a.keys = reinterpret_cast<u64*>(w.keys);
+  a.cls = w.cls;
   a.SL = a.P < 16384 ? a.P : 16384;
 
-  if (hipMemsetAsync(a.counts, 0, (size_t)d->batch * 4, st) != hipSuccess) return check_launch("dy_nms memset");
-  const long long total = (long long)d->batch * d->anchors;
-  long long blocks = (total + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(nms_filter_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
-  int rc = check_launch("nms_filter_kernel");
-  if (rc != DY_OK) return rc;
+  if (!d->prefiltered) {
+    if (hipMemsetAsync(a.counts, 0, (size_t)d->batch * 4, st) != hipSuccess) return check_launch("dy_nms memset");
+    const long long total = (long long)d->batch * d->anchors;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(nms_filter_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    const int rc = check_launch("nms_filter_kernel");
+    if (rc != DY_OK) return rc;
+  }
   const size_t smem = (size_t)a.SL * 8 + align_up((size_t)d->max_det * 5 * 4, 16);
   static const hipError_t attr_once = hipFuncSetAttribute((const void*)nms_suppress_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)attr_once;

@@ -87,16 +87,27 @@ class DetectionPredictor:
         a = self.args
         n, _, h, w = im.shape
         params = torch.tensor([[1.0, 0.0, 0.0, float(w), float(h)]] * n, dtype=torch.float32, device=self.device)
-        with H.record(cf.plan):
-            x = H.to_nhwc(im, self.dtype, mark_input=True)
-            y, _ = self.model._predict_once(x)
-            cf.pred = y
-            cf.nms = H.nms(y, float(a["conf"]), float(a["iou"]), max_det=int(a["max_det"]), max_nms=int(a["max_nms"]),
-                           max_wh=float(a["max_wh"]), agnostic=bool(a["agnostic_nms"]), nc=self.model.yaml["nc"],
-                           classes_mask=self._classes_mask)
-            # construct_result: scale_boxes(img.shape[2:], boxes, orig.shape) — tensor sources are their own
-            # original image, so gain 1 / pad 0 and the clip to (h, w) remain (detect/predict.py:59-73)
-            H.scale_boxes_(cf.nms, params)
+        det = self.model.model[-1]
+        holder = {}
+
+        def make_bufs(nb, anchors):  # Detect asks for the NMS buffers so that decode can fill the candidate list
+            holder["bufs"] = H.NmsBuffers(nb, anchors, int(a["max_det"]), self.device)
+            return holder["bufs"]
+
+        det.fused_nms = (make_bufs, float(a["conf"]), self._classes_mask)
+        try:
+            with H.record(cf.plan):
+                x = H.to_nhwc(im, self.dtype, mark_input=True)
+                y, _ = self.model._predict_once(x)
+                cf.pred = y
+                cf.nms = H.nms(y, float(a["conf"]), float(a["iou"]), max_det=int(a["max_det"]), max_nms=int(a["max_nms"]),
+                               max_wh=float(a["max_wh"]), agnostic=bool(a["agnostic_nms"]), nc=self.model.yaml["nc"],
+                               classes_mask=self._classes_mask, bufs=holder.get("bufs"), prefiltered="bufs" in holder)
+                # construct_result: scale_boxes(img.shape[2:], boxes, orig.shape) — tensor sources are their own
+                # original image, so gain 1 / pad 0 and the clip to (h, w) remain (detect/predict.py:59-73)
+                H.scale_boxes_(cf.nms, params)
+        finally:
+            det.fused_nms = None
         cf.plan.keep.append(params)
         return cf
 

@@ -300,8 +300,12 @@ def sppf_maxpool3(x: torch.Tensor, y1: torch.Tensor, y2: torch.Tensor, y3: torch
 
 
 def detect_decode(levels: Sequence[torch.Tensor], strides: Sequence[float], nc: int, reg_max: int,
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """levels[i]: fp32 NHWC view (N, 4*reg_max+nc, H_i, W_i) -> (N, 4+nc, A) fp32."""
+                  out: Optional[torch.Tensor] = None, nms_bufs: Optional["NmsBuffers"] = None, conf_thres: float = 0.25,
+                  classes_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """levels[i]: fp32 NHWC view (N, 4*reg_max+nc, H_i, W_i) -> (N, 4+nc, A) fp32.
+
+    ``nms_bufs``: fuse the NMS candidate filter into this pass (then call ``nms(..., prefiltered=True)``
+    with the same buffers, conf_thres and classes_mask)."""
     n = levels[0].shape[0]
     d = DecodeDesc()
     A = 0
@@ -316,7 +320,13 @@ def detect_decode(levels: Sequence[torch.Tensor], strides: Sequence[float], nc: 
     if out is None:
         out = torch.empty((n, 4 + nc, A), dtype=torch.float32, device=levels[0].device)
     d.out = out.data_ptr()
-    _launch(lib().dy_detect_decode, (C.byref(d),), keep=(d, out, *levels))
+    if nms_bufs is not None:
+        if (nms_bufs.batch, nms_bufs.anchors) != (n, A):
+            raise ValueError("detect_decode: nms_bufs were sized for another batch / anchor count")
+        d.nms_workspace, d.nms_workspace_bytes = nms_bufs.workspace.data_ptr(), nms_bufs.workspace.numel()
+        d.conf_thres = conf_thres
+        d.classes_mask = classes_mask.data_ptr() if classes_mask is not None else None
+    _launch(lib().dy_detect_decode, (C.byref(d),), keep=(d, out, nms_bufs, classes_mask, *levels))
     return out
 
 
@@ -334,14 +344,17 @@ class NmsBuffers:
 
 def nms(pred: torch.Tensor, conf_thres: float, iou_thres: float, max_det: int = 300, max_nms: int = 30000,
         max_wh: float = 7680.0, agnostic: bool = False, nc: int = 0, classes_mask: Optional[torch.Tensor] = None,
-        bufs: Optional[NmsBuffers] = None) -> NmsBuffers:
-    """Batched NMS on (N, 4+nc(+nm), A) fp32 predictions; results stay on the device."""
+        bufs: Optional[NmsBuffers] = None, prefiltered: bool = False) -> NmsBuffers:
+    """Batched NMS on (N, 4+nc(+nm), A) fp32 predictions; results stay on the device.
+    ``prefiltered``: ``bufs.workspace`` already holds the candidates (detect_decode(nms_bufs=bufs))."""
     require_device(pred, "prediction")
     if pred.dtype != torch.float32 or not pred.is_contiguous() or pred.dim() != 3:
         raise ValueError("nms expects a contiguous fp32 (N, 4+nc, A) tensor")
     n, ch, A = pred.shape
     nc = nc or ch - 4
     if bufs is None or (bufs.batch, bufs.anchors, bufs.max_det) != (n, A, max_det):
+        if prefiltered:
+            raise ValueError("nms(prefiltered=True) needs the NmsBuffers that detect_decode filled")
         bufs = NmsBuffers(n, A, max_det, pred.device)
     d = NmsDesc()
     d.pred, d.batch, d.nc, d.n_extra, d.anchors = pred.data_ptr(), n, nc, ch - 4 - nc, A
@@ -350,6 +363,7 @@ def nms(pred: torch.Tensor, conf_thres: float, iou_thres: float, max_det: int = 
     d.classes_mask = classes_mask.data_ptr() if classes_mask is not None else None
     d.out, d.out_count, d.out_index = bufs.out.data_ptr(), bufs.count.data_ptr(), bufs.index.data_ptr()
     d.workspace, d.workspace_bytes = bufs.workspace.data_ptr(), bufs.workspace.numel()
+    d.prefiltered = int(prefiltered)
     _launch(lib().dy_nms, (C.byref(d),), keep=(d, pred, bufs, classes_mask))
     return bufs
 

@@ -82,7 +82,13 @@ class Detect(nn.Module):
             feats.append(buf)
         if self.training:
             return feats
-        y = H.detect_decode(feats, [float(s) for s in self.stride], self.nc, self.reg_max)
+        fused = getattr(self, "fused_nms", None)  # set by the predictor: (NmsBuffers factory, conf, classes mask)
+        kw = {}
+        if fused is not None:
+            make_bufs, conf, mask = fused
+            A = sum(f.shape[2] * f.shape[3] for f in feats)
+            kw = dict(nms_bufs=make_bufs(feats[0].shape[0], A), conf_thres=conf, classes_mask=mask)
+        y = H.detect_decode(feats, [float(s) for s in self.stride], self.nc, self.reg_max, **kw)
         return y if self.export else (y, feats)
 
     def bias_init(self):

@@ -158,6 +158,14 @@ typedef struct dy_decode_desc {
   float stride[DY_MAX_LEVELS];
   int32_t n_levels, batch, nc, reg_max;
   float* out;
+  /* Optional fusion of the NMS candidate filter (ops.py:250,290-295) into the decode pass: when
+   * nms_workspace != NULL (a dy_nms workspace for the same batch/anchors) every anchor whose best class
+   * score > conf_thres (and passes classes_mask) is appended to it, and dy_nms can then be called with
+   * prefiltered = 1 on `out`, skipping its own pass over the predictions. */
+  void* nms_workspace;
+  int64_t nms_workspace_bytes;
+  float conf_thres;
+  const uint8_t* classes_mask;
 } dy_decode_desc;
 int32_t dy_detect_decode(const dy_decode_desc* d, dy_stream_t stream);
 
@@ -188,6 +196,8 @@ typedef struct dy_nms_desc {
   int32_t* out_index;
   void* workspace;
   int64_t workspace_bytes;
+  int32_t prefiltered; /* 1: the workspace already holds the candidates (dy_detect_decode fused filter,
+                          same conf_thres / classes_mask); only sort + suppress run */
 } dy_nms_desc;
 int64_t dy_nms_workspace_bytes(int32_t batch, int32_t anchors);
 int32_t dy_nms(const dy_nms_desc* d, dy_stream_t stream);

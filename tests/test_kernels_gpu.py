@@ -189,6 +189,32 @@ def test_detect_decode_matches_oracle(device):
     assert torch.allclose(yg.cpu(), torch.from_numpy(gp["det_y"]), rtol=1e-5, atol=2e-3)
 
 
+def test_decode_fused_filter_equals_separate_filter(device):
+    """dy_detect_decode with the fused candidate filter + dy_nms(prefiltered) == plain dy_nms on the same output."""
+    g = torch.Generator().manual_seed(23)
+    nc = 10
+    shapes = [(40, 36), (20, 18), (10, 9), (5, 5)]  # 1440 + 360 + 90 + 25 anchors: partial 256-anchor tiles at every level
+    strides = [4.0, 8.0, 16.0, 32.0]
+    feats = [torch.randn(3, 64 + nc, h, w, generator=g) * 2.0 for h, w in shapes]
+    dev = [nhwc(f, torch.float32, device, ld=76) for f in feats]
+    A = sum(h * w for h, w in shapes)
+    mask = torch.ones(nc, dtype=torch.uint8)
+    mask[3] = 0
+    mask = mask.to(device)
+    for cm in (None, mask):
+        bufs = H.NmsBuffers(3, A, 300, device)
+        y = H.detect_decode(dev, strides, nc, 16, nms_bufs=bufs, conf_thres=0.3, classes_mask=cm)
+        fused = H.nms(y, 0.3, 0.6, bufs=bufs, prefiltered=True, classes_mask=cm)
+        torch.cuda.synchronize()
+        f_out, f_cnt, f_idx = fused.out.clone(), fused.count.clone(), fused.index.clone()
+        y2 = H.detect_decode(dev, strides, nc, 16)
+        plain = H.nms(y2, 0.3, 0.6, classes_mask=cm)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y2) and int(f_cnt.sum()) > 0
+        assert torch.equal(f_cnt, plain.count) and torch.equal(f_out, plain.out) and torch.equal(f_idx, plain.index)
+        assert torch.allclose(y.cpu(), O.detect_decode(feats, strides, nc), rtol=1e-5, atol=2e-4)
+
+
 def _run_nms(pred, device, **kw):
     kw = dict(kw)
     classes = kw.pop("classes", None)
