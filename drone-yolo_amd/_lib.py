@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdyolo.so")
 DY_BF16, DY_F16, DY_F32 = 0, 1, 2
 DY_ACT_NONE, DY_ACT_SILU = 0, 1
 DY_MAX_LEVELS = 8
-DY_WLAYOUT_ROWS, DY_WLAYOUT_HALO3X3 = 0, 1
+DY_WLAYOUT_ROWS, DY_WLAYOUT_HALO3X3, DY_WLAYOUT_FRAG1X1 = 0, 1, 2
 
 _vp, _i32, _f32, _i64 = C.c_void_p, C.c_int32, C.c_float, C.c_int64
 

@@ -333,7 +333,8 @@ static int launch_dtype(const ConvArgs& a, hipStream_t st) {
   return small ? launch_tile<T, 64, 16, OUTF32>(a, st) : launch_tile<T, 128, 16, OUTF32>(a, st);
 }
 
-int conv3x3_halo_dispatch(const dy_conv_desc* d, hipStream_t st);  // conv3x3_halo.hip
+int conv3x3_halo_dispatch(const dy_conv_desc* d, hipStream_t st);    // conv3x3_halo.hip
+int conv1x1_stream_dispatch(const dy_conv_desc* d, hipStream_t st);  // conv1x1_stream.hip
 
 }  // namespace dy
 
@@ -398,6 +399,7 @@ extern "C" int32_t dy_conv2d_nhwc(const dy_conv_desc* d, dy_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
   if (d->w_layout == DY_WLAYOUT_HALO3X3) return conv3x3_halo_dispatch(d, st);
+  if (d->w_layout == DY_WLAYOUT_FRAG1X1) return conv1x1_stream_dispatch(d, st);
   DY_REQUIRE(d->w_layout == DY_WLAYOUT_ROWS, DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: unknown w_layout %d", d->w_layout);
 
   if (d->groups > 1) {

@@ -3,7 +3,7 @@
 // Reference: nn/modules/head.py:100-131 (_inference), block.py:58-76 (DFL),
 // utils/tal.py:333-357 (make_anchors grid_cell_offset 0.5, dist2bbox); filter: utils/ops.py:250,290-295.
 //
-// A 256-thread workgroup owns 256 consecutive anchors of one (image, level).  Their head rows
+// A single-wave workgroup owns 64 consecutive anchors of one (image, level).  Their head rows
 // (4*reg_max + nc logits each, pitch ld) are one contiguous span of the NHWC head buffer, so it is
 // copied to LDS with lane-linear 16-byte loads (every fetched byte is used once; a lane-per-row
 // float4 read pattern fetched ~4x the bytes) and each lane then reads its own row from LDS.
@@ -13,7 +13,7 @@
 
 namespace dy {
 
-constexpr int kDecTile = 256;
+constexpr int kDecTile = 64;  // one wave per tile: 64 rows x pitch floats of LDS (19 KB at pitch 76), 8 tiles resident per CU
 
 struct DecodeArgs {
   const float* level[DY_MAX_LEVELS];
@@ -31,7 +31,7 @@ struct DecodeArgs {
 };
 
 template <int REG_MAX>
-__global__ __launch_bounds__(256) void detect_decode_kernel(const DecodeArgs p) {
+__global__ __launch_bounds__(64) void detect_decode_kernel(const DecodeArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
   float* rows = reinterpret_cast<float*>(dyn_smem);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -47,8 +47,8 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(const DecodeArgs p) 
   const int ld = p.ld[l];
   const float* src = p.level[l] + ((size_t)b * hw + al0) * (size_t)ld;
   const int n4 = na * ld / 4;  // ld % 4 == 0
-  for (int i = tid; i < n4; i += 256) reinterpret_cast<f32x4*>(rows)[i] = reinterpret_cast<const f32x4*>(src)[i];
-  __syncthreads();
+  for (int i = tid; i < n4; i += kDecTile) reinterpret_cast<f32x4*>(rows)[i] = reinterpret_cast<const f32x4*>(src)[i];
+  __syncthreads();  // single wave: orders the LDS writes before the row reads
 
   const bool valid = tid < na;
   const int al = al0 + tid;
@@ -73,11 +73,11 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(const DecodeArgs p) 
       float den = 0.f, num = 0.f;
 #pragma unroll
       for (int i = 0; i < REG_MAX; ++i) {
-        const float e = expf(v[i] - mx);
+        const float e = __builtin_amdgcn_exp2f((v[i] - mx) * 1.4426950408889634f);
         den += e;
         num += e * (float)i;
       }
-      dist[side] = num / den;
+      dist[side] = num * __builtin_amdgcn_rcpf(den);
     }
     const float ax = (float)gx + 0.5f, ay = (float)gy + 0.5f;
     const float x1 = ax - dist[0], y1 = ay - dist[1], x2 = ax + dist[2], y2 = ay + dist[3];
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(const DecodeArgs p) 
     o[(size_t)3 * p.A] = (y2 - y1) * s;
     const float* cl = r + 4 * REG_MAX;
     for (int c = 0; c < p.nc; ++c) {
-      const float pr = 1.0f / (1.0f + expf(-cl[c]));
+      const float pr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cl[c] * -1.4426950408889634f));
       o[(size_t)(4 + c) * p.A] = pr;
       if (c == 0 || pr > best) {  // first arg-max, as cls.max(1) (ops.py:290)
         best = pr;
@@ -168,6 +168,6 @@ extern "C" int32_t dy_detect_decode(const dy_decode_desc* d, dy_stream_t stream)
   DY_REQUIRE(smem <= 160 * 1024, DY_ERR_UNSUPPORTED, "dy_detect_decode: head pitch %d too large for the LDS tile", ldmax);
   static const hipError_t once = hipFuncSetAttribute((const void*)detect_decode_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)once;
-  hipLaunchKernelGGL((detect_decode_kernel<16>), dim3((unsigned)(d->batch * T)), dim3(256), smem, st, a);
+  hipLaunchKernelGGL((detect_decode_kernel<16>), dim3((unsigned)(d->batch * T)), dim3(kDecTile), smem, st, a);
   return check_launch("detect_decode_kernel");
 }

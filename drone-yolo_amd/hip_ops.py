@@ -138,7 +138,10 @@ class PackedConv:
     """
 
     def __init__(self, weight: torch.Tensor, bias: torch.Tensor, stride: int, pad: int, groups: int, act: bool,
-                 dtype: torch.dtype, device, cin_pad: Optional[int] = None, halo: Optional[bool] = None):
+                 dtype: torch.dtype, device, cin_pad: Optional[int] = None, halo: Optional[bool] = None,
+                 for_out_f32: bool = False):
+        """``halo`` = False forces the generic row layout (both special layouts off); ``for_out_f32``: the conv
+        will be called with out_f32=True (Detect heads), which narrows the shapes the streaming kernel is built for."""
         L = lib()
         if cin_pad is not None and cin_pad > weight.shape[1]:
             # the input view carries zero-padded channels (the 3-channel image padded to one 16-byte chunk)
@@ -164,6 +167,25 @@ class PackedConv:
             wpad[:cout, : self.cin] = weight.detach().to(torch.float32).cpu()
             wp = wpad.view(nt, bn // 16, 16, nch, 4, e, 3, 3).permute(0, 3, 6, 7, 1, 4, 2, 5).contiguous().view(-1)
             self.k_pad, self.cout_pad = 0, L.dy_conv_cout_pad(cout)
+            bp = torch.zeros((self.cout_pad,), dtype=torch.float32)
+            bp[:cout] = bias.detach().to(torch.float32)
+            self.w = wp.to(dtype).contiguous().to(device)
+            self.b = bp.contiguous().to(device)
+            return
+        e = elems_per_chunk(dtype)
+        nkg = -(-self.cin // (4 * e))
+        frag_ok = nkg in (2, 3, 4, 6, 8, 12) and (cout > 16 or nkg == 2) and self.cin % e == 0
+        if for_out_f32 and dtype != torch.float32:
+            frag_ok = frag_ok and nkg == 2 and cout <= 64
+        if (halo is None or halo) and groups == 1 and k == 1 and stride == 1 and pad == 0 and frag_ok:
+            # streaming 1x1 kernel: fragment-ordered weights, single tap (include/dyolo.h, DY_WLAYOUT_FRAG1X1)
+            self.layout = _lib.DY_WLAYOUT_FRAG1X1
+            kc, bn = 4 * e, (128 if cout > 64 else (64 if cout > 16 else 16))
+            nt = -(-cout // bn)
+            wpad = torch.zeros((nt * bn, nkg * kc), dtype=torch.float32)
+            wpad[:cout, : self.cin] = weight.detach().to(torch.float32).cpu().view(cout, self.cin)
+            wp = wpad.view(nt, bn // 16, 16, nkg, 4, e).permute(0, 3, 1, 4, 2, 5).contiguous().view(-1)
+            self.k_pad, self.cout_pad = 0, max(L.dy_conv_cout_pad(cout), nt * bn)
             bp = torch.zeros((self.cout_pad,), dtype=torch.float32)
             bp[:cout] = bias.detach().to(torch.float32)
             self.w = wp.to(dtype).contiguous().to(device)

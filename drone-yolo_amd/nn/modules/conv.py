@@ -119,7 +119,7 @@ class PlainConv2d(_PackedMixin, nn.Conv2d):
 
     def _pack(self, dtype, device, cin_pad=None) -> H.PackedConv:
         return H.PackedConv(self.weight, self.bias, self.stride[0], self.padding[0], self.groups, False, dtype, device,
-                            cin_pad=cin_pad)
+                            cin_pad=cin_pad, for_out_f32=True)
 
     def forward(self, x, out=None, out_f32=False):
         return H.conv2d(x, self._packed_for(x), out=out, out_f32=out_f32)

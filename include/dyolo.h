@@ -48,7 +48,7 @@ typedef enum dy_status {
 typedef enum dy_dtype { DY_BF16 = 0, DY_F16 = 1, DY_F32 = 2 } dy_dtype;
 typedef enum dy_act { DY_ACT_NONE = 0, DY_ACT_SILU = 1 } dy_act;
 /* Packed weight layouts of dy_conv2d_nhwc (see dy_conv_desc.w_layout). */
-typedef enum dy_wlayout { DY_WLAYOUT_ROWS = 0, DY_WLAYOUT_HALO3X3 = 1 } dy_wlayout;
+typedef enum dy_wlayout { DY_WLAYOUT_ROWS = 0, DY_WLAYOUT_HALO3X3 = 1, DY_WLAYOUT_FRAG1X1 = 2 } dy_wlayout;
 
 /* ---- library -------------------------------------------------------------- */
 
@@ -106,7 +106,12 @@ typedef struct dy_conv_desc {
    * KC = 4*E channels per chunk, BN = (cout > 32 ? 64 : 32), NF = BN/16, the element
    *   w[co = nt*BN + j*16 + lr][r][q][ci = c*KC + lq*E + e]
    * lives at ((((nt*ceil(cin/KC) + c)*9 + (r*3+q))*NF + j)*64 + lq*16 + lr)*E + e, zero where co >= cout
-   * or ci >= cin.  k_pad / cout_pad are ignored; bias stays fp32[dy_conv_cout_pad(cout)]. */
+   * or ci >= cin.  k_pad / cout_pad are ignored; bias stays fp32[dy_conv_cout_pad(cout)].
+   * DY_WLAYOUT_FRAG1X1 (2): dense 1x1, stride 1, no residual (x2 / up2x allowed) — selects the streaming
+   * kernel.  Same fragment order with a single tap: BN = (cout > 64 ? 128 : cout > 16 ? 64 : 16), NF = BN/16,
+   *   w[co = nt*BN + j*16 + lr][ci = c*KC + lq*E + e]  at  (((nt*ceil(cin/KC) + c)*NF + j)*64 + lq*16 + lr)*E + e.
+   * Built for ceil(cin/KC) in {2,3,4,6,8,12}; cout <= 16 and fp32 output (out_f32 with a 16-bit dtype) only
+   * for 2 chunks; anything else returns DY_ERR_UNSUPPORTED (pack such layers with DY_WLAYOUT_ROWS). */
   int32_t w_layout;
 } dy_conv_desc;
 

@@ -60,6 +60,12 @@ CONV_CASES = [
     (128, 128, 3, 2, 2, 40, 40, True, "halo s2 deep"),
     (64, 32, 3, 2, 1, 80, 80, True, "halo s2 BN=32"),
     (64, 64, 3, 1, 40, 40, 40, True, "halo many tiles per block"),
+    (64, 64, 1, 1, 8, 160, 160, True, "1x1 stream 64->64 large M"),
+    (192, 128, 1, 1, 3, 80, 80, True, "1x1 stream 192->128 (NF=8)"),
+    (384, 128, 1, 1, 2, 40, 40, True, "1x1 stream 384->128 (12 k-groups)"),
+    (256, 256, 1, 1, 2, 40, 40, True, "1x1 stream 256->256 (2 n-tiles)"),
+    (128, 128, 1, 1, 1, 13, 11, True, "1x1 stream odd M tail"),
+    (64, 8, 1, 1, 1, 20, 20, False, "1x1 stream cout=8 (NF=1)"),
 ]
 
 
@@ -107,6 +113,19 @@ def test_conv_slices_residual_and_f32_out(dtype, device):
     torch.cuda.synchronize()
     check_close(back(head[:, 64:74]), F.conv2d(x, w10, b10), torch.float32 if dtype == torch.float32 else dtype, "conv f32-out nc=10", extra=1.0)
     assert float((head[:, :64] - 7.0).abs().max()) == 0.0 and float((head[:, 74:] - 7.0).abs().max()) == 0.0
+    # the Detect head shapes proper (cin 64): box bins 64 -> 64 and class logits 64 -> nc, fp32 out (streaming 1x1 kernel)
+    x64 = quantize(torch.randn(b, 64, h, w, generator=g), dtype)
+    xb = nhwc(x64, dtype, device)
+    for cout, lo in ((64, 0), (10, 64)):
+        wh = quantize(torch.randn(cout, 64, 1, 1, generator=g) * 0.2, dtype)
+        bh = torch.randn(cout, generator=g)
+        pch = H.PackedConv(wh, bh, 1, 0, 1, False, dtype, device, for_out_f32=True)
+        head = torch.full((b, h, w, 76), 7.0, dtype=torch.float32, device=device).permute(0, 3, 1, 2)
+        H.conv2d(xb, pch, out=head[:, lo : lo + cout], out_f32=True)
+        torch.cuda.synchronize()
+        check_close(back(head[:, lo : lo + cout]), F.conv2d(x64, wh, bh), dtype, f"head 64->{cout} f32-out")
+        rest = torch.cat((head[:, :lo], head[:, lo + cout :]), 1)
+        assert float((rest - 7.0).abs().max()) == 0.0, "head conv wrote outside its slice"
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
