@@ -86,6 +86,23 @@ __device__ __forceinline__ float silu_f32(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// Fence between the last MFMA of a tile and the epilogue's VALU code, fp32 (v_mfma_f32_16x16x4_f32) only.
+// hipcc (ROCm 7.2) was seen to interleave epilogue v_adds that overwrite a register quad right behind an
+// in-flight fp32 MFMA still reading that quad as its C operand, with only `s_nop 8` in between: elements 2,3
+// of the accumulator came out wrong (WAR wait-state miscount for this 8-pass shape).  Pin the order and wait
+// out the longest MFMA before any epilogue VALU write.  bf16/f16 shapes are unaffected and skip this.
+template <typename T>
+__device__ __forceinline__ void mfma_epilogue_fence() {
+  if constexpr (sizeof(T) == 4) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_nop(15);
+    __builtin_amdgcn_s_nop(15);
+    __builtin_amdgcn_s_nop(15);
+    __builtin_amdgcn_s_nop(15);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 __device__ __forceinline__ u32x4 zero_chunk() { return u32x4{0u, 0u, 0u, 0u}; }
 
 // XCD-aware block remap (guide T1, bijective form): blocks b and b+8 share an XCD's
@@ -94,6 +111,24 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
   const unsigned q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, i = bid >> 3;
   const unsigned base = (xcd < r) ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
   return base + i;
+}
+
+// ---- exact unsigned division by a runtime-invariant divisor (Granlund-Montgomery), for n < 2^31 -------------
+struct FastDiv {
+  unsigned m;  // magic multiplier
+  int l;       // ceil(log2(d)); 0 means d == 1
+};
+static inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  f.l = 0;
+  while ((1ull << f.l) < d) ++f.l;
+  f.m = (unsigned)(((1ull << 32) * ((1ull << f.l) - d)) / d + 1);
+  return f;
+}
+__device__ __forceinline__ unsigned fastdiv(unsigned n, FastDiv f) {
+  if (f.l == 0) return n;
+  const unsigned t = __umulhi(f.m, n);
+  return (t + ((n - t) >> 1)) >> (f.l - 1);
 }
 
 // ---- host-side error plumbing ----------------------------------------------------

@@ -32,6 +32,7 @@ struct Conv1Args {
   int up2x, H, W, HB, WB;  // output (= upsampled) dims and the dims of the x buffer
   int Cout, ldy, act;
   int tilesN, nMT;
+  FastDiv div_hw, div_w;  // m / (H*W) and r / W of the up2x pixel decode
 };
 
 template <typename T, int NKG, int MF, int NF, bool OUTF32>
@@ -76,9 +77,8 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const Conv1Args p) 
       m = m < p.M ? m : p.M - 1;  // rows past the end load a valid row and are never stored
       size_t off1, off2 = (size_t)m * (size_t)p.ldx2;
       if (p.up2x) {
-        const int hw = p.H * p.W;
-        const int n = m / hw, r = m - n * hw;
-        const int yy = r / p.W, xx = r - yy * p.W;
+        const int n = (int)fastdiv((unsigned)m, p.div_hw), r = m - n * (p.H * p.W);
+        const int yy = (int)fastdiv((unsigned)r, p.div_w), xx = r - yy * p.W;
         off1 = (size_t)((n * p.HB + (yy >> 1)) * p.WB + (xx >> 1)) * (size_t)p.ldx;
       } else {
         off1 = (size_t)m * (size_t)p.ldx;
@@ -114,6 +114,7 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const Conv1Args p) 
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = Elem<T>::mma(b[j], a[i][kg], acc[i][j]);  // D[cout][pixel]
     }
+    mfma_epilogue_fence<T>();
     // epilogue: bias + activation on registers, transpose through the wave's LDS scratch, row stores
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
@@ -153,25 +154,29 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const Conv1Args p) 
         if (co + VE <= p.Cout) {
           *reinterpret_cast<u32x4*>(yp) = val;
         } else {  // ragged channel tail (e.g. nc = 10 class logits)
-          const OutT* sv = reinterpret_cast<const OutT*>(&val);
-          for (int e = 0; e < p.Cout - co; ++e) yp[e] = sv[e];
+          typedef __attribute__((ext_vector_type(VE))) OutT vout_t;
+          const vout_t sv = __builtin_bit_cast(vout_t, val);
+#pragma unroll
+          for (int e = 0; e < VE; ++e)
+            if (e < p.Cout - co) yp[e] = sv[e];
         }
       }
     }
   };
 
-  // register double buffering, hand-unrolled by two so that both fragment sets are statically indexed
-  u32x4 a0[MF][NKG], a1[MF][NKG];
-  load_tile(mt, a0);
+  // register double buffering: the next tile's fragments are in flight (a_nxt) while the current tile
+  // (a_cur, a register copy) is multiplied.  One load body and one compute body keep the kernel inside
+  // the 256-VGPR budget of a 512-thread workgroup.
+  u32x4 a_cur[MF][NKG], a_nxt[MF][NKG];
+  load_tile(mt, a_nxt);
   while (true) {
-    int nx = mt + stride;
-    if (nx < p.nMT) load_tile(nx, a1);
-    process(mt, a0);
-    if (nx >= p.nMT) break;
-    mt = nx;
-    nx = mt + stride;
-    if (nx < p.nMT) load_tile(nx, a0);
-    process(mt, a1);
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+      for (int kg = 0; kg < NKG; ++kg) a_cur[i][kg] = a_nxt[i][kg];
+    const int nx = mt + stride;
+    if (nx < p.nMT) load_tile(nx, a_nxt);
+    process(mt, a_cur);
     if (nx >= p.nMT) break;
     mt = nx;
   }
@@ -202,7 +207,7 @@ static int launch_1x1(const Conv1Args& a, hipStream_t st) {
 
 template <typename T, int NKG>
 static int launch_1x1_nkg(const Conv1Args& a, bool out_f32, hipStream_t st) {
-  constexpr int MF = NKG <= 6 ? 2 : 1;
+  constexpr int MF = NKG <= 2 ? 2 : 1;  // fatter variants would spill (a_cur + a_nxt + acc + b fragments)
   if (out_f32 && sizeof(T) < 4) {
     if constexpr (NKG == 2) {  // Detect heads: 64 -> 64 box bins, 64 -> nc class logits
       if (a.Cout <= 16) return launch_1x1<T, 2, 2, 1, true>(a, st);
@@ -265,6 +270,8 @@ int conv1x1_stream_dispatch(const dy_conv_desc* d, hipStream_t st) {
   a.Cout = d->cout;
   a.ldy = d->ld_y;
   a.act = d->act;
+  a.div_hw = make_fastdiv((unsigned)(d->h * d->w_in));
+  a.div_w = make_fastdiv((unsigned)d->w_in);
   if (d->x2) {
     DY_REQUIRE(d->cin_split > 0 && d->cin_split < d->cin && d->cin_split % epc == 0, DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: bad cin_split %d", d->cin_split);
     DY_REQUIRE(aligned16(d->x2) && (d->ld_x2 * es) % 16 == 0, DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: x2 view misaligned");

@@ -207,6 +207,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
   OutT* __restrict__ yg = reinterpret_cast<OutT*>(p.y);
   const T* __restrict__ rg = reinterpret_cast<const T*>(p.res);
   auto epilogue = [&](const TileIt& t) {
+    mfma_epilogue_fence<T>();
     const int xx = t.tx * TW + lr;
     const int co0 = t.nt * BN + lq * 4;
     const int sb0 = WS ? t.nt * BN : 0;  // offset of the LDS bias window

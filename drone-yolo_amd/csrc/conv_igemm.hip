@@ -208,6 +208,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   }
 
   // ---- epilogue ----------------------------------------------------------------------
+  mfma_epilogue_fence<T>();
   float* cs = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int i = 0; i < MF; ++i)

@@ -177,6 +177,11 @@ class PackedConv:
         frag_ok = nkg in (2, 3, 4, 6, 8, 12) and (cout > 16 or nkg == 2) and self.cin % e == 0
         if for_out_f32 and dtype != torch.float32:
             frag_ok = frag_ok and nkg == 2 and cout <= 64
+        if frag_ok:  # the streaming kernel's LDS footprint (conv1x1_stream.hip::launch_1x1) must fit 160 KB
+            bn_ = 128 if cout > 64 else (64 if cout > 16 else 16)
+            osz = 4 if (for_out_f32 or dtype == torch.float32) else 2
+            smem = nkg * (bn_ // 16) * 1024 + bn_ * 4 + 8 * (2 if nkg <= 2 else 1) * 16 * (bn_ * osz + 16)
+            frag_ok = smem <= 160 * 1024
         if (halo is None or halo) and groups == 1 and k == 1 and stride == 1 and pad == 0 and frag_ok:
             # streaming 1x1 kernel: fragment-ordered weights, single tap (include/dyolo.h, DY_WLAYOUT_FRAG1X1)
             self.layout = _lib.DY_WLAYOUT_FRAG1X1
@@ -228,7 +233,8 @@ def conv2d(x: torch.Tensor, pc: PackedConv, out: Optional[torch.Tensor] = None, 
     ho, wo = conv_out_hw(h, w, pc.k, pc.stride, pc.pad)
     odt = torch.float32 if out_f32 else x.dtype
     if out is None:
-        out = alloc_nhwc(n, pc.cout, ho, wo, odt, x.device)
+        epc_o = elems_per_chunk(odt)  # keep every pixel row 16-byte aligned (vector stores in all kernels)
+        out = alloc_nhwc(n, pc.cout, ho, wo, odt, x.device, ld=-(-pc.cout // epc_o) * epc_o)
     elif tuple(out.shape) != (n, pc.cout, ho, wo) or out.dtype != odt:
         raise ValueError(f"conv2d: out has shape {tuple(out.shape)}/{out.dtype}, expected {(n, pc.cout, ho, wo)}/{odt}")
     xp, ldx = view_params(x)
