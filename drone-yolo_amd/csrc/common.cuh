@@ -95,10 +95,7 @@ template <typename T>
 __device__ __forceinline__ void mfma_epilogue_fence() {
   if constexpr (sizeof(T) == 4) {
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_nop(15);
-    __builtin_amdgcn_s_nop(15);
-    __builtin_amdgcn_s_nop(15);
-    __builtin_amdgcn_s_nop(15);
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   }
 }
