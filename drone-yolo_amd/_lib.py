@@ -72,6 +72,7 @@ SIGNATURES = {
     "dy_conv_k_pad": (_i32, [_i32, _i32, _i32]),
     "dy_conv_cout_pad": (_i32, [_i32]),
     "dy_conv2d_nhwc": (_i32, [C.POINTER(ConvDesc), _vp]),
+    "dy_stem_conv3x3s2_nchw": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dy_nchw_f32_to_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dy_nhwc_to_nchw_f32": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dy_upsample2x_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -176,11 +176,15 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
   };
 
   f32x4 acc[MF][NF];
-  auto zero_acc = [&]() {
+  // accumulators start from the bias (row constants as the initial C operand): saves the epilogue adds
+  auto init_acc = [&](int nt) {
+    const float* sb = sbias + (WS ? 0 : nt * BN) + lq * 4;
 #pragma unroll
-    for (int i = 0; i < MF; ++i)
+    for (int j = 0; j < NF; ++j) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(sb + j * 16);
 #pragma unroll
-      for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < MF; ++i) acc[i][j] = bb;
+    }
   };
 
   // byte offset of this lane's fragment element for tap (0,0), row i = 0 inside a halo stage
@@ -210,7 +214,6 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
     mfma_epilogue_fence<T>();
     const int xx = t.tx * TW + lr;
     const int co0 = t.nt * BN + lq * 4;
-    const int sb0 = WS ? t.nt * BN : 0;  // offset of the LDS bias window
     size_t m[MF];
     bool rowok[MF];
 #pragma unroll
@@ -245,11 +248,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
     }
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
-      const int co = co0 + j * 16;
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(sbias + co - sb0);  // zero beyond cout (padded buffer)
 #pragma unroll
       for (int i = 0; i < MF; ++i) {
-        float v[4] = {acc[i][j][0] + bb[0], acc[i][j][1] + bb[1], acc[i][j][2] + bb[2], acc[i][j][3] + bb[3]};
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};  // bias is already inside
         if (p.act == DY_ACT_SILU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
@@ -311,8 +312,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
   TileIt ct = lt;  // compute-side tile
   issue_loads();
   store_lds(0);
-  zero_acc();
   __syncthreads();
+  init_acc(ct.nt);
 
   // ---- item pipeline: one barrier per (tile, chunk) item -----------------------------------------------
   int c_chunk = 0;
@@ -325,8 +326,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
     if (++c_chunk == p.nChunks) {  // last chunk of a tile
       c_chunk = 0;
       if (!(p.dbg & 4)) epilogue(ct);
-      zero_acc();
       advance(ct);
+      init_acc(ct.nt);
     }
     __syncthreads();
   }

@@ -1,0 +1,220 @@
+// Fused stem: fp32 NCHW image -> 3x3 stride-2 pad-1 convolution (+bias, SiLU) -> NHWC activations.
+//
+// Replaces, in one pass over the image: the predictor's dtype/layout step (engine/predictor.py:118-136) and
+// the model's first layer Conv(3, c2, 3, 2) (yolov8-p2-repvgg.yaml layer 0; nn/modules/conv.py:37-55).
+// Without fusion the image is converted to NHWC (written, then read again by the conv): 2 x 6.5 MB per
+// 640x640 image of extra HBM traffic on a layer that is purely bandwidth bound (K = 27).
+//
+// A 256-thread workgroup produces an 8 x 32 patch of output pixels x all output channels:
+//   - the (17 x 65) x Cin fp32 input patch is loaded plane by plane with coalesced dword loads into LDS;
+//   - each lane assembles its MFMA operand on the fly: lane (quarter lq, pixel lr) gathers the 8 taps
+//     k = 8*lq .. 8*lq+7 of its pixel (k = c*9 + r*3 + q, zero beyond K) from LDS at 8 per-lane constant
+//     offsets, converts to the storage dtype and packs one 16-byte chunk (im2col never touches memory);
+//   - weights (cout x 32, OIHW order padded) sit in registers as MFMA A operands, so a lane ends up with
+//     4 consecutive output channels of one pixel; bias + SiLU on registers, per-wave LDS transpose,
+//     16-byte stores of whole pixel rows.
+// fp32 storage uses two 16-wide k-groups of the fp32 MFMA with the same gather.
+#include "common.cuh"
+#include <type_traits>
+
+namespace dy {
+
+struct StemArgs {
+  const float* x;
+  const void* w;      // [cout_pad16][32] T, k = c*9 + r*3 + q, zero padded
+  const float* bias;  // [cout_pad16]
+  void* y;
+  int N, Cin, H, W, Ho, Wo, Cout, ldy, act;
+  int tilesX, tilesY;
+};
+
+constexpr int kStemTH = 8, kStemTW = 32;
+constexpr int kStemPH = 2 * kStemTH + 1, kStemPW = 2 * kStemTW + 1;  // 17 x 65 input patch
+constexpr int kStemPitch = kStemPW + 2;                                // 67 floats per patch row
+
+template <typename T, int NF>
+__global__ __launch_bounds__(256) void conv_stem_kernel(const StemArgs p) {
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int NKG = 32 / (4 * EPC);  // k-groups covering K padded to 32: 1 (16-bit) or 2 (fp32)
+  constexpr int MF = 4;                // per wave: 2 rows x 32 cols = 4 fragments of 16 pixels
+  constexpr int BN = NF * 16;
+  constexpr int EP_PITCH = BN * (int)sizeof(T) + 16;
+  constexpr int EP_BYTES = MF * 16 * EP_PITCH;
+  constexpr int PLANE = kStemPH * kStemPitch;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  float* patch = reinterpret_cast<float*>(dyn_smem);                       // [Cin][17][67]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane >> 4, lr = lane & 15;
+  unsigned char* escr = dyn_smem + ((p.Cin * PLANE * 4 + 15) / 16) * 16 + wave * EP_BYTES;
+
+  int t = blockIdx.x;
+  const int tx = t % p.tilesX;
+  t /= p.tilesX;
+  const int ty = t % p.tilesY;
+  const int n = t / p.tilesY;
+  const int y0 = ty * kStemTH, x0 = tx * kStemTW;
+
+  // ---- input patch -> LDS (zero outside the image = the conv's zero padding) ----------------------------
+  const int gy0 = 2 * y0 - 1, gx0 = 2 * x0 - 1;
+  for (int i = tid; i < p.Cin * kStemPH * kStemPW; i += 256) {
+    const int c = i / (kStemPH * kStemPW);
+    const int r2 = i - c * (kStemPH * kStemPW);
+    const int py = r2 / kStemPW, px = r2 - py * kStemPW;
+    const int gy = gy0 + py, gx = gx0 + px;
+    float v = 0.f;
+    if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+      v = p.x[((size_t)(n * p.Cin + c) * p.H + gy) * p.W + gx];
+    patch[c * PLANE + py * kStemPitch + px] = v;
+  }
+
+  // ---- weights -> registers (A operand fragments), per-lane tap offsets -----------------------------------
+  u32x4 wfrag[NKG][NF];
+#pragma unroll
+  for (int kg = 0; kg < NKG; ++kg)
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+      wfrag[kg][j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.w) + (size_t)(j * 16 + lr) * 32 + kg * 4 * EPC + lq * EPC);
+  int koff[NKG][EPC];  // LDS float offset of tap k relative to the pixel's patch origin, or -1 beyond K
+#pragma unroll
+  for (int kg = 0; kg < NKG; ++kg)
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const int k = kg * 4 * EPC + lq * EPC + e;
+      const int c = k / 9, r = (k - c * 9) / 3, q = k - c * 9 - r * 3;
+      koff[kg][e] = (k < p.Cin * 9) ? c * PLANE + r * kStemPitch + q : -1;
+    }
+  __syncthreads();
+
+  // ---- MFMA: D[cout][pixel] ------------------------------------------------------------------------------------
+  f32x4 acc[MF][NF];
+#pragma unroll
+  for (int j = 0; j < NF; ++j) {
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + j * 16 + lq * 4);
+#pragma unroll
+    for (int i = 0; i < MF; ++i) acc[i][j] = bb;
+  }
+#pragma unroll
+  for (int i = 0; i < MF; ++i) {
+    const int row = wave * 2 + (i >> 1), col = (i & 1) * 16 + lr;  // output pixel inside the 8 x 32 patch
+    const float* org = patch + (2 * row) * kStemPitch + 2 * col;
+#pragma unroll
+    for (int kg = 0; kg < NKG; ++kg) {
+      float f[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) f[e] = koff[kg][e] >= 0 ? org[koff[kg][e]] : 0.f;
+      const u32x4 a = Chunk<T>::pack(f);
+#pragma unroll
+      for (int j = 0; j < NF; ++j) acc[i][j] = Elem<T>::mma(wfrag[kg][j], a, acc[i][j]);
+    }
+  }
+  mfma_epilogue_fence<T>();
+
+  // ---- epilogue: SiLU, per-wave transpose, 16-byte row stores --------------------------------------------
+#pragma unroll
+  for (int j = 0; j < NF; ++j)
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (p.act == DY_ACT_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
+      }
+      unsigned char* sp = escr + (i * 16 + lr) * EP_PITCH + (j * 16 + lq * 4) * (int)sizeof(T);
+      if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<f32x4*>(sp) = f32x4{v[0], v[1], v[2], v[3]};
+      } else {
+        typedef __attribute__((ext_vector_type(4))) T t4;
+        t4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f32(v[e]);
+        *reinterpret_cast<u32x2*>(sp) = __builtin_bit_cast(u32x2, o);
+      }
+    }
+  constexpr int CPR = BN * (int)sizeof(T) / 16;
+  constexpr int VE = 16 / (int)sizeof(T);
+  T* __restrict__ yg = reinterpret_cast<T*>(p.y);
+#pragma unroll
+  for (int k = 0; k < MF * 16 * CPR / 64; ++k) {
+    const int idx = k * 64 + lane;
+    const int pixl = idx / CPR, cc = idx - pixl * CPR;
+    const int i = pixl >> 4;
+    const int yy = y0 + wave * 2 + (i >> 1), xx = x0 + (i & 1) * 16 + (pixl & 15);
+    const int co = cc * VE;
+    const u32x4 val = *reinterpret_cast<const u32x4*>(escr + pixl * EP_PITCH + cc * 16);
+    if (yy < p.Ho && xx < p.Wo && co < p.Cout) {
+      T* yp = yg + ((size_t)(n * p.Ho + yy) * p.Wo + xx) * (size_t)p.ldy + co;
+      if (co + VE <= p.Cout) {
+        *reinterpret_cast<u32x4*>(yp) = val;
+      } else {
+        typedef __attribute__((ext_vector_type(VE))) T vt;
+        const vt sv = __builtin_bit_cast(vt, val);
+#pragma unroll
+        for (int e = 0; e < VE; ++e)
+          if (e < p.Cout - co) yp[e] = sv[e];
+      }
+    }
+  }
+}
+
+template <typename T, int NF>
+static int launch_stem(const StemArgs& a, hipStream_t st) {
+  StemArgs p = a;
+  p.tilesX = (p.Wo + kStemTW - 1) / kStemTW;
+  p.tilesY = (p.Ho + kStemTH - 1) / kStemTH;
+  const int smem = ((p.Cin * kStemPH * kStemPitch * 4 + 15) / 16) * 16 + 4 * 4 * 16 * (NF * 16 * (int)sizeof(T) + 16);
+  auto kern = conv_stem_kernel<T, NF>;
+  static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)once;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.N * p.tilesY * p.tilesX)), dim3(256), smem, st, p);
+  return check_launch("conv_stem_kernel");
+}
+
+template <typename T>
+static int launch_stem_dtype(const StemArgs& a, hipStream_t st) {
+  switch ((a.Cout + 15) / 16) {
+    case 1: return launch_stem<T, 1>(a, st);
+    case 2: return launch_stem<T, 2>(a, st);
+    case 3: return launch_stem<T, 3>(a, st);
+    case 4: return launch_stem<T, 4>(a, st);
+    case 5: return launch_stem<T, 5>(a, st);
+    default:
+      set_error("dy_stem_conv3x3s2_nchw: cout %d > 80 not built", a.Cout);
+      return DY_ERR_UNSUPPORTED;
+  }
+}
+
+}  // namespace dy
+
+using namespace dy;
+
+extern "C" int32_t dy_stem_conv3x3s2_nchw(const float* x, const void* w, const float* bias, void* y, int32_t n, int32_t cin,
+                                          int32_t h, int32_t w_in, int32_t cout, int32_t ld_y, int32_t act, int32_t dtype,
+                                          dy_stream_t stream) {
+  const int es = dy_dtype_size(dtype);
+  DY_REQUIRE(x && w && bias && y && es, DY_ERR_INVALID_ARG, "dy_stem_conv3x3s2_nchw: null pointer or bad dtype");
+  DY_REQUIRE(n > 0 && h > 0 && w_in > 0 && cout > 0 && cin >= 1 && cin * 9 <= 32, DY_ERR_INVALID_ARG,
+             "dy_stem_conv3x3s2_nchw: needs 1 <= cin <= 3 (K = 9*cin <= 32)");
+  DY_REQUIRE(ld_y >= cout && (ld_y * es) % 16 == 0 && aligned16(y) && aligned16(w) && aligned16(bias), DY_ERR_INVALID_ARG,
+             "dy_stem_conv3x3s2_nchw: y/w/bias must be 16-byte aligned, output pitch a multiple of 16 bytes");
+  StemArgs a{};
+  a.x = x;
+  a.w = w;
+  a.bias = bias;
+  a.y = y;
+  a.N = n;
+  a.Cin = cin;
+  a.H = h;
+  a.W = w_in;
+  a.Ho = (h + 2 - 3) / 2 + 1;
+  a.Wo = (w_in + 2 - 3) / 2 + 1;
+  a.Cout = cout;
+  a.ldy = ld_y;
+  a.act = act;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case DY_BF16: return launch_stem_dtype<bf16_t>(a, st);
+    case DY_F16: return launch_stem_dtype<f16_t>(a, st);
+    default: return launch_stem_dtype<float>(a, st);
+  }
+}

@@ -97,8 +97,7 @@ class DetectionPredictor:
         det.fused_nms = (make_bufs, float(a["conf"]), self._classes_mask)
         try:
             with H.record(cf.plan):
-                x = H.to_nhwc(im, self.dtype, mark_input=True)
-                y, _ = self.model._predict_once(x)
+                y, _ = self.model._predict_once(im, image_dtype=self.dtype)
                 cf.pred = y
                 cf.nms = H.nms(y, float(a["conf"]), float(a["iou"]), max_det=int(a["max_det"]), max_nms=int(a["max_nms"]),
                                max_wh=float(a["max_wh"]), agnostic=bool(a["agnostic_nms"]), nc=self.model.yaml["nc"],

@@ -259,6 +259,46 @@ def conv2d(x: torch.Tensor, pc: PackedConv, out: Optional[torch.Tensor] = None, 
     return out
 
 
+# ---- fused stem ---------------------------------------------------------------------------------------
+
+
+class PackedStem:
+    """Weights of the first layer Conv(cin<=3, cout, 3, 2) for ``dy_stem_conv3x3s2_nchw``: rows of the folded
+    OIHW taps (k = c*9 + r*3 + q) zero padded to 32, rows padded to a multiple of 16 (include/dyolo.h)."""
+
+    def __init__(self, weight: torch.Tensor, bias: torch.Tensor, act: bool, dtype: torch.dtype, device):
+        cout, cin, k, k2 = weight.shape
+        if not (k == k2 == 3 and cin * 9 <= 32 and cout <= 80):
+            raise ValueError("PackedStem: needs a 3x3 kernel, cin <= 3 and cout <= 80")
+        self.cout, self.cin, self.dtype = cout, cin, dtype
+        self.act = DY_ACT_SILU if act else DY_ACT_NONE
+        cp = -(-cout // 16) * 16
+        wp = torch.zeros((cp, 32), dtype=torch.float32)
+        wp[:cout, : cin * 9] = weight.detach().to(torch.float32).cpu().reshape(cout, cin * 9)
+        bp = torch.zeros((cp,), dtype=torch.float32)
+        bp[:cout] = bias.detach().to(torch.float32).cpu()
+        self.w = wp.to(dtype).contiguous().to(device)
+        self.b = bp.contiguous().to(device)
+
+
+def stem_conv(src: torch.Tensor, ps: PackedStem, out: Optional[torch.Tensor] = None, mark_input: bool = False) -> torch.Tensor:
+    """fp32 NCHW image -> act(conv3x3 s2 p1 + bias) as an NHWC view of ``ps.dtype`` (layout cast fused in)."""
+    require_device(src, "input")
+    if src.dtype != torch.float32 or not src.is_contiguous() or src.dim() != 4 or src.shape[1] != ps.cin:
+        raise ValueError(f"stem_conv expects a contiguous fp32 (N,{ps.cin},H,W) tensor")
+    n, c, h, w = src.shape
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    if out is None:
+        e = elems_per_chunk(ps.dtype)
+        out = alloc_nhwc(n, ps.cout, ho, wo, ps.dtype, src.device, ld=-(-ps.cout // e) * e)
+    op, ld = view_params(out)
+    args = (src.data_ptr(), ps.w.data_ptr(), ps.b.data_ptr(), op, n, c, h, w, ps.cout, ld, ps.act, dy_dtype(ps.dtype))
+    _launch(lib().dy_stem_conv3x3s2_nchw, args, keep=(out, ps))
+    if mark_input and _recording is not None:
+        _recording.input_slot = (len(_recording.ops) - 1, 0)
+    return out
+
+
 # ---- layout ops -------------------------------------------------------------------------------------
 
 

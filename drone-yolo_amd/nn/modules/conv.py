@@ -106,6 +106,23 @@ class Conv(_PackedMixin, nn.Module):
 
     forward_fuse = forward  # BN is always folded on this path
 
+    def is_stem(self) -> bool:
+        """First-layer shape the fused image kernel covers: Conv(c1<=3, c2<=80, 3, 2) with padding 1."""
+        c = self.conv
+        return (c.kernel_size == (3, 3) and c.stride == (2, 2) and c.padding == (1, 1) and c.groups == 1
+                and c.in_channels * 9 <= 32 and c.out_channels <= 80)
+
+    def forward_stem(self, im, dtype, out=None, mark_input=False):
+        """fp32 NCHW image -> this layer's NHWC output in ``dtype`` (layout cast + conv + BN + SiLU in one kernel)."""
+        _require_eval(self)
+        cache = self.__dict__.setdefault("_packed", {})
+        key = ("stem", dtype, im.device)
+        ps = cache.get(key)
+        if ps is None:
+            w, b = fold_conv_bn(self.conv.weight, self.conv.bias, self.bn)
+            ps = cache[key] = H.PackedStem(w, b, isinstance(self.act, nn.SiLU), dtype, im.device)
+        return H.stem_conv(im, ps, out=out, mark_input=mark_input)
+
 
 class DWConv(Conv):
     """Depth-wise convolution, g = gcd(c1, c2) — reference conv.py:102-107."""

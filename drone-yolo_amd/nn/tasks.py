@@ -183,10 +183,21 @@ class BaseModel(nn.Module):
                     self._place[s] = (m.i, off)
                 off += c
 
-    def _predict_once(self, x):
-        """Run every layer; ``x`` is an NHWC-view tensor (see hip_ops)."""
+    def _predict_once(self, x, image_dtype=None):
+        """Run every layer.  ``x`` is an NHWC-view tensor (see hip_ops) or, with ``image_dtype`` set, the raw
+        contiguous fp32 NCHW image: the first layer then runs the fused stem kernel (layout cast + conv) when
+        its shape allows, otherwise the image is converted first."""
         if not hasattr(self, "_place"):
             self._plan_graph()
+        stem_image = None
+        if image_dtype is not None:
+            first = self.model[0]
+            if isinstance(first, Conv) and first.is_stem() and 0 not in self._place and getattr(self, "fuse_stem", True):
+                stem_image = x
+                n, _, h, w = x.shape
+                x = torch.empty((n, 0, h, w), dtype=image_dtype, device=x.device)  # shape/dtype carrier only
+            else:
+                x = H.to_nhwc(x, image_dtype, mark_input=True)
         y: List[Optional[torch.Tensor]] = []
         cat_bufs: Dict[int, torch.Tensor] = {}
         for m in self.model:
@@ -212,7 +223,10 @@ class BaseModel(nn.Module):
                 kw["out"] = cat_bufs[ci][:, off : off + self._out_ch[i]]
             if isinstance(m, Concat) and i in cat_bufs:
                 kw["out"] = cat_bufs[i]
-            out = m(xin, **kw)
+            if i == 0 and stem_image is not None:
+                out = m.forward_stem(stem_image, image_dtype, mark_input=True, **kw)
+            else:
+                out = m(xin, **kw)
             y.append(out)
         return y[-1]
 

@@ -119,6 +119,16 @@ int32_t dy_conv_k_pad(int32_t cin, int32_t ksize, int32_t dtype);
 int32_t dy_conv_cout_pad(int32_t cout);
 int32_t dy_conv2d_nhwc(const dy_conv_desc* d, dy_stream_t stream);
 
+/* Fused stem.  Replaces in one pass: the predictor's dtype/layout step for tensor sources
+ * (engine/predictor.py:118-136) AND the model's first layer Conv(cin<=3, cout, 3, 2) (nn/modules/conv.py:37-55,
+ * yolov8-p2-repvgg.yaml layer 0), so the image is never materialised in NHWC.
+ * x: fp32 NCHW (n, cin, h, w) contiguous.  w: [ceil(cout/16)*16][32] of `dtype`, row co = the folded taps in
+ * k = c*9 + r*3 + q order (i.e. OIHW flattened), zero padded to 32; bias fp32[ceil(cout/16)*16].
+ * y: NHWC view (n, (h-1)/2+1, (w-1)/2+1, cout) of `dtype`, pitch ld_y.  cout <= 80. */
+int32_t dy_stem_conv3x3s2_nchw(const float* x, const void* w, const float* bias, void* y, int32_t n, int32_t cin,
+                               int32_t h, int32_t w_in, int32_t cout, int32_t ld_y, int32_t act, int32_t dtype,
+                               dy_stream_t stream);
+
 /* ---- layout / copy ops ------------------------------------------------------ */
 
 /* Replaces: predictor preprocess `.half()/.float()` + the NCHW->device layout step

@@ -150,6 +150,24 @@ def test_conv_dual_source_upsample_gather(dtype, device):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("shape", [(2, 3, 64, 96, 32), (1, 3, 50, 70, 16), (3, 3, 33, 31, 48), (1, 1, 40, 40, 80), (2, 3, 640, 640, 32)],
+                         ids=["64x96->32", "odd 50x70->16", "odd 33x31->48", "cin1 ->80", "640 ->32"])
+def test_fused_stem_matches_cpu(shape, dtype, device):
+    """dy_stem_conv3x3s2_nchw: fp32 NCHW image -> SiLU(conv3x3 s2 + bias) NHWC, vs F.conv2d on the rounded inputs."""
+    n, cin, h, w, cout = shape
+    g = torch.Generator().manual_seed(h * 7 + cout)
+    img = torch.rand(n, cin, h, w, generator=g)
+    wt = quantize(torch.randn(cout, cin, 3, 3, generator=g) * 0.4, dtype)
+    bias = torch.randn(cout, generator=g) * 0.2
+    ps = H.PackedStem(wt, bias, True, dtype, device)
+    y = H.stem_conv(img.to(device), ps)
+    torch.cuda.synchronize()
+    ref = F.silu(F.conv2d(quantize(img, dtype), wt, bias, 2, 1))
+    assert tuple(y.shape) == tuple(ref.shape)
+    check_close(back(y), ref, dtype, f"stem {shape}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 def test_grouped_conv(dtype, device):
     g = torch.Generator().manual_seed(11)
     x = quantize(torch.randn(2, 32, 12, 12, generator=g), dtype)
