@@ -79,6 +79,13 @@ def conv_work(plan):
 
     out = []
     for i, (fn, args, _) in enumerate(plan.ops):
+        if fn.__name__ == "dy_stem_conv3x3s2_nchw":  # fused stem: args = (x, w, bias, y, n, cin, h, w, cout, ld_y, act, dtype)
+            n, cin, h, w, cout, dt = args[4], args[5], args[6], args[7], args[8], args[11]
+            ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+            es = 4 if dt == _lib.DY_F32 else 2
+            out.append((i, 2.0 * n * ho * wo * cout * cin * 9, n * cin * h * w * 4 + n * ho * wo * cout * es + cout * cin * 9 * es,
+                        f"{cin}->{cout} k3 s2 {h}x{w} (stem, fp32 NCHW in)"))
+            continue
         if fn.__name__ != "dy_conv2d_nhwc":
             continue
         d = args[0]._obj
@@ -97,7 +104,7 @@ def time_convs(plan, iters: int = 5):
     """Per-launch durations of the conv kernels with HIP events on the launch stream (torch's current
     stream IS the stream every libdyolo call is issued on)."""
     work = conv_work(plan)
-    idx = {w[0] for w in work}
+    idx = {w[0] for w in work}  # every conv launch: dy_conv2d_nhwc (all three kernels behind it) + the fused stem
     stream = torch.cuda.current_stream().cuda_stream
     tot = {i: 0.0 for i in idx}
     for _ in range(iters):
@@ -196,7 +203,7 @@ def main():
             tj = json.load(open(tfile))
             if tj.get("batch") == a.batch and a.dtype == "bf16":
                 traffic = round(tj["families"]["conv"]["hbm_bytes_per_step"] / 1e9, 3)
-        roof = {"bound": "mfma", "kernel": "conv family: conv3x3_halo_kernel + conv_igemm_kernel (all launches of one pass)",
+        roof = {"bound": "mfma", "kernel": "conv family: conv3x3_halo + conv1x1_stream + conv_igemm + conv_stem kernels (all conv launches of one pass)",
                 "achieved": round(flops / tconv / 1e12, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(flops / tconv / 1e12 / peak, 4), "traffic": traffic,
                 "traffic_unit": "GB of HBM traffic per pass (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic_b128.json)",

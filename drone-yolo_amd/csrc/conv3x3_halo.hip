@@ -40,6 +40,7 @@ struct Conv3Args {
   int Ho, Wo, Cout, ldy, ldres;
   int act;
   int tilesX, tilesY, tilesN, nTiles, nChunks;
+  unsigned x_bytes, w_bytes;  // extents of the x view and of the packed weights (buffer descriptors)
   int dbg;  // ablation switches (DYOLO_DBG env): 1 skip global loads after the first item, 2 skip MFMAs,
             // 4 skip epilogue, 8 skip LDS staging writes, 16 force the streaming (non-WS) variant
 };
@@ -80,7 +81,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane >> 4, lr = lane & 15;
-  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+  // Staging loads are raw buffer loads: an out-of-range offset returns zero in hardware, so the zero padding
+  // of the convolution and the ragged channel tail need no branches, and hipcc can keep two items' loads in
+  // flight behind counted s_waitcnt vmcnt(N) (predicated global loads made it drain with vmcnt(0)).
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
   const u32x4* __restrict__ wg = reinterpret_cast<const u32x4*>(p.w);
   const int G = (int)gridDim.x;
 
@@ -120,8 +125,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
   // ---- loader state (runs one item ahead of the compute state) -----------------------------------
   TileIt lt = decode((int)blockIdx.x);
   int l_chunk = 0;
-  unsigned aoff[NA];  // element offset of this thread's halo slots for the loader's tile (~0u = outside)
-  u32x4 ra[NA], rw[NW];
+  unsigned aoff[NA];  // BYTE offset of this thread's halo slots for the loader's tile (~0u = outside the image)
+  // two static register sets: the loads of items it+1 and it+2 are in flight while item it is multiplied
+  u32x4 ra0[NA], rw0[NW], ra1[NA], rw1[NW];
+  int l_item = 0;
 
   auto tile_offsets = [&]() {
 #pragma unroll
@@ -131,33 +138,40 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
       const int hy = pix / HWD, hx = pix - hy * HWD;
       const int gy = lt.ty * (TH * S) - 1 + hy, gx = lt.tx * (TW * S) - 1 + hx;
       const bool ok = (pix < NPIX) && ((unsigned)gy < (unsigned)p.H) && ((unsigned)gx < (unsigned)p.W);
-      aoff[i] = ok ? (unsigned)((lt.n * p.H + gy) * p.W + gx) * (unsigned)p.ldx + (unsigned)((s & 3) * EPC) : ~0u;
+      aoff[i] = ok ? ((unsigned)((lt.n * p.H + gy) * p.W + gx) * (unsigned)p.ldx + (unsigned)((s & 3) * EPC)) * (unsigned)sizeof(T) : ~0u;
     }
   };
 
-  auto issue_loads = [&]() {  // loads of (lt, l_chunk), then advance the loader
+  auto issue_loads = [&](u32x4 (&ra)[NA], u32x4 (&rw)[NW]) {  // loads of (lt, l_chunk), then advance the loader
     if (l_chunk == 0) tile_offsets();
     const int cbase = l_chunk * KCE;
+    const bool chan_ok = cbase + (tid & 3) * EPC < p.Cin;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const bool ok = (aoff[i] != ~0u) && (cbase + (tid & 3) * EPC < p.Cin);
-      ra[i] = ok ? *reinterpret_cast<const u32x4*>(xg + (size_t)aoff[i] + cbase) : zero_chunk();
+      const unsigned voff = (aoff[i] != ~0u && chan_ok) ? aoff[i] + (unsigned)(cbase * (int)sizeof(T)) : 0xfffffff0u;
+      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, 0, 0);
     }
     if constexpr (!WS) {
-      const u32x4* wsrc = wg + (size_t)(lt.nt * p.nChunks + l_chunk) * W_CHUNKS;
+      const unsigned wbase = (unsigned)((lt.nt * p.nChunks + l_chunk) * W_CHUNKS) * 16u;
 #pragma unroll
       for (int i = 0; i < NW; ++i) {
         const int s = tid + NT * i;
-        if (W_CHUNKS % NT == 0 || s < W_CHUNKS) rw[i] = wsrc[s];
+        rw[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, (W_CHUNKS % NT == 0 || s < W_CHUNKS) ? wbase + (unsigned)s * 16u : 0xfffffff0u, 0, 0);
       }
     }
-    if (++l_chunk == p.nChunks) {
-      l_chunk = 0;
-      advance(lt);
+    // past the last item the loader stays put and harmlessly re-loads it: every issue is unconditional, so
+    // the compiler can use counted s_waitcnt vmcnt(N) instead of draining the younger prefetch
+    if (++l_item < nItems) {
+      if (++l_chunk == p.nChunks) {
+        l_chunk = 0;
+        advance(lt);
+      }
+    } else {
+      l_item = nItems - 1;
     }
   };
 
-  auto store_lds = [&](int stage) {
+  auto store_lds = [&](int stage, const u32x4 (&ra)[NA], const u32x4 (&rw)[NW]) {
     unsigned char* sa = stage0 + stage * STAGE;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -310,25 +324,35 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
     for (int s = tid; s < nb; s += NT) sb[s] = p.bias[b0 + s];
   }
   TileIt ct = lt;  // compute-side tile
-  issue_loads();
-  store_lds(0);
+  issue_loads(ra0, rw0);  // item 0
+  store_lds(0, ra0, rw0);
+  issue_loads(ra1, rw1);  // item 1
   __syncthreads();
   init_acc(ct.nt);
 
-  // ---- item pipeline: one barrier per (tile, chunk) item -----------------------------------------------
+  // ---- item pipeline: one barrier per (tile, chunk) item, prefetch depth two -------------------------
   int c_chunk = 0;
-  for (int it = 0; it < nItems; ++it) {
-    const bool more = (it + 1) < nItems;
-    if (more && !(p.dbg & 1)) issue_loads();
-    if (!(p.dbg & 2)) compute(it & 1, c_chunk);
-    // staging writes first: their vmcnt(0) then waits for the prefetch alone, not for epilogue traffic
-    if (more && !(p.dbg & 8)) store_lds((it + 1) & 1);
+  auto tile_end = [&]() {
     if (++c_chunk == p.nChunks) {  // last chunk of a tile
       c_chunk = 0;
       if (!(p.dbg & 4)) epilogue(ct);
       advance(ct);
       init_acc(ct.nt);
     }
+  };
+  for (int it = 0; it < nItems; it += 2) {
+    // even item: stage 0 holds it, set 1 holds (in flight) it+1, set 0 is free for it+2
+    if (!(p.dbg & 1)) issue_loads(ra0, rw0);
+    if (!(p.dbg & 2)) compute(0, c_chunk);
+    if (!(p.dbg & 8)) store_lds(1, ra1, rw1);  // waits for it+1 only: it+2 stays in flight
+    tile_end();
+    __syncthreads();
+    if (it + 1 >= nItems) break;
+    // odd item: stage 1 holds it+1, set 0 holds it+2, set 1 is free for it+3
+    if (!(p.dbg & 1)) issue_loads(ra1, rw1);
+    if (!(p.dbg & 2)) compute(1, c_chunk);
+    if (!(p.dbg & 8)) store_lds(0, ra0, rw0);
+    tile_end();
     __syncthreads();
   }
 }
@@ -412,7 +436,7 @@ int conv3x3_halo_dispatch(const dy_conv_desc* d, hipStream_t st) {
              "dy_conv2d_nhwc: views must be 16-byte aligned");
   DY_REQUIRE((d->ld_y * (d->out_f32 ? 4 : es)) % 16 == 0, DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: output pitch must be a multiple of 16 bytes");
   DY_REQUIRE(!d->residual || (aligned16(d->residual) && d->ld_res % 4 == 0), DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: residual view misaligned");
-  DY_REQUIRE((long long)d->batch * d->h * d->w_in * d->ld_x < (1ll << 32), DY_ERR_UNSUPPORTED, "dy_conv2d_nhwc: input view exceeds 2^32 elements");
+  DY_REQUIRE((long long)d->batch * d->h * d->w_in * d->ld_x * es < (1ll << 32) - 64, DY_ERR_UNSUPPORTED, "dy_conv2d_nhwc: input view exceeds 4 GiB (buffer descriptor range)");
   Conv3Args a{};
   a.x = d->x;
   a.w = d->w;
@@ -430,6 +454,11 @@ int conv3x3_halo_dispatch(const dy_conv_desc* d, hipStream_t st) {
   a.ldres = d->ld_res;
   a.act = d->act;
   a.nChunks = (d->cin + 4 * epc - 1) / (4 * epc);
+  a.x_bytes = (unsigned)((long long)d->batch * d->h * d->w_in * d->ld_x * es);
+  {
+    const int bn = d->cout > 32 ? 64 : 32;
+    a.w_bytes = (unsigned)((long long)((d->cout + bn - 1) / bn) * a.nChunks * 9 * (bn / 16) * 1024);
+  }
   {
     static const int dbg = getenv("DYOLO_DBG") ? atoi(getenv("DYOLO_DBG")) : 0;
     a.dbg = dbg;
