@@ -373,13 +373,88 @@ def e2e(R):
 
 import math  # noqa: E402
 
+
+# ---- training loss stack: bbox_iou(CIoU), TaskAlignedAssigner, v8DetectionLoss ---------------------------------
+def loss_vectors(R):
+    from ultralytics.utils import loss as rloss
+    from ultralytics.utils import metrics as rmetrics
+
+    from oracle import loss_oracle as LO
+
+    out = {}
+    g = torch.Generator().manual_seed(4242)
+    # CIoU on random xyxy boxes (incl. disjoint, nested and degenerate-height ones)
+    a = torch.rand(200, 2, generator=g) * 50
+    b1 = torch.cat((a, a + torch.rand(200, 2, generator=g) * 30 + 0.5), 1)
+    c = torch.rand(200, 2, generator=g) * 50
+    b2 = torch.cat((c, c + torch.rand(200, 2, generator=g) * 30 + 0.5), 1)
+    b2[:10] = b1[:10]
+    b2[10:20, 3] = b2[10:20, 1]  # zero-height boxes
+    ref = rmetrics.bbox_iou(b1, b2, xywh=False, CIoU=True)
+    rel_tol_check("bbox_iou CIoU", LO.bbox_ciou(b1, b2), ref, tol=1e-6)
+    out.update(ciou_b1=tnp(b1), ciou_b2=tnp(b2), ciou_out=tnp(ref))
+
+    # TaskAlignedAssigner on random predictions, with padded gts and an image without gts
+    B, A, nc, G = 3, 340, 10, 7
+    anc, st = O.make_anchors([(16, 16), (8, 8), (4, 4), (2, 2)], [4, 8, 16, 32])
+    anc_px = anc * st
+    pd_scores = torch.rand(B, A, nc, generator=g) ** 2
+    ctr = anc_px[None] + (torch.rand(B, A, 2, generator=g) - 0.5) * 6
+    half = torch.rand(B, A, 2, generator=g) * 14 + 2
+    pd_bboxes = torch.cat((ctr - half, ctr + half), 2)
+    gt = torch.zeros(B, G, 4)
+    gl = torch.zeros(B, G, 1)
+    n_gt = [5, 7, 0]
+    for bi, n in enumerate(n_gt):
+        cxy = torch.rand(n, 2, generator=g) * 50 + 7
+        wh = torch.rand(n, 2, generator=g) * 24 + 4
+        gt[bi, :n] = torch.cat((cxy - wh / 2, cxy + wh / 2), 1)
+        gl[bi, :n, 0] = torch.randint(0, nc, (n,), generator=g).float()
+    gt[1, 6] = gt[1, 5]  # duplicate gt: forces anchors claimed by two gts with equal overlaps
+    mask_gt = (gt.sum(2, keepdim=True) > 0).float()
+    assigner = R.tal.TaskAlignedAssigner(topk=10, num_classes=nc, alpha=0.5, beta=6.0)
+    ref = assigner(pd_scores, pd_bboxes, anc_px, gl, gt, mask_gt)
+    ours = LO.task_aligned_assign(pd_scores, pd_bboxes, anc_px, gl, gt, mask_gt, topk=10, num_classes=nc)
+    for name, r_, o_ in zip(("labels", "bboxes", "scores", "fg", "gt_idx"), ref, ours):
+        if name in ("fg",):
+            assert torch.equal(r_.bool(), o_.bool()), "assigner fg_mask differs"
+        elif name in ("labels", "gt_idx"):
+            assert torch.equal(r_.long()[ref[3].bool()], o_.long()[ref[3].bool()]), f"assigner {name} differs on fg anchors"
+        else:
+            rel_tol_check(f"TaskAlignedAssigner {name}", o_.float(), r_.float(), tol=1e-6)
+    print(f"  oracle vs reference  TaskAlignedAssigner: {int(ref[3].sum())} foreground anchors, identical assignment")
+    out.update(tal_scores=tnp(pd_scores), tal_bboxes=tnp(pd_bboxes), tal_gt=tnp(gt), tal_gl=tnp(gl),
+               tal_fg=tnp(ref[3].bool()), tal_gt_idx=tnp(ref[4]), tal_tscores=tnp(ref[2].float()), tal_tbboxes=tnp(ref[1]))
+
+    # v8DetectionLoss on random head outputs of the Drone-YOLO-n head layout (nc=10), two image sizes
+    model, _ = build_reference_model(R, "yolov8-p2-repvgg.yaml", "n", 10)
+    model.args = types.SimpleNamespace(box=7.5, cls=0.5, dfl=1.5)
+    crit = rloss.v8DetectionLoss(model)
+    for tag, (bs, hw, seed) in {"loss64": (2, 64, 7), "loss160": (3, 160, 8)}.items():
+        gg = torch.Generator().manual_seed(seed)
+        feats = [torch.randn(bs, 74, hw // s, hw // s, generator=gg) * 1.5 for s in (4, 8, 16, 32)]
+        labels = LO.synthetic_labels(bs, seed, n_mean=6.0 if hw == 64 else 14.0)
+        ref_total, ref_items = crit([f.clone() for f in feats], labels)
+        our_total, our_items, asg = LO.v8_detection_loss(feats, labels, [4.0, 8.0, 16.0, 32.0], 10, return_assign=True)
+        rel_tol_check(f"v8DetectionLoss {tag} items (box, cls, dfl)", our_items, ref_items, tol=2e-5)
+        rel_tol_check(f"v8DetectionLoss {tag} total", our_total.view(1), ref_total.detach().view(1), tol=2e-5)
+        print(f"    {tag}: loss {float(ref_total):.4f} items {[round(float(v), 5) for v in ref_items]} fg {int(asg['fg_mask'].sum())} labels {labels['cls'].numel()}")
+        out.update({f"{tag}_meta": np.array(repr(dict(bs=bs, hw=hw, seed=seed, n_mean=6.0 if hw == 64 else 14.0))),
+                    f"{tag}_total": np.array(float(ref_total)), f"{tag}_items": tnp(ref_items),
+                    f"{tag}_fg": tnp(asg["fg_mask"]), f"{tag}_gt_idx": tnp(asg["target_gt_idx"]),
+                    f"{tag}_tscore_sum": np.array(float(asg["target_scores"].sum()))})
+    np.savez_compressed(OUT / "loss.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     OUT.mkdir(parents=True, exist_ok=True)
     R = import_reference()
     print("reference imported from", REF)
-    per_op(R)
-    nms_cases(R)
-    e2e(R)
+    if "--loss-only" not in sys.argv:
+        per_op(R)
+        nms_cases(R)
+        e2e(R)
+    loss_vectors(R)
     for f in sorted(OUT.glob("*.npz")):
         print(f"wrote {f.relative_to(ROOT)}  {f.stat().st_size / 1024:.1f} KiB")

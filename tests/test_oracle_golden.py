@@ -132,3 +132,28 @@ def test_e2e_vectors():
         assert [len(r) for r in det] == list(g[f"{tag}__n"]), tag
         assert np.array_equal(np.concatenate([i.numpy() for i in idx]), g[f"{tag}__det_idx"]), tag
         assert np.allclose(np.concatenate([r.numpy() for r in det]), g[f"{tag}__det"], atol=2e-3), tag
+
+
+def test_loss_stack_vectors():
+    """bbox_iou(CIoU), TaskAlignedAssigner and v8DetectionLoss restatements against vectors captured from the
+    real reference (oracle/make_golden.py::loss_vectors)."""
+    from oracle import loss_oracle as LO
+
+    g = golden("loss.npz")
+    t = lambda k: torch.from_numpy(g[k])  # noqa: E731
+    assert torch.allclose(LO.bbox_ciou(t("ciou_b1"), t("ciou_b2")), t("ciou_out"), atol=1e-6)
+    anc, st = O.make_anchors([(16, 16), (8, 8), (4, 4), (2, 2)], [4, 8, 16, 32])
+    gt, gl = t("tal_gt"), t("tal_gl")
+    mask_gt = (gt.sum(2, keepdim=True) > 0).float()
+    tl, tb, ts, fg, gi = LO.task_aligned_assign(t("tal_scores"), t("tal_bboxes"), anc * st, gl, gt, mask_gt, topk=10, num_classes=10)
+    assert torch.equal(fg, t("tal_fg")) and torch.equal(gi[fg], t("tal_gt_idx")[fg])
+    assert torch.allclose(ts, t("tal_tscores"), atol=1e-6) and torch.allclose(tb[fg], t("tal_tbboxes")[fg])
+    for tag in ("loss64", "loss160"):
+        m = ast.literal_eval(str(g[f"{tag}_meta"]))
+        gg = torch.Generator().manual_seed(m["seed"])
+        feats = [torch.randn(m["bs"], 74, m["hw"] // s, m["hw"] // s, generator=gg) * 1.5 for s in (4, 8, 16, 32)]
+        labels = LO.synthetic_labels(m["bs"], m["seed"], n_mean=m["n_mean"])
+        total, items, asg = LO.v8_detection_loss(feats, labels, [4.0, 8.0, 16.0, 32.0], 10, return_assign=True)
+        assert torch.allclose(items, t(f"{tag}_items"), rtol=2e-5, atol=1e-5), tag
+        assert abs(float(total) - float(g[f"{tag}_total"])) <= 2e-5 * abs(float(g[f"{tag}_total"])), tag
+        assert torch.equal(asg["fg_mask"], t(f"{tag}_fg")) and torch.equal(asg["target_gt_idx"][asg["fg_mask"]], t(f"{tag}_gt_idx")[asg["fg_mask"]])
