@@ -63,6 +63,20 @@ class NmsDesc(C.Structure):
     ]  # fmt: skip
 
 
+class LossDesc(C.Structure):
+    """Mirror of ``dy_loss_desc``."""
+
+    _fields_ = [
+        ("level", _vp * DY_MAX_LEVELS),
+        ("h", _i32 * DY_MAX_LEVELS), ("w", _i32 * DY_MAX_LEVELS), ("ld", _i32 * DY_MAX_LEVELS),
+        ("stride", _f32 * DY_MAX_LEVELS),
+        ("n_levels", _i32), ("batch", _i32), ("nc", _i32), ("reg_max", _i32),
+        ("gt", _vp), ("gmax", _i32), ("topk", _i32),
+        ("alpha", _f32), ("beta", _f32), ("box_gain", _f32), ("cls_gain", _f32), ("dfl_gain", _f32),
+        ("out", _vp), ("out_owner", _vp), ("workspace", _vp), ("workspace_bytes", _i64),
+    ]  # fmt: skip
+
+
 # name -> (restype, argtypes); every symbol include/dyolo.h declares must appear here
 # (tests/test_cabi.py checks both directions).
 SIGNATURES = {
@@ -82,6 +96,8 @@ SIGNATURES = {
     "dy_nms_workspace_bytes": (_i64, [_i32, _i32]),
     "dy_nms": (_i32, [C.POINTER(NmsDesc), _vp]),
     "dy_scale_boxes": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
+    "dy_detection_loss_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
+    "dy_detection_loss": (_i32, [C.POINTER(LossDesc), _vp]),
 }
 
 _lib = None

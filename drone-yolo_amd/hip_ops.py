@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import DY_ACT_NONE, DY_ACT_SILU, ConvDesc, DecodeDesc, NmsDesc, check, lib
+from ._lib import DY_ACT_NONE, DY_ACT_SILU, ConvDesc, DecodeDesc, LossDesc, NmsDesc, check, lib
 
 _DTYPES = {torch.bfloat16: _lib.DY_BF16, torch.float16: _lib.DY_F16, torch.float32: _lib.DY_F32}
 
@@ -440,3 +440,40 @@ def scale_boxes_(bufs: NmsBuffers, params: torch.Tensor) -> None:
     """In-place scale_boxes + clip_boxes of the kept rows; params: device fp32 (N,5)."""
     _launch(lib().dy_scale_boxes, (bufs.out.data_ptr(), bufs.count.data_ptr(), params.data_ptr(), bufs.batch, bufs.max_det),
             keep=(bufs, params))
+
+
+# ---- training loss (forward) ----------------------------------------------------------------------------
+
+
+def detection_loss(levels: Sequence[torch.Tensor], gt: torch.Tensor, strides: Sequence[float], nc: int, reg_max: int = 16,
+                   topk: int = 10, alpha: float = 0.5, beta: float = 6.0, box: float = 7.5, cls: float = 0.5, dfl: float = 1.5,
+                   want_owner: bool = False):
+    """v8DetectionLoss forward through ``dy_detection_loss``.
+
+    levels[i]: fp32 NHWC view (N, 4*reg_max+nc, H_i, W_i) — Detect's training-mode outputs; gt: device fp32 (N, gmax, 5)
+    [cls, x1, y1, x2, y2] in pixels, zero rows = padding.  Returns (out[4] = box, cls, dfl, total, owner or None)."""
+    n = levels[0].shape[0]
+    d = LossDesc()
+    A = 0
+    for i, t in enumerate(levels):
+        require_device(t)
+        if t.dtype != torch.float32 or t.shape[1] != 4 * reg_max + nc:
+            raise ValueError("detection_loss: levels must be fp32 with 4*reg_max+nc channels")
+        p_, ld = view_params(t)
+        d.level[i], d.h[i], d.w[i], d.ld[i], d.stride[i] = p_, t.shape[2], t.shape[3], ld, float(strides[i])
+        A += t.shape[2] * t.shape[3]
+    dev = levels[0].device
+    gt = gt.to(dev, torch.float32).contiguous()
+    if gt.dim() != 3 or gt.shape[0] != n or gt.shape[2] != 5:
+        raise ValueError("detection_loss: gt must be (N, gmax, 5)")
+    gmax = gt.shape[1]
+    d.n_levels, d.batch, d.nc, d.reg_max = len(levels), n, nc, reg_max
+    d.gt, d.gmax, d.topk = (gt.data_ptr() if gmax else None), gmax, topk
+    d.alpha, d.beta, d.box_gain, d.cls_gain, d.dfl_gain = alpha, beta, box, cls, dfl
+    out = torch.empty(4, dtype=torch.float32, device=dev)
+    owner = torch.empty((n, A), dtype=torch.int32, device=dev) if want_owner else None
+    ws = torch.empty(lib().dy_detection_loss_workspace_bytes(n, A, gmax, topk), dtype=torch.uint8, device=dev)
+    d.out, d.out_owner = out.data_ptr(), (owner.data_ptr() if want_owner else None)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    _launch(lib().dy_detection_loss, (C.byref(d),), keep=(d, out, owner, ws, gt, *levels))
+    return out, owner

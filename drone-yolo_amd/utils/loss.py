@@ -1,0 +1,48 @@
+"""Detection training loss on the device (reference: ultralytics/utils/loss.py:157-260 ``v8DetectionLoss``).
+
+Forward only for now: TaskAlignedAssigner + BCE / CIoU / DFL through ``dy_detection_loss``; the returned
+tensors carry no autograd graph (the backward kernels of SURVEY §8 rows a28-a34 are not built yet)."""
+from __future__ import annotations
+
+import torch
+
+from .. import hip_ops as H
+from .ops import xywh2xyxy
+
+
+class v8DetectionLoss:
+    """Same constructor idea and call contract as the reference: ``loss, loss_items = criterion(preds, batch)``."""
+
+    def __init__(self, model, tal_topk: int = 10, box: float = 7.5, cls: float = 0.5, dfl: float = 1.5):
+        m = model.model[-1]  # Detect()
+        h = getattr(model, "args", None)
+        self.box, self.cls, self.dfl = (getattr(h, "box", box), getattr(h, "cls", cls), getattr(h, "dfl", dfl)) if h else (box, cls, dfl)
+        self.stride, self.nc, self.reg_max, self.no = m.stride, m.nc, m.reg_max, m.nc + m.reg_max * 4
+        self.topk = tal_topk
+
+    @staticmethod
+    def preprocess(targets: torch.Tensor, batch_size: int, scale_tensor: torch.Tensor) -> torch.Tensor:
+        """(N, 6) [image, cls, x, y, w, h normalised] -> (B, n_max, 5) [cls, x1, y1, x2, y2] pixels — loss.py:180-195 (host side)."""
+        targets = targets.detach().cpu().float()
+        nl, ne = targets.shape
+        if nl == 0:
+            return torch.zeros(batch_size, 0, ne - 1)
+        i = targets[:, 0]
+        counts = [int((i == j).sum()) for j in range(batch_size)]
+        out = torch.zeros(batch_size, max(counts), ne - 1)
+        for j in range(batch_size):
+            if counts[j]:
+                out[j, : counts[j]] = targets[i == j, 1:]
+        out[..., 1:5] = xywh2xyxy(out[..., 1:5] * scale_tensor)
+        return out
+
+    def __call__(self, preds, batch):
+        feats = preds[1] if isinstance(preds, tuple) else preds
+        bs = feats[0].shape[0]
+        imgsz = torch.tensor(feats[0].shape[2:], dtype=torch.float32) * float(self.stride[0])  # (h, w)
+        targets = torch.cat((batch["batch_idx"].view(-1, 1).float().cpu(), batch["cls"].view(-1, 1).float().cpu(),
+                             batch["bboxes"].float().cpu()), 1)
+        gt = self.preprocess(targets, bs, imgsz[[1, 0, 1, 0]])
+        out, _ = H.detection_loss(feats, gt, [float(s) for s in self.stride], self.nc, self.reg_max, topk=self.topk,
+                                  box=self.box, cls=self.cls, dfl=self.dfl)
+        return out[3], out[:3]

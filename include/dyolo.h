@@ -225,6 +225,31 @@ int32_t dy_nms(const dy_nms_desc* d, dy_stream_t stream);
 int32_t dy_scale_boxes(float* boxes, const int32_t* counts, const float* params, int32_t batch,
                        int32_t max_det, dy_stream_t stream);
 
+/* ---- training loss (forward) -----------------------------------------------------
+ * Replaces: v8DetectionLoss.__call__ (utils/loss.py:206-260) = TaskAlignedAssigner (utils/tal.py:14-295, topk /
+ * alpha / beta as given) + BCE class loss + CIoU box loss (utils/metrics.py:74-134) + DFL (loss.py:65-113), on the
+ * raw head outputs Detect returns in training mode (head.py:71-72).
+ * level[l]: fp32 NHWC view (batch, h_l, w_l, 4*reg_max + nc), pitch ld_l (the Detect head buffers).
+ * gt: DEVICE fp32 (batch, gmax, 5) = class, x1, y1, x2, y2 in input pixels, zero rows = padding (the output of
+ * v8DetectionLoss.preprocess, loss.py:180-195).  out: fp32[4] = box, cls, dfl (after gains), total = sum * batch.
+ * out_owner: optional int32 (batch, A): index of the ground-truth box each anchor is assigned to, or -1.
+ * Assignment is sparse (no (batch, gmax, A) tensors).  Gradients are not produced yet. */
+typedef struct dy_loss_desc {
+  const float* level[DY_MAX_LEVELS];
+  int32_t h[DY_MAX_LEVELS], w[DY_MAX_LEVELS], ld[DY_MAX_LEVELS];
+  float stride[DY_MAX_LEVELS];
+  int32_t n_levels, batch, nc, reg_max;
+  const float* gt;
+  int32_t gmax, topk;
+  float alpha, beta, box_gain, cls_gain, dfl_gain;
+  float* out;
+  int32_t* out_owner;
+  void* workspace;
+  int64_t workspace_bytes;
+} dy_loss_desc;
+int64_t dy_detection_loss_workspace_bytes(int32_t batch, int32_t anchors, int32_t gmax, int32_t topk);
+int32_t dy_detection_loss(const dy_loss_desc* d, dy_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
