@@ -48,6 +48,23 @@ class DecodeDesc(C.Structure):
     ]  # fmt: skip
 
 
+class HeadDecodeDesc(C.Structure):
+    """Mirror of ``dy_head_decode_desc``."""
+
+    _fields_ = [
+        ("x_box", _vp * DY_MAX_LEVELS), ("x_cls", _vp * DY_MAX_LEVELS),
+        ("w_box", _vp * DY_MAX_LEVELS), ("w_cls", _vp * DY_MAX_LEVELS),
+        ("b_box", _vp * DY_MAX_LEVELS), ("b_cls", _vp * DY_MAX_LEVELS),
+        ("ld_box", _i32 * DY_MAX_LEVELS), ("ld_cls", _i32 * DY_MAX_LEVELS),
+        ("h", _i32 * DY_MAX_LEVELS), ("w", _i32 * DY_MAX_LEVELS),
+        ("stride", _f32 * DY_MAX_LEVELS),
+        ("n_levels", _i32), ("batch", _i32), ("nc", _i32), ("reg_max", _i32),
+        ("c_box", _i32), ("c_cls", _i32), ("dtype", _i32),
+        ("out", _vp),
+        ("nms_workspace", _vp), ("nms_workspace_bytes", _i64), ("conf_thres", _f32), ("classes_mask", _vp),
+    ]  # fmt: skip
+
+
 class NmsDesc(C.Structure):
     """Mirror of ``dy_nms_desc``."""
 
@@ -93,6 +110,8 @@ SIGNATURES = {
     "dy_copy_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dy_sppf_maxpool3": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dy_detect_decode": (_i32, [C.POINTER(DecodeDesc), _vp]),
+    "dy_detect_head_decode_supported": (_i32, [_i32, _i32, _i32, _i32, _i32]),
+    "dy_detect_head_decode": (_i32, [C.POINTER(HeadDecodeDesc), _vp]),
     "dy_nms_workspace_bytes": (_i64, [_i32, _i32]),
     "dy_nms": (_i32, [C.POINTER(NmsDesc), _vp]),
     "dy_scale_boxes": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),

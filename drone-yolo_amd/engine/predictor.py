@@ -95,6 +95,7 @@ class DetectionPredictor:
             return holder["bufs"]
 
         det.fused_nms = (make_bufs, float(a["conf"]), self._classes_mask)
+        det.fuse_tail = True  # branch tails + decode + filter in one launch where the shape is built
         try:
             with H.record(cf.plan):
                 y, _ = self.model._predict_once(im, image_dtype=self.dtype)
@@ -107,6 +108,7 @@ class DetectionPredictor:
                 H.scale_boxes_(cf.nms, params)
         finally:
             det.fused_nms = None
+            det.fuse_tail = False
         cf.plan.keep.append(params)
         return cf
 

@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import DY_ACT_NONE, DY_ACT_SILU, ConvDesc, DecodeDesc, LossDesc, NmsDesc, check, lib
+from ._lib import DY_ACT_NONE, DY_ACT_SILU, ConvDesc, DecodeDesc, HeadDecodeDesc, LossDesc, NmsDesc, check, lib
 
 _DTYPES = {torch.bfloat16: _lib.DY_BF16, torch.float16: _lib.DY_F16, torch.float32: _lib.DY_F32}
 
@@ -395,6 +395,64 @@ def detect_decode(levels: Sequence[torch.Tensor], strides: Sequence[float], nc: 
         d.conf_thres = conf_thres
         d.classes_mask = classes_mask.data_ptr() if classes_mask is not None else None
     _launch(lib().dy_detect_decode, (C.byref(d),), keep=(d, out, nms_bufs, classes_mask, *levels))
+    return out
+
+
+def pack_frag1x1(weight: torch.Tensor, bias: torch.Tensor, dtype: torch.dtype, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(cout, cin[,1,1]) weights + bias in DY_WLAYOUT_FRAG1X1 order (include/dyolo.h), whatever kernel PackedConv would pick."""
+    e = elems_per_chunk(dtype)
+    w2 = weight.detach().to(torch.float32).cpu().reshape(weight.shape[0], -1)
+    cout, cin = w2.shape
+    kc, bn = 4 * e, (128 if cout > 64 else (64 if cout > 16 else 16))
+    nt, nkg = -(-cout // bn), -(-cin // kc)
+    wpad = torch.zeros((nt * bn, nkg * kc), dtype=torch.float32)
+    wpad[:cout, :cin] = w2
+    wp = wpad.view(nt, bn // 16, 16, nkg, 4, e).permute(0, 3, 1, 4, 2, 5).contiguous().view(-1)
+    bp = torch.zeros((nt * bn,), dtype=torch.float32)
+    bp[:cout] = bias.detach().to(torch.float32).cpu()
+    return wp.to(dtype).contiguous().to(device), bp.to(device)
+
+
+def head_decode_supported(c_box: int, c_cls: int, nc: int, reg_max: int, dtype: torch.dtype) -> bool:
+    return bool(lib().dy_detect_head_decode_supported(c_box, c_cls, nc, reg_max, dy_dtype(dtype)))
+
+
+def detect_head_decode(x_box: Sequence[torch.Tensor], x_cls: Sequence[torch.Tensor], packed_box, packed_cls,
+                       strides: Sequence[float], nc: int, reg_max: int, out: Optional[torch.Tensor] = None,
+                       nms_bufs: Optional["NmsBuffers"] = None, conf_thres: float = 0.25,
+                       classes_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Last 1x1 convs of both Detect branches + decode (+ NMS candidate filter) in one ``dy_detect_head_decode`` pass.
+
+    x_box[i] / x_cls[i]: NHWC views (N, c, H_i, W_i), the inputs of cv2[i][2] / cv3[i][2]; packed_box[i] / packed_cls[i]:
+    ``pack_frag1x1`` (w, b) of those convs.  Returns (N, 4+nc, A) fp32."""
+    n = x_box[0].shape[0]
+    d = HeadDecodeDesc()
+    A = 0
+    for i, (tb, tc) in enumerate(zip(x_box, x_cls)):
+        require_device(tb)
+        require_device(tc)
+        if tb.dtype != tc.dtype or tb.shape[2:] != tc.shape[2:] or tb.shape[0] != n or tc.shape[0] != n:
+            raise ValueError("detect_head_decode: branch inputs of one level must agree in dtype and size")
+        if tb.shape[1] != x_box[0].shape[1] or tc.shape[1] != x_cls[0].shape[1] or tb.dtype != x_box[0].dtype:
+            raise ValueError("detect_head_decode: all levels must have the same branch widths and dtype")
+        (d.x_box[i], d.ld_box[i]), (d.x_cls[i], d.ld_cls[i]) = view_params(tb), view_params(tc)
+        d.w_box[i], d.b_box[i] = packed_box[i][0].data_ptr(), packed_box[i][1].data_ptr()
+        d.w_cls[i], d.b_cls[i] = packed_cls[i][0].data_ptr(), packed_cls[i][1].data_ptr()
+        d.h[i], d.w[i], d.stride[i] = tb.shape[2], tb.shape[3], float(strides[i])
+        A += tb.shape[2] * tb.shape[3]
+    d.n_levels, d.batch, d.nc, d.reg_max = len(x_box), n, nc, reg_max
+    d.c_box, d.c_cls, d.dtype = x_box[0].shape[1], x_cls[0].shape[1], dy_dtype(x_box[0].dtype)
+    if out is None:
+        out = torch.empty((n, 4 + nc, A), dtype=torch.float32, device=x_box[0].device)
+    d.out = out.data_ptr()
+    if nms_bufs is not None:
+        if (nms_bufs.batch, nms_bufs.anchors) != (n, A):
+            raise ValueError("detect_head_decode: nms_bufs were sized for another batch / anchor count")
+        d.nms_workspace, d.nms_workspace_bytes = nms_bufs.workspace.data_ptr(), nms_bufs.workspace.numel()
+        d.conf_thres = conf_thres
+        d.classes_mask = classes_mask.data_ptr() if classes_mask is not None else None
+    _launch(lib().dy_detect_head_decode, (C.byref(d),),
+            keep=(d, out, nms_bufs, classes_mask, *x_box, *x_cls, *packed_box, *packed_cls))
     return out
 
 

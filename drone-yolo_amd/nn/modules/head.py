@@ -70,7 +70,48 @@ class Detect(nn.Module):
                 x = m(x)
         return mods[-1](x, out=out, out_f32=True)
 
+    fuse_tail = False  # opt-in (the predictor sets it): eval returns (y, None), the raw maps are never materialised
+
+    @staticmethod
+    def _run_trunk(seq, x):
+        """All but the last (plain 1x1) conv of one branch."""
+        for m in list(seq)[:-1]:
+            if isinstance(m, nn.Sequential):
+                for mm in m:
+                    x = mm(x)
+            else:
+                x = m(x)
+        return x
+
+    def _packed_tail(self, dtype, device):
+        tails = [s[-1] for s in self.cv2] + [s[-1] for s in self.cv3]
+        key = (dtype, str(device), tuple((m.weight.data_ptr(), m.weight._version, m.bias._version) for m in tails))
+        cache = getattr(self, "_tail_cache", None)
+        if cache is None or cache[0] != key:
+            pb = [H.pack_frag1x1(s[-1].weight, s[-1].bias, dtype, device) for s in self.cv2]
+            pc = [H.pack_frag1x1(s[-1].weight, s[-1].bias, dtype, device) for s in self.cv3]
+            cache = (key, pb, pc)
+            self._tail_cache = cache
+        return cache[1], cache[2]
+
+    def _forward_fused(self, x):
+        """Inference with the branch tails, decode and NMS filter in one launch (dy_detect_head_decode)."""
+        xb = [self._run_trunk(self.cv2[i], x[i]) for i in range(self.nl)]
+        xc = [self._run_trunk(self.cv3[i], x[i]) for i in range(self.nl)]
+        pb, pc = self._packed_tail(xb[0].dtype, xb[0].device)
+        fused = getattr(self, "fused_nms", None)
+        kw = {}
+        if fused is not None:
+            make_bufs, conf, mask = fused
+            A = sum(f.shape[2] * f.shape[3] for f in xb)
+            kw = dict(nms_bufs=make_bufs(xb[0].shape[0], A), conf_thres=conf, classes_mask=mask)
+        return H.detect_head_decode(xb, xc, pb, pc, [float(s) for s in self.stride], self.nc, self.reg_max, **kw)
+
     def forward(self, x):
+        if self.fuse_tail and not self.training and H.head_decode_supported(
+                self.cv2[0][-1].in_channels, self.cv3[0][-1].in_channels, self.nc, self.reg_max, x[0].dtype):
+            y = self._forward_fused(x)
+            return y if self.export else (y, None)
         nb = self.reg_max * 4
         ld = (self.no + 3) // 4 * 4  # keep every pixel row 16-byte aligned for the fp32 vector paths
         feats = []
@@ -98,3 +139,4 @@ class Detect(nn.Module):
             b[-1].bias.data[: self.nc] = math.log(5 / self.nc / (640 / float(s)) ** 2)
             a[-1].invalidate_packed()
             b[-1].invalidate_packed()
+        self._tail_cache = None

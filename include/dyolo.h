@@ -184,6 +184,37 @@ typedef struct dy_decode_desc {
 } dy_decode_desc;
 int32_t dy_detect_decode(const dy_decode_desc* d, dy_stream_t stream);
 
+/* ---- fused Detect tail: last 1x1 convs of both branches + decode (+ NMS filter) ---------------
+ * Replaces in ONE pass, per level l: cv2[l][2] = nn.Conv2d(c_box, 4*reg_max, 1) and cv3[l][2] =
+ * nn.Conv2d(c_cls, nc, 1) (nn/modules/head.py:43-57), their concat (head.py:69-70) and Detect._inference
+ * (head.py:100-131), i.e. dy_conv2d_nhwc x2 + dy_detect_decode without the (batch, 4*reg_max+nc, A) fp32
+ * logits ever reaching HBM.  Inference only: the raw per-level maps the reference also returns (head.py:74)
+ * are not produced (use the unfused calls when they are wanted, e.g. for the training loss).
+ * x_box[l] / x_cls[l]: NHWC views (batch, h_l, w_l, c_box / c_cls) of `dtype`, pitches ld_box / ld_cls —
+ * the outputs of cv2[l][1] / cv3[l][1].  w_box[l] / w_cls[l]: the 1x1 weights packed as DY_WLAYOUT_FRAG1X1
+ * for (cout = 4*reg_max, cin = c_box) / (cout = nc, cin = c_cls); b_box / b_cls: fp32 bias padded like there.
+ * out, nms_workspace, conf_thres, classes_mask: exactly as in dy_decode_desc.
+ * Built for reg_max 16, nc <= 128, c_box = 64, c_cls in {64, 96, 128, 160} (16-bit) or {64, 80} (fp32);
+ * dy_detect_head_decode_supported() tells (1/0); unsupported shapes return DY_ERR_UNSUPPORTED. */
+typedef struct dy_head_decode_desc {
+  const void* x_box[DY_MAX_LEVELS];
+  const void* x_cls[DY_MAX_LEVELS];
+  const void* w_box[DY_MAX_LEVELS];
+  const void* w_cls[DY_MAX_LEVELS];
+  const float* b_box[DY_MAX_LEVELS];
+  const float* b_cls[DY_MAX_LEVELS];
+  int32_t ld_box[DY_MAX_LEVELS], ld_cls[DY_MAX_LEVELS], h[DY_MAX_LEVELS], w[DY_MAX_LEVELS];
+  float stride[DY_MAX_LEVELS];
+  int32_t n_levels, batch, nc, reg_max, c_box, c_cls, dtype;
+  float* out;
+  void* nms_workspace;
+  int64_t nms_workspace_bytes;
+  float conf_thres;
+  const uint8_t* classes_mask;
+} dy_head_decode_desc;
+int32_t dy_detect_head_decode_supported(int32_t c_box, int32_t c_cls, int32_t nc, int32_t reg_max, int32_t dtype);
+int32_t dy_detect_head_decode(const dy_head_decode_desc* d, dy_stream_t stream);
+
 /* ---- NMS --------------------------------------------------------------------
  * Replaces: ops.non_max_suppression single-label path (utils/ops.py:181-332)
  * including torchvision.ops.nms (called at ops.py:312): candidates = anchors

@@ -252,6 +252,52 @@ def test_decode_fused_filter_equals_separate_filter(device):
         assert torch.allclose(y.cpu(), O.detect_decode(feats, strides, nc), rtol=1e-5, atol=2e-4)
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("nc,c_cls", [(10, 64), (80, 128), (17, 64)])
+def test_fused_head_tail_decode(nc, c_cls, dtype, device):
+    """dy_detect_head_decode (branch-tail 1x1 convs + decode + filter in one launch) against the oracle's
+    conv2d -> Detect decode on the same (dtype-rounded) operands, and against the unfused device calls."""
+    if dtype == torch.float32 and c_cls == 128:
+        c_cls = 80  # the fp32 build holds at most 5 k-groups of 16 channels per branch in registers
+    g = torch.Generator().manual_seed(31 + nc)
+    shapes = [(40, 36), (20, 20), (10, 9), (5, 5), (1, 1)]  # 1440/400/90/25/1 anchors: several tiles, ragged tails, one anchor
+    strides = [4.0, 8.0, 16.0, 32.0, 64.0]
+    n = 3
+    rnd = lambda t: t.to(dtype).float()
+    xb = [rnd(torch.randn(n, 64, h, w, generator=g)) for h, w in shapes]
+    xc = [rnd(torch.randn(n, c_cls, h, w, generator=g)) for h, w in shapes]
+    wb = [rnd(torch.randn(64, 64, 1, 1, generator=g) * 0.25) for _ in shapes]
+    wc = [rnd(torch.randn(nc, c_cls, 1, 1, generator=g) * 0.2) for _ in shapes]
+    bb = [torch.randn(64, generator=g) for _ in shapes]
+    bc = [torch.randn(nc, generator=g) - 1.0 for _ in shapes]
+    feats = [torch.cat([F.conv2d(xb[i].double(), wb[i].double(), bb[i].double()), F.conv2d(xc[i].double(), wc[i].double(), bc[i].double())], 1).float()
+             for i in range(len(shapes))]
+    ref = O.detect_decode(feats, strides, nc)
+    assert H.head_decode_supported(64, c_cls, nc, 16, dtype)
+    dxb = [nhwc(t, dtype, device) for t in xb]
+    dxc = [nhwc(t, dtype, device) for t in xc]
+    pb = [H.pack_frag1x1(wb[i], bb[i], dtype, device) for i in range(len(shapes))]
+    pc = [H.pack_frag1x1(wc[i], bc[i], dtype, device) for i in range(len(shapes))]
+    A = sum(h * w for h, w in shapes)
+    bufs = H.NmsBuffers(n, A, 300, device)
+    y = H.detect_head_decode(dxb, dxc, pb, pc, strides, nc, 16, nms_bufs=bufs, conf_thres=0.3)
+    kept = H.nms(y, 0.3, 0.6, bufs=bufs, prefiltered=True)
+    torch.cuda.synchronize()
+    f_out, f_cnt, f_idx = kept.out.clone(), kept.count.clone(), kept.index.clone()
+    # operands are exactly representable, products accumulate in fp32 on the device: only summation order differs
+    assert torch.allclose(y.cpu(), ref, rtol=1e-4, atol=2e-3), float((y.cpu() - ref).abs().max())
+    plain = H.nms(y, 0.3, 0.6)
+    torch.cuda.synchronize()
+    assert int(f_cnt.sum()) > 0 and torch.equal(f_cnt, plain.count) and torch.equal(f_out, plain.out) and torch.equal(f_idx, plain.index)
+
+
+def test_fused_head_unsupported_shapes_are_refused(device):
+    assert not H.head_decode_supported(64, 80, 80, 16, torch.bfloat16)  # 80 channels: not whole 32-channel k-groups
+    assert not H.head_decode_supported(32, 64, 10, 16, torch.bfloat16)
+    assert not H.head_decode_supported(64, 64, 10, 8, torch.bfloat16)
+    assert H.head_decode_supported(64, 80, 80, 16, torch.float32)
+
+
 def _run_nms(pred, device, **kw):
     kw = dict(kw)
     classes = kw.pop("classes", None)

@@ -8,8 +8,12 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         fam = "conv" if "conv" in r["Kernel_Name"] else ("nms" if "nms" in r["Kernel_Name"] else ("decode" if "decode" in r["Kernel_Name"] else
               ("layout" if ("nchw" in r["Kernel_Name"] or "sppf" in r["Kernel_Name"] or "copy_chunks" in r["Kernel_Name"]) else "other")))
         acc[fam][r["Counter_Name"]] += float(r["Counter_Value"])
-out = {"batch": batch, "passes_profiled": passes_per_run, "note": "bytes per pass = (2*FETCH_SIZE + WRITE_SIZE) KiB summed over the family's launches / passes"}
+out = {"round": 1, "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph  (bf16)",
+       "correction": "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); counters are KiB; "
+                     "%d passes profiled (1 record + 1 warm-up + 2 steps + 5 event-timing passes of the conv launches)" % passes_per_run,
+       "batch": batch, "families": {}}
 for fam, d in acc.items():
-    out[fam] = {"fetch_bytes_per_step": 2 * d.get("FETCH_SIZE", 0) * 1024 / passes_per_run, "write_bytes_per_step": d.get("WRITE_SIZE", 0) * 1024 / passes_per_run}
-    out[fam]["hbm_bytes_per_step"] = out[fam]["fetch_bytes_per_step"] + out[fam]["write_bytes_per_step"]
+    e = {"fetch_bytes_per_step": 2 * d.get("FETCH_SIZE", 0) * 1024 / passes_per_run, "write_bytes_per_step": d.get("WRITE_SIZE", 0) * 1024 / passes_per_run}
+    e["hbm_bytes_per_step"] = e["fetch_bytes_per_step"] + e["write_bytes_per_step"]
+    out["families"][fam] = e
 print(json.dumps(out, indent=1))
