@@ -1,0 +1,28 @@
+// Kernel-side argument block shared by the implicit-GEMM convolution kernels (conv_igemm.hip, conv_gemm_glds.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dy {
+
+struct ConvArgs {
+  const void* x;
+  const void* x2;
+  const void* w;
+  const float* bias;
+  const void* res;
+  void* y;
+  int H, W, Cin, ldx, ldx2, split;  // split: channels [0,split) come from x, the rest from x2
+  int HB, WB;                        // buffer dims of x (H/2, W/2 when up2x)
+  int Ho, Wo, Cout, ldy, ldres;
+  int ks, stride, pad;
+  int Kpad, M, HoWo;
+  int act, up2x;
+  int tilesN, nblk;
+  int vec_store;
+};
+
+// conv_gemm_glds.hip: LDS-DMA staged 128 x {64,128} tile.  Returns 1 when the shape is not one it is built for
+// (the caller then runs the generic kernel), else the launch status.
+int conv_gemm_glds_try(const ConvArgs& a, int dtype, bool out_f32, hipStream_t st);
+
+}  // namespace dy

@@ -1,0 +1,246 @@
+// Implicit-GEMM convolution with LDS-DMA staging (global_load_lds_dwordx4) for the deep layers: 1x1 convolutions
+// with many input channels, stride-2 3x3 downsamples and 3x3 layers on small maps, where the halo kernel's spatial
+// tiles waste lanes (20x20 maps fill 39 % of a 16x16 tile) and the generic kernel's 32x64 wave tiles are LDS-read bound.
+//
+// GEMM view as in conv_igemm.hip: C[M][N] = A[M][K] * W[N][K]^T, M = batch*Ho*Wo pixels flattened (no spatial
+// tile, so any map size fills the tile), N = Cout, K = (r, q, c) with c fastest; weights in DY_WLAYOUT_ROWS.
+//
+// Workgroup = 256 threads = 4 waves as 2 (M) x 2 (N); tile 128 pixels x BN couts (BN = 128 or 64); each wave owns
+// 64 x BN/2 -> per 32-deep k-group 4 + BN/32 fragment reads feed 4 * BN/32 MFMAs (0.5 reads per MFMA at BN = 128).
+// K-step = 128 bytes of K per row (64 bf16 / 32 fp32 channels of ONE tap: Cin % that == 0 is required).
+//
+// Staging: every wave-instruction of the LDS-DMA moves a PIECE = 8 rows x 128 B = 1 KiB: lane l fetches the 16-byte
+// chunk (l & 7) ^ swz(row) of row 8*piece + (l >> 3), so eight consecutive lanes cover one full 128-byte line of
+// global memory (coalesced) and the LDS image is plain row-major [rows][128 B] with the chunks of a row XOR-swizzled
+// by swz(row) = (row >> 1) & 7 — the swizzle is applied on the SOURCE address because the LDS side of the DMA is
+// lane-linear.  The MFMA operand read (lane (lr, lq): row lr, chunk 4*s + lq) then hits 16 distinct 16-byte units of
+// the 256-byte bank row in every 16-lane group of ds_read_b128.
+// Rows outside the image (zero padding) or beyond M fetch from a zero page instead.
+// Two LDS stages; the DMA of step s+1 is issued right after the barrier that publishes step s and runs under its MFMAs.
+// Epilogue: weights are the MFMA A operand, so a lane holds 4 consecutive couts of one pixel: bias (accumulator
+// init), SiLU, residual, per-wave LDS transpose, 16-byte row stores.
+#include "common.cuh"
+#include "conv_args.h"
+
+namespace dy {
+
+__device__ __attribute__((aligned(256))) const unsigned int g_zero_page[64] = {0};
+
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const ConvArgs p) {
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int BM = 128;
+  constexpr int BKE = 8 * EPC;          // K elements per step (128 bytes)
+  constexpr int NFR = BN / 32;          // cout fragments per wave (wave tile 64 x BN/2)
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int PA = BM / 8 / 4;        // A pieces per wave per step
+  constexpr int PB = BN / 8 / 4;        // W pieces per wave per step
+  constexpr int EG0 = 128 / (16 * (int)sizeof(T));  // cout fragments whose 16 couts fill 128 bytes of a pixel row
+  constexpr int EG = NFR < EG0 ? NFR : EG0;          // fragments per epilogue group
+  constexpr int CPP = EG * (int)sizeof(T);           // 16-byte chunks per pixel and group
+  constexpr int EP_PITCH = 128 + 16;
+  static_assert(64 * EP_PITCH * 4 <= 2 * STAGE, "epilogue scratch must fit the stage memory");
+
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lq = lane >> 4, lr = lane & 15;
+  const unsigned L = xcd_remap(blockIdx.x, (unsigned)p.nblk);
+  const int tileN = (int)(L % (unsigned)p.tilesN);
+  const int tileM = (int)(L / (unsigned)p.tilesN);
+
+  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ x2g = reinterpret_cast<const T*>(p.x2);
+  const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+  const T* zp = reinterpret_cast<const T*>(g_zero_page) + (lane & 7) * EPC;
+
+  // ---- per-lane gather bookkeeping: the rows this lane fetches never change over the K loop ----
+  const int prow = lane >> 3;  // row inside a piece
+  int a_n[PA], a_hi0[PA], a_wi0[PA], a_sw[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int row = (wave * PA + i) * 8 + prow;
+    const int m = tileM * BM + row;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    const int n = mm / p.HoWo;
+    const int rem = mm - n * p.HoWo;
+    const int ho = rem / p.Wo;
+    const int wo = rem - ho * p.Wo;
+    a_n[i] = n;
+    a_hi0[i] = ok ? ho * p.stride - p.pad : -(1 << 28);
+    a_wi0[i] = wo * p.stride - p.pad;
+    a_sw[i] = (((lane & 7) ^ ((row >> 1) & 7))) * EPC;
+  }
+  const T* b_ptr[PB];
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    const int row = (wave * PB + j) * 8 + prow;
+    b_ptr[j] = wg + (size_t)(tileN * BN + row) * (size_t)p.Kpad + (size_t)(((lane & 7) ^ ((row >> 1) & 7)) * EPC);
+  }
+
+  int kc = 0, kr = 0, kq = 0;  // (tap, channel) of the NEXT step to issue (wave-uniform)
+  auto issue = [&](int step, int stage) {
+    unsigned char* sa = smem + stage * STAGE;
+    unsigned char* sb = sa + A_BYTES;
+    const bool from_x = kc < p.split;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int hi = a_hi0[i] + kr, wi = a_wi0[i] + kq;
+      const bool ok = ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
+      const T* ptr;  // computed for every lane (never dereferenced when !ok): keeps the gather branch-free
+      if (from_x) {
+        const int hb = p.up2x ? (hi >> 1) : hi, wb = p.up2x ? (wi >> 1) : wi;
+        ptr = xg + (long long)((a_n[i] * p.HB + hb) * p.WB + wb) * (long long)p.ldx + (long long)(kc + a_sw[i]);
+      } else {
+        ptr = x2g + (long long)((a_n[i] * p.H + hi) * p.W + wi) * (long long)p.ldx2 + (long long)(kc - p.split + a_sw[i]);
+      }
+      const T* src = ok ? ptr : zp;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sa + (wave * PA + i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[j] + (size_t)step * BKE),
+                                       (__attribute__((address_space(3))) void*)(sb + (wave * PB + j) * 1024), 16, 0, 0);
+    kc += BKE;
+    if (kc >= p.Cin) {
+      kc = 0;
+      if (++kq == p.ks) {
+        kq = 0;
+        ++kr;
+      }
+    }
+  };
+
+  // ---- accumulators, initialised with the bias of this lane's couts ----
+  f32x4 acc[NFR][4];
+#pragma unroll
+  for (int j = 0; j < NFR; ++j) {
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + tileN * BN + wn * (BN / 2) + j * 16 + lq * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = bb;
+  }
+
+  const int swz = lr >> 1;  // (row >> 1) & 7 of every fragment row this lane reads (fragment bases are multiples of 16)
+  auto compute = [&](int stage) {
+    const unsigned char* sa = smem + stage * STAGE + (wm * 64 + lr) * 128;
+    const unsigned char* sb = smem + stage * STAGE + A_BYTES + (wn * (BN / 2) + lr) * 128;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int slot = ((s * 4 + lq) ^ swz) * 16;
+      u32x4 a[4], b[NFR];
+#pragma unroll
+      for (int j = 0; j < NFR; ++j) b[j] = *reinterpret_cast<const u32x4*>(sb + j * 16 * 128 + slot);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const u32x4*>(sa + i * 16 * 128 + slot);
+#pragma unroll
+      for (int j = 0; j < NFR; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = Elem<T>::mma(b[j], a[i], acc[j][i]);
+    }
+  };
+
+  // ---- main loop: one barrier per K-step, the next step's DMA runs under this step's MFMAs ----
+  const int nsteps = p.Kpad / BKE;
+  issue(0, 0);
+  for (int s = 0; s < nsteps; ++s) {
+    __syncthreads();  // drains this wave's DMA (vmcnt(0)) and publishes stage s&1; everyone is done with stage (s+1)&1
+    if (s + 1 < nsteps) issue(s + 1, (s + 1) & 1);
+    compute(s & 1);
+  }
+  mfma_epilogue_fence<T>();
+  __syncthreads();  // stage memory becomes the per-wave transpose scratch
+
+  // ---- epilogue ----
+  unsigned char* escr = smem + wave * (64 * EP_PITCH);
+  T* __restrict__ yg = reinterpret_cast<T*>(p.y);
+  const T* __restrict__ rg = reinterpret_cast<const T*>(p.res);
+  const int m0 = tileM * BM + wm * 64;
+  const int n0 = tileN * BN + wn * (BN / 2);
+#pragma unroll
+  for (int g = 0; g < NFR / EG; ++g) {
+#pragma unroll
+    for (int jj = 0; jj < EG; ++jj) {
+      const int j = g * EG + jj;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
+        if (p.act == DY_ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
+        }
+        if (rg != nullptr) {
+          const int m = m0 + i * 16 + lr;
+          if (m < p.M) {
+            typedef __attribute__((ext_vector_type(4))) T t4;
+            const t4 rv = *reinterpret_cast<const t4*>(rg + (size_t)m * (size_t)p.ldres + (size_t)(n0 + j * 16 + lq * 4));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += Elem<T>::to_f32(rv[e]);
+          }
+        }
+        unsigned char* sp = escr + (i * 16 + lr) * EP_PITCH + (jj * 16 + lq * 4) * (int)sizeof(T);
+        if constexpr (sizeof(T) == 4) {
+          *reinterpret_cast<f32x4*>(sp) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+          typedef __attribute__((ext_vector_type(4))) T t4;
+          t4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f32(v[e]);
+          *reinterpret_cast<u32x2*>(sp) = __builtin_bit_cast(u32x2, o);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < CPP; ++k) {  // 64 pixels x CPP chunks of 16 bytes
+      const int idx = k * 64 + lane;
+      const int px = idx / CPP, cc = idx % CPP;
+      const int m = m0 + px;
+      if (m < p.M) {
+        const u32x4 val = *reinterpret_cast<const u32x4*>(escr + px * EP_PITCH + cc * 16);
+        *reinterpret_cast<u32x4*>(yg + (size_t)m * (size_t)p.ldy + (size_t)(n0 + g * EG * 16 + cc * EPC)) = val;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+template <typename T, int BN>
+static int launch_glds(const ConvArgs& a, hipStream_t st) {
+  ConvArgs p = a;
+  const int tilesM = (p.M + 127) / 128;
+  p.tilesN = p.Cout / BN;
+  p.nblk = tilesM * p.tilesN;
+  hipLaunchKernelGGL((conv_gemm_glds_kernel<T, BN>), dim3((unsigned)p.nblk), dim3(256), 0, st, p);
+  return check_launch("conv_gemm_glds_kernel");
+}
+
+template <typename T>
+static int launch_glds_dtype(const ConvArgs& a, hipStream_t st) {
+  if (a.Cout % 128 == 0) return launch_glds<T, 128>(a, st);
+  return launch_glds<T, 64>(a, st);
+}
+
+int conv_gemm_glds_try(const ConvArgs& a, int dtype, bool out_f32, hipStream_t st) {
+  static const int off = getenv("DYOLO_NO_GLDS") ? atoi(getenv("DYOLO_NO_GLDS")) : 0;
+  const int es = dy_dtype_size(dtype);
+  const int bke = 8 * (16 / es);
+  if (off || out_f32 || !a.vec_store) return 1;
+  if (a.Cin % bke || a.split % bke || a.Cout % 64 || a.Kpad != a.ks * a.ks * a.Cin) return 1;
+  // no threshold on M: which kernel runs must not depend on the batch size, so that an image's result is bit-identical
+  // whatever batch it arrives in (tests/test_model_gpu.py::test_full_size_properties)
+  if (a.res && a.ldres % 4) return 1;
+  switch (dtype) {
+    case DY_BF16: return launch_glds_dtype<bf16_t>(a, st);
+    case DY_F16: return launch_glds_dtype<f16_t>(a, st);
+    default: return launch_glds_dtype<float>(a, st);
+  }
+}
+
+}  // namespace dy

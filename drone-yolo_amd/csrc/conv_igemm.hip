@@ -21,26 +21,11 @@
 // Reference semantics: nn/modules/conv.py:37-55 (Conv), block.py:337-350 (Bottleneck
 // residual), block.py:1480-1490 (RepVGGBlock, folded), head.py:43-57 (Detect convs).
 #include "common.cuh"
+#include "conv_args.h"
 #include <type_traits>
 
 namespace dy {
 
-struct ConvArgs {
-  const void* x;
-  const void* x2;
-  const void* w;
-  const float* bias;
-  const void* res;
-  void* y;
-  int H, W, Cin, ldx, ldx2, split;  // split: channels [0,split) come from x, the rest from x2
-  int HB, WB;                        // buffer dims of x (H/2, W/2 when up2x)
-  int Ho, Wo, Cout, ldy, ldres;
-  int ks, stride, pad;
-  int Kpad, M, HoWo;
-  int act, up2x;
-  int tilesN, nblk;
-  int vec_store;
-};
 
 template <typename T, int BM, int BN, bool OUTF32>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
@@ -451,6 +436,10 @@ extern "C" int32_t dy_conv2d_nhwc(const dy_conv_desc* d, dy_stream_t stream) {
   const int oes = d->out_f32 ? 4 : es;
   a.vec_store = (aligned16(d->y) && (d->ld_y * oes) % 16 == 0) ? 1 : 0;
 
+  {
+    const int rc = conv_gemm_glds_try(a, d->dtype, d->out_f32 != 0, st);  // big-tile LDS-DMA kernel where it is built
+    if (rc <= 0) return rc;
+  }
   switch (d->dtype) {
     case DY_BF16:
       return d->out_f32 ? launch_dtype<bf16_t, true>(a, st) : launch_dtype<bf16_t, false>(a, st);

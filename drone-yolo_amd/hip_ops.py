@@ -156,7 +156,12 @@ class PackedConv:
         self.layout = _lib.DY_WLAYOUT_ROWS
         # stride-2 halo tiles are 17x33 pixels (2 x 45 KB of LDS): only a weight set of <= 36 KB fits beside them
         s2_fits = self.cin <= 4 * elems_per_chunk(dtype) and cout > 32 or self.cin <= 8 * elems_per_chunk(dtype) and cout <= 32
-        if (halo is None or halo) and groups == 1 and k == 3 and pad == 1 and (stride == 1 or (stride == 2 and s2_fits)) \
+        # deep 3x3 layers (small maps, weight sets far beyond LDS) run faster as a flat-M implicit GEMM on the LDS-DMA
+        # big-tile kernel behind DY_WLAYOUT_ROWS (conv_gemm_glds.hip): measured at batch 128, 256->256 @20x20 90 vs 162 us
+        kstep = 8 * elems_per_chunk(dtype)
+        deep3x3 = halo is None and k == 3 and stride == 1 and self.cin % kstep == 0 and cout % 64 == 0 and \
+            ((self.cin >= 128 and cout >= 128) or self.cin >= 512)
+        if (halo is None or halo) and not deep3x3 and groups == 1 and k == 3 and pad == 1 and (stride == 1 or (stride == 2 and s2_fits)) \
                 and cout % 4 == 0 and self.cin >= 4 * elems_per_chunk(dtype) // 2:
             # LDS-halo 3x3 kernel: MFMA-fragment-ordered weights (include/dyolo.h, DY_WLAYOUT_HALO3X3)
             self.layout = _lib.DY_WLAYOUT_HALO3X3

@@ -87,6 +87,52 @@ def test_conv_matches_cpu(case, dtype, device):
     check_close(back(y), ref, dtype, f"conv {tag}")
 
 
+GLDS_CASES = [
+    # cin, cout, k, s, B, H, W, tag — ROWS layout, M >= 8192 and whole 128-byte K-steps: the LDS-DMA big-tile kernel
+    (128, 128, 3, 1, 6, 40, 40, "3x3 s1 BN=128"),
+    (256, 64, 3, 1, 6, 40, 40, "3x3 s1 BN=64"),
+    (128, 256, 3, 2, 3, 111, 97, "3x3 s2 odd dims, M tail"),
+    (768, 512, 1, 1, 24, 20, 20, "1x1 wide K"),
+    (64, 192, 1, 1, 3, 64, 63, "1x1 cout=192 (BN=64), M tail"),
+    (256, 256, 3, 1, 22, 20, 20, "3x3 on 20x20 maps"),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("case", GLDS_CASES, ids=[c[-1] for c in GLDS_CASES])
+def test_conv_glds_big_tile_matches_cpu(case, dtype, device):
+    cin, cout, k, s, b, h, w, tag = case
+    g = torch.Generator().manual_seed(hash(tag) % 1000)
+    x = quantize(torch.randn(b, cin, h, w, generator=g), dtype)
+    wt = quantize(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5, dtype)
+    bias = torch.randn(cout, generator=g) * 0.2
+    ref = F.silu(F.conv2d(x, wt, bias, s, k // 2))
+    pc = H.PackedConv(wt, bias, s, k // 2, 1, True, dtype, device, halo=False)
+    xd = nhwc(x, dtype, device, ld=cin + 16, c_off=8)  # a channel slice of a wider buffer
+    y = H.conv2d(xd, pc)
+    torch.cuda.synchronize()
+    check_close(back(y), ref, dtype, f"glds conv {tag}")
+    if k == 3 and s == 1 and cin == cout:  # Bottleneck residual
+        y2 = H.conv2d(xd, pc, residual=xd)
+        torch.cuda.synchronize()
+        check_close(back(y2), ref + x, dtype, f"glds conv + residual {tag}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+def test_conv_glds_dual_source_upsample(dtype, device):
+    """C2f.cv1 on cat(upsample2x(a), b) at a size that takes the LDS-DMA kernel (split on a K-step boundary)."""
+    g = torch.Generator().manual_seed(19)
+    a = quantize(torch.randn(3, 128, 30, 32, generator=g), dtype)
+    bsk = quantize(torch.randn(3, 64, 60, 64, generator=g), dtype)
+    wt = quantize(torch.randn(128, 192, 1, 1, generator=g) * 0.1, dtype)
+    bias = torch.randn(128, generator=g) * 0.1
+    pc = H.PackedConv(wt, bias, 1, 0, 1, True, dtype, device, halo=False)
+    y = H.conv2d(nhwc(a, dtype, device), pc, up2x=True, x2=nhwc(bsk, dtype, device))
+    torch.cuda.synchronize()
+    ref = F.silu(F.conv2d(torch.cat((F.interpolate(a, scale_factor=2.0, mode="nearest"), bsk), 1), wt, bias))
+    check_close(back(y), ref, dtype, "glds dual-source up2x conv")
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 def test_conv_slices_residual_and_f32_out(dtype, device):
     g = torch.Generator().manual_seed(7)
