@@ -26,25 +26,29 @@ namespace dy {
 
 __device__ __attribute__((aligned(256))) const unsigned int g_zero_page[64] = {0};
 
-template <typename T, int BN>
-__global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const ConvArgs p) {
+// BM x BN tile, WM x 2 waves (wave tile 64 x BN/2), STAGES LDS stages.  STAGES == 2: plain barrier per K-step, one step of
+// DMA in flight (2 workgroups per CU cover for each other).  STAGES == 3: two steps in flight behind a counted
+// s_waitcnt vmcnt(N) and a raw s_barrier (a __syncthreads() would drain the DMA), one 8-wave workgroup per CU.
+template <typename T, int BM, int BN, int STAGES>
+__global__ __launch_bounds__(BM * 2) void conv_gemm_glds_kernel(const ConvArgs p) {
   constexpr int EPC = Elem<T>::EPC;
-  constexpr int BM = 128;
+  constexpr int NW = BM / 64 * 2;       // waves: BM/64 along M x 2 along N
   constexpr int BKE = 8 * EPC;          // K elements per step (128 bytes)
   constexpr int NFR = BN / 32;          // cout fragments per wave (wave tile 64 x BN/2)
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int PA = BM / 8 / 4;        // A pieces per wave per step
-  constexpr int PB = BN / 8 / 4;        // W pieces per wave per step
+  constexpr int PA = BM / 8 / NW;       // A pieces per wave per step
+  constexpr int PB = BN / 8 / NW;       // W pieces per wave per step
+  static_assert(PA >= 1 && PB >= 1, "every wave stages at least one piece of each operand");
   constexpr int EG0 = 128 / (16 * (int)sizeof(T));  // cout fragments whose 16 couts fill 128 bytes of a pixel row
   constexpr int EG = NFR < EG0 ? NFR : EG0;          // fragments per epilogue group
   constexpr int CPP = EG * (int)sizeof(T);           // 16-byte chunks per pixel and group
   constexpr int EP_PITCH = 128 + 16;
-  static_assert(64 * EP_PITCH * 4 <= 2 * STAGE, "epilogue scratch must fit the stage memory");
+  static_assert(64 * EP_PITCH * NW <= STAGES * STAGE, "epilogue scratch must fit the stage memory");
 
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[STAGES * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave >> 1, wn = wave & 1;  // BM/64 x 2 wave grid
   const int lq = lane >> 4, lr = lane & 15;
   const unsigned L = xcd_remap(blockIdx.x, (unsigned)p.nblk);
   const int tileN = (int)(L % (unsigned)p.tilesN);
@@ -144,11 +148,33 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const ConvArgs p) {
 
   // ---- main loop: one barrier per K-step, the next step's DMA runs under this step's MFMAs ----
   const int nsteps = p.Kpad / BKE;
-  issue(0, 0);
-  for (int s = 0; s < nsteps; ++s) {
-    __syncthreads();  // drains this wave's DMA (vmcnt(0)) and publishes stage s&1; everyone is done with stage (s+1)&1
-    if (s + 1 < nsteps) issue(s + 1, (s + 1) & 1);
-    compute(s & 1);
+  if constexpr (STAGES == 2) {
+    issue(0, 0);
+    for (int s = 0; s < nsteps; ++s) {
+      __syncthreads();  // drains this wave's DMA (vmcnt(0)) and publishes stage s&1; everyone is done with stage (s+1)&1
+      if (s + 1 < nsteps) issue(s + 1, (s + 1) & 1);
+      compute(s & 1);
+    }
+  } else {
+    issue(0, 0);
+    if (nsteps > 1) issue(1, 1);
+    int st = 0;  // stage of step s
+    for (int s = 0; s < nsteps; ++s) {
+      // step s must have landed; step s+1 (PA + PB younger DMAs of this wave) may stay in flight
+      if (s + 1 < nsteps) {
+        if constexpr (PA + PB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (PA + PB == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if constexpr (PA + PB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();  // every wave's step-s DMA landed, every wave finished the MFMAs of step s-1
+      const int st2 = st == 0 ? 2 : st - 1;  // stage of step s+2 == stage of step s-1, free again
+      if (s + 2 < nsteps) issue(s + 2, st2);
+      compute(st);
+      st = st == 2 ? 0 : st + 1;
+    }
   }
   mfma_epilogue_fence<T>();
   __syncthreads();  // stage memory becomes the per-wave transpose scratch
@@ -211,20 +237,25 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const ConvArgs p) {
   }
 }
 
-template <typename T, int BN>
+template <typename T, int BM, int BN, int STAGES>
 static int launch_glds(const ConvArgs& a, hipStream_t st) {
   ConvArgs p = a;
-  const int tilesM = (p.M + 127) / 128;
+  const int tilesM = (p.M + BM - 1) / BM;
   p.tilesN = p.Cout / BN;
   p.nblk = tilesM * p.tilesN;
-  hipLaunchKernelGGL((conv_gemm_glds_kernel<T, BN>), dim3((unsigned)p.nblk), dim3(256), 0, st, p);
+  auto kern = conv_gemm_glds_kernel<T, BM, BN, STAGES>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)p.nblk), dim3(BM * 2), 0, st, p);  // static LDS only (up to 144 KiB)
   return check_launch("conv_gemm_glds_kernel");
 }
 
 template <typename T>
 static int launch_glds_dtype(const ConvArgs& a, hipStream_t st) {
-  if (a.Cout % 128 == 0) return launch_glds<T, 128>(a, st);
-  return launch_glds<T, 64>(a, st);
+  static const int big = getenv("DYOLO_GLDS_BIG") ? atoi(getenv("DYOLO_GLDS_BIG")) : 0;
+  if (a.Cout % 128 == 0) {
+    if (big) return launch_glds<T, 256, 128, 3>(a, st);
+    return launch_glds<T, 128, 128, 2>(a, st);
+  }
+  return launch_glds<T, 128, 64, 2>(a, st);
 }
 
 int conv_gemm_glds_try(const ConvArgs& a, int dtype, bool out_f32, hipStream_t st) {

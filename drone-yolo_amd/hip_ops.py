@@ -160,7 +160,7 @@ class PackedConv:
         # big-tile kernel behind DY_WLAYOUT_ROWS (conv_gemm_glds.hip): measured at batch 128, 256->256 @20x20 90 vs 162 us
         kstep = 8 * elems_per_chunk(dtype)
         deep3x3 = halo is None and k == 3 and stride == 1 and self.cin % kstep == 0 and cout % 64 == 0 and \
-            ((self.cin >= 128 and cout >= 128) or self.cin >= 512)
+            self.cin >= 128 and cout >= 128
         if (halo is None or halo) and not deep3x3 and groups == 1 and k == 3 and pad == 1 and (stride == 1 or (stride == 2 and s2_fits)) \
                 and cout % 4 == 0 and self.cin >= 4 * elems_per_chunk(dtype) // 2:
             # LDS-halo 3x3 kernel: MFMA-fragment-ordered weights (include/dyolo.h, DY_WLAYOUT_HALO3X3)

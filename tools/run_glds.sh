@@ -1,4 +1,3 @@
-SH="256,256,3,1,20 512,64,3,1,20 128,128,3,1,40 256,64,3,1,40 128,64,3,1,80 64,128,3,2,160 128,256,3,2,80 256,512,3,2,40 64,64,3,2,160 128,128,3,2,80 256,256,3,2,40 768,512,1,1,20 1024,512,1,1,20 512,256,1,1,40 768,256,1,1,40 384,256,1,1,40 512,512,1,1,20 256,256,1,1,40 256,128,1,1,80 384,128,1,1,80 192,128,1,1,80 128,128,1,1,80 192,64,1,1,160"
-echo "== halo/frag default"; python tools/bench_conv.py --batch 128 --halo 1 $SH
-echo "== rows + glds"; python tools/bench_conv.py --batch 128 --halo 0 $SH
-echo "== rows generic"; DYOLO_NO_GLDS=1 python tools/bench_conv.py --batch 128 --halo 0 $SH
+SH="256,256,3,1,20 128,128,3,1,40 64,128,3,2,160 128,256,3,2,80 256,512,3,2,40 128,128,3,2,80 256,256,3,2,40 768,512,1,1,20 1024,512,1,1,20 512,256,1,1,40 768,256,1,1,40 512,512,1,1,20"
+echo "== rows + glds 128x128x2"; python tools/bench_conv.py --batch 128 --halo 0 $SH
+echo "== rows + glds 256x128x3"; DYOLO_GLDS_BIG=1 python tools/bench_conv.py --batch 128 --halo 0 $SH
