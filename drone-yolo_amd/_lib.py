@@ -91,6 +91,7 @@ class LossDesc(C.Structure):
         ("gt", _vp), ("gmax", _i32), ("topk", _i32),
         ("alpha", _f32), ("beta", _f32), ("box_gain", _f32), ("cls_gain", _f32), ("dfl_gain", _f32),
         ("out", _vp), ("out_owner", _vp), ("workspace", _vp), ("workspace_bytes", _i64),
+        ("grad_level", _vp * DY_MAX_LEVELS), ("ld_grad", _i32 * DY_MAX_LEVELS),
     ]  # fmt: skip
 
 

@@ -36,6 +36,8 @@ struct LossArgs {
   unsigned* gmax_ov; // (batch, gmax) max overlap
   double* acc;       // [0] sum softplus, [1] sum t, [2] sum x_cls*t, [3] sum (1-ciou)*t, [4] sum dfl*t, [5] n_fg
   float* out;        // [4] box, cls, dfl (after gains), total = sum * batch
+  float* glevel[DY_MAX_LEVELS];  // optional: d total / d level[l], same NHWC geometry, pitch gld[l]
+  int gld[DY_MAX_LEVELS];
 };
 
 constexpr int kRegMax = 16;
@@ -281,6 +283,130 @@ __global__ __launch_bounds__(256) void loss_fg_kernel(const LossArgs p) {
   }
 }
 
+// ---- K7: gradient of total = (box + cls + dfl) * batch w.r.t. the raw head outputs -----------------------------------
+// What autograd gives the reference for loss.sum() * batch_size (loss.py:260, trainer.py:381-389): the assignment, the
+// soft targets and target_scores_sum are constants (assigner under no_grad, tal.py:60); CIoU's alpha is a constant
+// (metrics.py:127-128).  Forward-mode differentiation of CIoU w.r.t. the four predicted corners.
+struct D4 {
+  float v, g[4];
+};
+__device__ __forceinline__ D4 dconst(float c) { return D4{c, {0.f, 0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ D4 dvar(float c, int i) {
+  D4 r = dconst(c);
+  r.g[i] = 1.f;
+  return r;
+}
+__device__ __forceinline__ D4 operator+(D4 a, D4 b) { return D4{a.v + b.v, {a.g[0] + b.g[0], a.g[1] + b.g[1], a.g[2] + b.g[2], a.g[3] + b.g[3]}}; }
+__device__ __forceinline__ D4 operator-(D4 a, D4 b) { return D4{a.v - b.v, {a.g[0] - b.g[0], a.g[1] - b.g[1], a.g[2] - b.g[2], a.g[3] - b.g[3]}}; }
+__device__ __forceinline__ D4 operator*(D4 a, D4 b) {
+  return D4{a.v * b.v, {a.g[0] * b.v + a.v * b.g[0], a.g[1] * b.v + a.v * b.g[1], a.g[2] * b.v + a.v * b.g[2], a.g[3] * b.v + a.v * b.g[3]}};
+}
+__device__ __forceinline__ D4 operator/(D4 a, D4 b) {
+  const float q = a.v / b.v, ib = 1.f / b.v;
+  return D4{q, {(a.g[0] - q * b.g[0]) * ib, (a.g[1] - q * b.g[1]) * ib, (a.g[2] - q * b.g[2]) * ib, (a.g[3] - q * b.g[3]) * ib}};
+}
+__device__ __forceinline__ D4 dscale(D4 a, float c) { return D4{a.v * c, {a.g[0] * c, a.g[1] * c, a.g[2] * c, a.g[3] * c}}; }
+__device__ __forceinline__ D4 dmaxc(D4 a, float c) { return a.v >= c ? a : dconst(c); }  // torch.maximum(a, const) / clamp(min=c)
+__device__ __forceinline__ D4 dminc(D4 a, float c) { return a.v <= c ? a : dconst(c); }
+__device__ __forceinline__ D4 datan(D4 a) {
+  const float d = 1.f / (1.f + a.v * a.v);
+  return D4{atanf(a.v), {a.g[0] * d, a.g[1] * d, a.g[2] * d, a.g[3] * d}};
+}
+
+// 1 - CIoU(pred, target) differentiated w.r.t. pred = (x1, y1, x2, y2); same arithmetic as ciou() above with box1 = pred.
+__device__ __forceinline__ D4 ciou_dual(const float* pb, const float* tb) {
+  const float eps = 1e-7f;
+  const D4 x1 = dvar(pb[0], 0), y1 = dvar(pb[1], 1), x2 = dvar(pb[2], 2), y2 = dvar(pb[3], 3);
+  const D4 w1 = x2 - x1, h1 = (y2 - y1) + dconst(eps);
+  const float w2 = tb[2] - tb[0], h2 = tb[3] - tb[1] + eps;
+  const D4 iw = dmaxc(dminc(x2, tb[2]) - dmaxc(x1, tb[0]), 0.f), ih = dmaxc(dminc(y2, tb[3]) - dmaxc(y1, tb[1]), 0.f);
+  const D4 inter = iw * ih;
+  const D4 uni = w1 * h1 + dconst(w2 * h2) - inter + dconst(eps);
+  const D4 iou = inter / uni;
+  const D4 cw = dmaxc(x2, tb[2]) - dminc(x1, tb[0]), ch = dmaxc(y2, tb[3]) - dminc(y1, tb[1]);
+  const D4 c2 = cw * cw + ch * ch + dconst(eps);
+  const D4 dx = dconst(tb[0] + tb[2]) - x1 - x2, dy_ = dconst(tb[1] + tb[3]) - y1 - y2;
+  const D4 rho2 = dscale(dx * dx + dy_ * dy_, 0.25f);
+  const D4 dat = dconst(atanf(w2 / h2)) - datan(w1 / h1);
+  const D4 v = dscale(dat * dat, 0.4052847345693511f);
+  const float alpha = v.v / (v.v - iou.v + (1.f + eps));  // constant under autograd (metrics.py:127)
+  return iou - (rho2 / c2 + dscale(v, alpha));
+}
+
+__global__ __launch_bounds__(256) void loss_grad_kernel(const LossArgs p) {
+  const long long total = (long long)p.batch * p.A;
+  const double tss_d = p.acc[1] > 1.0 ? p.acc[1] : 1.0;
+  const float inv = (float)((double)p.batch / tss_d);  // d total / d (sum of a loss term's numerator)
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int b = (int)(idx / p.A), a = (int)(idx - (long long)b * p.A);
+    int l, gx, gy;
+    const float* r = row_ptr(p, b, a, &l, &gx, &gy);
+    const int al = a - p.a0[l];
+    float* go = p.glevel[l] + ((size_t)b * p.h[l] * p.w[l] + al) * (size_t)p.gld[l];
+    const int g = p.owner[idx];
+    float t = 0.f;
+    int tc = -1;
+    const float* g5 = nullptr;
+    if (g >= 0) {
+      g5 = p.gt + ((size_t)b * p.gmax + g) * 5;
+      float m, ov;
+      pair_metric(p, b, g5, a, &m, &ov);
+      const float pal = __uint_as_float(p.gmax_al[(size_t)b * p.gmax + g]), pov = __uint_as_float(p.gmax_ov[(size_t)b * p.gmax + g]);
+      t = m * pov / (pal + 1e-9f);
+      tc = (int)g5[0];
+    }
+    // class logits: d BCE / dx = sigmoid(x) - target
+    const float* cl = r + 4 * kRegMax;
+    for (int c = 0; c < p.nc; ++c) {
+      const float sg = 1.0f / (1.0f + expf(-cl[c]));
+      go[4 * kRegMax + c] = (sg - (c == tc ? t : 0.f)) * p.cls_gain * inv;
+    }
+    if (g < 0) {  // background anchor: no box / DFL term
+      for (int i = 0; i < 4 * kRegMax; ++i) go[i] = 0.f;
+      continue;
+    }
+    // box bins of a foreground anchor
+    const float st = p.stride[l];
+    const float ax = (float)gx + 0.5f, ay = (float)gy + 0.5f;
+    float pr[4][kRegMax], d[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float* q = r + s * kRegMax;
+      float mx = q[0];
+      for (int i = 1; i < kRegMax; ++i) mx = fmaxf(mx, q[i]);
+      float den = 0.f;
+      for (int i = 0; i < kRegMax; ++i) {
+        pr[s][i] = expf(q[i] - mx);
+        den += pr[s][i];
+      }
+      float num = 0.f;
+      for (int i = 0; i < kRegMax; ++i) {
+        pr[s][i] /= den;
+        num += pr[s][i] * (float)i;
+      }
+      d[s] = num;
+    }
+    const float pb[4] = {ax - d[0], ay - d[1], ax + d[2], ay + d[3]};
+    const float tb[4] = {g5[1] / st, g5[2] / st, g5[3] / st, g5[4] / st};
+    const D4 c = ciou_dual(pb, tb);
+    // d/d dist: x1 = ax - d0, y1 = ay - d1, x2 = ax + d2, y2 = ay + d3; loss term (1 - ciou) * t
+    const float kb = -t * p.box_gain * inv;
+    const float gd[4] = {-c.g[0] * kb, -c.g[1] * kb, c.g[2] * kb, c.g[3] * kb};
+    const float tgt[4] = {ax - tb[0], ay - tb[1], tb[2] - ax, tb[3] - ay};
+    const float kd = t * p.dfl_gain * inv * 0.25f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float tv = fminf(fmaxf(tgt[s], 0.f), (float)(kRegMax - 1) - 0.01f);
+      const int tl = (int)tv;
+      const float wl = (float)(tl + 1) - tv, wr = 1.f - wl;
+      for (int i = 0; i < kRegMax; ++i) {
+        const float onehot = (i == tl ? wl : 0.f) + (i == tl + 1 ? wr : 0.f);
+        go[s * kRegMax + i] = gd[s] * pr[s][i] * ((float)i - d[s]) + kd * (pr[s][i] - onehot);
+      }
+    }
+  }
+}
+
 __global__ void loss_final_kernel(const LossArgs p) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const double tss = p.acc[1] > 1.0 ? p.acc[1] : 1.0;  // loss.py:247
@@ -369,6 +495,14 @@ extern "C" int32_t dy_detection_loss(const dy_loss_desc* d, dy_stream_t stream) 
     hipLaunchKernelGGL(loss_fg_kernel, dim3(blocks), dim3(256), 0, st, a);
   }
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, a);
+  if (d->grad_level[0]) {
+    for (int i = 0; i < d->n_levels; ++i) {
+      DY_REQUIRE(d->grad_level[i] && d->ld_grad[i] >= 4 * d->reg_max + d->nc, DY_ERR_INVALID_ARG, "dy_detection_loss: grad level %d invalid", i);
+      a.glevel[i] = d->grad_level[i];
+      a.gld[i] = d->ld_grad[i];
+    }
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(blocks), dim3(256), 0, st, a);
+  }
   if (d->out_owner) {
     if (hipMemcpyAsync(d->out_owner, a.owner, ba * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return check_launch("dy_detection_loss copy");
   }

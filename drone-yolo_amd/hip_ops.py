@@ -510,11 +510,12 @@ def scale_boxes_(bufs: NmsBuffers, params: torch.Tensor) -> None:
 
 def detection_loss(levels: Sequence[torch.Tensor], gt: torch.Tensor, strides: Sequence[float], nc: int, reg_max: int = 16,
                    topk: int = 10, alpha: float = 0.5, beta: float = 6.0, box: float = 7.5, cls: float = 0.5, dfl: float = 1.5,
-                   want_owner: bool = False):
+                   want_owner: bool = False, want_grad: bool = False):
     """v8DetectionLoss forward through ``dy_detection_loss``.
 
     levels[i]: fp32 NHWC view (N, 4*reg_max+nc, H_i, W_i) — Detect's training-mode outputs; gt: device fp32 (N, gmax, 5)
-    [cls, x1, y1, x2, y2] in pixels, zero rows = padding.  Returns (out[4] = box, cls, dfl, total, owner or None)."""
+    [cls, x1, y1, x2, y2] in pixels, zero rows = padding.  Returns (out[4] = box, cls, dfl, total, owner or None) and,
+    with ``want_grad``, a third item: the list of d total / d levels[i] (fp32 NHWC views shaped like the inputs)."""
     n = levels[0].shape[0]
     d = LossDesc()
     A = 0
@@ -538,5 +539,12 @@ def detection_loss(levels: Sequence[torch.Tensor], gt: torch.Tensor, strides: Se
     ws = torch.empty(lib().dy_detection_loss_workspace_bytes(n, A, gmax, topk), dtype=torch.uint8, device=dev)
     d.out, d.out_owner = out.data_ptr(), (owner.data_ptr() if want_owner else None)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-    _launch(lib().dy_detection_loss, (C.byref(d),), keep=(d, out, owner, ws, gt, *levels))
-    return out, owner
+    grads = None
+    if want_grad:
+        grads = []
+        for i, t in enumerate(levels):
+            gt_ = alloc_nhwc(n, t.shape[1], t.shape[2], t.shape[3], torch.float32, dev, ld=d.ld[i])
+            d.grad_level[i], d.ld_grad[i] = view_params(gt_)
+            grads.append(gt_)
+    _launch(lib().dy_detection_loss, (C.byref(d),), keep=(d, out, owner, ws, gt, *levels, *(grads or ())))
+    return (out, owner, grads) if want_grad else (out, owner)

@@ -256,7 +256,7 @@ int32_t dy_nms(const dy_nms_desc* d, dy_stream_t stream);
 int32_t dy_scale_boxes(float* boxes, const int32_t* counts, const float* params, int32_t batch,
                        int32_t max_det, dy_stream_t stream);
 
-/* ---- training loss (forward) -----------------------------------------------------
+/* ---- training loss (forward + gradient w.r.t. the head outputs) -----------------------------------------------------
  * Replaces: v8DetectionLoss.__call__ (utils/loss.py:206-260) = TaskAlignedAssigner (utils/tal.py:14-295, topk /
  * alpha / beta as given) + BCE class loss + CIoU box loss (utils/metrics.py:74-134) + DFL (loss.py:65-113), on the
  * raw head outputs Detect returns in training mode (head.py:71-72).
@@ -264,7 +264,11 @@ int32_t dy_scale_boxes(float* boxes, const int32_t* counts, const float* params,
  * gt: DEVICE fp32 (batch, gmax, 5) = class, x1, y1, x2, y2 in input pixels, zero rows = padding (the output of
  * v8DetectionLoss.preprocess, loss.py:180-195).  out: fp32[4] = box, cls, dfl (after gains), total = sum * batch.
  * out_owner: optional int32 (batch, A): index of the ground-truth box each anchor is assigned to, or -1.
- * Assignment is sparse (no (batch, gmax, A) tensors).  Gradients are not produced yet. */
+ * Assignment is sparse (no (batch, gmax, A) tensors).
+ * grad_level[l] (optional, all or none): fp32 NHWC (batch, h_l, w_l, 4*reg_max + nc), pitch ld_grad[l]; receives
+ * d total / d level[l] — what loss.backward() hands to the Detect head in the reference trainer (engine/trainer.py:381-389);
+ * the assignment, soft targets, target_scores_sum and CIoU's alpha are constants exactly as under autograd
+ * (tal.py:60 no_grad, metrics.py:127-128). */
 typedef struct dy_loss_desc {
   const float* level[DY_MAX_LEVELS];
   int32_t h[DY_MAX_LEVELS], w[DY_MAX_LEVELS], ld[DY_MAX_LEVELS];
@@ -277,6 +281,8 @@ typedef struct dy_loss_desc {
   int32_t* out_owner;
   void* workspace;
   int64_t workspace_bytes;
+  float* grad_level[DY_MAX_LEVELS];
+  int32_t ld_grad[DY_MAX_LEVELS];
 } dy_loss_desc;
 int64_t dy_detection_loss_workspace_bytes(int32_t batch, int32_t anchors, int32_t gmax, int32_t topk);
 int32_t dy_detection_loss(const dy_loss_desc* d, dy_stream_t stream);

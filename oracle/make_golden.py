@@ -434,15 +434,26 @@ def loss_vectors(R):
         gg = torch.Generator().manual_seed(seed)
         feats = [torch.randn(bs, 74, hw // s, hw // s, generator=gg) * 1.5 for s in (4, 8, 16, 32)]
         labels = LO.synthetic_labels(bs, seed, n_mean=6.0 if hw == 64 else 14.0)
-        ref_total, ref_items = crit([f.clone() for f in feats], labels)
-        our_total, our_items, asg = LO.v8_detection_loss(feats, labels, [4.0, 8.0, 16.0, 32.0], 10, return_assign=True)
+        rfeats = [f.clone().requires_grad_(True) for f in feats]
+        ref_total, ref_items = crit(rfeats, labels)
+        ref_total.backward()  # d(loss.sum() * B) / d head outputs: what the trainer back-propagates (trainer.py:381-389)
+        ofeats = [f.clone().requires_grad_(True) for f in feats]
+        our_total, our_items, asg = LO.v8_detection_loss(ofeats, labels, [4.0, 8.0, 16.0, 32.0], 10, return_assign=True)
+        our_total.backward()
+        for li, (rf, of) in enumerate(zip(rfeats, ofeats)):
+            rel_tol_check(f"v8DetectionLoss {tag} grad level {li}", of.grad, rf.grad, tol=2e-5)
+        our_total = our_total.detach()
         rel_tol_check(f"v8DetectionLoss {tag} items (box, cls, dfl)", our_items, ref_items, tol=2e-5)
         rel_tol_check(f"v8DetectionLoss {tag} total", our_total.view(1), ref_total.detach().view(1), tol=2e-5)
         print(f"    {tag}: loss {float(ref_total):.4f} items {[round(float(v), 5) for v in ref_items]} fg {int(asg['fg_mask'].sum())} labels {labels['cls'].numel()}")
         out.update({f"{tag}_meta": np.array(repr(dict(bs=bs, hw=hw, seed=seed, n_mean=6.0 if hw == 64 else 14.0))),
                     f"{tag}_total": np.array(float(ref_total)), f"{tag}_items": tnp(ref_items),
                     f"{tag}_fg": tnp(asg["fg_mask"]), f"{tag}_gt_idx": tnp(asg["target_gt_idx"]),
-                    f"{tag}_tscore_sum": np.array(float(asg["target_scores"].sum()))})
+                    f"{tag}_tscore_sum": np.array(float(asg["target_scores"].sum())),
+                    f"{tag}_grad_abs_sum": np.array([float(f.grad.abs().sum()) for f in rfeats]),
+                    f"{tag}_grad_sum": np.array([float(f.grad.double().sum()) for f in rfeats])})
+        if tag == "loss64":  # the full gradient of the small case (the big one is pinned by its sums)
+            out.update({f"{tag}_grad{li}": tnp(f.grad) for li, f in enumerate(rfeats)})
     np.savez_compressed(OUT / "loss.npz", **out)
 
 

@@ -75,3 +75,39 @@ def test_loss_class_api_and_empty_labels(device):
     loss0, items0 = crit(_dev_feats(feats, device), empty)
     t0, i0 = LO.v8_detection_loss(feats, empty, STRIDES, 10)
     assert torch.allclose(items0.cpu(), i0, rtol=2e-4, atol=1e-5) and float(items0[0]) == 0.0 and float(items0[2]) == 0.0
+
+
+@pytest.mark.parametrize("bs,hw,seed,n_mean", [(2, 64, 7, 6.0), (3, 160, 8, 14.0), (2, 320, 11, 30.0)])
+def test_loss_gradient_matches_autograd(bs, hw, seed, n_mean, device):
+    """d(loss.sum() * B)/d head outputs from the device against autograd through the oracle (itself equal to the
+    reference's gradient to the last bit: oracle/make_golden.py loss_vectors), tolerance 1e-4 of the largest entry."""
+    gg = torch.Generator().manual_seed(seed)
+    feats = [(torch.randn(bs, 74, hw // int(s), hw // int(s), generator=gg) * 1.5).requires_grad_(True) for s in STRIDES]
+    labels = LO.synthetic_labels(bs, seed, n_mean=n_mean)
+    total, _ = LO.v8_detection_loss(feats, labels, STRIDES, 10)
+    total.backward()
+    out, _, grads = H.detection_loss(_dev_feats([f.detach() for f in feats], device), _gt(labels, bs, hw), STRIDES, 10, want_grad=True)
+    torch.cuda.synchronize()
+    assert abs(float(out[3]) - float(total)) <= 2e-4 * abs(float(total))
+    for f, gd in zip(feats, grads):
+        ref = f.grad
+        err = float((gd.cpu() - ref).abs().max())
+        assert err <= 1e-4 * float(ref.abs().max()) + 1e-7, (err, float(ref.abs().max()))
+
+
+def test_loss_gradient_golden_reference(device):
+    """The small case's full gradient and the big case's per-level sums as captured from the REAL reference."""
+    g = golden("loss.npz")
+    for tag in ("loss64", "loss160"):
+        m = ast.literal_eval(str(g[f"{tag}_meta"]))
+        gg = torch.Generator().manual_seed(m["seed"])
+        feats = [torch.randn(m["bs"], 74, m["hw"] // int(s), m["hw"] // int(s), generator=gg) * 1.5 for s in STRIDES]
+        labels = LO.synthetic_labels(m["bs"], m["seed"], n_mean=m["n_mean"])
+        _, _, grads = H.detection_loss(_dev_feats(feats, device), _gt(labels, m["bs"], m["hw"]), STRIDES, 10, want_grad=True)
+        torch.cuda.synchronize()
+        for li, gd in enumerate(grads):
+            gd = gd.cpu()
+            assert abs(float(gd.abs().sum()) - float(g[f"{tag}_grad_abs_sum"][li])) <= 2e-4 * float(g[f"{tag}_grad_abs_sum"][li])
+            if tag == "loss64":
+                ref = torch.from_numpy(g[f"{tag}_grad{li}"])
+                assert float((gd - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
