@@ -95,6 +95,19 @@ class LossDesc(C.Structure):
     ]  # fmt: skip
 
 
+class BnDesc(C.Structure):
+    """Mirror of ``dy_bn_desc``."""
+
+    _fields_ = [
+        ("z", _vp), ("y", _vp), ("addend", _vp), ("dy", _vp), ("dz", _vp),
+        ("rows", _i64),
+        ("c", _i32), ("ld_z", _i32), ("ld_y", _i32), ("ld_add", _i32), ("ld_dy", _i32), ("ld_dz", _i32), ("dtype", _i32), ("act", _i32),
+        ("gamma", _vp), ("beta", _vp), ("mean", _vp), ("rstd", _vp), ("running_mean", _vp), ("running_var", _vp),
+        ("eps", _f32), ("momentum", _f32),
+        ("dgamma", _vp), ("dbeta", _vp), ("workspace", _vp), ("workspace_bytes", _i64),
+    ]  # fmt: skip
+
+
 # name -> (restype, argtypes); every symbol include/dyolo.h declares must appear here
 # (tests/test_cabi.py checks both directions).
 SIGNATURES = {
@@ -117,6 +130,11 @@ SIGNATURES = {
     "dy_nms": (_i32, [C.POINTER(NmsDesc), _vp]),
     "dy_scale_boxes": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "dy_detection_loss_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
+    "dy_bn_workspace_bytes": (_i64, [_i32]),
+    "dy_bn_train_fwd": (_i32, [C.POINTER(BnDesc), _vp]),
+    "dy_bn_train_bwd": (_i32, [C.POINTER(BnDesc), _vp]),
+    "dy_silu_fwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "dy_silu_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dy_detection_loss": (_i32, [C.POINTER(LossDesc), _vp]),
 }
 

@@ -1,0 +1,316 @@
+// Train-mode BatchNorm2d (+ SiLU) forward and backward on NHWC activations.
+// Reference: Conv.forward = act(bn(conv(x))) in training mode (nn/modules/conv.py:37-55), BatchNorm2d with
+// eps 1e-3 / momentum 0.03 (utils/torch_utils.py:423-433); RepVGGBlock.forward sums two BN branches before the
+// activation (nn/modules/block.py:1480-1490) — served by `addend` (forward) and by running the backward twice on the
+// same incoming gradient.
+//
+// Layout: z is (rows, c) with pitch ld — channels fastest, so a per-channel reduction walks rows.  A 256-thread
+// workgroup is arranged as R rows x NCH 16-byte channel chunks; each thread keeps fp32 partial sums of its chunk over
+// its rows of the slab, the R partials of a chunk are combined through LDS and added to per-channel DOUBLE
+// accumulators with atomics (sum and sum of squares in double: var = E[z^2] - mean^2 stays accurate at 3.3 M rows).
+// All kernels are bandwidth bound: forward reads z twice (stats, apply) and writes y once; backward reads dy and z
+// twice and writes dz once.
+#include "common.cuh"
+
+namespace dy {
+
+struct BnArgs {
+  const void* z;
+  void* y;
+  const void* addend;
+  const void* dy;
+  void* dz;
+  long long rows;
+  int c, ld_z, ld_y, ld_add, ld_dy, ld_dz, act;
+  const float* gamma;
+  const float* beta;
+  float* mean;
+  float* rstd;
+  float* running_mean;
+  float* running_var;
+  float eps, momentum;
+  float* dgamma;
+  float* dbeta;
+  double* acc;  // [2][c]
+  int nch, R, rows_per_block;
+};
+
+__device__ __forceinline__ float silu_grad(float u) {  // d/du u*sigmoid(u)
+  const float s = 1.0f / (1.0f + __expf(-u));
+  return s * (1.0f + u * (1.0f - s));
+}
+
+// MODE 0: sum z, sum z^2.   MODE 1: sum du, sum du*xhat with du = dy * act'(u), u = gamma*xhat + beta.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const BnArgs p) {
+  constexpr int E = Elem<T>::EPC;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  float* red = reinterpret_cast<float*>(dyn_smem);  // [2][R][c]
+  const int tid = threadIdx.x;
+  const int ch = tid % p.nch, rr = tid / p.nch;
+  float s0[E], s1[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) s0[e] = 0.f, s1[e] = 0.f;
+  if (rr < p.R) {
+    float mu[E], rs[E], ga[E], be[E];
+    if (MODE == 1) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        mu[e] = p.mean[ch * E + e], rs[e] = p.rstd[ch * E + e], ga[e] = p.gamma[ch * E + e], be[e] = p.beta[ch * E + e];
+      }
+    }
+    const long long r0 = (long long)blockIdx.x * p.rows_per_block;
+    long long r1 = r0 + p.rows_per_block;
+    if (r1 > p.rows) r1 = p.rows;
+    const T* zb = reinterpret_cast<const T*>(p.z) + ch * E;
+    const T* db = reinterpret_cast<const T*>(p.dy) + ch * E;
+    for (long long r = r0 + rr; r < r1; r += p.R) {
+      float zf[E];
+      Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(zb + r * p.ld_z), zf);
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) s0[e] += zf[e], s1[e] += zf[e] * zf[e];
+      } else {
+        float df[E];
+        Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(db + r * p.ld_dy), df);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const float xh = (zf[e] - mu[e]) * rs[e];
+          float du = df[e];
+          if (p.act == DY_ACT_SILU) du *= silu_grad(ga[e] * xh + be[e]);
+          s0[e] += du, s1[e] += du * xh;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      red[(0 * p.R + rr) * p.c + ch * E + e] = s0[e];
+      red[(1 * p.R + rr) * p.c + ch * E + e] = s1[e];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * p.c; i += 256) {
+    const int which = i / p.c, cc = i - which * p.c;
+    double t = 0.0;
+    for (int k = 0; k < p.R; ++k) t += (double)red[(which * p.R + k) * p.c + cc];
+    atomicAdd(p.acc + which * p.c + cc, t);
+  }
+}
+
+// mean / rstd from the double sums, running statistics update (unbiased variance, torch semantics)
+__global__ void bn_finalize_kernel(const BnArgs p) {
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc >= p.c) return;
+  const double n = (double)p.rows;
+  const double m = p.acc[cc] / n;
+  double var = p.acc[p.c + cc] / n - m * m;
+  if (var < 0.0) var = 0.0;
+  p.mean[cc] = (float)m;
+  p.rstd[cc] = (float)(1.0 / sqrt(var + (double)p.eps));
+  if (p.running_mean) {
+    const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+    p.running_mean[cc] = (1.f - p.momentum) * p.running_mean[cc] + p.momentum * (float)m;
+    p.running_var[cc] = (1.f - p.momentum) * p.running_var[cc] + p.momentum * (float)unb;
+  }
+}
+
+// y = act(gamma * (z - mean) * rstd + beta (+ addend))
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs p) {
+  constexpr int E = Elem<T>::EPC;
+  const long long total = p.rows * p.nch;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / p.nch;
+    const int ch = (int)(i - r * p.nch);
+    float zf[E], o[E];
+    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.z) + r * p.ld_z + ch * E), zf);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int cc = ch * E + e;
+      o[e] = p.gamma[cc] * ((zf[e] - p.mean[cc]) * p.rstd[cc]) + p.beta[cc];
+    }
+    if (p.addend) {
+      float af[E];
+      Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.addend) + r * p.ld_add + ch * E), af);
+#pragma unroll
+      for (int e = 0; e < E; ++e) o[e] += af[e];
+    }
+    if (p.act == DY_ACT_SILU) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) o[e] = o[e] / (1.0f + __expf(-o[e]));
+    }
+    *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.y) + r * p.ld_y + ch * E) = Chunk<T>::pack(o);
+  }
+}
+
+// dz = gamma * rstd * (du - mean(du) - xhat * mean(du * xhat));  dgamma = sum du*xhat, dbeta = sum du
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs p) {
+  constexpr int E = Elem<T>::EPC;
+  const long long total = p.rows * p.nch;
+  const double invn = 1.0 / (double)p.rows;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / p.nch;
+    const int ch = (int)(i - r * p.nch);
+    float zf[E], df[E], o[E];
+    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.z) + r * p.ld_z + ch * E), zf);
+    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.dy) + r * p.ld_dy + ch * E), df);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int cc = ch * E + e;
+      const float xh = (zf[e] - p.mean[cc]) * p.rstd[cc];
+      float du = df[e];
+      if (p.act == DY_ACT_SILU) du *= silu_grad(p.gamma[cc] * xh + p.beta[cc]);
+      const float mdu = (float)(p.acc[cc] * invn), mdx = (float)(p.acc[p.c + cc] * invn);
+      o[e] = p.gamma[cc] * p.rstd[cc] * (du - mdu - xh * mdx);
+    }
+    *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.dz) + r * p.ld_dz + ch * E) = Chunk<T>::pack(o);
+  }
+  if (blockIdx.x == 0) {
+    for (int cc = threadIdx.x; cc < p.c; cc += 256) {
+      if (p.dbeta) p.dbeta[cc] = (float)p.acc[cc];
+      if (p.dgamma) p.dgamma[cc] = (float)p.acc[p.c + cc];
+    }
+  }
+}
+
+// y = silu(u)  /  du = dy * silu'(u)   (RepVGG: the activation after the sum of two BN branches)
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void silu_kernel(const void* u_, const void* dy_, void* out_, long long rows, int nch, int ld_u, int ld_dy, int ld_o) {
+  constexpr int E = Elem<T>::EPC;
+  const long long total = rows * nch;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / nch;
+    const int ch = (int)(i - r * nch);
+    float uf[E], o[E];
+    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(u_) + r * ld_u + ch * E), uf);
+    if (BWD) {
+      float df[E];
+      Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(dy_) + r * ld_dy + ch * E), df);
+#pragma unroll
+      for (int e = 0; e < E; ++e) o[e] = df[e] * silu_grad(uf[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) o[e] = uf[e] / (1.0f + __expf(-uf[e]));
+    }
+    *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(out_) + r * ld_o + ch * E) = Chunk<T>::pack(o);
+  }
+}
+
+static int bn_prepare(const dy_bn_desc* d, BnArgs* a, const char* who, bool bwd) {
+  DY_REQUIRE(d && d->z && d->gamma && d->beta && d->mean && d->rstd && d->workspace, DY_ERR_INVALID_ARG, "%s: null pointer", who);
+  const int es = dy_dtype_size(d->dtype);
+  DY_REQUIRE(es != 0 && d->rows > 0 && d->c > 0, DY_ERR_INVALID_ARG, "%s: bad dtype/rows/c", who);
+  const int epc = 16 / es;
+  DY_REQUIRE(d->c % epc == 0 && d->c <= 8192, DY_ERR_UNSUPPORTED, "%s: c %d must be a multiple of %d (one 16-byte chunk) and <= 8192", who, d->c, epc);
+  DY_REQUIRE(aligned16(d->z) && d->ld_z >= d->c && (d->ld_z * es) % 16 == 0, DY_ERR_INVALID_ARG, "%s: z view misaligned", who);
+  DY_REQUIRE(d->workspace_bytes >= (int64_t)(2 * d->c * 8) && (reinterpret_cast<uintptr_t>(d->workspace) & 7) == 0, DY_ERR_WORKSPACE,
+             "%s: workspace needs %d bytes", who, 2 * d->c * 8);
+  if (bwd) {
+    DY_REQUIRE(d->dy && d->dz && aligned16(d->dy) && aligned16(d->dz) && d->ld_dy >= d->c && d->ld_dz >= d->c && (d->ld_dy * es) % 16 == 0 &&
+                   (d->ld_dz * es) % 16 == 0, DY_ERR_INVALID_ARG, "%s: dy/dz views null or misaligned", who);
+  } else {
+    DY_REQUIRE(d->y && aligned16(d->y) && d->ld_y >= d->c && (d->ld_y * es) % 16 == 0, DY_ERR_INVALID_ARG, "%s: y view null or misaligned", who);
+    DY_REQUIRE(!d->addend || (aligned16(d->addend) && d->ld_add >= d->c && (d->ld_add * es) % 16 == 0), DY_ERR_INVALID_ARG, "%s: addend misaligned", who);
+  }
+  a->z = d->z, a->y = d->y, a->addend = d->addend, a->dy = d->dy, a->dz = d->dz;
+  a->rows = d->rows, a->c = d->c, a->ld_z = d->ld_z, a->ld_y = d->ld_y, a->ld_add = d->ld_add, a->ld_dy = d->ld_dy, a->ld_dz = d->ld_dz;
+  a->act = d->act, a->gamma = d->gamma, a->beta = d->beta, a->mean = d->mean, a->rstd = d->rstd;
+  a->running_mean = d->running_mean, a->running_var = d->running_mean ? d->running_var : nullptr;
+  a->eps = d->eps, a->momentum = d->momentum, a->dgamma = d->dgamma, a->dbeta = d->dbeta;
+  a->acc = reinterpret_cast<double*>(d->workspace);
+  a->nch = d->c / epc;
+  int R = 256 / a->nch;
+  if (R < 1) R = 1;
+  a->R = R;
+  DY_REQUIRE(a->nch <= 256, DY_ERR_UNSUPPORTED, "%s: c %d too wide for one workgroup row (max %d)", who, d->c, 256 * epc);
+  // slabs: enough workgroups to fill the chip, at least 4 passes of R rows each
+  long long blocks = (d->rows + 4LL * R - 1) / (4LL * R);
+  if (blocks > 2048) blocks = 2048;
+  a->rows_per_block = (int)((d->rows + blocks - 1) / blocks);
+  return 0;
+}
+
+template <typename T>
+static int bn_fwd_t(const BnArgs& a, hipStream_t st) {
+  if (hipMemsetAsync(a.acc, 0, (size_t)2 * a.c * 8, st) != hipSuccess) return check_launch("dy_bn_train_fwd memset");
+  const unsigned blocks = (unsigned)((a.rows + a.rows_per_block - 1) / a.rows_per_block);
+  const size_t smem = (size_t)2 * a.R * a.c * 4;
+  hipLaunchKernelGGL((bn_reduce_kernel<T, 0>), dim3(blocks), dim3(256), smem, st, a);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((a.c + 255) / 256)), dim3(256), 0, st, a);
+  const long long total = a.rows * a.nch;
+  const unsigned ab = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ab), dim3(256), 0, st, a);
+  return check_launch("dy_bn_train_fwd");
+}
+
+template <typename T>
+static int bn_bwd_t(const BnArgs& a, hipStream_t st) {
+  if (hipMemsetAsync(a.acc, 0, (size_t)2 * a.c * 8, st) != hipSuccess) return check_launch("dy_bn_train_bwd memset");
+  const unsigned blocks = (unsigned)((a.rows + a.rows_per_block - 1) / a.rows_per_block);
+  const size_t smem = (size_t)2 * a.R * a.c * 4;
+  hipLaunchKernelGGL((bn_reduce_kernel<T, 1>), dim3(blocks), dim3(256), smem, st, a);
+  const long long total = a.rows * a.nch;
+  const unsigned ab = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ab), dim3(256), 0, st, a);
+  return check_launch("dy_bn_train_bwd");
+}
+
+}  // namespace dy
+
+using namespace dy;
+
+extern "C" int64_t dy_bn_workspace_bytes(int32_t c) { return c <= 0 ? -1 : (int64_t)2 * c * 8; }
+
+extern "C" int32_t dy_bn_train_fwd(const dy_bn_desc* d, dy_stream_t stream) {
+  BnArgs a{};
+  const int rc = bn_prepare(d, &a, "dy_bn_train_fwd", false);
+  if (rc) return rc;
+  DY_REQUIRE((size_t)2 * a.R * a.c * 4 <= 160 * 1024, DY_ERR_UNSUPPORTED, "dy_bn_train_fwd: reduction scratch exceeds LDS");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  switch (d->dtype) {
+    case DY_BF16: return bn_fwd_t<bf16_t>(a, st);
+    case DY_F16: return bn_fwd_t<f16_t>(a, st);
+    default: return bn_fwd_t<float>(a, st);
+  }
+}
+
+extern "C" int32_t dy_bn_train_bwd(const dy_bn_desc* d, dy_stream_t stream) {
+  BnArgs a{};
+  const int rc = bn_prepare(d, &a, "dy_bn_train_bwd", true);
+  if (rc) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  switch (d->dtype) {
+    case DY_BF16: return bn_bwd_t<bf16_t>(a, st);
+    case DY_F16: return bn_bwd_t<f16_t>(a, st);
+    default: return bn_bwd_t<float>(a, st);
+  }
+}
+
+template <bool BWD>
+static int silu_launch(const void* u, const void* dy, void* out, int64_t rows, int32_t c, int32_t ld_u, int32_t ld_dy, int32_t ld_o, int32_t dtype,
+                       hipStream_t st, const char* who) {
+  const int es = dy_dtype_size(dtype);
+  DY_REQUIRE(es && u && out && (!BWD || dy) && rows > 0 && c > 0, DY_ERR_INVALID_ARG, "%s: null pointer or bad dims", who);
+  const int epc = 16 / es;
+  DY_REQUIRE(c % epc == 0 && aligned16(u) && aligned16(out) && (ld_u * es) % 16 == 0 && (ld_o * es) % 16 == 0 && ld_u >= c && ld_o >= c &&
+                 (!BWD || (aligned16(dy) && (ld_dy * es) % 16 == 0 && ld_dy >= c)), DY_ERR_INVALID_ARG, "%s: views must be 16-byte aligned chunks", who);
+  const int nch = c / epc;
+  const long long total = rows * nch;
+  const unsigned ab = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  switch (dtype) {
+    case DY_BF16: hipLaunchKernelGGL((silu_kernel<bf16_t, BWD>), dim3(ab), dim3(256), 0, st, u, dy, out, (long long)rows, nch, ld_u, ld_dy, ld_o); break;
+    case DY_F16: hipLaunchKernelGGL((silu_kernel<f16_t, BWD>), dim3(ab), dim3(256), 0, st, u, dy, out, (long long)rows, nch, ld_u, ld_dy, ld_o); break;
+    default: hipLaunchKernelGGL((silu_kernel<float, BWD>), dim3(ab), dim3(256), 0, st, u, dy, out, (long long)rows, nch, ld_u, ld_dy, ld_o); break;
+  }
+  return check_launch(who);
+}
+
+extern "C" int32_t dy_silu_fwd(const void* u, void* y, int64_t rows, int32_t c, int32_t ld_u, int32_t ld_y, int32_t dtype, dy_stream_t stream) {
+  return silu_launch<false>(u, nullptr, y, rows, c, ld_u, 0, ld_y, dtype, reinterpret_cast<hipStream_t>(stream), "dy_silu_fwd");
+}
+
+extern "C" int32_t dy_silu_bwd(const void* u, const void* dy, void* du, int64_t rows, int32_t c, int32_t ld_u, int32_t ld_dy, int32_t ld_du,
+                               int32_t dtype, dy_stream_t stream) {
+  return silu_launch<true>(u, dy, du, rows, c, ld_u, ld_dy, ld_du, dtype, reinterpret_cast<hipStream_t>(stream), "dy_silu_bwd");
+}

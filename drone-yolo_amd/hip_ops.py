@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import DY_ACT_NONE, DY_ACT_SILU, ConvDesc, DecodeDesc, HeadDecodeDesc, LossDesc, NmsDesc, check, lib
+from ._lib import DY_ACT_NONE, DY_ACT_SILU, BnDesc, ConvDesc, DecodeDesc, HeadDecodeDesc, LossDesc, NmsDesc, check, lib
 
 _DTYPES = {torch.bfloat16: _lib.DY_BF16, torch.float16: _lib.DY_F16, torch.float32: _lib.DY_F32}
 
@@ -548,3 +548,79 @@ def detection_loss(levels: Sequence[torch.Tensor], gt: torch.Tensor, strides: Se
             grads.append(gt_)
     _launch(lib().dy_detection_loss, (C.byref(d),), keep=(d, out, owner, ws, gt, *levels, *(grads or ())))
     return (out, owner, grads) if want_grad else (out, owner)
+
+
+# ---- train-mode BatchNorm (+ SiLU) -------------------------------------------------------------------------------
+
+
+class BnState:
+    """Saved batch statistics + workspace of one BatchNorm layer for one training step."""
+
+    def __init__(self, c: int, device):
+        self.mean = torch.empty(c, dtype=torch.float32, device=device)
+        self.rstd = torch.empty(c, dtype=torch.float32, device=device)
+        self.ws = torch.empty(lib().dy_bn_workspace_bytes(c), dtype=torch.uint8, device=device)
+
+
+def _rows(t: torch.Tensor) -> int:
+    return t.shape[0] * t.shape[2] * t.shape[3]
+
+
+def bn_train_fwd(z: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, state: BnState, act: bool, eps: float = 1e-3,
+                 momentum: float = 0.03, running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None,
+                 addend: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = act(BN_batchstats(z) (+ addend)) through ``dy_bn_train_fwd``; z, y, addend: NHWC views (N, C, H, W)."""
+    require_device(z, "bn input")
+    n, c, h, w = z.shape
+    if out is None:
+        out = alloc_nhwc(n, c, h, w, z.dtype, z.device)
+    d = BnDesc()
+    (d.z, d.ld_z), (d.y, d.ld_y) = view_params(z), view_params(out)
+    if addend is not None:
+        d.addend, d.ld_add = view_params(addend)
+    d.rows, d.c, d.dtype, d.act = _rows(z), c, dy_dtype(z.dtype), DY_ACT_SILU if act else DY_ACT_NONE
+    d.gamma, d.beta, d.mean, d.rstd = gamma.data_ptr(), beta.data_ptr(), state.mean.data_ptr(), state.rstd.data_ptr()
+    if running_mean is not None:
+        d.running_mean, d.running_var = running_mean.data_ptr(), running_var.data_ptr()
+    d.eps, d.momentum = eps, momentum
+    d.workspace, d.workspace_bytes = state.ws.data_ptr(), state.ws.numel()
+    _launch(lib().dy_bn_train_fwd, (C.byref(d),), keep=(d, z, out, addend, gamma, beta, state, running_mean, running_var))
+    return out
+
+
+def bn_train_bwd(dy: torch.Tensor, z: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, state: BnState, act: bool,
+                 dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    """(dz, dgamma, dbeta) of y = act(BN_batchstats(z)) given dy, through ``dy_bn_train_bwd`` (state from the forward)."""
+    n, c, h, w = z.shape
+    if out is None:
+        out = alloc_nhwc(n, c, h, w, z.dtype, z.device)
+    if dgamma is None:
+        dgamma = torch.empty(c, dtype=torch.float32, device=z.device)
+    if dbeta is None:
+        dbeta = torch.empty(c, dtype=torch.float32, device=z.device)
+    d = BnDesc()
+    (d.z, d.ld_z), (d.dy, d.ld_dy), (d.dz, d.ld_dz) = view_params(z), view_params(dy), view_params(out)
+    d.rows, d.c, d.dtype, d.act = _rows(z), c, dy_dtype(z.dtype), DY_ACT_SILU if act else DY_ACT_NONE
+    d.gamma, d.beta, d.mean, d.rstd = gamma.data_ptr(), beta.data_ptr(), state.mean.data_ptr(), state.rstd.data_ptr()
+    d.dgamma, d.dbeta = dgamma.data_ptr(), dbeta.data_ptr()
+    d.workspace, d.workspace_bytes = state.ws.data_ptr(), state.ws.numel()
+    _launch(lib().dy_bn_train_bwd, (C.byref(d),), keep=(d, z, dy, out, gamma, beta, state, dgamma, dbeta))
+    return out, dgamma, dbeta
+
+
+def silu_fwd(u: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    n, c, h, w = u.shape
+    if out is None:
+        out = alloc_nhwc(n, c, h, w, u.dtype, u.device)
+    (up, ldu), (op, ldo) = view_params(u), view_params(out)
+    _launch(lib().dy_silu_fwd, (up, op, _rows(u), c, ldu, ldo, dy_dtype(u.dtype)), keep=(u, out))
+    return out
+
+
+def silu_bwd(u: torch.Tensor, dy: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    n, c, h, w = u.shape
+    if out is None:
+        out = alloc_nhwc(n, c, h, w, u.dtype, u.device)
+    (up, ldu), (dp, ldd), (op, ldo) = view_params(u), view_params(dy), view_params(out)
+    _launch(lib().dy_silu_bwd, (up, dp, op, _rows(u), c, ldu, ldd, ldo, dy_dtype(u.dtype)), keep=(u, dy, out))
+    return out

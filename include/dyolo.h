@@ -287,6 +287,46 @@ typedef struct dy_loss_desc {
 int64_t dy_detection_loss_workspace_bytes(int32_t batch, int32_t anchors, int32_t gmax, int32_t topk);
 int32_t dy_detection_loss(const dy_loss_desc* d, dy_stream_t stream);
 
+/* ---- train-mode BatchNorm2d (+ SiLU) -----------------------------------------------------
+ * Replaces: the BatchNorm2d + SiLU half of Conv.forward in training mode (nn/modules/conv.py:37-55; eps 1e-3 and
+ * momentum 0.03 are set by initialize_weights, utils/torch_utils.py:423-433) and their autograd backward; the two-branch
+ * sum of RepVGGBlock.forward (nn/modules/block.py:1480-1490) through `addend` + dy_silu_fwd / dy_silu_bwd.
+ * z: the convolution output, (rows, c) of `dtype`, pitch ld_z (rows = batch*h*w of the NHWC view), c a multiple of one
+ * 16-byte chunk and <= 2048 (16-bit) / 1024 (fp32).
+ * Forward:  mean/rstd (fp32[c], outputs, saved for backward) = batch statistics of z (biased variance);
+ *   y = act(gamma * (z - mean) * rstd + beta (+ addend));  running_mean / running_var (optional) are updated as torch
+ *   does: r = (1 - momentum) * r + momentum * stat, the variance unbiased.
+ * Backward: dy = gradient w.r.t. y; dz = gradient w.r.t. z; dgamma / dbeta fp32[c] (optional).  With act = SILU the
+ *   pre-activation is recomputed from z.  `addend` is not used (its gradient is dy * act'(u): dy_silu_bwd).
+ * workspace: dy_bn_workspace_bytes(c) bytes, 8-byte aligned.  Sums are accumulated in double. */
+typedef struct dy_bn_desc {
+  const void* z;
+  void* y;
+  const void* addend;
+  const void* dy;
+  void* dz;
+  int64_t rows;
+  int32_t c, ld_z, ld_y, ld_add, ld_dy, ld_dz, dtype, act;
+  const float* gamma;
+  const float* beta;
+  float* mean;
+  float* rstd;
+  float* running_mean;
+  float* running_var;
+  float eps, momentum;
+  float* dgamma;
+  float* dbeta;
+  void* workspace;
+  int64_t workspace_bytes;
+} dy_bn_desc;
+int64_t dy_bn_workspace_bytes(int32_t c);
+int32_t dy_bn_train_fwd(const dy_bn_desc* d, dy_stream_t stream);
+int32_t dy_bn_train_bwd(const dy_bn_desc* d, dy_stream_t stream);
+/* y = u * sigmoid(u);  du = dy * d/du(u * sigmoid(u)).  (rows, c) views of `dtype`. */
+int32_t dy_silu_fwd(const void* u, void* y, int64_t rows, int32_t c, int32_t ld_u, int32_t ld_y, int32_t dtype, dy_stream_t stream);
+int32_t dy_silu_bwd(const void* u, const void* dy, void* du, int64_t rows, int32_t c, int32_t ld_u, int32_t ld_dy, int32_t ld_du,
+                    int32_t dtype, dy_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,85 @@
+"""GPU parity of the training-path kernels (train-mode BatchNorm + SiLU forward/backward, conv dgrad / wgrad,
+optimizer) against PyTorch CPU autograd in fp32 on the same (dtype-rounded) inputs.
+Tolerances: fp32 1e-4 of the output scale; bf16 / f16 storage: outputs are rounded once to the storage type, so
+2^-8 / 2^-10 of the scale (arithmetic is fp32 / double inside the kernels)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from drone_yolo_amd import hip_ops as H
+from tests._util import quantize
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+TOL = {torch.float32: 1e-4, torch.bfloat16: 1.2e-2, torch.float16: 2e-3}
+
+
+def nhwc(t, dtype, dev, ld=None, c_off=0):
+    n, c, h, w = t.shape
+    ld = ld or c
+    buf = torch.zeros((n, h, w, ld), dtype=dtype, device=dev)
+    buf[..., c_off : c_off + c] = t.permute(0, 2, 3, 1).to(dtype).to(dev)
+    return buf.permute(0, 3, 1, 2)[:, c_off : c_off + c]
+
+
+def close(got, ref, dtype, what, extra=1.0):
+    scale = max(float(ref.abs().max()), 1e-6)
+    err = float((got.float().cpu() - ref).abs().max())
+    assert err <= TOL[dtype] * extra * scale, f"{what}: max|err| {err:.3e} vs scale {scale:.3f}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("shape,act", [((4, 32, 40, 36), True), ((2, 96, 17, 13), True), ((3, 256, 10, 10), False), ((2, 1024, 5, 5), True),
+                                       ((16, 64, 80, 80), True)])
+def test_bn_train_forward_backward(shape, act, dtype, device):
+    g = torch.Generator().manual_seed(shape[1])
+    n, c, h, w = shape
+    z = quantize(torch.randn(shape, generator=g) * 1.7 + torch.randn(1, c, 1, 1, generator=g), dtype).requires_grad_(True)
+    gamma = (torch.rand(c, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(c, generator=g) * 0.3).requires_grad_(True)
+    rm, rv = torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    u = F.batch_norm(z, rm_ref, rv_ref, gamma, beta, training=True, momentum=0.03, eps=1e-3)
+    y = F.silu(u) if act else u
+    dy = quantize(torch.randn(shape, generator=g), dtype)
+    y.backward(dy)
+    st = H.BnState(c, device)
+    zd = nhwc(z.detach(), dtype, device, ld=c + 16, c_off=8)
+    gd, bd, rmd, rvd = gamma.detach().to(device), beta.detach().to(device), rm.to(device), rv.to(device)
+    yd = H.bn_train_fwd(zd, gd, bd, st, act, running_mean=rmd, running_var=rvd)
+    dz, dgam, dbet = H.bn_train_bwd(nhwc(dy, dtype, device), zd, gd, bd, st, act)
+    torch.cuda.synchronize()
+    close(yd, y.detach(), dtype, "bn fwd")
+    assert torch.allclose(st.mean.cpu(), z.detach().mean((0, 2, 3)), atol=1e-4, rtol=1e-4)
+    assert torch.allclose(rmd.cpu(), rm_ref, atol=1e-5, rtol=1e-4) and torch.allclose(rvd.cpu(), rv_ref, atol=1e-5, rtol=1e-4)
+    close(dz, z.grad, dtype, "bn dz", extra=2.0)
+    assert torch.allclose(dgam.cpu(), gamma.grad, rtol=2e-3, atol=2e-3 * float(gamma.grad.abs().max()))
+    assert torch.allclose(dbet.cpu(), beta.grad, rtol=2e-3, atol=2e-3 * float(beta.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+def test_two_branch_bn_sum_then_silu(dtype, device):
+    """RepVGGBlock training form: silu(bn3(z3) + bn1(z1)) and its backward through dy_silu_bwd + two dy_bn_train_bwd."""
+    g = torch.Generator().manual_seed(5)
+    shape = (3, 64, 20, 24)
+    c = shape[1]
+    z3 = quantize(torch.randn(shape, generator=g), dtype).requires_grad_(True)
+    z1 = quantize(torch.randn(shape, generator=g) * 0.5, dtype).requires_grad_(True)
+    g3, b3, g1, b1 = (torch.rand(c, generator=g) + 0.5 for _ in range(4))
+    u = F.batch_norm(z3, None, None, g3, b3, True, 0.03, 1e-3) + F.batch_norm(z1, None, None, g1, b1, True, 0.03, 1e-3)
+    y = F.silu(u)
+    dy = quantize(torch.randn(shape, generator=g), dtype)
+    y.backward(dy)
+    s3, s1 = H.BnState(c, device), H.BnState(c, device)
+    z3d, z1d = nhwc(z3.detach(), dtype, device), nhwc(z1.detach(), dtype, device)
+    dev = lambda t: t.to(device)
+    u3 = H.bn_train_fwd(z3d, dev(g3), dev(b3), s3, False)
+    ud = H.bn_train_fwd(z1d, dev(g1), dev(b1), s1, False, addend=u3)
+    yd = H.silu_fwd(ud)
+    du = H.silu_bwd(ud, nhwc(dy, dtype, device))
+    dz3, _, _ = H.bn_train_bwd(du, z3d, dev(g3), dev(b3), s3, False)
+    dz1, _, _ = H.bn_train_bwd(du, z1d, dev(g1), dev(b1), s1, False)
+    torch.cuda.synchronize()
+    close(yd, y.detach(), dtype, "repvgg fwd", extra=2.0)
+    close(dz3, z3.grad, dtype, "repvgg dz3", extra=3.0)
+    close(dz1, z1.grad, dtype, "repvgg dz1", extra=3.0)
