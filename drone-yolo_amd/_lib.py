@@ -130,6 +130,8 @@ SIGNATURES = {
     "dy_nms": (_i32, [C.POINTER(NmsDesc), _vp]),
     "dy_scale_boxes": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "dy_detection_loss_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
+    "dy_conv2d_wgrad_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _i32, _vp, _vp]),
+    "dy_colsum": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "dy_bn_workspace_bytes": (_i64, [_i32]),
     "dy_bn_train_fwd": (_i32, [C.POINTER(BnDesc), _vp]),
     "dy_bn_train_bwd": (_i32, [C.POINTER(BnDesc), _vp]),

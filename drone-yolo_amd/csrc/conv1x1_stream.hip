@@ -279,7 +279,7 @@ int conv1x1_stream_dispatch(const dy_conv_desc* d, hipStream_t st) {
     a.ldx2 = d->ld_x2;
     a.split = d->cin_split;
   }
-  if (d->up2x) DY_REQUIRE(d->h % 2 == 0 && d->w_in % 2 == 0, DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: up2x needs even h,w");
+  if (d->up2x) DY_REQUIRE(d->up2x == 1 && d->h % 2 == 0 && d->w_in % 2 == 0, DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: FRAG1X1 takes up2x 0/1 only and needs even h,w");
   const bool of = d->out_f32 != 0;
   switch (d->dtype) {
     case DY_BF16: return launch_1x1_dtype<bf16_t>(a, of, st);

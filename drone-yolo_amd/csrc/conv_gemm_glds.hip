@@ -92,7 +92,7 @@ __global__ __launch_bounds__(BM * 2) void conv_gemm_glds_kernel(const ConvArgs p
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       const int hi = a_hi0[i] + kr, wi = a_wi0[i] + kq;
-      const bool ok = ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
+      const bool ok = ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W) && !(p.up2x == 2 && ((hi | wi) & 1));
       const T* ptr;  // computed for every lane (never dereferenced when !ok): keeps the gather branch-free
       if (from_x) {
         const int hb = p.up2x ? (hi >> 1) : hi, wb = p.up2x ? (wi >> 1) : wi;

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     for (int i = 0; i < NA; ++i) {
       const int hi = a_hi0[i] + kr;
       const int wi = a_wi0[i] + kq;
-      const bool ok = (kr < p.ks) && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
+      const bool ok = (kr < p.ks) && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W) && !(p.up2x == 2 && ((hi | wi) & 1));
       u32x4 v = zero_chunk();
       if (ok) {
         if (kc < p.split) {
@@ -381,7 +381,7 @@ extern "C" int32_t dy_conv2d_nhwc(const dy_conv_desc* d, dy_stream_t stream) {
   a.M = d->batch * ho * wo;
   a.HoWo = ho * wo;
   a.act = d->act;
-  a.up2x = d->up2x ? 1 : 0;
+  a.up2x = d->up2x;  // 0 plain, 1 nearest-upsampled source, 2 zero-dilated source (stride-2 transposed conv)
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
   if (d->w_layout == DY_WLAYOUT_HALO3X3) return conv3x3_halo_dispatch(d, st);
@@ -425,7 +425,8 @@ extern "C" int32_t dy_conv2d_nhwc(const dy_conv_desc* d, dy_stream_t stream) {
   DY_REQUIRE(d->cout_pad == dy_conv_cout_pad(d->cout), DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: cout_pad %d != dy_conv_cout_pad()",
              d->cout_pad);
   if (d->up2x) {
-    DY_REQUIRE(d->h % 2 == 0 && d->w_in % 2 == 0, DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: up2x needs even h,w");
+    DY_REQUIRE(d->h % 2 == 0 && d->w_in % 2 == 0 && (d->up2x == 1 || d->up2x == 2), DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: up2x must be 1 or 2 and needs even h,w");
+    DY_REQUIRE(d->up2x == 1 || !d->x2, DY_ERR_UNSUPPORTED, "dy_conv2d_nhwc: a zero-dilated source cannot be combined with x2");
     a.HB = d->h / 2;
     a.WB = d->w_in / 2;
   }

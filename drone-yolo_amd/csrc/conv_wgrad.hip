@@ -1,0 +1,287 @@
+// Convolution weight gradient:  dW[co][r][q][ci] += sum_m dz[m][co] * x[pix(m; r, q)][ci]
+// (autograd of F.conv2d w.r.t. the weight for Conv / RepVGGBlock / Detect convolutions in training,
+// nn/modules/conv.py:37-55 called under engine/trainer.py:381-389).
+//
+// A GEMM whose contraction index is the PIXEL: M' = cout, N' = cin (one tap per workgroup), K' = batch*Ho*Wo.  Both
+// operands are stored pixel-major (NHWC rows), i.e. "K-major": the MFMA operand of lane (row lr, k-chunk lq) needs 8
+// different pixels of ONE channel.  gfx950's ds_read_b64_tr_b16 does that transpose for free: per 16-lane group it
+// reads a 4-pixel x 16-channel block of the row-major LDS tile and hands lane i channel i of the 4 pixels.  The 8
+// k-values of lane group lq are pixels {4lq..4lq+3} and {16+4lq..16+4lq+3} of the 32-pixel step (any k permutation is
+// fine as long as both operands use it): the 32 lanes of a half then touch 8 consecutive tile rows, and with a row pitch
+// of (columns*2 + 32) bytes those 8 x 32-byte segments fall into distinct banks.
+// fp32 storage: v_mfma_f32_16x16x4_f32 takes one element per lane, so plain ds_read_b32 (no transpose needed).
+//
+// Workgroup = 4 waves, each wave owns a 64 (cout) x 64 (cin) tile: 2 x 2 waves when cout and cin >= 128, otherwise the
+// waves split the pixel range (WK = 4 / (WCO*WCI) independent 32-pixel steps per iteration).  Pixel slabs are spread
+// over gridDim.x; partial sums are added to dW with fp32 atomics (dW must be zero before the call).
+#include "common.cuh"
+#include <type_traits>
+
+namespace dy {
+
+struct WgradArgs {
+  const void* x;
+  const void* dz;
+  float* dw;  // [cout][ks*ks][cin]
+  int H, W, Cin, ldx, Ho, Wo, Cout, lddz, ks, stride, pad;
+  long long M;
+  int HoWo, tilesCo, tilesCi, rows_per_block;
+};
+
+// The four 16-channel fragments of one operand for this lane: 8 transposed reads and their wait in ONE asm statement
+// (the compiler does not track asm loads, so results must not be touched before the s_waitcnt inside the statement).
+template <int PITCH>
+__device__ __forceinline__ void tr_read_frags(const void* base, u32x4 (&out)[4]) {
+  u32x2 r0, r1, r2, r3, r4, r5, r6, r7;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8 offset:%9\n\t"
+      "ds_read_b64_tr_b16 %1, %8 offset:%10\n\t"
+      "ds_read_b64_tr_b16 %2, %8 offset:%11\n\t"
+      "ds_read_b64_tr_b16 %3, %8 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %4, %8 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %5, %8 offset:%14\n\t"
+      "ds_read_b64_tr_b16 %6, %8 offset:%15\n\t"
+      "ds_read_b64_tr_b16 %7, %8 offset:%16\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+      : "v"((unsigned)(uintptr_t)base), "n"(0), "n"(16 * PITCH), "n"(32), "n"(32 + 16 * PITCH), "n"(64), "n"(64 + 16 * PITCH), "n"(96),
+        "n"(96 + 16 * PITCH)
+      : "memory");
+  out[0] = u32x4{r0[0], r0[1], r1[0], r1[1]};
+  out[1] = u32x4{r2[0], r2[1], r3[0], r3[1]};
+  out[2] = u32x4{r4[0], r4[1], r5[0], r5[1]};
+  out[3] = u32x4{r6[0], r6[1], r7[0], r7[1]};
+}
+
+template <typename T, int WCO, int WCI>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
+  constexpr int E = Elem<T>::EPC;
+  constexpr int WK = 4 / (WCO * WCI);
+  constexpr int TCO = 64 * WCO, TCI = 64 * WCI;
+  constexpr int PA = TCO * (int)sizeof(T) + 32, PB = TCI * (int)sizeof(T) + 32;  // row pitches (bytes)
+  constexpr int TILE = 32 * (PA + PB);                                            // one 32-pixel step of both operands
+  constexpr int CA = TCO / E, CB = TCI / E;                                       // 16-byte chunks per row
+  constexpr int NCH = WK * 32 * (CA + CB);                                        // chunks per iteration
+  constexpr int PER = (NCH + 255) / 256;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[WK * TILE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int wk = wave / (WCO * WCI), wco = (wave / WCI) % WCO, wci = wave % WCI;
+  int t = blockIdx.y;
+  const int tci = t % p.tilesCi;
+  t /= p.tilesCi;
+  const int tco = t % p.tilesCo;
+  const int tap = t / p.tilesCo;
+  const int r_ = tap / p.ks, q_ = tap - r_ * p.ks;
+  const int co0 = tco * TCO, ci0 = tci * TCI;
+
+  const long long m_begin = (long long)blockIdx.x * p.rows_per_block;
+  long long m_end = m_begin + p.rows_per_block;
+  if (m_end > p.M) m_end = p.M;
+
+  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ dg = reinterpret_cast<const T*>(p.dz);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 stage[PER];
+  auto load_step = [&](long long m0) {  // chunk id -> (k-split, operand, row, chunk): global -> registers
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int id = k * 256 + tid;
+      u32x4 v = zero_chunk();
+      if (id < NCH) {
+        const int ws = id / (32 * (CA + CB));
+        const int rem = id - ws * 32 * (CA + CB);
+        const long long m = m0 + ws * 32;
+        if (rem < 32 * CA) {
+          const int row = rem / CA, ch = rem - row * CA;
+          const long long mm = m + row;
+          const int co = co0 + ch * E;
+          if (mm < m_end && co < p.Cout) v = *reinterpret_cast<const u32x4*>(dg + mm * p.lddz + co);
+        } else {
+          const int rem2 = rem - 32 * CA;
+          const int row = rem2 / CB, ch = rem2 - row * CB;
+          const long long mm = m + row;
+          const int ci = ci0 + ch * E;
+          if (mm < m_end && ci < p.Cin) {
+            const int n = (int)(mm / p.HoWo);
+            const int rr = (int)(mm - (long long)n * p.HoWo);
+            const int ho = rr / p.Wo, wo = rr - ho * p.Wo;
+            const int hi = ho * p.stride - p.pad + r_, wi = wo * p.stride - p.pad + q_;
+            if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+              v = *reinterpret_cast<const u32x4*>(xg + ((long long)(n * p.H + hi) * p.W + wi) * p.ldx + ci);
+          }
+        }
+      }
+      stage[k] = v;
+    }
+  };
+  auto store_step = [&]() {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int id = k * 256 + tid;
+      if (id < NCH) {
+        const int ws = id / (32 * (CA + CB));
+        const int rem = id - ws * 32 * (CA + CB);
+        unsigned char* base = smem + ws * TILE;
+        if (rem < 32 * CA) {
+          const int row = rem / CA, ch = rem - row * CA;
+          *reinterpret_cast<u32x4*>(base + row * PA + ch * 16) = stage[k];
+        } else {
+          const int rem2 = rem - 32 * CA;
+          const int row = rem2 / CB, ch = rem2 - row * CB;
+          *reinterpret_cast<u32x4*>(base + 32 * PA + row * PB + ch * 16) = stage[k];
+        }
+      }
+    }
+  };
+
+  const unsigned char* ta = smem + wk * TILE + wco * 64 * (int)sizeof(T);            // this wave's 64 cout columns
+  const unsigned char* tb = smem + wk * TILE + 32 * PA + wci * 64 * (int)sizeof(T);  // this wave's 64 cin columns
+  // operand fragments of this lane for k-group kg (16-bit: the whole 32-pixel step; fp32: 16 pixels)
+  auto frags = [&](const unsigned char* tile, auto pitch_c, int kg, u32x4 (&out)[4]) {
+    constexpr int PITCH = decltype(pitch_c)::value;
+    if constexpr (sizeof(T) == 2) {
+      // transposed reads: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of the 4 x 16 block;
+      // lane group lq takes pixels 4lq..4lq+3 (first read) and 16+4lq.. (second read, +16 rows)
+      const int q = lr >> 2, pp = lr & 3;
+      tr_read_frags<PITCH>(tile + (lq * 4 + q) * PITCH + pp * 8, out);
+      (void)kg;
+    } else {
+      // fp32: lane quarter lq holds pixels 4lq..4lq+3 of channel lr
+      const unsigned char* a0 = tile + (kg * 16 + lq * 4) * PITCH + lr * 4;
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[f][j] = *reinterpret_cast<const unsigned*>(a0 + f * 64 + j * PITCH);
+    }
+  };
+
+  const long long step = 32LL * WK;
+  if (m_begin < m_end) load_step(m_begin);
+  for (long long m0 = m_begin; m0 < m_end; m0 += step) {
+    __syncthreads();  // previous iteration's fragment reads are done
+    store_step();
+    __syncthreads();
+    if (m0 + step < m_end) load_step(m0 + step);  // in flight during the MFMAs
+    constexpr int KG = sizeof(T) == 2 ? 1 : 2;
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) {
+      u32x4 a[4], b[4];
+      frags(ta, std::integral_constant<int, PA>{}, kg, a);
+      frags(tb, std::integral_constant<int, PB>{}, kg, b);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = Elem<T>::mma(a[i], b[j], acc[i][j]);
+    }
+  }
+  mfma_epilogue_fence<T>();
+
+  // D[co][ci]: lane holds rows co = 4*lq + reg, column ci = lr of every 16 x 16 fragment
+  const int kk = p.ks * p.ks;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ci = ci0 + wci * 64 + j * 16 + lr;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = co0 + wco * 64 + i * 16 + lq * 4 + e;
+        if (co < p.Cout && ci < p.Cin) atomicAdd(p.dw + ((size_t)co * kk + tap) * p.Cin + ci, acc[i][j][e]);
+      }
+    }
+}
+
+template <typename T, int WCO, int WCI>
+static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
+  WgradArgs p = a;
+  p.tilesCo = (p.Cout + 64 * WCO - 1) / (64 * WCO);
+  p.tilesCi = (p.Cin + 64 * WCI - 1) / (64 * WCI);
+  const int ny = p.ks * p.ks * p.tilesCo * p.tilesCi;
+  constexpr int STEP = 32 * (4 / (WCO * WCI));
+  // pixel slabs: fill ~4 workgroups per CU overall, but keep every slab at least 8 steps long
+  long long slabs = (1024 + ny - 1) / ny;
+  const long long max_slabs = (p.M + 8LL * STEP - 1) / (8LL * STEP);
+  if (slabs > max_slabs) slabs = max_slabs;
+  if (slabs < 1) slabs = 1;
+  long long rpb = (p.M + slabs - 1) / slabs;
+  rpb = (rpb + STEP - 1) / STEP * STEP;
+  p.rows_per_block = (int)rpb;
+  const unsigned gx = (unsigned)((p.M + rpb - 1) / rpb);
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, WCO, WCI>), dim3(gx, (unsigned)ny), dim3(256), 0, st, p);
+  return check_launch("conv_wgrad_kernel");
+}
+
+template <typename T>
+static int launch_wgrad_dtype(const WgradArgs& a, hipStream_t st) {
+  const bool bco = a.Cout > 64, bci = a.Cin > 64;
+  if (bco && bci) return launch_wgrad<T, 2, 2>(a, st);
+  if (bco) return launch_wgrad<T, 2, 1>(a, st);
+  if (bci) return launch_wgrad<T, 1, 2>(a, st);
+  return launch_wgrad<T, 1, 1>(a, st);
+}
+
+// column sums of a (rows, c) view: the bias gradient of the plain Detect convolutions (head.py:43-57)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* z, float* out, long long rows, int c, int ld, int rows_per_block) {
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  long long r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  for (int cc = threadIdx.x; cc < c; cc += 256) {
+    float s = 0.f;
+    for (long long r = r0; r < r1; ++r) s += Elem<T>::to_f32(z[r * ld + cc]);
+    atomicAdd(out + cc, s);
+  }
+}
+
+}  // namespace dy
+
+using namespace dy;
+
+extern "C" int32_t dy_conv2d_wgrad_nhwc(const dy_conv_desc* d, const void* dz, int32_t ld_dz, float* dw, dy_stream_t stream) {
+  DY_REQUIRE(d && d->x && dz && dw, DY_ERR_INVALID_ARG, "dy_conv2d_wgrad_nhwc: null pointer");
+  const int es = dy_dtype_size(d->dtype);
+  DY_REQUIRE(es != 0 && d->batch > 0 && d->h > 0 && d->w_in > 0 && d->cin > 0 && d->cout > 0 && d->ksize >= 1 && d->stride >= 1 && d->pad >= 0,
+             DY_ERR_INVALID_ARG, "dy_conv2d_wgrad_nhwc: bad dims");
+  DY_REQUIRE(d->groups <= 1 && !d->up2x && !d->x2, DY_ERR_UNSUPPORTED, "dy_conv2d_wgrad_nhwc: dense single-source convolutions only");
+  const int epc = 16 / es;
+  DY_REQUIRE(d->cin % epc == 0 && d->cout % epc == 0, DY_ERR_UNSUPPORTED, "dy_conv2d_wgrad_nhwc: cin and cout must be multiples of %d", epc);
+  DY_REQUIRE(aligned16(d->x) && aligned16(dz) && (d->ld_x * es) % 16 == 0 && (ld_dz * es) % 16 == 0 && d->ld_x >= d->cin && ld_dz >= d->cout,
+             DY_ERR_INVALID_ARG, "dy_conv2d_wgrad_nhwc: x / dz views must be 16-byte aligned with pitches covering the channels");
+  const int ho = (d->h + 2 * d->pad - d->ksize) / d->stride + 1, wo = (d->w_in + 2 * d->pad - d->ksize) / d->stride + 1;
+  DY_REQUIRE(ho == d->ho && wo == d->wo, DY_ERR_INVALID_ARG, "dy_conv2d_wgrad_nhwc: ho/wo (%d,%d) != expected (%d,%d)", d->ho, d->wo, ho, wo);
+  WgradArgs a{};
+  a.x = d->x, a.dz = dz, a.dw = dw;
+  a.H = d->h, a.W = d->w_in, a.Cin = d->cin, a.ldx = d->ld_x, a.Ho = ho, a.Wo = wo, a.Cout = d->cout, a.lddz = ld_dz;
+  a.ks = d->ksize, a.stride = d->stride, a.pad = d->pad;
+  a.M = (long long)d->batch * ho * wo;
+  a.HoWo = ho * wo;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  switch (d->dtype) {
+    case DY_BF16: return launch_wgrad_dtype<bf16_t>(a, st);
+    case DY_F16: return launch_wgrad_dtype<f16_t>(a, st);
+    default: return launch_wgrad_dtype<float>(a, st);
+  }
+}
+
+extern "C" int32_t dy_colsum(const void* z, float* out, int64_t rows, int32_t c, int32_t ld, int32_t dtype, dy_stream_t stream) {
+  DY_REQUIRE(z && out && rows > 0 && c > 0 && ld >= c && dy_dtype_size(dtype), DY_ERR_INVALID_ARG, "dy_colsum: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  long long blocks = (rows + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  const int rpb = (int)((rows + blocks - 1) / blocks);
+  const unsigned gx = (unsigned)((rows + rpb - 1) / rpb);
+  switch (dtype) {
+    case DY_BF16: hipLaunchKernelGGL((colsum_kernel<bf16_t>), dim3(gx), dim3(256), 0, st, reinterpret_cast<const bf16_t*>(z), out, (long long)rows, c, ld, rpb); break;
+    case DY_F16: hipLaunchKernelGGL((colsum_kernel<f16_t>), dim3(gx), dim3(256), 0, st, reinterpret_cast<const f16_t*>(z), out, (long long)rows, c, ld, rpb); break;
+    default: hipLaunchKernelGGL((colsum_kernel<float>), dim3(gx), dim3(256), 0, st, reinterpret_cast<const float*>(z), out, (long long)rows, c, ld, rpb); break;
+  }
+  return check_launch("dy_colsum");
+}

@@ -149,6 +149,7 @@ class PackedConv:
                 raise ValueError("cin_pad is only meaningful for dense convolutions")
             weight = torch.nn.functional.pad(weight.detach().float(), (0, 0, 0, 0, 0, cin_pad - weight.shape[1]))
         cout, cin_g, k, k2 = weight.shape
+        wdev = weight.device  # pack where the weights live (CPU for inference setup, the GPU in training: no host round trip)
         assert k == k2, "square kernels only"
         self.cout, self.cin, self.k, self.stride, self.pad, self.groups = cout, cin_g * groups, k, stride, pad, groups
         self.act = DY_ACT_SILU if act else DY_ACT_NONE
@@ -168,12 +169,12 @@ class PackedConv:
             e = elems_per_chunk(dtype)
             kc, bn = 4 * e, (64 if cout > 32 else 32)
             nt, nch = -(-cout // bn), -(-self.cin // kc)
-            wpad = torch.zeros((nt * bn, nch * kc, 3, 3), dtype=torch.float32)
-            wpad[:cout, : self.cin] = weight.detach().to(torch.float32).cpu()
+            wpad = torch.zeros((nt * bn, nch * kc, 3, 3), dtype=torch.float32, device=wdev)
+            wpad[:cout, : self.cin] = weight.detach().to(torch.float32)
             wp = wpad.view(nt, bn // 16, 16, nch, 4, e, 3, 3).permute(0, 3, 6, 7, 1, 4, 2, 5).contiguous().view(-1)
             self.k_pad, self.cout_pad = 0, L.dy_conv_cout_pad(cout)
-            bp = torch.zeros((self.cout_pad,), dtype=torch.float32)
-            bp[:cout] = bias.detach().to(torch.float32)
+            bp = torch.zeros((self.cout_pad,), dtype=torch.float32, device=wdev)
+            bp[:cout] = bias.detach().to(torch.float32).to(wdev)
             self.w = wp.to(dtype).contiguous().to(device)
             self.b = bp.contiguous().to(device)
             return
@@ -192,12 +193,12 @@ class PackedConv:
             self.layout = _lib.DY_WLAYOUT_FRAG1X1
             kc, bn = 4 * e, (128 if cout > 64 else (64 if cout > 16 else 16))
             nt = -(-cout // bn)
-            wpad = torch.zeros((nt * bn, nkg * kc), dtype=torch.float32)
-            wpad[:cout, : self.cin] = weight.detach().to(torch.float32).cpu().view(cout, self.cin)
+            wpad = torch.zeros((nt * bn, nkg * kc), dtype=torch.float32, device=wdev)
+            wpad[:cout, : self.cin] = weight.detach().to(torch.float32).view(cout, self.cin)
             wp = wpad.view(nt, bn // 16, 16, nkg, 4, e).permute(0, 3, 1, 4, 2, 5).contiguous().view(-1)
             self.k_pad, self.cout_pad = 0, max(L.dy_conv_cout_pad(cout), nt * bn)
-            bp = torch.zeros((self.cout_pad,), dtype=torch.float32)
-            bp[:cout] = bias.detach().to(torch.float32)
+            bp = torch.zeros((self.cout_pad,), dtype=torch.float32, device=wdev)
+            bp[:cout] = bias.detach().to(torch.float32).to(wdev)
             self.w = wp.to(dtype).contiguous().to(device)
             self.b = bp.contiguous().to(device)
             return
@@ -205,10 +206,10 @@ class PackedConv:
         if groups == 1:
             self.k_pad = L.dy_conv_k_pad(self.cin, k, dy_dtype(dtype))
             self.cout_pad = L.dy_conv_cout_pad(cout)
-            wp = torch.zeros((self.cout_pad, self.k_pad), dtype=torch.float32)
+            wp = torch.zeros((self.cout_pad, self.k_pad), dtype=torch.float32, device=wdev)
             wp[:cout, : w.shape[1]] = w
-            bp = torch.zeros((self.cout_pad,), dtype=torch.float32)
-            bp[:cout] = bias.detach().to(torch.float32)
+            bp = torch.zeros((self.cout_pad,), dtype=torch.float32, device=wdev)
+            bp[:cout] = bias.detach().to(torch.float32).to(wdev)
         else:
             self.k_pad, self.cout_pad = w.shape[1], cout
             wp, bp = w, bias.detach().to(torch.float32)
@@ -221,17 +222,18 @@ def conv_out_hw(h: int, w: int, k: int, s: int, p: int) -> Tuple[int, int]:
 
 
 def conv2d(x: torch.Tensor, pc: PackedConv, out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-           out_f32: bool = False, up2x: bool = False, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
+           out_f32: bool = False, up2x: bool = False, x2: Optional[torch.Tensor] = None, dil2: bool = False) -> torch.Tensor:
     """act(conv(x) + bias) (+ residual) through ``dy_conv2d_nhwc``.
 
     ``x2``: optional second input whose channels follow x's (Concat folded into the gather);
     ``up2x``: x is consumed through a fused 2x nearest upsample.
+    ``dil2``: x is consumed zero-dilated by 2 (value at even (h, w) only): the gather of a stride-2 transposed conv.
     """
     require_device(x, "conv2d input")
     if x.dtype != pc.dtype:
         raise TypeError(f"conv2d: input dtype {x.dtype} != packed weight dtype {pc.dtype}")
     n, c1, hb, wb = x.shape
-    h, w = (2 * hb, 2 * wb) if up2x else (hb, wb)
+    h, w = (2 * hb, 2 * wb) if (up2x or dil2) else (hb, wb)
     cin = c1 + (x2.shape[1] if x2 is not None else 0)
     if cin != pc.cin:
         raise ValueError(f"conv2d: input has {cin} channels, weights expect {pc.cin}")
@@ -250,7 +252,7 @@ def conv2d(x: torch.Tensor, pc: PackedConv, out: Optional[torch.Tensor] = None, 
     d.ho, d.wo, d.cout, d.ld_y = ho, wo, pc.cout, ldy
     d.ksize, d.stride, d.pad, d.groups = pc.k, pc.stride, pc.pad, pc.groups
     d.act, d.dtype, d.out_f32 = pc.act, dy_dtype(x.dtype), int(out_f32)
-    d.k_pad, d.cout_pad, d.up2x, d.w_layout = pc.k_pad, pc.cout_pad, int(up2x), pc.layout
+    d.k_pad, d.cout_pad, d.up2x, d.w_layout = pc.k_pad, pc.cout_pad, (2 if dil2 else int(up2x)), pc.layout
     if residual is not None:
         if tuple(residual.shape) != tuple(out.shape) or residual.dtype != x.dtype:
             raise ValueError("conv2d: residual must match the output shape and the input dtype")
@@ -624,3 +626,49 @@ def silu_bwd(u: torch.Tensor, dy: torch.Tensor, out: Optional[torch.Tensor] = No
     (up, ldu), (dp, ldd), (op, ldo) = view_params(u), view_params(dy), view_params(out)
     _launch(lib().dy_silu_bwd, (up, dp, op, _rows(u), c, ldu, ldd, ldo, dy_dtype(u.dtype)), keep=(u, dy, out))
     return out
+
+
+# ---- convolution gradients ----------------------------------------------------------------------------------------
+
+
+def conv_wgrad(x: torch.Tensor, dz: torch.Tensor, ksize: int, stride: int, pad: int) -> torch.Tensor:
+    """d loss / d weight of z = conv2d(x, w, stride, pad): fp32 (cout, cin, k, k), through ``dy_conv2d_wgrad_nhwc``."""
+    require_device(x, "wgrad input")
+    n, cin, h, w = x.shape
+    cout, ho, wo = dz.shape[1], dz.shape[2], dz.shape[3]
+    if (ho, wo) != conv_out_hw(h, w, ksize, stride, pad) or dz.shape[0] != n or dz.dtype != x.dtype:
+        raise ValueError("conv_wgrad: dz does not match the forward geometry / dtype")
+    d = ConvDesc()
+    (d.x, d.ld_x), (dzp, lddz) = view_params(x), view_params(dz)
+    d.batch, d.h, d.w_in, d.cin, d.ho, d.wo, d.cout = n, h, w, cin, ho, wo, cout
+    d.ksize, d.stride, d.pad, d.groups, d.dtype = ksize, stride, pad, 1, dy_dtype(x.dtype)
+    dw = torch.zeros((cout, ksize, ksize, cin), dtype=torch.float32, device=x.device)
+    _launch(lib().dy_conv2d_wgrad_nhwc, (C.byref(d), dzp, lddz, dw.data_ptr()), keep=(d, x, dz, dw))
+    return dw.permute(0, 3, 1, 2)
+
+
+def colsum(z: torch.Tensor) -> torch.Tensor:
+    """Per-channel sum over (N, H, W) of an NHWC view: the bias gradient of a plain convolution."""
+    zp, ld = view_params(z)
+    out = torch.zeros(z.shape[1], dtype=torch.float32, device=z.device)
+    _launch(lib().dy_colsum, (zp, out.data_ptr(), _rows(z), z.shape[1], ld, dy_dtype(z.dtype)), keep=(z, out))
+    return out
+
+
+def pack_dgrad(weight: torch.Tensor, stride: int, dtype: torch.dtype, device) -> PackedConv:
+    """Weights of the convolution that computes dx from dz: w'[ci][co][r][q] = w[co][ci][k-1-r][k-1-q], stride 1,
+    pad k-1-pad (= pad for the 'same' convolutions of this model); stride-2 layers run on the generic / LDS-DMA kernels
+    (zero-dilated gather), stride-1 3x3 layers may take the halo kernel."""
+    wt = weight.detach().flip(2, 3).permute(1, 0, 2, 3).contiguous()
+    k = weight.shape[2]
+    return PackedConv(wt, torch.zeros(wt.shape[0], device=wt.device), 1, k // 2, 1, False, dtype, device,
+                      halo=None if (stride == 1 and k == 3) else False)  # the streaming 1x1 kernel has no residual (accumulate) input
+
+
+def conv_dgrad(dz: torch.Tensor, pc: PackedConv, stride: int, out: Optional[torch.Tensor] = None,
+               accumulate: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx of z = conv2d(x, w, stride, k//2) given dz, with ``pc = pack_dgrad(w, stride, ...)``; ``accumulate``: a gradient
+    already held for x (another consumer's contribution), added in the epilogue."""
+    if stride not in (1, 2):
+        raise NotImplementedError("conv_dgrad: stride 1 or 2")
+    return conv2d(dz, pc, out=out, residual=accumulate, dil2=(stride == 2))

@@ -94,7 +94,10 @@ typedef struct dy_conv_desc {
   int32_t k_pad, cout_pad;
   int32_t up2x;          /* 1: x is read through a fused 2x nearest upsample
                             (nn.Upsample(None,2,'nearest') folded into this conv's gather):
-                            h,w_in are the UPSAMPLED dims, the buffer holds (h/2, w_in/2) */
+                            h,w_in are the UPSAMPLED dims, the buffer holds (h/2, w_in/2).
+                            2: x is read ZERO-DILATED by 2 (logical (h, w_in) = 2x the buffer dims, value at even
+                            (row, col) only, zero elsewhere): the gather of a stride-2 transposed convolution, used for
+                            the input gradient of stride-2 layers.  DY_WLAYOUT_ROWS only, no x2. */
   /* Optional second source = Concat folded into the gather (conv.py:323-333): input
    * channels [0,cin_split) are read from x (through up2x if set), channels
    * [cin_split,cin) from x2 (never upsampled), pitch ld_x2.  x2 = NULL: single source. */
@@ -286,6 +289,19 @@ typedef struct dy_loss_desc {
 } dy_loss_desc;
 int64_t dy_detection_loss_workspace_bytes(int32_t batch, int32_t anchors, int32_t gmax, int32_t topk);
 int32_t dy_detection_loss(const dy_loss_desc* d, dy_stream_t stream);
+
+/* ---- convolution gradients ------------------------------------------------------------------
+ * Replaces: autograd of F.conv2d inside Conv / RepVGGBlock / Detect (nn/modules/conv.py:37-55) during
+ * loss.backward() (engine/trainer.py:381-389).
+ * Weight gradient: dw[co][(r*ksize + q)][ci] += sum over output pixels m of dz[m][co] * x[pixel(m) + tap (r,q)][ci].
+ *   d describes the FORWARD convolution (x, batch, h, w_in, cin, ld_x, ho, wo, cout, ksize, stride, pad, dtype; w / bias /
+ *   y are ignored); dz: NHWC view (batch, ho, wo, cout) of `dtype`, pitch ld_dz; dw: fp32, cout*ksize*ksize*cin, ZEROED by
+ *   the caller (partial sums of pixel slabs are added with fp32 atomics).  cin, cout multiples of one 16-byte chunk.
+ * Input gradient: dx = conv_transpose(dz, w) is run through dy_conv2d_nhwc itself on re-packed weights
+ *   (w'[ci][2-r][2-q][co] = w[co][r][q][ci], stride 1; stride-2 layers read dz through `dil2`, a zero-dilated gather).
+ * dy_colsum: out[c] += sum over rows of z[row][c] (bias gradient of the plain Detect convolutions); out zeroed by the caller. */
+int32_t dy_conv2d_wgrad_nhwc(const dy_conv_desc* d, const void* dz, int32_t ld_dz, float* dw, dy_stream_t stream);
+int32_t dy_colsum(const void* z, float* out, int64_t rows, int32_t c, int32_t ld, int32_t dtype, dy_stream_t stream);
 
 /* ---- train-mode BatchNorm2d (+ SiLU) -----------------------------------------------------
  * Replaces: the BatchNorm2d + SiLU half of Conv.forward in training mode (nn/modules/conv.py:37-55; eps 1e-3 and

@@ -83,3 +83,54 @@ def test_two_branch_bn_sum_then_silu(dtype, device):
     close(yd, y.detach(), dtype, "repvgg fwd", extra=2.0)
     close(dz3, z3.grad, dtype, "repvgg dz3", extra=3.0)
     close(dz1, z1.grad, dtype, "repvgg dz1", extra=3.0)
+
+
+GRAD_CASES = [
+    # cin, cout, k, s, B, H, W, tag
+    (64, 64, 3, 1, 3, 24, 20, "3x3 s1 64->64"),
+    (32, 32, 3, 1, 2, 33, 31, "3x3 s1 32->32 odd dims"),
+    (128, 256, 3, 2, 2, 24, 28, "3x3 s2 128->256"),
+    (32, 64, 3, 2, 2, 40, 40, "3x3 s2 32->64"),
+    (32, 64, 1, 2, 2, 40, 40, "1x1 s2 (RepVGG side branch)"),
+    (192, 128, 1, 1, 2, 20, 20, "1x1 192->128"),
+    (768, 512, 1, 1, 2, 10, 10, "1x1 768->512"),
+    (256, 256, 3, 1, 2, 10, 10, "3x3 s1 256->256"),
+    (64, 16, 3, 1, 2, 16, 16, "3x3 cout=16"),
+    (8, 32, 3, 2, 2, 32, 32, "stem (cin padded to 8)"),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("case", GRAD_CASES, ids=[c[-1] for c in GRAD_CASES])
+def test_conv_wgrad_dgrad_match_autograd(case, dtype, device):
+    cin, cout, k, s, b, h, w, tag = case
+    g = torch.Generator().manual_seed(hash(tag) % 997)
+    x = quantize(torch.randn(b, cin, h, w, generator=g), dtype).requires_grad_(True)
+    wt = quantize(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5, dtype).requires_grad_(True)
+    z = F.conv2d(x, wt, None, s, k // 2)
+    dz = quantize(torch.randn(z.shape, generator=g), dtype)
+    z.backward(dz)
+    xd, dzd = nhwc(x.detach(), dtype, device), nhwc(dz, dtype, device, ld=cout + 8)
+    dw = H.conv_wgrad(xd, dzd, k, s, k // 2)
+    torch.cuda.synchronize()
+    close(dw, wt.grad, torch.float32, f"wgrad {tag}", extra=30.0 if dtype == torch.float32 else 10.0)  # fp32 accumulate of exact products, atomics order
+    if cin >= 16:  # the image itself needs no gradient
+        pc = H.pack_dgrad(wt.detach().to(device), s, dtype, device)
+        dx = H.conv_dgrad(dzd, pc, s)
+        torch.cuda.synchronize()
+        assert tuple(dx.shape) == tuple(x.shape)
+        close(dx, x.grad, dtype, f"dgrad {tag}")
+        prev = quantize(torch.randn(x.shape, generator=g), dtype)
+        dx2 = H.conv_dgrad(dzd, pc, s, accumulate=nhwc(prev, dtype, device))
+        torch.cuda.synchronize()
+        close(dx2, x.grad + prev, dtype, f"dgrad+accumulate {tag}")
+
+
+def test_colsum_bias_grad(device):
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(3, 10, 17, 19, generator=g)
+    for dtype in DTYPES:
+        zq = quantize(z, dtype)
+        out = H.colsum(nhwc(zq, dtype, device, ld=16 if dtype != torch.float32 else 12))
+        torch.cuda.synchronize()
+        assert torch.allclose(out.cpu(), zq.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
