@@ -80,6 +80,17 @@ def bn_eval(x: Tensor, sd: SD, p: str) -> Tensor:
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], False, 0.0, BN_EPS)
 
 
+BN_MOMENTUM = 0.03  # utils/torch_utils.py:423-433 (initialize_weights)
+
+
+def bn_apply(x: Tensor, sd: SD, p: str, fused) -> Tensor:
+    """BatchNorm2d of the unfused module graph: eval statistics, or — ``fused == "train"`` — batch statistics with the
+    running buffers of ``sd`` updated in place (module.train(), the form engine/trainer.py:381 runs)."""
+    if fused == "train":
+        return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], True, BN_MOMENTUM, BN_EPS)
+    return bn_eval(x, sd, p)
+
+
 def fuse_conv_bn(w: Tensor, sd: SD, bn: str) -> Tuple[Tensor, Tensor]:
     """utils/torch_utils.py:242-269: W' = diag(g/sqrt(eps+var)) W ; b' = beta - g*mean/sqrt(var+eps)."""
     w_bn = torch.diag(sd[bn + ".weight"].div(torch.sqrt(BN_EPS + sd[bn + ".running_var"])))
@@ -91,18 +102,18 @@ def fuse_conv_bn(w: Tensor, sd: SD, bn: str) -> Tuple[Tensor, Tensor]:
 def conv_block(x: Tensor, sd: SD, p: str, k: int, s: int, g: int = 1, fused: bool = True) -> Tensor:
     """Conv.forward / forward_fuse (conv.py:49-55): SiLU(BN(conv(x))) or SiLU(conv'(x) + b')."""
     w = sd[p + ".conv.weight"]
-    if fused:
+    if fused is True:
         wf, bf = fuse_conv_bn(w, sd, p + ".bn")
         return F.silu(F.conv2d(x, wf, bf, s, autopad(k), 1, g))
-    return F.silu(bn_eval(F.conv2d(x, w, None, s, autopad(k), 1, g), sd, p + ".bn"))
+    return F.silu(bn_apply(F.conv2d(x, w, None, s, autopad(k), 1, g), sd, p + ".bn", fused))
 
 
-def repvgg_block(x: Tensor, sd: SD, p: str, stride: int, has_identity: bool) -> Tensor:
+def repvgg_block(x: Tensor, sd: SD, p: str, stride: int, has_identity: bool, fused=False) -> Tensor:
     """RepVGGBlock.forward, non-deploy (block.py:1480-1490): SiLU(BN(conv3x3) + BN(conv1x1) + BN(x)).
     BaseModel.fuse() does not touch this block (tasks.py:193-221), so this is also the predict form."""
-    dense = bn_eval(F.conv2d(x, sd[p + ".rbr_dense.conv.weight"], None, stride, 1), sd, p + ".rbr_dense.bn")
-    one = bn_eval(F.conv2d(x, sd[p + ".rbr_1x1.conv.weight"], None, stride, 0), sd, p + ".rbr_1x1.bn")
-    idt = bn_eval(x, sd, p + ".rbr_identity") if has_identity else 0
+    dense = bn_apply(F.conv2d(x, sd[p + ".rbr_dense.conv.weight"], None, stride, 1), sd, p + ".rbr_dense.bn", fused)
+    one = bn_apply(F.conv2d(x, sd[p + ".rbr_1x1.conv.weight"], None, stride, 0), sd, p + ".rbr_1x1.bn", fused)
+    idt = bn_apply(x, sd, p + ".rbr_identity", fused) if has_identity else 0
     return F.silu(dense + one + idt)
 
 
@@ -224,7 +235,8 @@ def forward(d: dict, sd: SD, x: Tensor, fused: bool = True, return_all: bool = F
     """BaseModel._predict_once (tasks.py:134-161) over the YAML graph, eval mode.
 
     fused=True is the predictor's form (AutoBackend fuse=True, autobackend.py:143-155: Conv+BN folded,
-    RepVGGBlock left 3-branch); fused=False is the freshly built module graph.
+    RepVGGBlock left 3-branch); fused=False is the freshly built module graph; fused="train" is that graph in
+    training mode (batch-statistics BatchNorm updating the running buffers in ``sd``, Detect returning the raw maps).
     Returns (y, feats): decoded (B, 4+nc, A) and the raw per-level head outputs, like Detect eval.
     """
     layers = resolve_layers(d, x.shape[1])
@@ -240,7 +252,7 @@ def forward(d: dict, sd: SD, x: Tensor, fused: bool = True, return_all: bool = F
         elif m == "DWConv":
             cur = conv_block(cur, sd, p, args[2], args[3], g=math.gcd(args[0], args[1]), fused=fused)
         elif m == "RepVGGBlock":
-            cur = repvgg_block(cur, sd, p, args[3], has_identity=(args[0] == args[1] and args[3] == 1))
+            cur = repvgg_block(cur, sd, p, args[3], has_identity=(args[0] == args[1] and args[3] == 1), fused=fused)
         elif m == "C2f":
             cur = c2f(cur, sd, p, args[2], bool(args[3]) if len(args) > 3 else False, fused)
         elif m == "SPPF":
@@ -251,7 +263,7 @@ def forward(d: dict, sd: SD, x: Tensor, fused: bool = True, return_all: bool = F
             cur = torch.cat(cur, 1)
         elif m == "Detect":
             feats = detect_head(cur, sd, p, args[0], fused)
-            cur = (detect_decode(feats, strides, args[0]), feats)
+            cur = feats if fused == "train" else (detect_decode(feats, strides, args[0]), feats)  # head.py:71-74
         else:
             raise NotImplementedError(m)
         ys.append(cur)

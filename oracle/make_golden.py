@@ -457,15 +457,100 @@ def loss_vectors(R):
     np.savez_compressed(OUT / "loss.npz", **out)
 
 
+def train_vectors(R):
+    """One training step of the REAL reference (module.train(), v8DetectionLoss, backward, SGD / AdamW step, EMA) against
+    oracle/train_oracle.py on the same seeded weights, uint8 image batch and labels."""
+    from ultralytics.utils import loss as rloss
+
+    from oracle import loss_oracle as LO
+    from oracle import train_oracle as TO
+
+    out = {}
+    for tag, yname, scale, nc, (b, h, w), seed in [("tn64", "yolov8-p2-repvgg.yaml", "n", 10, (2, 64, 64), 201),
+                                                   ("tn96", "yolov8-p2-repvgg.yaml", "n", 10, (3, 96, 128), 202)]:
+        torch.manual_seed(0)
+        model, _ = build_reference_model(R, yname, scale, nc)
+        d = our_yaml(yname, scale, nc)
+        template = {k: v for k, v in model.state_dict().items()}
+        sd = O.seeded_state_dict(template, seed, cls_bias=-3.0)
+        model.load_state_dict(sd)
+        R.tu.initialize_weights(model)
+        model.args = types.SimpleNamespace(box=7.5, cls=0.5, dfl=1.5)
+        model.train()
+        img = torch.randint(0, 256, (b, 3, h, w), generator=torch.Generator().manual_seed(seed), dtype=torch.uint8)
+        labels = LO.synthetic_labels(b, seed, n_mean=8.0)
+        crit = rloss.v8DetectionLoss(model)
+        preds = model(img.float() / 255)
+        ref_total, ref_items = crit(preds, labels)
+        ref_total.backward()
+        ref_grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        ref_sd_after = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        o_total, o_items, o_grads, o_sd = TO.loss_and_grads(d, sd, img, labels)
+        rel_tol_check(f"{tag} train loss total", o_total.view(1), ref_total.detach().view(1), tol=2e-5)
+        rel_tol_check(f"{tag} train loss items", o_items, ref_items, tol=2e-5)
+        worst = 0.0
+        for k, g in ref_grads.items():
+            e = maxerr(o_grads[k], g) / max(float(g.abs().max()), 1e-12)
+            worst = max(worst, e)
+        print(f"  oracle vs reference  {tag} gradients of {len(ref_grads)} parameters: worst relative max-error {worst:.2e}")
+        assert worst < 5e-4, "oracle training gradients deviate from the reference"
+        for k in ref_sd_after:
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                assert maxerr(o_sd[k], ref_sd_after[k]) <= 1e-5 * max(1.0, float(ref_sd_after[k].abs().max())), f"BN buffer {k} differs"
+        # optimizer + EMA: torch.optim on the reference modules vs the oracle's restatement, on these gradients
+        g0, g1, g2 = TO.param_groups(sd)
+        names = dict(model.named_parameters())
+        for opt_name in ("sgd", "adamw"):
+            psd = {k: v.detach().clone() for k, v in sd.items()}
+            prm = {k: torch.nn.Parameter(psd[k].clone()) for k in g0 + g1 + g2}
+            for k in prm:
+                prm[k].grad = ref_grads[k].clone()
+            torch.nn.utils.clip_grad_norm_(list(prm.values()), 10.0)
+            if opt_name == "sgd":
+                opt = torch.optim.SGD([prm[k] for k in g2], lr=0.01, momentum=0.937, nesterov=True)
+            else:
+                opt = torch.optim.AdamW([prm[k] for k in g2], lr=0.002, betas=(0.937, 0.999), weight_decay=0.0)
+            opt.add_param_group({"params": [prm[k] for k in g0], "weight_decay": 0.0005})
+            opt.add_param_group({"params": [prm[k] for k in g1], "weight_decay": 0.0})
+            opt.step()
+            og = {k: v.clone() for k, v in ref_grads.items()}
+            TO.clip_grad_norm_(og, 10.0)
+            if opt_name == "sgd":
+                TO.sgd_step(psd, og, {}, 0.01, 0.937, 0.0005)
+            else:
+                TO.adamw_step(psd, og, {}, 0.002, (0.937, 0.999), 1e-8, 0.0005)
+            w = max(maxerr(psd[k], prm[k].detach()) / max(float(prm[k].detach().abs().max()), 1e-12) for k in prm)
+            print(f"  oracle vs torch.optim  {tag} {opt_name} step (3 groups, clip 10): worst relative error {w:.2e}")
+            assert w < 1e-5
+        keys = sorted(ref_grads.keys())
+        out[f"{tag}__meta"] = np.array(repr(dict(yaml=yname, scale=scale, nc=nc, shape=(b, h, w), seed=seed, cls_bias=-3.0, n_mean=8.0)))
+        out[f"{tag}__keys"] = np.array(sorted(template.keys()))
+        out[f"{tag}__shapes"] = np.array([repr(tuple(template[k].shape)) for k in sorted(template.keys())])
+        out[f"{tag}__total"] = np.array(float(ref_total))
+        out[f"{tag}__items"] = tnp(ref_items)
+        out[f"{tag}__grad_keys"] = np.array(keys)
+        out[f"{tag}__grad_norm"] = np.array([float(ref_grads[k].double().norm()) for k in keys])
+        out[f"{tag}__grad_absmax"] = np.array([float(ref_grads[k].abs().max()) for k in keys])
+        for k in ("model.0.conv.weight", "model.28.cv3.0.2.bias", "model.28.cv2.3.2.weight", "model.1.rbr_1x1.conv.weight", "model.9.cv2.bn.weight"):
+            if k in ref_grads:
+                out[f"{tag}__grad::{k}"] = tnp(ref_grads[k])
+    np.savez_compressed(OUT / "train.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     OUT.mkdir(parents=True, exist_ok=True)
     R = import_reference()
     print("reference imported from", REF)
-    if "--loss-only" not in sys.argv:
+    if "--train-only" in sys.argv:
+        train_vectors(R)
+    elif "--loss-only" in sys.argv:
+        loss_vectors(R)
+    else:
         per_op(R)
         nms_cases(R)
         e2e(R)
-    loss_vectors(R)
+        loss_vectors(R)
+        train_vectors(R)
     for f in sorted(OUT.glob("*.npz")):
         print(f"wrote {f.relative_to(ROOT)}  {f.stat().st_size / 1024:.1f} KiB")

@@ -157,3 +157,33 @@ def test_loss_stack_vectors():
         assert torch.allclose(items, t(f"{tag}_items"), rtol=2e-5, atol=1e-5), tag
         assert abs(float(total) - float(g[f"{tag}_total"])) <= 2e-5 * abs(float(g[f"{tag}_total"])), tag
         assert torch.equal(asg["fg_mask"], t(f"{tag}_fg")) and torch.equal(asg["target_gt_idx"][asg["fg_mask"]], t(f"{tag}_gt_idx")[asg["fg_mask"]])
+
+
+def test_train_step_vectors():
+    """oracle/train_oracle.py (train-mode forward, loss, autograd) against the gradients captured from the REAL
+    reference's module.train() + v8DetectionLoss + backward (oracle/make_golden.py::train_vectors)."""
+    import drone_yolo_amd as D
+    from oracle import loss_oracle as LO
+    from oracle import train_oracle as TO
+
+    g = golden("train.npz")
+    for tag in ("tn64",):
+        m = meta(g, tag)
+        d = load_yaml(m["yaml"], m["scale"], m["nc"])
+        tmpl = D.DetectionModel(dict(d), nc=m["nc"], verbose=False).state_dict()
+        assert sorted(tmpl.keys()) == [str(k) for k in g[f"{tag}__keys"]]
+        sd = O.seeded_state_dict(tmpl, m["seed"], cls_bias=m["cls_bias"])
+        b, h, w = m["shape"]
+        img = torch.randint(0, 256, (b, 3, h, w), generator=torch.Generator().manual_seed(m["seed"]), dtype=torch.uint8)
+        labels = LO.synthetic_labels(b, m["seed"], n_mean=m["n_mean"])
+        total, items, grads, _ = TO.loss_and_grads(d, sd, img, labels)
+        assert abs(float(total) - float(g[f"{tag}__total"])) <= 2e-5 * abs(float(g[f"{tag}__total"]))
+        assert torch.allclose(items, torch.from_numpy(g[f"{tag}__items"]), rtol=2e-5)
+        keys = [str(k) for k in g[f"{tag}__grad_keys"]]
+        norms = np.array([float(grads[k].double().norm()) for k in keys])
+        assert np.allclose(norms, g[f"{tag}__grad_norm"], rtol=2e-4, atol=1e-7)
+        for f in g.files:
+            if f.startswith(f"{tag}__grad::"):
+                k = f.split("::", 1)[1]
+                ref = torch.from_numpy(g[f])
+                assert float((grads[k] - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-9, k
