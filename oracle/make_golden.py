@@ -519,9 +519,9 @@ def train_vectors(R):
                 TO.sgd_step(psd, og, {}, 0.01, 0.937, 0.0005)
             else:
                 TO.adamw_step(psd, og, {}, 0.002, (0.937, 0.999), 1e-8, 0.0005)
-            w = max(maxerr(psd[k], prm[k].detach()) / max(float(prm[k].detach().abs().max()), 1e-12) for k in prm)
-            print(f"  oracle vs torch.optim  {tag} {opt_name} step (3 groups, clip 10): worst relative error {w:.2e}")
-            assert w < 1e-5
+            werr = max(maxerr(psd[k], prm[k].detach()) / max(float(prm[k].detach().abs().max()), 1e-12) for k in prm)
+            print(f"  oracle vs torch.optim  {tag} {opt_name} step (3 groups, clip 10): worst relative error {werr:.2e}")
+            assert werr < 1e-5
         keys = sorted(ref_grads.keys())
         out[f"{tag}__meta"] = np.array(repr(dict(yaml=yname, scale=scale, nc=nc, shape=(b, h, w), seed=seed, cls_bias=-3.0, n_mean=8.0)))
         out[f"{tag}__keys"] = np.array(sorted(template.keys()))
