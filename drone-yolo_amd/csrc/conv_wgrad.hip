@@ -252,9 +252,11 @@ extern "C" int32_t dy_conv2d_wgrad_nhwc(const dy_conv_desc* d, const void* dz, i
              DY_ERR_INVALID_ARG, "dy_conv2d_wgrad_nhwc: bad dims");
   DY_REQUIRE(d->groups <= 1 && !d->up2x && !d->x2, DY_ERR_UNSUPPORTED, "dy_conv2d_wgrad_nhwc: dense single-source convolutions only");
   const int epc = 16 / es;
-  DY_REQUIRE(d->cin % epc == 0 && d->cout % epc == 0, DY_ERR_UNSUPPORTED, "dy_conv2d_wgrad_nhwc: cin and cout must be multiples of %d", epc);
-  DY_REQUIRE(aligned16(d->x) && aligned16(dz) && (d->ld_x * es) % 16 == 0 && (ld_dz * es) % 16 == 0 && d->ld_x >= d->cin && ld_dz >= d->cout,
-             DY_ERR_INVALID_ARG, "dy_conv2d_wgrad_nhwc: x / dz views must be 16-byte aligned with pitches covering the channels");
+  // channels are read in whole 16-byte chunks: the pitches must cover cin / cout ROUNDED UP to a chunk (what lies in the
+  // padding only reaches gradient rows / columns that are never written)
+  DY_REQUIRE(aligned16(d->x) && aligned16(dz) && (d->ld_x * es) % 16 == 0 && (ld_dz * es) % 16 == 0 && d->ld_x >= (d->cin + epc - 1) / epc * epc &&
+                 ld_dz >= (d->cout + epc - 1) / epc * epc,
+             DY_ERR_INVALID_ARG, "dy_conv2d_wgrad_nhwc: x / dz views must be 16-byte aligned with pitches covering the channels rounded up to %d", epc);
   const int ho = (d->h + 2 * d->pad - d->ksize) / d->stride + 1, wo = (d->w_in + 2 * d->pad - d->ksize) / d->stride + 1;
   DY_REQUIRE(ho == d->ho && wo == d->wo, DY_ERR_INVALID_ARG, "dy_conv2d_wgrad_nhwc: ho/wo (%d,%d) != expected (%d,%d)", d->ho, d->wo, ho, wo);
   WgradArgs a{};

@@ -1,0 +1,276 @@
+// Small bandwidth-bound kernels of the training path: gradients of nn.Upsample(None, 2, 'nearest')
+// (yolov8-p2-repvgg.yaml:30,34,38), of SPPF's MaxPool2d(k, 1, k//2) (nn/modules/block.py:185-191), the element-wise add
+// of Bottleneck's shortcut (block.py:348-350), and the optimizer / EMA / clipping updates of the trainer
+// (engine/trainer.py:591-599, 764-825; utils/torch_utils.py:515-545).
+#include "common.cuh"
+
+namespace dy {
+
+// ---- dx[n,h,w,:] = sum of the 2x2 block of g it was copied to -----------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ g, T* __restrict__ dx, int n, int h, int w, int cchunks, int ldg, int ldx) {
+  constexpr int E = Elem<T>::EPC;
+  const long long total = (long long)n * h * w * cchunks;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cc = (int)(i % cchunks);
+    long long t = i / cchunks;
+    const int x = (int)(t % w);
+    t /= w;
+    const int y = (int)(t % h);
+    const int img = (int)(t / h);
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int dyy = 0; dyy < 2; ++dyy)
+#pragma unroll
+      for (int dxx = 0; dxx < 2; ++dxx) {
+        float f[E];
+        Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(g + ((size_t)(img * 2 * h + 2 * y + dyy) * (2 * w) + 2 * x + dxx) * (size_t)ldg + cc * E), f);
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] += f[e];
+      }
+    *reinterpret_cast<u32x4*>(dx + ((size_t)(img * h + y) * w + x) * (size_t)ldx + cc * E) = Chunk<T>::pack(acc);
+  }
+}
+
+// ---- max-pool k x k, stride 1, pad k/2: gradient goes to the FIRST maximum of each window in (row, column) scan order,
+// as torch's max_pool2d does.  One workgroup per (image, 16-byte channel chunk): the plane of x and of the incoming
+// gradient sit in LDS; phase 1 finds the arg-max offset of every output, phase 2 gathers per input position.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ go, T* __restrict__ gi, int h, int w, int cchunks,
+                                                          int ldx, int ldgo, int ldgi, int r, int accumulate) {
+  constexpr int E = Elem<T>::EPC;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  const int hw = h * w;
+  float* xs = reinterpret_cast<float*>(dyn_smem);   // [hw][E]
+  float* gs = xs + hw * E;                          // [hw][E]
+  unsigned char* am = reinterpret_cast<unsigned char*>(gs + hw * E);  // [hw][E] arg-max offset (dy+r)*(2r+1) + (dx+r)
+  const int img = blockIdx.x / cchunks, cc = blockIdx.x - img * cchunks;
+  const int k = 2 * r + 1;
+  for (int p = threadIdx.x; p < hw; p += 256) {
+    float f[E], q[E];
+    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(x + ((size_t)img * hw + p) * (size_t)ldx + cc * E), f);
+    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(go + ((size_t)img * hw + p) * (size_t)ldgo + cc * E), q);
+#pragma unroll
+    for (int e = 0; e < E; ++e) xs[p * E + e] = f[e], gs[p * E + e] = q[e];
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < hw; p += 256) {
+    const int yy = p / w, xx = p - yy * w;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      float best = -3.4e38f;
+      int bo = 0;
+      bool first = true;
+      for (int dyy = -r; dyy <= r; ++dyy) {
+        const int y2 = yy + dyy;
+        if ((unsigned)y2 >= (unsigned)h) continue;
+        for (int dxx = -r; dxx <= r; ++dxx) {
+          const int x2 = xx + dxx;
+          if ((unsigned)x2 >= (unsigned)w) continue;
+          const float v = xs[(y2 * w + x2) * E + e];
+          if (first || v > best) {
+            best = v;
+            bo = (dyy + r) * k + (dxx + r);
+            first = false;
+          }
+        }
+      }
+      am[p * E + e] = (unsigned char)bo;
+    }
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < hw; p += 256) {
+    const int yy = p / w, xx = p - yy * w;
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    // output o = (yy - dyy, xx - dxx) sees this position at window offset (dyy, dxx)
+    for (int dyy = -r; dyy <= r; ++dyy) {
+      const int y2 = yy - dyy;
+      if ((unsigned)y2 >= (unsigned)h) continue;
+      for (int dxx = -r; dxx <= r; ++dxx) {
+        const int x2 = xx - dxx;
+        if ((unsigned)x2 >= (unsigned)w) continue;
+        const int o = y2 * w + x2;
+        const unsigned char want = (unsigned char)((dyy + r) * k + (dxx + r));
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+          if (am[o * E + e] == want) acc[e] += gs[o * E + e];
+      }
+    }
+    T* dst = gi + ((size_t)img * hw + p) * (size_t)ldgi + cc * E;
+    if (accumulate) {
+      float f[E];
+      Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(dst), f);
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[e] += f[e];
+    }
+    *reinterpret_cast<u32x4*>(dst) = Chunk<T>::pack(acc);
+  }
+}
+
+// ---- out = a + b on (rows, c) views ----------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, long long rows, int cchunks, int lda, int ldb, int ldo) {
+  constexpr int E = Elem<T>::EPC;
+  const long long total = rows * cchunks;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / cchunks;
+    const int cc = (int)(i - r * cchunks);
+    float fa[E], fb[E];
+    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(a + r * lda + cc * E), fa);
+    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(b + r * ldb + cc * E), fb);
+#pragma unroll
+    for (int e = 0; e < E; ++e) fa[e] += fb[e];
+    *reinterpret_cast<u32x4*>(o + r * ldo + cc * E) = Chunk<T>::pack(fa);
+  }
+}
+
+// ---- optimizer over ONE flat fp32 tensor ------------------------------------------------------------------------------
+// sum of squares (double) for clip_grad_norm_
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, double* out) {
+  double s = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += (double)g[i] * (double)g[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if ((threadIdx.x & 63) == 0 && s != 0.0) atomicAdd(out, s);
+}
+
+// torch.optim.SGD (momentum, nesterov, weight decay) with the clip coefficient folded in:
+//   g = clip * grad + wd * p;  buf = first ? g : mom * buf + g;  p -= lr * (nesterov ? g + mom * buf : buf)
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ buf, long long n, float lr, float mom,
+                                                  float wd, int nesterov, int first, const double* sumsq, float max_norm) {
+  float clip = 1.f;
+  if (sumsq) {
+    const float c = max_norm / ((float)sqrt(*sumsq) + 1e-6f);
+    clip = c < 1.f ? c : 1.f;
+  }
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float g = grad[i] * clip + wd * p[i];
+    const float b = first ? g : mom * buf[i] + g;
+    buf[i] = b;
+    g = nesterov ? g + mom * b : b;
+    p[i] -= lr * g;
+  }
+}
+
+// torch.optim.AdamW: p *= 1 - lr*wd;  m, v moments;  p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v, long long n,
+                                                    float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s, const double* sumsq, float max_norm) {
+  float clip = 1.f;
+  if (sumsq) {
+    const float c = max_norm / ((float)sqrt(*sumsq) + 1e-6f);
+    clip = c < 1.f ? c : 1.f;
+  }
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float g = grad[i] * clip;
+    float pp = p[i] * (1.f - lr * wd);
+    const float mm = m[i] * b1 + (1.f - b1) * g;
+    const float vv = v[i] * b2 + (1.f - b2) * g * g;
+    m[i] = mm;
+    v[i] = vv;
+    pp -= (lr / bc1) * mm / (sqrtf(vv) / bc2s + eps);
+    p[i] = pp;
+  }
+}
+
+// ModelEMA.update: e = d * e + (1 - d) * p
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ e, const float* __restrict__ p, long long n, float d) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) e[i] = e[i] * d + (1.f - d) * p[i];
+}
+
+static inline unsigned grid1(long long items) {
+  long long b = (items + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace dy
+
+using namespace dy;
+
+#define DY_VIEW_OK(p, ld, c, es) (aligned16(p) && (ld) >= (c) && ((ld) * (es)) % 16 == 0)
+
+extern "C" int32_t dy_upsample2x_bwd_nhwc(const void* g, void* dx, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ld_g, int32_t ld_dx, int32_t dtype,
+                                          dy_stream_t stream) {
+  const int es = dy_dtype_size(dtype);
+  DY_REQUIRE(es && g && dx && n > 0 && h > 0 && w > 0 && c > 0, DY_ERR_INVALID_ARG, "dy_upsample2x_bwd_nhwc: bad arguments");
+  const int epc = 16 / es;
+  DY_REQUIRE(c % epc == 0 && DY_VIEW_OK(g, ld_g, c, es) && DY_VIEW_OK(dx, ld_dx, c, es), DY_ERR_INVALID_ARG, "dy_upsample2x_bwd_nhwc: views must be whole 16-byte chunks");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int cch = c / epc;
+  const unsigned grid = grid1((long long)n * h * w * cch);
+  if (dtype == DY_BF16) hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)g, (bf16_t*)dx, n, h, w, cch, ld_g, ld_dx);
+  else if (dtype == DY_F16) hipLaunchKernelGGL((upsample2x_bwd_kernel<f16_t>), dim3(grid), dim3(256), 0, st, (const f16_t*)g, (f16_t*)dx, n, h, w, cch, ld_g, ld_dx);
+  else hipLaunchKernelGGL((upsample2x_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)g, (float*)dx, n, h, w, cch, ld_g, ld_dx);
+  return check_launch("dy_upsample2x_bwd_nhwc");
+}
+
+extern "C" int32_t dy_maxpool_bwd_nhwc(const void* x, const void* g_out, void* g_in, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ld_x, int32_t ld_go,
+                                       int32_t ld_gi, int32_t k, int32_t accumulate, int32_t dtype, dy_stream_t stream) {
+  const int es = dy_dtype_size(dtype);
+  DY_REQUIRE(es && x && g_out && g_in && n > 0 && h > 0 && w > 0 && c > 0 && k >= 1 && (k & 1) && k <= 15, DY_ERR_INVALID_ARG, "dy_maxpool_bwd_nhwc: bad arguments");
+  const int epc = 16 / es;
+  DY_REQUIRE(c % epc == 0 && DY_VIEW_OK(x, ld_x, c, es) && DY_VIEW_OK(g_out, ld_go, c, es) && DY_VIEW_OK(g_in, ld_gi, c, es), DY_ERR_INVALID_ARG,
+             "dy_maxpool_bwd_nhwc: views must be whole 16-byte chunks");
+  const size_t smem = (size_t)h * w * epc * 9;
+  DY_REQUIRE(smem <= 160 * 1024, DY_ERR_UNSUPPORTED, "dy_maxpool_bwd_nhwc: plane %dx%d too large for LDS", h, w);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const unsigned grid = (unsigned)(n * (c / epc));
+#define DY_MPB(T)                                                                                                                               \
+  do {                                                                                                                                          \
+    static const hipError_t once = hipFuncSetAttribute((const void*)maxpool_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)once;                                                                                                                                 \
+    hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid), dim3(256), smem, st, (const T*)x, (const T*)g_out, (T*)g_in, h, w, c / epc, ld_x, ld_go, ld_gi, k / 2, accumulate); \
+  } while (0)
+  if (dtype == DY_BF16) DY_MPB(bf16_t);
+  else if (dtype == DY_F16) DY_MPB(f16_t);
+  else DY_MPB(float);
+#undef DY_MPB
+  return check_launch("dy_maxpool_bwd_nhwc");
+}
+
+extern "C" int32_t dy_add_nhwc(const void* a, const void* b, void* out, int64_t rows, int32_t c, int32_t ld_a, int32_t ld_b, int32_t ld_o, int32_t dtype, dy_stream_t stream) {
+  const int es = dy_dtype_size(dtype);
+  DY_REQUIRE(es && a && b && out && rows > 0 && c > 0, DY_ERR_INVALID_ARG, "dy_add_nhwc: bad arguments");
+  const int epc = 16 / es;
+  DY_REQUIRE(c % epc == 0 && DY_VIEW_OK(a, ld_a, c, es) && DY_VIEW_OK(b, ld_b, c, es) && DY_VIEW_OK(out, ld_o, c, es), DY_ERR_INVALID_ARG,
+             "dy_add_nhwc: views must be whole 16-byte chunks");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int cch = c / epc;
+  const unsigned grid = grid1(rows * cch);
+  if (dtype == DY_BF16) hipLaunchKernelGGL((add_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, (long long)rows, cch, ld_a, ld_b, ld_o);
+  else if (dtype == DY_F16) hipLaunchKernelGGL((add_kernel<f16_t>), dim3(grid), dim3(256), 0, st, (const f16_t*)a, (const f16_t*)b, (f16_t*)out, (long long)rows, cch, ld_a, ld_b, ld_o);
+  else hipLaunchKernelGGL((add_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, (long long)rows, cch, ld_a, ld_b, ld_o);
+  return check_launch("dy_add_nhwc");
+}
+
+extern "C" int32_t dy_sumsq_f32(const float* g, int64_t n, double* out, dy_stream_t stream) {
+  DY_REQUIRE(g && out && n > 0, DY_ERR_INVALID_ARG, "dy_sumsq_f32: bad arguments");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid1(n) > 1024 ? 1024 : grid1(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, (long long)n, out);
+  return check_launch("dy_sumsq_f32");
+}
+
+extern "C" int32_t dy_sgd_step(float* p, const float* grad, float* buf, int64_t n, float lr, float momentum, float weight_decay, int32_t nesterov, int32_t first_step,
+                               const double* grad_sumsq, float max_norm, dy_stream_t stream) {
+  DY_REQUIRE(p && grad && buf && n > 0, DY_ERR_INVALID_ARG, "dy_sgd_step: bad arguments");
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid1(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, grad, buf, (long long)n, lr, momentum, weight_decay, nesterov,
+                     first_step, grad_sumsq, max_norm);
+  return check_launch("dy_sgd_step");
+}
+
+extern "C" int32_t dy_adamw_step(float* p, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                 int32_t step, const double* grad_sumsq, float max_norm, dy_stream_t stream) {
+  DY_REQUIRE(p && grad && m && v && n > 0 && step >= 1, DY_ERR_INVALID_ARG, "dy_adamw_step: bad arguments");
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid1(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, grad, m, v, (long long)n, lr, beta1, beta2, eps, weight_decay, bc1,
+                     bc2s, grad_sumsq, max_norm);
+  return check_launch("dy_adamw_step");
+}
+
+extern "C" int32_t dy_ema_update(float* ema, const float* p, int64_t n, float decay, dy_stream_t stream) {
+  DY_REQUIRE(ema && p && n > 0, DY_ERR_INVALID_ARG, "dy_ema_update: bad arguments");
+  hipLaunchKernelGGL(ema_kernel, dim3(grid1(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ema, p, (long long)n, decay);
+  return check_launch("dy_ema_update");
+}

@@ -672,3 +672,52 @@ def conv_dgrad(dz: torch.Tensor, pc: PackedConv, stride: int, out: Optional[torc
     if stride not in (1, 2):
         raise NotImplementedError("conv_dgrad: stride 1 or 2")
     return conv2d(dz, pc, out=out, residual=accumulate, dil2=(stride == 2))
+
+
+# ---- small training-path ops + optimizer --------------------------------------------------------------------------
+
+
+def upsample2x_bwd(g: torch.Tensor) -> torch.Tensor:
+    n, c, h2, w2 = g.shape
+    out = alloc_nhwc(n, c, h2 // 2, w2 // 2, g.dtype, g.device)
+    (gp, ldg), (op, ldo) = view_params(g), view_params(out)
+    _launch(lib().dy_upsample2x_bwd_nhwc, (gp, op, n, h2 // 2, w2 // 2, c, ldg, ldo, dy_dtype(g.dtype)), keep=(g, out))
+    return out
+
+
+def maxpool_bwd(x: torch.Tensor, g_out: torch.Tensor, g_in: torch.Tensor, k: int, accumulate: bool) -> torch.Tensor:
+    """g_in (+)= gradient of max_pool2d(x, k, 1, k//2) given g_out; all NHWC views of one dtype."""
+    n, c, h, w = x.shape
+    (xp, ldx), (gop, ldgo), (gip, ldgi) = view_params(x), view_params(g_out), view_params(g_in)
+    _launch(lib().dy_maxpool_bwd_nhwc, (xp, gop, gip, n, h, w, c, ldx, ldgo, ldgi, k, int(accumulate), dy_dtype(x.dtype)), keep=(x, g_out, g_in))
+    return g_in
+
+
+def add_nhwc(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    n, c, h, w = a.shape
+    if out is None:
+        out = alloc_nhwc(n, c, h, w, a.dtype, a.device)
+    (ap, lda), (bp, ldb), (op, ldo) = view_params(a), view_params(b), view_params(out)
+    _launch(lib().dy_add_nhwc, (ap, bp, op, _rows(a), c, lda, ldb, ldo, dy_dtype(a.dtype)), keep=(a, b, out))
+    return out
+
+
+def sumsq_into(acc: torch.Tensor, g: torch.Tensor) -> None:
+    """acc (device double scalar) += sum(g^2); g: contiguous fp32."""
+    _launch(lib().dy_sumsq_f32, (g.data_ptr(), g.numel(), acc.data_ptr()), keep=(acc, g))
+
+
+def sgd_step_(p: torch.Tensor, grad: torch.Tensor, buf: torch.Tensor, lr: float, momentum: float, weight_decay: float, nesterov: bool,
+              first_step: bool, grad_sumsq: Optional[torch.Tensor] = None, max_norm: float = 10.0) -> None:
+    _launch(lib().dy_sgd_step, (p.data_ptr(), grad.data_ptr(), buf.data_ptr(), p.numel(), lr, momentum, weight_decay, int(nesterov), int(first_step),
+                                grad_sumsq.data_ptr() if grad_sumsq is not None else None, max_norm), keep=(p, grad, buf, grad_sumsq))
+
+
+def adamw_step_(p: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, betas, eps: float, weight_decay: float, step: int,
+                grad_sumsq: Optional[torch.Tensor] = None, max_norm: float = 10.0) -> None:
+    _launch(lib().dy_adamw_step, (p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, betas[0], betas[1], eps, weight_decay, step,
+                                  grad_sumsq.data_ptr() if grad_sumsq is not None else None, max_norm), keep=(p, grad, m, v, grad_sumsq))
+
+
+def ema_update_(ema: torch.Tensor, p: torch.Tensor, decay: float) -> None:
+    _launch(lib().dy_ema_update, (ema.data_ptr(), p.data_ptr(), p.numel(), decay), keep=(ema, p))

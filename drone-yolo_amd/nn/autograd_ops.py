@@ -1,0 +1,243 @@
+"""Training-mode building blocks: every compute step is a libdyolo kernel; ``torch.autograd.Function`` only records the
+graph (which gradient feeds which op) the way the reference relies on autograd (engine/trainer.py:381-389).
+
+Reference semantics: Conv.forward in training = SiLU(BatchNorm_batchstats(conv(x))) (nn/modules/conv.py:49-51),
+RepVGGBlock.forward = SiLU(BN(conv3x3(x)) + BN(conv1x1(x))) (nn/modules/block.py:1480-1490), Detect.forward's training
+return (nn/modules/head.py:64-72), C2f / SPPF / Bottleneck / Concat / Upsample (block.py:172-350, conv.py:323-333).
+
+Activations are NHWC-view tensors in the storage dtype (bf16 / fp16 / fp32); parameters are the modules' fp32 master
+tensors on the device; gradients of activations come back in the storage dtype, of parameters in fp32.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import torch
+
+from .. import hip_ops as H
+
+
+def as_nhwc(t: torch.Tensor) -> torch.Tensor:
+    """A gradient handed over by autograd as an NHWC view with whole 16-byte chunks per pixel (no copy when it already is)."""
+    n, c, h, w = t.shape
+    st = t.stride()
+    es = t.element_size()
+    if st[1] == 1 and st[3] % (16 // es) == 0 and st[2] == w * st[3] and st[0] == h * st[2] and t.data_ptr() % 16 == 0 and st[3] >= c:
+        return t
+    out = H.alloc_nhwc(n, c, h, w, t.dtype, t.device)
+    out.copy_(t)
+    return out
+
+
+class ConvBnAct(torch.autograd.Function):
+    """y = act(BN_train(conv2d(x, w))) — dy_conv2d_nhwc + dy_bn_train_fwd; backward: dy_bn_train_bwd + wgrad + dgrad."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, bn, stride, pad, act, need_dx):
+        dtype, dev = x.dtype, x.device
+        cin_pad = x.shape[1] if x.shape[1] != weight.shape[1] else None  # image padded to one chunk
+        pc = H.PackedConv(weight, torch.zeros(weight.shape[0], device=dev), stride, pad, 1, False, dtype, dev, cin_pad=cin_pad)
+        z = H.conv2d(x, pc)
+        st = H.BnState(weight.shape[0], dev)
+        y = H.bn_train_fwd(z, gamma, beta, st, act, eps=bn.eps, momentum=bn.momentum, running_mean=bn.running_mean, running_var=bn.running_var)
+        ctx.save_for_backward(x, z, weight, gamma, beta)
+        ctx.st, ctx.stride, ctx.pad, ctx.act, ctx.need_dx = st, stride, pad, act, need_dx
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z, weight, gamma, beta = ctx.saved_tensors
+        dz, dgamma, dbeta = H.bn_train_bwd(as_nhwc(dy), z, gamma, beta, ctx.st, ctx.act)
+        k = weight.shape[2]
+        dw = H.conv_wgrad(x, dz, k, ctx.stride, ctx.pad)[:, : weight.shape[1]]
+        dx = None
+        if ctx.need_dx:
+            dx = H.conv_dgrad(dz, H.pack_dgrad(weight, ctx.stride, x.dtype, x.device), ctx.stride)
+        return dx, dw, dgamma, dbeta, None, None, None, None, None
+
+
+class RepVGGTrain(torch.autograd.Function):
+    """y = SiLU(BN3(conv3x3 s(x)) + BN1(conv1x1 s(x))) (no identity branch: the model's RepVGG blocks are stride 2)."""
+
+    @staticmethod
+    def forward(ctx, x, w3, g3, b3, w1, g1, b1, bn3, bn1, stride):
+        dtype, dev = x.dtype, x.device
+        zero = lambda w: torch.zeros(w.shape[0], device=dev)  # noqa: E731
+        z3 = H.conv2d(x, H.PackedConv(w3, zero(w3), stride, 1, 1, False, dtype, dev))
+        z1 = H.conv2d(x, H.PackedConv(w1, zero(w1), stride, 0, 1, False, dtype, dev, halo=False))
+        s3, s1 = H.BnState(w3.shape[0], dev), H.BnState(w1.shape[0], dev)
+        u3 = H.bn_train_fwd(z3, g3, b3, s3, False, eps=bn3.eps, momentum=bn3.momentum, running_mean=bn3.running_mean, running_var=bn3.running_var)
+        u = H.bn_train_fwd(z1, g1, b1, s1, False, eps=bn1.eps, momentum=bn1.momentum, running_mean=bn1.running_mean, running_var=bn1.running_var,
+                           addend=u3)
+        y = H.silu_fwd(u)
+        ctx.save_for_backward(x, z3, z1, u, w3, g3, b3, w1, g1, b1)
+        ctx.s3, ctx.s1, ctx.stride = s3, s1, stride
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z3, z1, u, w3, g3, b3, w1, g1, b1 = ctx.saved_tensors
+        du = H.silu_bwd(u, as_nhwc(dy))
+        dz3, dg3, db3 = H.bn_train_bwd(du, z3, g3, b3, ctx.s3, False)
+        dz1, dg1, db1 = H.bn_train_bwd(du, z1, g1, b1, ctx.s1, False)
+        dw3 = H.conv_wgrad(x, dz3, 3, ctx.stride, 1)
+        dw1 = H.conv_wgrad(x, dz1, 1, ctx.stride, 0)
+        dx = H.conv_dgrad(dz3, H.pack_dgrad(w3, ctx.stride, x.dtype, x.device), ctx.stride)
+        dx = H.conv_dgrad(dz1, H.pack_dgrad(w1, ctx.stride, x.dtype, x.device), ctx.stride, accumulate=dx)
+        return dx, dw3, dg3, db3, dw1, dg1, db1, None, None, None
+
+
+HEAD_PAD = 16  # class logits are kept in a 16-channel (one fp32 x4 / bf16 x2 chunk multiple) slot of the head buffer
+
+
+class HeadTail(torch.autograd.Function):
+    """cat(conv1x1(xb, wb) + bb, conv1x1(xc, wc) + bc) as ONE fp32 NHWC map per level (Detect's training output,
+    head.py:69-72); the class slot is padded to a multiple of 16 channels (pitch = 4*reg_max + pad)."""
+
+    @staticmethod
+    def forward(ctx, xb, xc, wb, bb, wc, bc):
+        dtype, dev = xb.dtype, xb.device
+        n, _, h, w = xb.shape
+        nb, nc = wb.shape[0], wc.shape[0]
+        ncp = -(-nc // HEAD_PAD) * HEAD_PAD
+        buf = H.alloc_nhwc(n, nb + ncp, h, w, torch.float32, dev)
+        buf.zero_()
+        H.conv2d(xb, H.PackedConv(wb, bb, 1, 0, 1, False, dtype, dev, for_out_f32=True), out=buf[:, :nb], out_f32=True)
+        H.conv2d(xc, H.PackedConv(wc, bc, 1, 0, 1, False, dtype, dev, for_out_f32=True), out=buf[:, nb : nb + nc], out_f32=True)
+        ctx.save_for_backward(xb, xc, wb, wc)
+        ctx.dims = (nb, nc, ncp)
+        return buf[:, : nb + nc]
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, xc, wb, wc = ctx.saved_tensors
+        nb, nc, ncp = ctx.dims
+        dtype, dev = xb.dtype, xb.device
+        n, _, h, w = xb.shape
+        dzb = H.alloc_nhwc(n, nb, h, w, dtype, dev)
+        dzb.copy_(dy[:, :nb])
+        dzc = H.alloc_nhwc(n, ncp, h, w, dtype, dev)
+        dzc.zero_()
+        dzc[:, :nc].copy_(dy[:, nb:])
+        dwb = H.conv_wgrad(xb, dzb, 1, 1, 0)
+        dwc = H.conv_wgrad(xc, dzc[:, :nc], 1, 1, 0)
+        dbb, dbc = H.colsum(dzb), H.colsum(dzc[:, :nc])
+        dxb = H.conv_dgrad(dzb, H.pack_dgrad(wb, 1, dtype, dev), 1)
+        wcp = torch.zeros((ncp, wc.shape[1], 1, 1), device=dev, dtype=wc.dtype)
+        wcp[:nc] = wc.detach()
+        dxc = H.conv_dgrad(dzc, H.pack_dgrad(wcp, 1, dtype, dev), 1)
+        return dxb, dxc, dwb, dbb, dwc, dbc
+
+
+class Upsample2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return H.upsample2x(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return H.upsample2x_bwd(as_nhwc(g))
+
+
+class ConcatC(torch.autograd.Function):
+    """torch.cat(xs, 1) into one NHWC buffer (dy_copy_nhwc); backward hands out channel slices of the gradient."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        n, _, h, w = xs[0].shape
+        ctx.sizes = [t.shape[1] for t in xs]
+        out = H.alloc_nhwc(n, sum(ctx.sizes), h, w, xs[0].dtype, xs[0].device)
+        c0 = 0
+        for t in xs:
+            H.copy_nhwc(t, out[:, c0 : c0 + t.shape[1]])
+            c0 += t.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = as_nhwc(g)
+        outs, c0 = [], 0
+        for c in ctx.sizes:
+            outs.append(g[:, c0 : c0 + c])
+            c0 += c
+        return tuple(outs)
+
+
+class Chunk2(torch.autograd.Function):
+    """y.chunk(2, 1) as two channel-slice views (C2f, block.py:239); backward rebuilds one NHWC gradient."""
+
+    @staticmethod
+    def forward(ctx, y):
+        c = y.shape[1] // 2
+        ctx.c = c
+        return y[:, :c], y[:, c:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        ref = ga if ga is not None else gb
+        n, _, h, w = ref.shape
+        out = H.alloc_nhwc(n, 2 * ctx.c, h, w, ref.dtype, ref.device)
+        for i, g in enumerate((ga, gb)):
+            sl = out[:, i * ctx.c : (i + 1) * ctx.c]
+            if g is None:
+                sl.zero_()
+            else:
+                H.copy_nhwc(as_nhwc(g), sl)
+        return out
+
+
+class AddT(torch.autograd.Function):
+    """a + b (Bottleneck shortcut) through dy_add_nhwc."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return H.add_nhwc(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class SppfPool(torch.autograd.Function):
+    """cat(x, m(x), m(m(x)), m(m(m(x)))) with m = MaxPool2d(k, 1, k//2) (SPPF, block.py:187-191)."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        n, c, h, w = x.shape
+        buf = H.alloc_nhwc(n, 4 * c, h, w, x.dtype, x.device)
+        H.copy_nhwc(x, buf[:, :c])
+        H.sppf_maxpool3(buf[:, :c], buf[:, c : 2 * c], buf[:, 2 * c : 3 * c], buf[:, 3 * c :], k)
+        ctx.save_for_backward(buf)
+        ctx.k, ctx.c = k, c
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        (buf,) = ctx.saved_tensors
+        c, k = ctx.c, ctx.k
+        g0 = as_nhwc(g)
+        g = H.alloc_nhwc(g0.shape[0], g0.shape[1], g0.shape[2], g0.shape[3], g0.dtype, g0.device)  # private copy: accumulated in place
+        H.copy_nhwc(g0, g)
+        s = lambda t, i: t[:, i * c : (i + 1) * c]  # noqa: E731
+        H.maxpool_bwd(s(buf, 2), s(g, 3), s(g, 2), k, True)  # g2 += bwd(y2 -> y3, g3)
+        H.maxpool_bwd(s(buf, 1), s(g, 2), s(g, 1), k, True)  # g1 += bwd(y1 -> y2, g2)
+        H.maxpool_bwd(s(buf, 0), s(g, 1), s(g, 0), k, True)  # gx += bwd(x -> y1, g1)
+        return s(g, 0), None
+
+
+class DetectionLossFn(torch.autograd.Function):
+    """v8DetectionLoss on the per-level fp32 head maps through dy_detection_loss (value + gradient in one call)."""
+
+    @staticmethod
+    def forward(ctx, gt, strides, nc, reg_max, hyp, *levels):
+        out, _, grads = H.detection_loss(levels, gt, strides, nc, reg_max, box=hyp[0], cls=hyp[1], dfl=hyp[2], want_grad=True)
+        ctx.grads = grads
+        ctx.nch = levels[0].shape[1]
+        total, items = out[3].clone(), out[:3].clone()
+        ctx.mark_non_differentiable(items)
+        return total, items
+
+    @staticmethod
+    def backward(ctx, g_total, g_items):
+        gs = [g[:, : ctx.nch] * g_total for g in ctx.grads] if g_total is not None else [None] * len(ctx.grads)
+        return (None, None, None, None, None, *gs)

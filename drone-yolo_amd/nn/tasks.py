@@ -264,8 +264,20 @@ class BaseModel(nn.Module):
         if verbose:
             LOGGER.info(f"Transferred {len(ok)}/{len(own)} items from pretrained weights")
 
+    train_dtype = torch.bfloat16  # storage type of activations in training (the reference trains under AMP, trainer.py:379)
+
+    def forward_train(self, img, dtype=None):
+        """Training-mode forward (batch-statistics BatchNorm, autograd graph): Detect's raw per-level maps."""
+        from .train_forward import model_train_forward
+
+        return model_train_forward(self, img, dtype or self.train_dtype)
+
     def loss(self, batch, preds=None):
-        raise NotImplementedError("v8DetectionLoss / training step: not built yet on the HIP path (SURVEY §8 a28-a35)")
+        """criterion(model(batch['img']), batch) — reference tasks.py:280-292."""
+        if getattr(self, "criterion", None) is None:
+            self.criterion = self.init_criterion()
+        preds = self.forward_train(batch["img"]) if preds is None else preds
+        return self.criterion(preds, batch)
 
 
 class DetectionModel(BaseModel):
@@ -314,7 +326,9 @@ class DetectionModel(BaseModel):
             self.info()
 
     def init_criterion(self):
-        raise NotImplementedError("v8DetectionLoss is not built yet on the HIP path")
+        from ..utils.loss import v8DetectionLoss
+
+        return v8DetectionLoss(self)
 
 
 def _module_out_channels(m: nn.Module) -> int:

@@ -1,0 +1,96 @@
+"""Training-mode forward of the Drone-YOLO modules (module.train()): what BaseModel._predict_once does in the
+reference (nn/tasks.py:134-161) with every module in training mode, built from the autograd ops in autograd_ops.py.
+
+Dispatch is by module type; parameters stay in the reference-compatible children (``conv.weight``, ``bn.weight`` ...).
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from .. import hip_ops as H
+from . import autograd_ops as A
+
+
+def conv_train(m, x, need_dx: bool = True):
+    c = m.conv
+    if c.groups != 1:
+        raise NotImplementedError("training of grouped convolutions (DWConv, the -sf YAML) is not built on the HIP path")
+    return A.ConvBnAct.apply(x, c.weight, m.bn.weight, m.bn.bias, m.bn, c.stride[0], c.padding[0], isinstance(m.act, nn.SiLU), need_dx)
+
+
+def repvgg_train(m, x):
+    if getattr(m, "rbr_identity", None) is not None or hasattr(m, "rbr_reparam") or m.groups != 1:
+        raise NotImplementedError("RepVGGBlock training is built for the stride-2 two-branch form of the Drone-YOLO YAMLs")
+    d, o = m.rbr_dense, m.rbr_1x1
+    return A.RepVGGTrain.apply(x, d.conv.weight, d.bn.weight, d.bn.bias, o.conv.weight, o.bn.weight, o.bn.bias, d.bn, o.bn, m.stride)
+
+
+def bottleneck_train(m, x):
+    y = conv_train(m.cv2, conv_train(m.cv1, x))
+    return A.AddT.apply(x, y) if m.add else y
+
+
+def c2f_train(m, x):
+    a, b = A.Chunk2.apply(conv_train(m.cv1, x))
+    ys = [a, b]
+    for mm in m.m:
+        ys.append(bottleneck_train(mm, ys[-1]))
+    return conv_train(m.cv2, A.ConcatC.apply(*ys))
+
+
+def sppf_train(m, x):
+    return conv_train(m.cv2, A.SppfPool.apply(conv_train(m.cv1, x), m.k))
+
+
+def detect_train(m, xs: List[torch.Tensor]) -> List[torch.Tensor]:
+    """Detect.forward's training return (head.py:64-72): one (N, 4*reg_max+nc, H, W) fp32 map per level."""
+    if not m.legacy:
+        raise NotImplementedError("Detect training is built for the legacy (two 3x3) class branch of the v8 YAMLs")
+    out = []
+    for i, x in enumerate(xs):
+        b, c = m.cv2[i], m.cv3[i]
+        xb = conv_train(b[1], conv_train(b[0], x))
+        xc = conv_train(c[1], conv_train(c[0], x))
+        out.append(A.HeadTail.apply(xb, xc, b[2].weight, b[2].bias, c[2].weight, c[2].bias))
+    return out
+
+
+def module_train(m, x, first: bool = False):
+    from .modules import C2f, Concat, Conv, Detect, RepVGGBlock, SPPF, Upsample
+
+    if isinstance(m, nn.Sequential):
+        for mm in m:
+            x = module_train(mm, x)
+        return x
+    if isinstance(m, Conv):
+        return conv_train(m, x, need_dx=not first)
+    if isinstance(m, RepVGGBlock):
+        return repvgg_train(m, x)
+    if isinstance(m, C2f):
+        return c2f_train(m, x)
+    if isinstance(m, SPPF):
+        return sppf_train(m, x)
+    if isinstance(m, Upsample):
+        return A.Upsample2x.apply(x)
+    if isinstance(m, Concat):
+        return A.ConcatC.apply(*x)
+    if isinstance(m, Detect):
+        return detect_train(m, x)
+    raise NotImplementedError(f"no training forward for {type(m).__name__}")
+
+
+def model_train_forward(model, img: torch.Tensor, dtype: torch.dtype):
+    """img: (N, 3, H, W) uint8 or float on the device -> Detect's per-level training outputs."""
+    H.require_device(img, "training image")
+    x = img.float() / 255 if img.dtype == torch.uint8 else img.float()  # preprocess_batch, detect/train.py:59
+    x = H.to_nhwc(x.contiguous(), dtype)
+    ys = []
+    for m in model.model:
+        if m.f != -1:
+            x = ys[m.f] if isinstance(m.f, int) else [x if j == -1 else ys[j] for j in m.f]
+        x = module_train(m, x, first=(m.i == 0))
+        ys.append(x if m.i in model.save else None)
+    return x

@@ -1,7 +1,8 @@
 """Detection training loss on the device (reference: ultralytics/utils/loss.py:157-260 ``v8DetectionLoss``).
 
-Forward only for now: TaskAlignedAssigner + BCE / CIoU / DFL through ``dy_detection_loss``; the returned
-tensors carry no autograd graph (the backward kernels of SURVEY §8 rows a28-a34 are not built yet)."""
+TaskAlignedAssigner + BCE / CIoU / DFL, value and gradient, through ``dy_detection_loss``.  When the head maps carry an
+autograd graph (training forward) the returned loss is differentiable: ``loss.backward()`` feeds the kernel's gradient
+w.r.t. the head outputs into the backward of the model (nn/autograd_ops.py)."""
 from __future__ import annotations
 
 import torch
@@ -43,6 +44,13 @@ class v8DetectionLoss:
         targets = torch.cat((batch["batch_idx"].view(-1, 1).float().cpu(), batch["cls"].view(-1, 1).float().cpu(),
                              batch["bboxes"].float().cpu()), 1)
         gt = self.preprocess(targets, bs, imgsz[[1, 0, 1, 0]])
-        out, _ = H.detection_loss(feats, gt, [float(s) for s in self.stride], self.nc, self.reg_max, topk=self.topk,
-                                  box=self.box, cls=self.cls, dfl=self.dfl)
+        strides = [float(s) for s in self.stride]
+        if any(f.requires_grad for f in feats):
+            if self.topk != 10:
+                raise NotImplementedError("the differentiable path uses the default tal_topk of 10")
+            from ..nn.autograd_ops import DetectionLossFn
+
+            total, items = DetectionLossFn.apply(gt, strides, self.nc, self.reg_max, (self.box, self.cls, self.dfl), *feats)
+            return total, items
+        out, _ = H.detection_loss(feats, gt, strides, self.nc, self.reg_max, topk=self.topk, box=self.box, cls=self.cls, dfl=self.dfl)
         return out[3], out[:3]

@@ -296,7 +296,8 @@ int32_t dy_detection_loss(const dy_loss_desc* d, dy_stream_t stream);
  * Weight gradient: dw[co][(r*ksize + q)][ci] += sum over output pixels m of dz[m][co] * x[pixel(m) + tap (r,q)][ci].
  *   d describes the FORWARD convolution (x, batch, h, w_in, cin, ld_x, ho, wo, cout, ksize, stride, pad, dtype; w / bias /
  *   y are ignored); dz: NHWC view (batch, ho, wo, cout) of `dtype`, pitch ld_dz; dw: fp32, cout*ksize*ksize*cin, ZEROED by
- *   the caller (partial sums of pixel slabs are added with fp32 atomics).  cin, cout multiples of one 16-byte chunk.
+ *   the caller (partial sums of pixel slabs are added with fp32 atomics).  ld_x / ld_dz must cover cin / cout rounded up to one
+ *   16-byte chunk (the padding is read but only reaches entries that are never written).
  * Input gradient: dx = conv_transpose(dz, w) is run through dy_conv2d_nhwc itself on re-packed weights
  *   (w'[ci][2-r][2-q][co] = w[co][r][q][ci], stride 1; stride-2 layers read dz through `dil2`, a zero-dilated gather).
  * dy_colsum: out[c] += sum over rows of z[row][c] (bias gradient of the plain Detect convolutions); out zeroed by the caller. */
@@ -342,6 +343,37 @@ int32_t dy_bn_train_bwd(const dy_bn_desc* d, dy_stream_t stream);
 int32_t dy_silu_fwd(const void* u, void* y, int64_t rows, int32_t c, int32_t ld_u, int32_t ld_y, int32_t dtype, dy_stream_t stream);
 int32_t dy_silu_bwd(const void* u, const void* dy, void* du, int64_t rows, int32_t c, int32_t ld_u, int32_t ld_dy, int32_t ld_du,
                     int32_t dtype, dy_stream_t stream);
+
+/* ---- small training-path ops -----------------------------------------------------------------
+ * dy_upsample2x_bwd_nhwc: gradient of nn.Upsample(None, 2, 'nearest') (yolov8-p2-repvgg.yaml:30,34,38):
+ *   dx (n,h,w,c) = sum of the 2x2 blocks of g (n,2h,2w,c).
+ * dy_maxpool_bwd_nhwc: gradient of MaxPool2d(k, 1, k//2) inside SPPF (nn/modules/block.py:185-191): every output's
+ *   gradient goes to the FIRST maximum of its window in (row, column) order (torch semantics); g_in = (accumulate ?
+ *   g_in : 0) + that.  h*w*(16/elem_size)*9 bytes of LDS per workgroup (h*w <= ~2200).
+ * dy_add_nhwc: out = a + b, (rows, c) views (Bottleneck's shortcut, block.py:348-350).  c % one 16-byte chunk == 0. */
+int32_t dy_upsample2x_bwd_nhwc(const void* g, void* dx, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ld_g, int32_t ld_dx,
+                               int32_t dtype, dy_stream_t stream);
+int32_t dy_maxpool_bwd_nhwc(const void* x, const void* g_out, void* g_in, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ld_x,
+                            int32_t ld_go, int32_t ld_gi, int32_t k, int32_t accumulate, int32_t dtype, dy_stream_t stream);
+int32_t dy_add_nhwc(const void* a, const void* b, void* out, int64_t rows, int32_t c, int32_t ld_a, int32_t ld_b, int32_t ld_o,
+                    int32_t dtype, dy_stream_t stream);
+
+/* ---- optimizer step, gradient clipping, EMA (flat fp32 tensors) -------------------------------------
+ * Replaces: torch.nn.utils.clip_grad_norm_(max_norm 10) + optimizer.step() (engine/trainer.py:591-599) for the SGD
+ * (nesterov) / AdamW optimizers build_optimizer creates (trainer.py:764-825: weight decay on the weight group only,
+ * so call once per group with its decay), and ModelEMA.update (utils/torch_utils.py:515-545).
+ * dy_sumsq_f32: *out += sum g^2 (double; zero it first; call per tensor / bucket, then pass `out` as grad_sumsq).
+ * grad_sumsq (optional DEVICE double): total sum of squared gradients; the gradient is scaled by
+ *   min(1, max_norm / (sqrt(*grad_sumsq) + 1e-6)) inside the step — no host synchronisation.
+ * dy_sgd_step:   g = clip*grad + wd*p;  buf = first_step ? g : momentum*buf + g;  p -= lr * (nesterov ? g + momentum*buf : buf).
+ * dy_adamw_step: p *= 1 - lr*wd;  m,v = moments of clip*grad;  p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps); step >= 1.
+ * dy_ema_update: ema = decay*ema + (1-decay)*p. */
+int32_t dy_sumsq_f32(const float* g, int64_t n, double* out, dy_stream_t stream);
+int32_t dy_sgd_step(float* p, const float* grad, float* buf, int64_t n, float lr, float momentum, float weight_decay, int32_t nesterov,
+                    int32_t first_step, const double* grad_sumsq, float max_norm, dy_stream_t stream);
+int32_t dy_adamw_step(float* p, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, int32_t step, const double* grad_sumsq, float max_norm, dy_stream_t stream);
+int32_t dy_ema_update(float* ema, const float* p, int64_t n, float decay, dy_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -134,3 +134,91 @@ def test_colsum_bias_grad(device):
         out = H.colsum(nhwc(zq, dtype, device, ld=16 if dtype != torch.float32 else 12))
         torch.cuda.synchronize()
         assert torch.allclose(out.cpu(), zq.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+
+
+# ---- whole-model training step ---------------------------------------------------------------------------------------
+
+
+def _train_case(tag):
+    import drone_yolo_amd as D
+    from oracle import drone_yolo_oracle as O
+    from oracle import loss_oracle as LO
+    from tests._util import golden, load_yaml, meta
+
+    g = golden("train.npz")
+    m = meta(g, tag)
+    d = load_yaml(m["yaml"], m["scale"], m["nc"])
+    model = D.DetectionModel(dict(d), nc=m["nc"], verbose=False)
+    sd = O.seeded_state_dict(model.state_dict(), m["seed"], cls_bias=m["cls_bias"])
+    model.load_state_dict(sd)
+    b, h, w = m["shape"]
+    img = torch.randint(0, 256, (b, 3, h, w), generator=torch.Generator().manual_seed(m["seed"]), dtype=torch.uint8)
+    labels = LO.synthetic_labels(b, m["seed"], n_mean=m["n_mean"])
+    return g, m, d, model, sd, img, labels
+
+
+@pytest.mark.parametrize("tag", ["tn64", "tn96"])
+def test_model_train_step_gradients_fp32(tag, device):
+    """module.train() forward + v8DetectionLoss + backward on the device in fp32 storage against autograd through the
+    oracle (bit-identical to the real reference, oracle/make_golden.py::train_vectors) and the reference's golden norms.
+    Tolerance: every parameter gradient within 2e-3 of its own max (fp32 MFMA sums in another order, atomics)."""
+    from oracle import train_oracle as TO
+
+    g, m, d, model, sd, img, labels = _train_case(tag)
+    total_ref, items_ref, grads_ref, sd_after = TO.loss_and_grads(d, sd, img, labels)
+    model = model.to(device).train()
+    model.train_dtype = torch.float32
+    batch = dict(img=img.to(device), **labels)
+    loss, items = model(batch)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(total_ref)) <= 5e-4 * abs(float(total_ref)), (float(loss), float(total_ref))
+    assert torch.allclose(items.cpu(), items_ref, rtol=5e-4, atol=1e-5)
+    assert abs(float(loss) - float(g[f"{tag}__total"])) <= 5e-4 * abs(float(g[f"{tag}__total"]))
+    worst, worst_k = 0.0, None
+    params = dict(model.named_parameters())
+    for k, gr in grads_ref.items():
+        got = params[k].grad
+        assert got is not None, f"no gradient for {k}"
+        e = float((got.cpu() - gr).abs().max()) / max(float(gr.abs().max()), 1e-9)
+        if e > worst:
+            worst, worst_k = e, k
+    assert worst <= 2e-3, (worst, worst_k)
+    keys = [str(k) for k in g[f"{tag}__grad_keys"]]
+    norms = torch.tensor([float(params[k].grad.double().norm()) for k in keys], dtype=torch.float64)
+    assert torch.allclose(norms, torch.from_numpy(g[f"{tag}__grad_norm"]), rtol=2e-3, atol=1e-7)
+    # BatchNorm running statistics moved exactly as module.train() moves them
+    own = model.state_dict()
+    for k, v in sd_after.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert torch.allclose(own[k].cpu(), v, rtol=1e-4, atol=1e-5), k
+
+
+def test_model_train_step_gradients_bf16(device):
+    """bf16 storage (the AMP analogue): gradients agree with the fp32 oracle in direction and size."""
+    from oracle import train_oracle as TO
+
+    g, m, d, model, sd, img, labels = _train_case("tn96")
+    total_ref, items_ref, grads_ref, _ = TO.loss_and_grads(d, sd, img, labels)
+    model = model.to(device).train()
+    model.train_dtype = torch.bfloat16
+    loss, items = model(dict(img=img.to(device), **labels))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(total_ref)) <= 3e-2 * abs(float(total_ref))
+    params = dict(model.named_parameters())
+    def cos_of(keys):
+        a = torch.cat([params[k].grad.flatten().cpu().double() for k in keys])
+        b = torch.cat([grads_ref[k].flatten().double() for k in keys])
+        return float((a * b).sum() / (a.norm() * b.norm())), float(a.norm() / b.norm())
+
+    # bf16 activations perturb the (discrete) task-aligned assignment and the tiny-sample BatchNorm statistics of this
+    # 3-image batch, so deep-layer gradients decorrelate; the layers next to the loss must still agree closely
+    tails = [k for k in grads_ref if k.startswith("model.28.") and (".2.weight" in k or ".2.bias" in k)]
+    head = [k for k in grads_ref if k.startswith("model.28.")]
+    c_t, r_t = cos_of(tails)
+    c_h, r_h = cos_of(head)
+    c_a, r_a = cos_of(list(grads_ref))
+    print(f"bf16 vs fp32-oracle gradient cosine: head tails {c_t:.4f} (norm ratio {r_t:.3f}), head {c_h:.4f} ({r_h:.3f}), all {c_a:.4f} ({r_a:.3f})")
+    assert c_t > 0.99 and 0.95 < r_t < 1.05, (c_t, r_t)
+    assert c_h > 0.9 and c_a > 0.8 and 0.85 < r_a < 1.15, (c_h, c_a, r_a)
