@@ -3,8 +3,9 @@
 Inference (the metric path) shards by image: rank r takes a contiguous slice of the batch, runs the
 whole pass on its own GPU and exchanges nothing — the reference itself is single-device for predict
 (`select_device('0,1')` still yields cuda:0, utils/torch_utils.py:202-219).  The only collectives
-are control-plane: a barrier and a MAX-reduce of the elapsed time for measurement.  (Training adds
-the gradient all-reduce of engine/trainer.py:274,389; not built yet.)
+are control-plane: a barrier and a MAX-reduce of the elapsed time for measurement.
+Training is data parallel as in the reference (engine/trainer.py:274, 286, 382-389): per-rank batch, loss * world_size
+followed by DDP's mean, i.e. a SUM all-reduce of the gradients — ``allreduce_gradients`` on the trainer's flat buffer.
 """
 from __future__ import annotations
 
@@ -72,6 +73,15 @@ def sum_over_ranks(value: float, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def allreduce_gradients(flat_grad: torch.Tensor) -> torch.Tensor:
+    """In-place SUM all-reduce of the flat gradient buffer over all ranks (reference: loss *= world_size, trainer.py:382-383,
+    then DistributedDataParallel's gradient mean — the product is the plain sum).  One bucket: for Drone-YOLO-s 43 MB fp32,
+    a single ring pass over the xGMI links; BatchNorm statistics stay per rank (no SyncBN in the reference)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    return flat_grad
 
 
 def gather_detections(rows: torch.Tensor, counts: torch.Tensor) -> Optional[List[Tuple[torch.Tensor, torch.Tensor]]]:
