@@ -154,6 +154,56 @@ def cpu_baseline(d, sd, batch: int, budget_s: float = 15.0):
             "sample": f"{n} synthetic 640x640 images in batches of {batch}, fp32 torch-CPU oracle (forward+decode+NMS), {dt:.1f} s"}
 
 
+def synthetic_labels(batch: int, seed: int, nc: int = 10):
+    """n ~ Poisson(50) clipped to [1, 300] boxes per image, class uniform, centres uniform(0.05, 0.95),
+    wh lognormal(median 0.03, sigma 0.6) clipped to [0.004, 0.5], normalised xywh, batch_idx sorted."""
+    g = torch.Generator().manual_seed(seed)
+    counts = torch.poisson(torch.full((batch,), 50.0), generator=g).clamp(1, 300).long()
+    n = int(counts.sum())
+    bi = torch.repeat_interleave(torch.arange(batch), counts).float()
+    cls = torch.randint(0, nc, (n, 1), generator=g).float()
+    cxy = torch.rand(n, 2, generator=g) * 0.9 + 0.05
+    wh = (torch.randn(n, 2, generator=g) * 0.6 + math.log(0.03)).exp().clamp(0.004, 0.5)
+    return dict(batch_idx=bi, cls=cls, bboxes=torch.cat((cxy, wh), 1))
+
+
+def train_bench(a):
+    """Secondary line: Drone-YOLO-s training step, B images per GPU, bf16 storage, SGD nesterov."""
+    import drone_yolo_amd as D
+    from drone_yolo_amd import parallel as P
+    from drone_yolo_amd.engine.trainer import DetectionTrainer
+
+    rank, local_rank, world = P.init_distributed()
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    model = D.DetectionModel(a.model, nc=10, verbose=False)
+    model.load_state_dict(synthetic_state_dict(model, seed=0))
+    tr = DetectionTrainer(model, dict(optimizer="SGD", lr0=0.01, momentum=0.937, batch=a.batch * world, dtype={"bf16": "bf16", "fp16": "fp16", "fp32": "fp32"}[a.dtype]))
+    img = torch.randint(0, 256, (a.batch, 3, 640, 640), generator=torch.Generator().manual_seed(1000 + rank), dtype=torch.uint8).to(dev)
+    labels = synthetic_labels(a.batch, 1000 + rank)
+    batch = dict(img=img, **labels)
+    for _ in range(a.warmup):
+        tr.step(batch)
+    P.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss, items = tr.step(batch)
+    torch.cuda.synchronize()
+    P.barrier()
+    dt = P.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        total = a.batch * world * a.steps
+        print(json.dumps({"metric": "train images/sec @640x640 Drone-YOLO-s", "value": round(total / dt, 2), "unit": "images/sec", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+                          "config": {"workload": "Drone-YOLO-s training step 640x640: uint8 batch -> forward (batch-stat BN) -> v8DetectionLoss -> backward -> "
+                                                 "SUM all-reduce -> clip -> SGD nesterov -> EMA", "batch_per_gpu": a.batch, "global_batch": a.batch * world,
+                                     "labels_per_image": "Poisson(50)", "parallelism": f"data parallel x{world}, one flat fp32 gradient all-reduce",
+                                     "loss": round(float(loss), 3)},
+                          "flops_per_image_G": 111.2}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,7 +215,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="replay the launch plan from Python instead of a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", default="", help="write a per-conv-launch timing table to this file")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"], help="infer = the headline metric (default); train = SURVEY §8(d) config 3")
     a = ap.parse_args()
+    if a.mode == "train":
+        return train_bench(a)
 
     import drone_yolo_amd as D
     from drone_yolo_amd import parallel as P

@@ -36,7 +36,7 @@ struct BnArgs {
 };
 
 __device__ __forceinline__ float silu_grad(float u) {  // d/du u*sigmoid(u)
-  const float s = 1.0f / (1.0f + __expf(-u));
+  const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f));
   return s * (1.0f + u * (1.0f - s));
 }
 
@@ -114,32 +114,40 @@ __global__ void bn_finalize_kernel(const BnArgs p) {
   }
 }
 
-// y = act(gamma * (z - mean) * rstd + beta (+ addend))
+// y = act(gamma * (z - mean) * rstd + beta (+ addend)).  Threads keep their channel chunk (tid % nch) and walk rows, so the
+// per-channel constants are loaded once into registers.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs p) {
   constexpr int E = Elem<T>::EPC;
-  const long long total = p.rows * p.nch;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long r = i / p.nch;
-    const int ch = (int)(i - r * p.nch);
-    float zf[E], o[E];
-    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.z) + r * p.ld_z + ch * E), zf);
+  const int tid = threadIdx.x;
+  const int ch = tid % p.nch, rr = tid / p.nch;
+  if (rr >= p.R) return;
+  float sc[E], sh[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const int cc = ch * E + e;
-      o[e] = p.gamma[cc] * ((zf[e] - p.mean[cc]) * p.rstd[cc]) + p.beta[cc];
-    }
+  for (int e = 0; e < E; ++e) {
+    const int cc = ch * E + e;
+    sc[e] = p.gamma[cc] * p.rstd[cc];
+    sh[e] = p.beta[cc] - p.mean[cc] * sc[e];
+  }
+  const T* zb = reinterpret_cast<const T*>(p.z) + ch * E;
+  const T* ab = reinterpret_cast<const T*>(p.addend) + ch * E;
+  T* yb = reinterpret_cast<T*>(p.y) + ch * E;
+  for (long long r = (long long)blockIdx.x * p.R + rr; r < p.rows; r += (long long)gridDim.x * p.R) {
+    float zf[E], o[E];
+    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(zb + r * p.ld_z), zf);
+#pragma unroll
+    for (int e = 0; e < E; ++e) o[e] = zf[e] * sc[e] + sh[e];
     if (p.addend) {
       float af[E];
-      Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.addend) + r * p.ld_add + ch * E), af);
+      Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(ab + r * p.ld_add), af);
 #pragma unroll
       for (int e = 0; e < E; ++e) o[e] += af[e];
     }
     if (p.act == DY_ACT_SILU) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) o[e] = o[e] / (1.0f + __expf(-o[e]));
+      for (int e = 0; e < E; ++e) o[e] = silu_f32(o[e]);
     }
-    *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.y) + r * p.ld_y + ch * E) = Chunk<T>::pack(o);
+    *reinterpret_cast<u32x4*>(yb + r * p.ld_y) = Chunk<T>::pack(o);
   }
 }
 
@@ -147,30 +155,39 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs p) {
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs p) {
   constexpr int E = Elem<T>::EPC;
-  const long long total = p.rows * p.nch;
-  const double invn = 1.0 / (double)p.rows;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long r = i / p.nch;
-    const int ch = (int)(i - r * p.nch);
-    float zf[E], df[E], o[E];
-    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.z) + r * p.ld_z + ch * E), zf);
-    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.dy) + r * p.ld_dy + ch * E), df);
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const int cc = ch * E + e;
-      const float xh = (zf[e] - p.mean[cc]) * p.rstd[cc];
-      float du = df[e];
-      if (p.act == DY_ACT_SILU) du *= silu_grad(p.gamma[cc] * xh + p.beta[cc]);
-      const float mdu = (float)(p.acc[cc] * invn), mdx = (float)(p.acc[p.c + cc] * invn);
-      o[e] = p.gamma[cc] * p.rstd[cc] * (du - mdu - xh * mdx);
-    }
-    *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.dz) + r * p.ld_dz + ch * E) = Chunk<T>::pack(o);
-  }
+  const int tid = threadIdx.x;
   if (blockIdx.x == 0) {
-    for (int cc = threadIdx.x; cc < p.c; cc += 256) {
+    for (int cc = tid; cc < p.c; cc += 256) {
       if (p.dbeta) p.dbeta[cc] = (float)p.acc[cc];
       if (p.dgamma) p.dgamma[cc] = (float)p.acc[p.c + cc];
     }
+  }
+  const int ch = tid % p.nch, rr = tid / p.nch;
+  if (rr >= p.R) return;
+  const double invn = 1.0 / (double)p.rows;
+  float mu[E], rs[E], ga[E], be[E], gr[E], mdu[E], mdx[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int cc = ch * E + e;
+    mu[e] = p.mean[cc], rs[e] = p.rstd[cc], ga[e] = p.gamma[cc], be[e] = p.beta[cc];
+    gr[e] = ga[e] * rs[e];
+    mdu[e] = (float)(p.acc[cc] * invn), mdx[e] = (float)(p.acc[p.c + cc] * invn);
+  }
+  const T* zb = reinterpret_cast<const T*>(p.z) + ch * E;
+  const T* db = reinterpret_cast<const T*>(p.dy) + ch * E;
+  T* ob = reinterpret_cast<T*>(p.dz) + ch * E;
+  for (long long r = (long long)blockIdx.x * p.R + rr; r < p.rows; r += (long long)gridDim.x * p.R) {
+    float zf[E], df[E], o[E];
+    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(zb + r * p.ld_z), zf);
+    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(db + r * p.ld_dy), df);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float xh = (zf[e] - mu[e]) * rs[e];
+      float du = df[e];
+      if (p.act == DY_ACT_SILU) du *= silu_grad(ga[e] * xh + be[e]);
+      o[e] = gr[e] * (du - mdu[e] - xh * mdx[e]);
+    }
+    *reinterpret_cast<u32x4*>(ob + r * p.ld_dz) = Chunk<T>::pack(o);
   }
 }
 
@@ -238,8 +255,8 @@ static int bn_fwd_t(const BnArgs& a, hipStream_t st) {
   const size_t smem = (size_t)2 * a.R * a.c * 4;
   hipLaunchKernelGGL((bn_reduce_kernel<T, 0>), dim3(blocks), dim3(256), smem, st, a);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((a.c + 255) / 256)), dim3(256), 0, st, a);
-  const long long total = a.rows * a.nch;
-  const unsigned ab = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  const long long nb = (a.rows + a.R - 1) / a.R;
+  const unsigned ab = (unsigned)(nb < 4096 ? nb : 4096);
   hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ab), dim3(256), 0, st, a);
   return check_launch("dy_bn_train_fwd");
 }
@@ -250,8 +267,8 @@ static int bn_bwd_t(const BnArgs& a, hipStream_t st) {
   const unsigned blocks = (unsigned)((a.rows + a.rows_per_block - 1) / a.rows_per_block);
   const size_t smem = (size_t)2 * a.R * a.c * 4;
   hipLaunchKernelGGL((bn_reduce_kernel<T, 1>), dim3(blocks), dim3(256), smem, st, a);
-  const long long total = a.rows * a.nch;
-  const unsigned ab = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  const long long nb = (a.rows + a.R - 1) / a.R;
+  const unsigned ab = (unsigned)(nb < 4096 ? nb : 4096);
   hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ab), dim3(256), 0, st, a);
   return check_launch("dy_bn_train_bwd");
 }

@@ -26,6 +26,7 @@ struct WgradArgs {
   int H, W, Cin, ldx, Ho, Wo, Cout, lddz, ks, stride, pad;
   long long M;
   int HoWo, tilesCo, tilesCi, rows_per_block;
+  FastDiv div_howo, div_wo;  // pixel index -> (image, row, column) without integer division (M < 2^31)
 };
 
 // The four 16-channel fragments of one operand for this lane: 8 transposed reads and their wait in ONE asm statement
@@ -110,9 +111,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
           const long long mm = m + row;
           const int ci = ci0 + ch * E;
           if (mm < m_end && ci < p.Cin) {
-            const int n = (int)(mm / p.HoWo);
-            const int rr = (int)(mm - (long long)n * p.HoWo);
-            const int ho = rr / p.Wo, wo = rr - ho * p.Wo;
+            const int n = (int)fastdiv((unsigned)mm, p.div_howo);
+            const int rr = (int)mm - n * p.HoWo;
+            const int ho = (int)fastdiv((unsigned)rr, p.div_wo), wo = rr - ho * p.Wo;
             const int hi = ho * p.stride - p.pad + r_, wi = wo * p.stride - p.pad + q_;
             if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
               v = *reinterpret_cast<const u32x4*>(xg + ((long long)(n * p.H + hi) * p.W + wi) * p.ldx + ci);
@@ -264,7 +265,10 @@ extern "C" int32_t dy_conv2d_wgrad_nhwc(const dy_conv_desc* d, const void* dz, i
   a.H = d->h, a.W = d->w_in, a.Cin = d->cin, a.ldx = d->ld_x, a.Ho = ho, a.Wo = wo, a.Cout = d->cout, a.lddz = ld_dz;
   a.ks = d->ksize, a.stride = d->stride, a.pad = d->pad;
   a.M = (long long)d->batch * ho * wo;
+  DY_REQUIRE(a.M < (1ll << 31), DY_ERR_UNSUPPORTED, "dy_conv2d_wgrad_nhwc: pixel count exceeds int32");
   a.HoWo = ho * wo;
+  a.div_howo = make_fastdiv((unsigned)a.HoWo);
+  a.div_wo = make_fastdiv((unsigned)wo);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   switch (d->dtype) {
     case DY_BF16: return launch_wgrad_dtype<bf16_t>(a, st);
