@@ -264,7 +264,7 @@ def main():
         if os.path.exists(tfile):
             tj = json.load(open(tfile))
             if tj.get("batch") == a.batch and a.dtype == "bf16":
-                traffic = round(tj["families"]["conv"]["hbm_bytes_per_step"] / 1e9, 3)
+                traffic = round((tj["families"]["conv"]["hbm_bytes_per_step"] + tj["families"].get("head", {}).get("hbm_bytes_per_step", 0.0)) / 1e9, 3)
         roof = {"bound": "mfma", "kernel": "conv family: conv3x3_halo + conv1x1_stream + conv_igemm + conv_stem + detect_head kernels (every launch that convolves, one pass)",
                 "achieved": round(flops / tconv / 1e12, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(flops / tconv / 1e12 / peak, 4), "traffic": traffic,
