@@ -26,11 +26,13 @@ struct StemArgs {
   void* y;
   int N, Cin, H, W, Ho, Wo, Cout, ldy, act;
   int tilesX, tilesY;
+  int vec4;  // image rows can be fetched as aligned float4 (W % 4 == 0, 16-byte aligned base)
 };
 
 constexpr int kStemTH = 8, kStemTW = 32;
 constexpr int kStemPH = 2 * kStemTH + 1, kStemPW = 2 * kStemTW + 1;  // 17 x 65 input patch
-constexpr int kStemPitch = kStemPW + 2;                                // 67 floats per patch row
+constexpr int kStemPitch = 68;  // floats per patch row: 17 aligned float4 = image columns gx0-3 .. gx0+64 (column px at index px+3)
+constexpr int kStemShift = 3;
 
 template <typename T, int NF>
 __global__ __launch_bounds__(256) void conv_stem_kernel(const StemArgs p) {
@@ -56,16 +58,32 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const StemArgs p) {
   const int y0 = ty * kStemTH, x0 = tx * kStemTW;
 
   // ---- input patch -> LDS (zero outside the image = the conv's zero padding) ----------------------------
+  // Row py of plane c holds image columns gx0-3 .. gx0+64 with gx0 = 2*x0 - 1; x0 is a multiple of 32, so gx0-3 is a
+  // multiple of 4: with W % 4 == 0 and a 16-byte aligned image every row is 17 ALIGNED float4 loads, each entirely
+  // inside or entirely outside the image (867 wide loads per workgroup instead of 3315 dword loads).
   const int gy0 = 2 * y0 - 1, gx0 = 2 * x0 - 1;
-  for (int i = tid; i < p.Cin * kStemPH * kStemPW; i += 256) {
-    const int c = i / (kStemPH * kStemPW);
-    const int r2 = i - c * (kStemPH * kStemPW);
-    const int py = r2 / kStemPW, px = r2 - py * kStemPW;
-    const int gy = gy0 + py, gx = gx0 + px;
-    float v = 0.f;
-    if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-      v = p.x[((size_t)(n * p.Cin + c) * p.H + gy) * p.W + gx];
-    patch[c * PLANE + py * kStemPitch + px] = v;
+  if (p.vec4) {
+    constexpr int V = kStemPitch / 4;  // float4 per row
+    for (int i = tid; i < p.Cin * kStemPH * V; i += 256) {
+      const int row = i / V, j = i - row * V;
+      const int c = row / kStemPH, py = row - c * kStemPH;
+      const int gy = gy0 + py, gx = gx0 - kStemShift + 4 * j;
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+        v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(n * p.Cin + c) * p.H + gy) * p.W + gx);
+      *reinterpret_cast<f32x4*>(patch + c * PLANE + py * kStemPitch + 4 * j) = v;
+    }
+  } else {
+    for (int i = tid; i < p.Cin * kStemPH * kStemPW; i += 256) {
+      const int c = i / (kStemPH * kStemPW);
+      const int r2 = i - c * (kStemPH * kStemPW);
+      const int py = r2 / kStemPW, px = r2 - py * kStemPW;
+      const int gy = gy0 + py, gx = gx0 + px;
+      float v = 0.f;
+      if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+        v = p.x[((size_t)(n * p.Cin + c) * p.H + gy) * p.W + gx];
+      patch[c * PLANE + py * kStemPitch + px + kStemShift] = v;
+    }
   }
 
   // ---- weights -> registers (A operand fragments), per-lane tap offsets -----------------------------------
@@ -97,7 +115,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const StemArgs p) {
 #pragma unroll
   for (int i = 0; i < MF; ++i) {
     const int row = wave * 2 + (i >> 1), col = (i & 1) * 16 + lr;  // output pixel inside the 8 x 32 patch
-    const float* org = patch + (2 * row) * kStemPitch + 2 * col;
+    const float* org = patch + (2 * row) * kStemPitch + 2 * col + kStemShift;
 #pragma unroll
     for (int kg = 0; kg < NKG; ++kg) {
       float f[EPC];
@@ -162,6 +180,7 @@ static int launch_stem(const StemArgs& a, hipStream_t st) {
   StemArgs p = a;
   p.tilesX = (p.Wo + kStemTW - 1) / kStemTW;
   p.tilesY = (p.Ho + kStemTH - 1) / kStemTH;
+  p.vec4 = (p.W % 4 == 0 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0) ? 1 : 0;
   const int smem = ((p.Cin * kStemPH * kStemPitch * 4 + 15) / 16) * 16 + 4 * 4 * 16 * (NF * 16 * (int)sizeof(T) + 16);
   auto kern = conv_stem_kernel<T, NF>;
   static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

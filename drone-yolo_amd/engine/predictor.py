@@ -53,7 +53,7 @@ class DetectionPredictor:
 
     def __init__(self, model, overrides: Optional[dict] = None):
         a = dict(conf=0.25, iou=0.7, max_det=300, classes=None, agnostic_nms=False, half=False, dtype=None, device="",
-                 verbose=False, graph=False, max_nms=30000, max_wh=7680)
+                 verbose=False, graph=False, max_nms=30000, max_wh=7680, imgsz=640)
         a.update(overrides or {})
         self.args = a
         self.device = select_device(a["device"])
@@ -69,10 +69,30 @@ class DetectionPredictor:
 
     # ---- stages (names follow the reference) -------------------------------------------------------
     def preprocess(self, im) -> torch.Tensor:
-        """Tensor source: BCHW float in [0,1], moved to the device (predictor.py:118-136; tensors are not /255)."""
+        """Tensor source: BCHW float in [0,1], moved to the device (predictor.py:118-136; tensors are not /255).
+        Array source — a list of HWC BGR uint8 numpy frames of ONE shape, or a uint8 (N, H, W, 3) tensor: LetterBox
+        (``auto`` = minimum rectangle, as pre_transform picks for same-shape batches, predictor.py:147-163), BGR->RGB,
+        HWC->CHW and /255 in one kernel; ``self.letterbox_info`` then holds what postprocess needs to map boxes back."""
+        self.letterbox_info = None
+        if isinstance(im, (list, tuple)) or (isinstance(im, torch.Tensor) and im.dtype == torch.uint8 and im.dim() == 4 and im.shape[-1] == 3) \
+                or type(im).__name__ == "ndarray":
+            import numpy as np
+
+            from ..data.augment import LetterBox
+
+            if not isinstance(im, torch.Tensor):
+                frames = [im] if type(im).__name__ == "ndarray" and im.ndim == 3 else list(im)
+                if len({f.shape for f in frames}) != 1:
+                    raise NotImplementedError("image sources of different shapes in one batch are not built (one LetterBox geometry per launch)")
+                im = torch.from_numpy(np.ascontiguousarray(np.stack(frames)))
+            frames = im.to(self.device).contiguous()
+            lb = LetterBox(self.args.get("imgsz", 640), auto=True, stride=int(self.model.stride.max()))
+            out = lb(frames, swap_rb=True)
+            n, h0, w0, _ = frames.shape
+            self.letterbox_info = (h0, w0, out.shape[2], out.shape[3])
+            return out
         if not isinstance(im, torch.Tensor):
-            raise NotImplementedError("only torch.Tensor (BCHW, float, [0,1]) sources are built on the device path; "
-                                      "LetterBox for image files/arrays is SURVEY §8(f) rank 2")
+            raise NotImplementedError("sources: a float BCHW tensor in [0,1], or uint8 HWC BGR frames (list of numpy arrays / uint8 NHWC tensor)")
         if im.dim() == 3:
             im = im[None]
         if im.shape[1] != self.model.yaml.get("ch", 3):
@@ -86,7 +106,8 @@ class DetectionPredictor:
         cf = CompiledForward()
         a = self.args
         n, _, h, w = im.shape
-        params = torch.tensor([[1.0, 0.0, 0.0, float(w), float(h)]] * n, dtype=torch.float32, device=self.device)
+        params = torch.tensor([self._box_params(h, w)] * n, dtype=torch.float32, device=self.device)
+        cf.box_params, cf.box_key = params, self._box_params(h, w)
         det = self.model.model[-1]
         holder = {}
 
@@ -112,10 +133,24 @@ class DetectionPredictor:
         cf.plan.keep.append(params)
         return cf
 
+    def _box_params(self, h: int, w: int):
+        """(gain, pad_x, pad_y, clip_w, clip_h) of ops.scale_boxes (utils/ops.py:92-127) for the current source."""
+        info = getattr(self, "letterbox_info", None)
+        if info is None:
+            return [1.0, 0.0, 0.0, float(w), float(h)]
+        h0, w0, hn, wn = info
+        gain = min(hn / h0, wn / w0)
+        return [gain, float(round((wn - w0 * gain) / 2 - 0.1)), float(round((hn - h0 * gain) / 2 - 0.1)), float(w0), float(h0)]
+
     def forward_device(self, im: torch.Tensor) -> CompiledForward:
         """Run one batch; outputs stay on the device in the returned object's ``nms`` buffers."""
         key = (tuple(im.shape), self.dtype)
         cf = self._compiled.get(key)
+        if cf is not None:  # the recorded dy_scale_boxes launch reads this device tensor: refresh it when the source geometry changed
+            bp = self._box_params(im.shape[2], im.shape[3])
+            if bp != cf.box_key:
+                cf.box_params.copy_(torch.tensor([bp] * im.shape[0], dtype=torch.float32))
+                cf.box_key = bp
         if cf is None:
             cf = self._compiled[key] = self._record(im)  # recording also executes the launches
             if self.args["graph"]:
@@ -149,8 +184,9 @@ class DetectionPredictor:
         names = self.model.names
         out = []
         for i, k in enumerate(counts):
+            info = getattr(self, "letterbox_info", None)
             out.append(Results(im[i], paths[i] if paths else f"image{i}.jpg", names, boxes=cf.nms.out[i, :k].clone(),
-                               orig_shape=im.shape[2:]))
+                               orig_shape=(info[0], info[1]) if info else im.shape[2:]))
         return out
 
     def __call__(self, source, stream: bool = False):

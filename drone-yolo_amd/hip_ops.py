@@ -721,3 +721,18 @@ def adamw_step_(p: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torch.T
 
 def ema_update_(ema: torch.Tensor, p: torch.Tensor, decay: float) -> None:
     _launch(lib().dy_ema_update, (ema.data_ptr(), p.data_ptr(), p.numel(), decay), keep=(ema, p))
+
+
+# ---- image sources ------------------------------------------------------------------------------------------------------
+
+
+def letterbox(frames: torch.Tensor, new_w: int, new_h: int, top: int, left: int, hn: int, wn: int, swap_rb: bool = True,
+              pad_value: float = 114.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """uint8 (N, H, W, 3) frames -> fp32 NCHW (N, 3, hn, wn) / 255 with the resized image at (top, left), 114 elsewhere."""
+    require_device(frames, "frames")
+    n, h0, w0, _ = frames.shape
+    if out is None:
+        out = torch.empty((n, 3, hn, wn), dtype=torch.float32, device=frames.device)
+    _launch(lib().dy_letterbox_u8_to_nchw_f32, (frames.data_ptr(), out.data_ptr(), n, h0, w0, new_w, new_h, top, left, hn, wn, int(swap_rb), pad_value),
+            keep=(frames, out))
+    return out

@@ -132,6 +132,19 @@ int32_t dy_stem_conv3x3s2_nchw(const float* x, const void* w, const float* bias,
                                int32_t h, int32_t w_in, int32_t cout, int32_t ld_y, int32_t act, int32_t dtype,
                                dy_stream_t stream);
 
+/* ---- image sources: LetterBox + BGR->RGB + HWC->CHW + /255 ------------------------------------------
+ * Replaces: LetterBox.__call__ (ultralytics/data/augment.py:1545-1608: cv2.resize INTER_LINEAR to (new_w, new_h), then
+ * cv2.copyMakeBorder with 114) and the non-tensor branch of BasePredictor.preprocess (engine/predictor.py:125-135:
+ * `im[..., ::-1].transpose(0,3,1,2)`, `.float()`, `/= 255`), in one pass.
+ * src: DEVICE uint8 (n, h0, w0, 3), all frames one shape, channel order as decoded (BGR): swap_rb = 1 reverses it.
+ * dst: fp32 (n, 3, hn, wn) contiguous = what dy_stem_conv3x3s2_nchw consumes.  The resized image occupies rows
+ * [top, top+new_h) x columns [left, left+new_w); everything else is pad_value (114).  The geometry (new_w, new_h, top,
+ * left, hn, wn) is LetterBox's own host arithmetic (augment.py:1566-1591).  8-bit bilinear arithmetic: OpenCV's
+ * (11-bit coefficients), bit-exact against oracle/letterbox_oracle.py; new size == source size copies. */
+int32_t dy_letterbox_u8_to_nchw_f32(const uint8_t* src, float* dst, int32_t n, int32_t h0, int32_t w0, int32_t new_w, int32_t new_h,
+                                    int32_t top, int32_t left, int32_t hn, int32_t wn, int32_t swap_rb, float pad_value,
+                                    dy_stream_t stream);
+
 /* ---- layout / copy ops ------------------------------------------------------ */
 
 /* Replaces: predictor preprocess `.half()/.float()` + the NCHW->device layout step

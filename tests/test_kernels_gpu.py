@@ -425,3 +425,25 @@ def test_scale_boxes_kernel(device):
     exp = O.scale_boxes((384, 640), rows[0, :3, :4].clone(), (480, 800))
     assert torch.allclose(b.out[0, :3, :4].cpu(), exp, atol=1e-4)
     assert torch.equal(b.out[1, 1:].cpu(), rows[1, 1:]) and torch.equal(b.out[0, :, 4:].cpu(), rows[0, :, 4:])
+
+
+# ---- image sources: LetterBox + BGR->RGB + CHW + /255 ------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("shape,imgsz,auto", [((1080, 1920), 640, True), ((480, 640), 640, True), ((640, 640), 640, False), ((333, 517), 640, False),
+                                               ((97, 1201), (320, 640), True), ((720, 1280), 1280, True)])
+def test_letterbox_kernel_bit_exact(shape, imgsz, auto, device):
+    """dy_letterbox_u8_to_nchw_f32 against oracle/letterbox_oracle.py (LetterBox + 8-bit bilinear + preprocess): identical."""
+    from drone_yolo_amd.data.augment import LetterBox
+    from oracle import letterbox_oracle as LB
+
+    rng = np.random.default_rng(shape[0])
+    frames = [rng.integers(0, 256, (*shape, 3), dtype=np.uint8) for _ in range(2)]
+    new_shape = (imgsz, imgsz) if isinstance(imgsz, int) else imgsz
+    ref = LB.preprocess(frames, new_shape, auto=auto, stride=32)
+    lb = LetterBox(new_shape, auto=auto, stride=32)
+    assert lb.geometry(shape) == LB.letterbox_geometry(shape, new_shape, auto=auto, stride=32)
+    out = lb(torch.from_numpy(np.stack(frames)).to(device))
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == ref.shape
+    assert np.array_equal(out.cpu().numpy(), ref), float(np.abs(out.cpu().numpy() - ref).max()) * 255

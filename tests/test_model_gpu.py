@@ -214,3 +214,32 @@ def test_full_size_properties(device):
         assert bool((sc[:-1] >= sc[1:]).all()) and float(sc.min()) > 0.25
         assert float(out[i, :c, :4].min()) >= 0 and float(out[i, :c, :4].max()) <= 640
         assert len(set(idx[i, :c].tolist())) == c
+
+
+def test_image_sources_letterbox_to_results(device):
+    """Array sources end to end: list of BGR uint8 frames -> LetterBox kernel -> model -> NMS -> boxes mapped back to the
+    original frame (scale_boxes), against the oracle chain (letterbox_oracle.preprocess -> forward -> NMS -> scale_boxes)."""
+    from oracle import letterbox_oracle as LB
+
+    g = golden("e2e.npz")
+    m, d, sd, model, _ = _build("n128", g, device)
+    rng = np.random.default_rng(11)
+    frames = [rng.integers(0, 256, (180, 300, 3), dtype=np.uint8) for _ in range(2)]
+    x = torch.from_numpy(LB.preprocess(frames, (128, 128), auto=True, stride=32))
+    assert tuple(x.shape) == (2, 3, 96, 128)  # minimum rectangle: 300x180 -> 128x77 + 19 rows of padding (mod 32)
+    with torch.no_grad():
+        y, _ = O.forward(d, sd, x)
+    det, _ = O.non_max_suppression(y, 0.25, 0.7, max_det=300, nc=m["nc"], return_index=True)
+    pred = D.engine.predictor.DetectionPredictor(model, dict(conf=0.25, iou=0.7, dtype=torch.float32, device=0, imgsz=128))
+    res = pred(frames)
+    assert len(res) == 2 and res[0].orig_shape == (180, 300)
+    for i in range(2):
+        exp = det[i].clone()
+        exp[:, :4] = O.scale_boxes(x.shape[2:], exp[:, :4], (180, 300))
+        got = res[i].boxes.data.cpu()
+        assert got.shape == exp.shape and len(exp) > 0
+        assert torch.equal(got[:, 5], exp[:, 5]) and torch.allclose(got[:, :5], exp[:, :5], atol=2e-2, rtol=1e-4)
+    # a second call with frames of another shape re-uses the recorded pass only when the letterboxed size matches
+    frames2 = [rng.integers(0, 256, (128, 128, 3), dtype=np.uint8)]
+    res2 = pred(frames2)
+    assert res2[0].orig_shape == (128, 128)

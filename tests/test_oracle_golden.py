@@ -187,3 +187,17 @@ def test_train_step_vectors():
                 k = f.split("::", 1)[1]
                 ref = torch.from_numpy(g[f])
                 assert float((grads[k] - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-9, k
+
+
+def test_letterbox_oracle_resize_sane():
+    """The restated 8-bit bilinear stays within 1 LSB of a float bilinear (it is the same interpolation, fixed point)."""
+    from oracle import letterbox_oracle as LB
+
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (211, 173, 3), dtype=np.uint8)
+    r = LB.resize_linear_u8(img, 301, 97).astype(np.float32)
+    import torch.nn.functional as F
+
+    t = torch.from_numpy(img).permute(2, 0, 1)[None].float()
+    f = F.interpolate(t, size=(97, 301), mode="bilinear", align_corners=False)[0].permute(1, 2, 0).numpy()
+    assert np.abs(r - f).max() <= 1.0
