@@ -243,3 +243,33 @@ def test_image_sources_letterbox_to_results(device):
     frames2 = [rng.integers(0, 256, (128, 128, 3), dtype=np.uint8)]
     res2 = pred(frames2)
     assert res2[0].orig_shape == (128, 128)
+
+
+@pytest.mark.parametrize("scale", ["m", "l", "x"])
+def test_other_scales_match_oracle(scale, device):
+    """The wider/deeper scales of the YAML (m, l, x: channel widths 48..640, repeats up to 3; SURVEY §8d configs 4-5 use l
+    and x) through the same kernels, fp32 storage, against the oracle on seeded weights."""
+    d = load_yaml("yolov8-p2-repvgg.yaml", scale, 10)
+    model = D.DetectionModel(dict(d), nc=10, verbose=False)
+    sd = O.seeded_state_dict(model.state_dict(), 300 + ord(scale), cls_bias=-2.0)
+    model.load_state_dict(sd)
+    x = torch.rand(2, 3, 96, 64, generator=torch.Generator().manual_seed(ord(scale)))
+    with torch.no_grad():
+        y, _ = O.forward(d, sd, x)
+    det, idx = O.non_max_suppression(y, 0.25, 0.7, max_det=300, nc=10, return_index=True)
+    pred = D.engine.predictor.DetectionPredictor(model, dict(conf=0.25, iou=0.7, dtype=torch.float32, device=0))
+    cf = pred.forward_device(pred.preprocess(x))
+    torch.cuda.synchronize()
+    err = float((cf.pred.cpu() - y).abs().max())
+    assert err < 5e-2, err
+    counts = cf.nms.count.cpu().tolist()
+    assert counts == [len(r) for r in det] and sum(counts) > 0
+    for i, c in enumerate(counts):
+        assert np.array_equal(np.sort(cf.nms.index[i, :c].cpu().numpy()), np.sort(idx[i].numpy()))
+    # and the throughput dtype runs
+    pred16 = D.engine.predictor.DetectionPredictor(model, dict(conf=0.25, iou=0.7, dtype=torch.bfloat16, device=0))
+    cf16 = pred16.forward_device(pred16.preprocess(x))
+    torch.cuda.synchronize()
+    e16 = (cf16.pred.cpu() - y).abs()
+    # untrained seeded weights: a few P5 anchors (stride 32, boxes ~100 px wide) move by several pixels in bf16
+    assert bool(torch.isfinite(cf16.pred).all()) and float(e16.median()) < 0.05 and float(e16[:, 4:].max()) < 0.4, (float(e16.median()), float(e16.max()))
