@@ -48,17 +48,13 @@ class Model(nn.Module):
         self.overrides["task"] = self.task
 
     def _load(self, weights: str, task=None) -> None:
-        """Load {'yaml': cfg dict, 'model': state_dict} checkpoints written by ``save``.
+        """Load a checkpoint: either {'yaml': cfg dict, 'model': state_dict} as written by ``save``, or the reference's
+        pickled module graph (``ema`` / ``model`` entries, tasks.py:786-926) through the restricted unpickler of
+        nn/checkpoint.py — no ``ultralytics`` package needed."""
+        from ..nn.checkpoint import load_reference_checkpoint
 
-        The reference's checkpoints pickle whole ``ultralytics`` module graphs (tasks.py:786-926);
-        reading those is SURVEY §8(f) rank 4 and not built yet.
-        """
-        ckpt = torch.load(weights, map_location="cpu", weights_only=True)
-        if not (isinstance(ckpt, dict) and "yaml" in ckpt and "model" in ckpt):
-            raise NotImplementedError("only checkpoints written by Model.save() are supported for now")
-        self.model = DetectionModel(ckpt["yaml"], verbose=False)
-        self.model.load_state_dict(ckpt["model"])
-        self.ckpt, self.ckpt_path = ckpt, weights
+        self.model, meta = load_reference_checkpoint(str(weights))
+        self.ckpt, self.ckpt_path = meta, weights
         self.overrides["model"] = weights
 
     def save(self, filename: Union[str, Path] = "saved_model.pt") -> None:

@@ -1,0 +1,111 @@
+"""Reading the reference's pickled ``.pt`` checkpoints without the ``ultralytics`` package.
+
+Reference: ``torch_safe_load`` / ``attempt_load_one_weight`` (ultralytics/nn/tasks.py:786-926) unpickle a dict whose
+``"ema"`` / ``"model"`` entries are whole ``ultralytics.nn.tasks.DetectionModel`` module graphs (saved fp16 by
+``BaseTrainer.save_model``, engine/trainer.py:514-545) — which needs the ultralytics classes importable.  Here a restricted
+unpickler resolves every ``ultralytics.*`` class name to the same-named class of this package when it has one (Conv,
+C2f, SPPF, RepVGGBlock, Detect, DetectionModel ... keep the reference's attribute and child names, so the restored objects
+are ordinary ``nn.Module``s whose ``state_dict()`` has the reference's keys) and to an inert placeholder otherwise
+(trainer arguments, loss objects, callbacks).  Only ``torch``, ``collections``, ``numpy`` reconstruction helpers and those
+classes can be instantiated: stricter than the reference's own ``torch.load``.
+
+The result is turned into THIS package's ``DetectionModel`` built from the pickled model's ``yaml`` dict and loaded with
+the pickled weights (fp32); BatchNorm eps / momentum are set by ``initialize_weights`` as in the reference.
+"""
+from __future__ import annotations
+
+import importlib
+import pickle
+import types
+from typing import Any, Dict, Tuple
+
+import torch
+import torch.nn as nn
+
+
+class _Placeholder:
+    """Stands in for reference classes this package has no use for (their state is kept but inert)."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, state):
+        self.__dict__.update(state if isinstance(state, dict) else {"_state": state})
+
+    def __call__(self, *a, **k):
+        return self
+
+
+_ALLOWED_PREFIXES = ("torch", "collections", "numpy", "_codecs", "builtins", "pathlib", "argparse", "copyreg", "types")
+_BUILTINS_OK = {"set", "frozenset", "dict", "list", "tuple", "int", "float", "bool", "str", "bytes", "bytearray", "complex", "slice", "range", "object",
+                "getattr"}
+
+
+def _own_classes() -> Dict[str, type]:
+    from . import modules as M
+    from . import tasks as T
+
+    out = {n: getattr(M, n) for n in dir(M) if isinstance(getattr(M, n), type)}
+    out["DetectionModel"] = T.DetectionModel
+    out["BaseModel"] = T.BaseModel
+    return out
+
+
+class RefUnpickler(pickle.Unpickler):
+    def find_class(self, module: str, name: str):
+        if module.startswith("ultralytics") or module.startswith("models.") or module == "models":
+            own = _own_classes()
+            return own.get(name.split(".")[-1], type(name.split(".")[-1], (_Placeholder,), {}))
+        root = module.split(".")[0]
+        if root in ("builtins", "__builtin__"):  # torch.save writes protocol-2 pickles: builtins appear as __builtin__
+            if name not in _BUILTINS_OK:
+                raise pickle.UnpicklingError(f"refusing builtins.{name} in a checkpoint")
+            return super().find_class("builtins", name)
+        if root in _ALLOWED_PREFIXES:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"refusing to import {module}.{name} while reading a checkpoint")
+
+
+def _pickle_module():
+    m = types.ModuleType("dyolo_ref_pickle")
+    m.Unpickler = RefUnpickler
+    m.load = lambda f, **kw: RefUnpickler(f, **kw).load()
+    m.__name__ = "pickle"  # torch.load inspects only Unpickler / load
+    return m
+
+
+def read_reference_checkpoint(path: str) -> Tuple[dict, Dict[str, torch.Tensor], Dict[str, Any]]:
+    """(model yaml dict, fp32 state dict with the reference's keys, remaining checkpoint entries)."""
+    ckpt = torch.load(path, map_location="cpu", pickle_module=_pickle_module(), weights_only=False)
+    if isinstance(ckpt, dict) and "yaml" in ckpt and isinstance(ckpt.get("model"), dict):
+        return ckpt["yaml"], {k: v.float() if v.is_floating_point() else v for k, v in ckpt["model"].items()}, {}
+    mod = (ckpt.get("ema") or ckpt["model"]) if isinstance(ckpt, dict) else ckpt  # tasks.py:906
+    if not isinstance(mod, nn.Module):
+        raise TypeError(f"{path}: no module under 'ema' / 'model' (got {type(mod).__name__})")
+    yaml_d = getattr(mod, "yaml", None)
+    if not isinstance(yaml_d, dict):
+        raise ValueError(f"{path}: the pickled model carries no yaml dict")
+    sd = {k: (v.float() if v.is_floating_point() else v) for k, v in mod.state_dict().items()}
+    meta = {k: v for k, v in ckpt.items() if k not in ("model", "ema", "optimizer")} if isinstance(ckpt, dict) else {}
+    names = getattr(mod, "names", None)
+    if names is not None:
+        meta["names"] = names
+    return dict(yaml_d), sd, meta
+
+
+def load_reference_checkpoint(path: str, verbose: bool = False):
+    """A ``DetectionModel`` of this package carrying the checkpoint's architecture and weights."""
+    from .tasks import DetectionModel
+
+    yaml_d, sd, meta = read_reference_checkpoint(path)
+    model = DetectionModel(dict(yaml_d), ch=yaml_d.get("ch", 3), nc=yaml_d.get("nc"), verbose=verbose)
+    own = model.state_dict()
+    missing = [k for k in own if k not in sd]
+    extra = [k for k in sd if k not in own]
+    bad = [k for k in own if k in sd and tuple(own[k].shape) != tuple(sd[k].shape)]
+    if missing or bad:
+        raise ValueError(f"{path}: checkpoint does not fit the model built from its yaml (missing {missing[:3]}, shape mismatch {bad[:3]}, extra {extra[:3]})")
+    model.load_state_dict({k: sd[k] for k in own})
+    if isinstance(meta.get("names"), dict):
+        model.names = meta["names"]
+    return model, meta

@@ -537,12 +537,53 @@ def train_vectors(R):
     np.savez_compressed(OUT / "train.npz", **out)
 
 
+def checkpoint_fixture(R):
+    """A checkpoint exactly as the reference's trainer writes it (engine/trainer.py:514-545: pickled module graph, fp16,
+    under 'ema'), for a tiny custom scale so that the fixture stays small; plus the outputs the reference computes from it."""
+    import io
+    from copy import deepcopy as dc
+
+    import yaml as _yaml
+
+    d = _yaml.safe_load(open(REF / "ultralytics" / "cfg" / "models" / "v8" / "yolov8-p2-repvgg.yaml"))
+    d["scales"]["t"] = [0.33, 0.125, 1024]
+    d["scale"], d["nc"] = "t", 10
+    rep = [i for i, l in enumerate(d["backbone"] + d["head"]) if l[2] == "RepVGGBlock"]
+    d2 = deepcopy(d)
+    for l in d2["backbone"] + d2["head"]:
+        if l[2] == "RepVGGBlock":
+            l[2] = "Conv"
+    torch.manual_seed(0)
+    model = R.tasks.DetectionModel(d2, ch=3, nc=10, verbose=False)
+    for i in rep:
+        old = model.model[i]
+        new = R.block.RepVGGBlock(old.conv.in_channels, old.conv.out_channels, 3, 2)
+        new.i, new.f, new.type, new.np = old.i, old.f, "ultralytics.nn.modules.block.RepVGGBlock", sum(p.numel() for p in new.parameters())
+        model.model[i] = new
+    model.yaml = d  # what a checkpoint of the fork carries: the RepVGG YAML itself
+    sd = O.seeded_state_dict({k: v for k, v in model.state_dict().items()}, 77, cls_bias=-1.0)
+    model.load_state_dict(sd)
+    R.tu.initialize_weights(model)
+    model.names = {i: f"class{i}" for i in range(10)}
+    model.eval()
+    ck = {"epoch": 3, "best_fitness": None, "model": None, "ema": dc(model).half(), "updates": 10, "optimizer": None,
+          "train_args": {"imgsz": 640, "batch": 16}, "date": "2025-01-01", "version": "8.3.0"}
+    torch.save(ck, OUT / "ref_checkpoint_t.pt")
+    x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        y, _ = dc(ck["ema"]).float()(x)  # the weights as stored (fp16-rounded)
+    np.savez_compressed(OUT / "ref_checkpoint_t.npz", y=tnp(y), n_params=np.array(sum(p.numel() for p in model.parameters())))
+    print(f"wrote tests/golden/ref_checkpoint_t.pt  {(OUT / 'ref_checkpoint_t.pt').stat().st_size / 1024:.1f} KiB (pickled reference module graph, scale t)")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     OUT.mkdir(parents=True, exist_ok=True)
     R = import_reference()
     print("reference imported from", REF)
-    if "--train-only" in sys.argv:
+    if "--ckpt-only" in sys.argv:
+        checkpoint_fixture(R)
+    elif "--train-only" in sys.argv:
         train_vectors(R)
     elif "--loss-only" in sys.argv:
         loss_vectors(R)
@@ -552,5 +593,6 @@ if __name__ == "__main__":
         e2e(R)
         loss_vectors(R)
         train_vectors(R)
+        checkpoint_fixture(R)
     for f in sorted(OUT.glob("*.npz")):
         print(f"wrote {f.relative_to(ROOT)}  {f.stat().st_size / 1024:.1f} KiB")

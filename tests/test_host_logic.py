@@ -134,3 +134,40 @@ def test_ops_host_helpers():
     assert ops.make_divisible(65, 8) == 72
     bb = torch.tensor([[-5.0, 10, 700, 500], [30, 40, 50, 60]])
     assert torch.allclose(ops.scale_boxes((384, 640), bb.clone(), (480, 800)), O.scale_boxes((384, 640), bb.clone(), (480, 800)))
+
+
+def test_reference_checkpoint_reader():
+    """A checkpoint pickled by the REAL reference (module graph under 'ema', fp16; oracle/make_golden.py::checkpoint_fixture)
+    is read without the ultralytics package: same keys/shapes/parameter count, and the oracle forward on the loaded
+    weights reproduces the output the reference computed from that checkpoint."""
+    import os
+    import pickle
+
+    import numpy as np
+    import pytest
+    import torch
+
+    from drone_yolo_amd.nn.checkpoint import RefUnpickler, load_reference_checkpoint, read_reference_checkpoint
+    from oracle import drone_yolo_oracle as O
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "tests", "golden", "ref_checkpoint_t.pt")
+    g = np.load(os.path.join(root, "tests", "golden", "ref_checkpoint_t.npz"))
+    yaml_d, sd, meta = read_reference_checkpoint(path)
+    assert yaml_d["scale"] == "t" and yaml_d["nc"] == 10 and meta["epoch"] == 3 and meta["names"][3] == "class3"
+    assert all(v.dtype == torch.float32 for v in sd.values() if v.is_floating_point())
+    model, _ = load_reference_checkpoint(path)
+    assert sum(p.numel() for p in model.parameters()) == int(g["n_params"])
+    assert model.names[3] == "class3"
+    x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        y, _ = O.forward(dict(yaml_d), {k: v for k, v in model.state_dict().items()}, x, fused=False)
+    assert torch.allclose(y, torch.from_numpy(g["y"]), atol=2e-3, rtol=1e-4)
+    # the unpickler refuses anything outside torch / collections / numpy / the mapped reference classes
+    import io
+
+    class _E:
+        def __reduce__(self):
+            return (os.system, ("true",))
+    with pytest.raises(pickle.UnpicklingError):
+        RefUnpickler(io.BytesIO(pickle.dumps(_E()))).load()

@@ -273,3 +273,17 @@ def test_other_scales_match_oracle(scale, device):
     e16 = (cf16.pred.cpu() - y).abs()
     # untrained seeded weights: a few P5 anchors (stride 32, boxes ~100 px wide) move by several pixels in bf16
     assert bool(torch.isfinite(cf16.pred).all()) and float(e16.median()) < 0.05 and float(e16[:, 4:].max()) < 0.4, (float(e16.median()), float(e16.max()))
+
+
+def test_yolo_from_reference_checkpoint(device):
+    """YOLO('<reference-pickled>.pt').predict on the device reproduces what the reference computed from that checkpoint."""
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = np.load(os.path.join(root, "tests", "golden", "ref_checkpoint_t.npz"))
+    yolo = D.YOLO(os.path.join(root, "tests", "golden", "ref_checkpoint_t.pt"))
+    x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(5))
+    pred = D.engine.predictor.DetectionPredictor(yolo.model, dict(conf=0.25, iou=0.7, dtype=torch.float32, device=0))
+    cf = pred.forward_device(pred.preprocess(x))
+    torch.cuda.synchronize()
+    assert torch.allclose(cf.pred.cpu(), torch.from_numpy(g["y"]), atol=5e-3, rtol=1e-4)
