@@ -133,6 +133,8 @@ SIGNATURES = {
     "dy_conv2d_wgrad_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _i32, _vp, _vp]),
     "dy_colsum": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "dy_letterbox_u8_to_nchw_f32": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "dy_tiles_u8_to_nchw_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "dy_rows_to_pred": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "dy_upsample2x_bwd_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dy_maxpool_bwd_nhwc": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dy_add_nhwc": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),

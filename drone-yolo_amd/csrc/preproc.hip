@@ -93,3 +93,78 @@ extern "C" int32_t dy_letterbox_u8_to_nchw_f32(const uint8_t* src, float* dst, i
   hipLaunchKernelGGL(letterbox_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
   return check_launch("dy_letterbox_u8_to_nchw_f32");
 }
+
+// ---- tiled inference on large frames ---------------------------------------------
+// The reference delegates slicing to third-party packages that are not vendored (mix6.py:84-89 `sv.InferenceSlicer`,
+// examples/YOLOv8-SAHI-Inference-Video/yolov8_sahi.py:50-55): tiles of a fixed size with a fractional overlap, one
+// inference per tile, detections shifted back and merged by class-aware NMS.  This build defines it:
+//   dy_tiles_u8_to_nchw_f32: K crops (th x tw at offsets[k] = (y, x)) of ONE uint8 HWC frame -> fp32 (K, 3, th, tw) / 255,
+//                            channel order swapped when asked; pixels beyond the frame edge take pad_value;
+//   dy_rows_to_pred:         per-tile NMS rows (K, max_det, 6) + counts -> one (1, 4+nc, K*max_det) prediction tensor in
+//                            frame coordinates (xywh + the row's score in its class channel) for a final dy_nms.
+namespace dy {
+
+__global__ __launch_bounds__(256) void tiles_kernel(const uint8_t* __restrict__ src, const int* __restrict__ offs, float* __restrict__ dst, int k, int hf, int wf,
+                                                    int th, int tw, int swap_rb, float pad) {
+  const long long total = (long long)k * th * tw;
+  const size_t plane = (size_t)th * tw;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % tw);
+    long long t = i / tw;
+    const int y = (int)(t % th);
+    const int tile = (int)(t / th);
+    const int sy = offs[2 * tile] + y, sx = offs[2 * tile + 1] + x;
+    float v[3] = {pad, pad, pad};
+    if ((unsigned)sy < (unsigned)hf && (unsigned)sx < (unsigned)wf) {
+      const uint8_t* q = src + ((size_t)sy * wf + sx) * 3;
+      v[0] = (float)q[0], v[1] = (float)q[1], v[2] = (float)q[2];
+    }
+    float* d = dst + (size_t)tile * 3 * plane + (size_t)y * tw + x;
+    d[0] = (swap_rb ? v[2] : v[0]) / 255.0f;
+    d[plane] = v[1] / 255.0f;
+    d[2 * plane] = (swap_rb ? v[0] : v[2]) / 255.0f;
+  }
+}
+
+__global__ __launch_bounds__(256) void rows_to_pred_kernel(const float* __restrict__ rows, const int* __restrict__ counts, const int* __restrict__ offs,
+                                                           float* __restrict__ pred, int k, int max_det, int nc) {
+  const int A = k * max_det;
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < A; j += gridDim.x * 256) {
+    const int tile = j / max_det, r = j - tile * max_det;
+    const bool valid = r < counts[tile];
+    const float* q = rows + (size_t)j * 6;
+    float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, sc = 0.f;
+    int c = 0;
+    if (valid) {
+      const float oy = (float)offs[2 * tile], ox = (float)offs[2 * tile + 1];
+      x1 = q[0] + ox, y1 = q[1] + oy, x2 = q[2] + ox, y2 = q[3] + oy, sc = q[4], c = (int)q[5];
+    }
+    pred[j] = (x1 + x2) * 0.5f;
+    pred[(size_t)A + j] = (y1 + y2) * 0.5f;
+    pred[(size_t)2 * A + j] = x2 - x1;
+    pred[(size_t)3 * A + j] = y2 - y1;
+    for (int cc = 0; cc < nc; ++cc) pred[(size_t)(4 + cc) * A + j] = (valid && cc == c) ? sc : 0.f;
+  }
+}
+
+}  // namespace dy
+
+extern "C" int32_t dy_tiles_u8_to_nchw_f32(const uint8_t* frame, const int32_t* offsets_yx, float* dst, int32_t k, int32_t hf, int32_t wf, int32_t th, int32_t tw,
+                                           int32_t swap_rb, float pad_value, dy_stream_t stream) {
+  DY_REQUIRE(frame && offsets_yx && dst && k > 0 && hf > 0 && wf > 0 && th > 0 && tw > 0, DY_ERR_INVALID_ARG, "dy_tiles_u8_to_nchw_f32: bad arguments");
+  const long long total = (long long)k * th * tw;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(dy::tiles_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), frame, offsets_yx, dst, k, hf, wf, th, tw, swap_rb,
+                     pad_value);
+  return dy::check_launch("dy_tiles_u8_to_nchw_f32");
+}
+
+extern "C" int32_t dy_rows_to_pred(const float* rows, const int32_t* counts, const int32_t* offsets_yx, float* pred, int32_t k, int32_t max_det, int32_t nc,
+                                   dy_stream_t stream) {
+  DY_REQUIRE(rows && counts && offsets_yx && pred && k > 0 && max_det > 0 && nc > 0, DY_ERR_INVALID_ARG, "dy_rows_to_pred: bad arguments");
+  const int A = k * max_det;
+  hipLaunchKernelGGL(dy::rows_to_pred_kernel, dim3((unsigned)((A + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rows, counts, offsets_yx, pred, k,
+                     max_det, nc);
+  return dy::check_launch("dy_rows_to_pred");
+}

@@ -145,6 +145,19 @@ int32_t dy_letterbox_u8_to_nchw_f32(const uint8_t* src, float* dst, int32_t n, i
                                     int32_t top, int32_t left, int32_t hn, int32_t wn, int32_t swap_rb, float pad_value,
                                     dy_stream_t stream);
 
+/* ---- tiled inference on large frames -----------------------------------------------------------------
+ * The reference slices through third-party packages that are not vendored (mix6.py:84-89 `sv.InferenceSlicer`,
+ * examples/YOLOv8-SAHI-Inference-Video/yolov8_sahi.py:50-55): fixed-size tiles with a fractional overlap, one inference
+ * per tile, detections shifted back and merged by class-aware NMS.  Parity is unpinned there; this build defines it.
+ * dy_tiles_u8_to_nchw_f32: k crops (th x tw at offsets_yx[k] = (y, x), DEVICE int32) of ONE uint8 HWC frame (hf, wf, 3) ->
+ *   fp32 (k, 3, th, tw) / 255 (swap_rb as in dy_letterbox_u8_to_nchw_f32); beyond the frame edge: pad_value.
+ * dy_rows_to_pred: per-tile dy_nms outputs rows (k, max_det, 6) + counts (k) -> pred (1, 4+nc, k*max_det) fp32 in FRAME
+ *   coordinates (xywh, the row's score in its class channel, zeros elsewhere and for rows >= counts) for a final dy_nms. */
+int32_t dy_tiles_u8_to_nchw_f32(const uint8_t* frame, const int32_t* offsets_yx, float* dst, int32_t k, int32_t hf, int32_t wf, int32_t th,
+                                int32_t tw, int32_t swap_rb, float pad_value, dy_stream_t stream);
+int32_t dy_rows_to_pred(const float* rows, const int32_t* counts, const int32_t* offsets_yx, float* pred, int32_t k, int32_t max_det,
+                        int32_t nc, dy_stream_t stream);
+
 /* ---- layout / copy ops ------------------------------------------------------ */
 
 /* Replaces: predictor preprocess `.half()/.float()` + the NCHW->device layout step

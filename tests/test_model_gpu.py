@@ -287,3 +287,43 @@ def test_yolo_from_reference_checkpoint(device):
     cf = pred.forward_device(pred.preprocess(x))
     torch.cuda.synchronize()
     assert torch.allclose(cf.pred.cpu(), torch.from_numpy(g["y"]), atol=5e-3, rtol=1e-4)
+
+
+def test_tiled_inference_matches_oracle_chain(device):
+    """Tile slicer + per-tile pass + cross-tile merge NMS on the device against the same chain on the CPU oracle
+    (numpy crops -> O.forward -> O.non_max_suppression per tile -> shift -> O.non_max_suppression over the union)."""
+    from drone_yolo_amd.engine.tiling import TiledPredictor, tile_offsets
+
+    assert tile_offsets(2160, 3840, 1280, 0.2) == [(y, x) for y in (0, 880) for x in (0, 1024, 2048, 2560)]  # SURVEY §8d config 4
+    assert tile_offsets(100, 100, 128, 0.2) == [(0, 0)]
+    g = golden("e2e.npz")
+    m, d, sd, model, _ = _build("n128", g, device)
+    rng = np.random.default_rng(21)
+    frame = rng.integers(0, 256, (200, 300, 3), dtype=np.uint8)
+    tile, nc = 128, m["nc"]
+    offs = tile_offsets(200, 300, tile, 0.25)
+    assert len(offs) == 2 * 3
+    x = torch.stack([torch.from_numpy(np.ascontiguousarray(frame[y : y + tile, xx : xx + tile, ::-1].transpose(2, 0, 1))).float() / 255 for y, xx in offs])
+    with torch.no_grad():
+        yy, _ = O.forward(d, sd, x)
+    det, _ = O.non_max_suppression(yy, 0.25, 0.7, max_det=300, nc=nc, return_index=True)
+    rows = []
+    for (oy, ox), r in zip(offs, det):
+        r = r.clone()
+        r[:, :4] = O.clip_boxes(r[:, :4], (tile, tile))  # each tile is an image of its own to the predictor (detect/predict.py:59-73)
+        r[:, [0, 2]] += ox
+        r[:, [1, 3]] += oy
+        rows.append(r)
+    allr = torch.cat(rows)
+    pred = torch.zeros(1, 4 + nc, len(allr))
+    pred[0, 0], pred[0, 1] = (allr[:, 0] + allr[:, 2]) / 2, (allr[:, 1] + allr[:, 3]) / 2
+    pred[0, 2], pred[0, 3] = allr[:, 2] - allr[:, 0], allr[:, 3] - allr[:, 1]
+    pred[0, 4 + allr[:, 5].long(), torch.arange(len(allr))] = allr[:, 4]
+    merged, _ = O.non_max_suppression(pred, 0.0, 0.6, max_det=1000, nc=nc, return_index=True)
+    exp = merged[0]
+    tp = TiledPredictor(model, tile=tile, overlap=0.25, merge_iou=0.6, conf=0.25, iou=0.7, dtype=torch.float32, device=0)
+    res = tp(frame)
+    got = res.boxes.data.cpu()
+    assert res.orig_shape == (200, 300) and 0 < len(exp) < len(allr)  # the merge removed cross-tile duplicates
+    assert got.shape == exp.shape, (got.shape, exp.shape)
+    assert torch.equal(got[:, 5], exp[:, 5]) and torch.allclose(got[:, :5], exp[:, :5], atol=3e-2, rtol=1e-4)
