@@ -2,17 +2,19 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype bf16|fp16|fp32]
 
-One "step" = one whole pass over a batch of B synthetic 640x640 images already resident in HBM:
-fp32 NCHW -> NHWC conversion, 83 convolutions (implicit-GEMM MFMA kernels), SPPF pools, Detect decode,
-batched NMS and box rescale — everything `YOLO.predict` does on the device for a tensor source.
+One "step" = one whole pass over a batch of B synthetic 640x640 images already resident in HBM (B = 256 by default,
+SURVEY §8d config 2): fused stem (fp32 NCHW in), 70 convolution launches (MFMA kernels), SPPF pools, fused Detect tail
+(1x1 convs + decode + NMS filter), batched NMS and box rescale — everything `YOLO.predict` does on the device for a
+tensor source.
 N > 1 (launched by torch.distributed.run, one rank per GPU) shards by image with no data-path
 collective: every rank runs B images, value = N*B*K / max-over-ranks time ("weak" scaling).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  roofline      MFMA-bound view of the dominant kernel family (conv_igemm_kernel): algorithmic conv
+  roofline      MFMA-bound view of the dominant kernel family (every launch that convolves): algorithmic conv
                 FLOPs per pass / summed per-launch durations measured with HIP events on the launch stream
   cpu_baseline  the oracle (CPU restatement of the reference path, oracle/) timed on the host cores on a
                 bounded sample of the same workload (rank 0, N=1 only)
+`--mode train` prints the secondary line of SURVEY §8d config 3 (training step, B = 64 per GPU).
 """
 from __future__ import annotations
 
@@ -209,7 +211,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("DYOLO_BENCH_BATCH", 128)), help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 256 for infer, SURVEY §8d config 2; 64 for train, config 3)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--model", default="yolov8s-p2-repvgg.yaml")
     ap.add_argument("--no-graph", action="store_true", help="replay the launch plan from Python instead of a hipGraph")
@@ -217,6 +219,8 @@ def main():
     ap.add_argument("--layers", default="", help="write a per-conv-launch timing table to this file")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"], help="infer = the headline metric (default); train = SURVEY §8(d) config 3")
     a = ap.parse_args()
+    if a.batch is None:
+        a.batch = 64 if a.mode == "train" else int(os.environ.get("DYOLO_BENCH_BATCH", 256))
     if a.mode == "train":
         return train_bench(a)
 
@@ -260,7 +264,7 @@ def main():
         tconv = sum(times.values())
         peak = MFMA_PEAK_TFLOPS[a.dtype]
         traffic = None  # HBM bytes of the conv launches of one pass, from the committed PMC summary (same batch only)
-        tfile = os.path.join(ROOT, "profiles", "r01_traffic_b128.json")
+        tfile = os.path.join(ROOT, "profiles", f"r01_traffic_b{a.batch}.json")
         if os.path.exists(tfile):
             tj = json.load(open(tfile))
             if tj.get("batch") == a.batch and a.dtype == "bf16":
@@ -268,7 +272,7 @@ def main():
         roof = {"bound": "mfma", "kernel": "conv family: conv3x3_halo + conv1x1_stream + conv_igemm + conv_stem + detect_head kernels (every launch that convolves, one pass)",
                 "achieved": round(flops / tconv / 1e12, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(flops / tconv / 1e12 / peak, 4), "traffic": traffic,
-                "traffic_unit": "GB of HBM traffic per pass (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic_b128.json)",
+                "traffic_unit": f"GB of HBM traffic per pass (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic_b{a.batch}.json)",
                 "launches": len(work), "flops_per_image": round(flops / a.batch / 1e9, 3), "conv_ms_per_step": round(tconv * 1e3, 3),
                 "hbm_view": {"algorithmic_GB_per_step": round(nbytes / 1e9, 4), "achieved_GBs": round(nbytes / tconv / 1e9, 1),
                              "peak_GBs": HBM_PEAK_GBS, "frac": round(nbytes / tconv / 1e9 / HBM_PEAK_GBS, 4)}}
