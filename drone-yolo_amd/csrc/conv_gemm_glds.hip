@@ -151,7 +151,8 @@ __global__ __launch_bounds__(BM * 2) void conv_gemm_glds_kernel(const ConvArgs p
   if constexpr (STAGES == 2) {
     issue(0, 0);
     for (int s = 0; s < nsteps; ++s) {
-      __syncthreads();  // drains this wave's DMA (vmcnt(0)) and publishes stage s&1; everyone is done with stage (s+1)&1
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of step s has landed (explicit: see the persistent kernel)
+      __syncthreads();  // publishes stage s&1; everyone is done with stage (s+1)&1
       if (s + 1 < nsteps) issue(s + 1, (s + 1) & 1);
       compute(s & 1);
     }
@@ -237,6 +238,227 @@ __global__ __launch_bounds__(BM * 2) void conv_gemm_glds_kernel(const ConvArgs p
   }
 }
 
+// ---- persistent variant (default): a workgroup walks tiles blockIdx.x, +gridDim.x, ... and requests the FIRST K-step of
+// its next tile before it runs the epilogue of the current one, so the pipeline fill (one L2->LDS round trip, ~1 us: 12 % of
+// a K = 512 tile) and the SiLU / transpose / store epilogue overlap.  Two LDS stages as above; the epilogue scratch is cut
+// to 32 pixels per wave and pass (18 KiB) so that it fits the stage the prefetch does not use.
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void conv_gemm_glds_persist_kernel(const ConvArgs p) {
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int BM = 128, NW = 4;
+  constexpr int BKE = 8 * EPC;
+  constexpr int NFR = BN / 32;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;
+  constexpr int EG0 = 128 / (16 * (int)sizeof(T));
+  constexpr int EG = NFR < EG0 ? NFR : EG0;
+  constexpr int CPP = EG * (int)sizeof(T);
+  constexpr int EP_PITCH = 128 + 16;
+  static_assert(32 * EP_PITCH * NW <= STAGE, "half-tile epilogue scratch must fit one stage");
+
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lq = lane >> 4, lr = lane & 15;
+  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ x2g = reinterpret_cast<const T*>(p.x2);
+  const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+  const T* zp = reinterpret_cast<const T*>(g_zero_page) + (lane & 7) * EPC;
+  T* __restrict__ yg = reinterpret_cast<T*>(p.y);
+  const T* __restrict__ rg = reinterpret_cast<const T*>(p.res);
+  const int prow = lane >> 3;
+  const int nsteps = p.Kpad / BKE;
+  const int G = (int)gridDim.x;
+
+  // gather state of the tile whose K-steps are being ISSUED
+  int a_n[PA], a_hi0[PA], a_wi0[PA], a_sw[PA];
+  const T* b_ptr[PB];
+  int kc = 0, kr = 0, kq = 0;
+  auto setup_tile = [&](int tile, int* tM, int* tN) {
+    const unsigned L = xcd_remap((unsigned)tile, (unsigned)p.nblk);
+    *tN = (int)(L % (unsigned)p.tilesN);
+    *tM = (int)(L / (unsigned)p.tilesN);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int row = (wave * PA + i) * 8 + prow;
+      const int m = *tM * BM + row;
+      const bool ok = m < p.M;
+      const int mm = ok ? m : 0;
+      const int n = mm / p.HoWo;
+      const int rem = mm - n * p.HoWo;
+      const int ho = rem / p.Wo;
+      const int wo = rem - ho * p.Wo;
+      a_n[i] = n;
+      a_hi0[i] = ok ? ho * p.stride - p.pad : -(1 << 28);
+      a_wi0[i] = wo * p.stride - p.pad;
+      a_sw[i] = (((lane & 7) ^ ((row >> 1) & 7))) * EPC;
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      const int row = (wave * PB + j) * 8 + prow;
+      b_ptr[j] = wg + (size_t)(*tN * BN + row) * (size_t)p.Kpad + (size_t)(((lane & 7) ^ ((row >> 1) & 7)) * EPC);
+    }
+    kc = 0, kr = 0, kq = 0;
+  };
+  auto issue = [&](int step, int stage) {
+    unsigned char* sa = smem + stage * STAGE;
+    unsigned char* sb = sa + A_BYTES;
+    const bool from_x = kc < p.split;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int hi = a_hi0[i] + kr, wi = a_wi0[i] + kq;
+      const bool ok = ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W) && !(p.up2x == 2 && ((hi | wi) & 1));
+      const T* ptr;
+      if (from_x) {
+        const int hb = p.up2x ? (hi >> 1) : hi, wb = p.up2x ? (wi >> 1) : wi;
+        ptr = xg + (long long)((a_n[i] * p.HB + hb) * p.WB + wb) * (long long)p.ldx + (long long)(kc + a_sw[i]);
+      } else {
+        ptr = x2g + (long long)((a_n[i] * p.H + hi) * p.W + wi) * (long long)p.ldx2 + (long long)(kc - p.split + a_sw[i]);
+      }
+      const T* src = ok ? ptr : zp;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sa + (wave * PA + i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[j] + (size_t)step * BKE),
+                                       (__attribute__((address_space(3))) void*)(sb + (wave * PB + j) * 1024), 16, 0, 0);
+    kc += BKE;
+    if (kc >= p.Cin) {
+      kc = 0;
+      if (++kq == p.ks) {
+        kq = 0;
+        ++kr;
+      }
+    }
+  };
+
+  f32x4 acc[NFR][4];
+  const int swz = lr >> 1;
+  auto compute = [&](int stage) {
+    const unsigned char* sa = smem + stage * STAGE + (wm * 64 + lr) * 128;
+    const unsigned char* sb = smem + stage * STAGE + A_BYTES + (wn * (BN / 2) + lr) * 128;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int slot = ((s * 4 + lq) ^ swz) * 16;
+      u32x4 a[4], b[NFR];
+#pragma unroll
+      for (int j = 0; j < NFR; ++j) b[j] = *reinterpret_cast<const u32x4*>(sb + j * 16 * 128 + slot);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const u32x4*>(sa + i * 16 * 128 + slot);
+#pragma unroll
+      for (int j = 0; j < NFR; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = Elem<T>::mma(b[j], a[i], acc[j][i]);
+    }
+  };
+
+  int tile = (int)blockIdx.x;
+  if (tile >= p.nblk) return;
+  int tM, tN;
+  setup_tile(tile, &tM, &tN);
+  int st0 = 0;  // stage that receives step 0 of the current tile
+  issue(0, st0);
+  while (true) {
+    const int m0 = tM * BM + wm * 64, n0 = tN * BN + wn * (BN / 2);
+#pragma unroll
+    for (int j = 0; j < NFR; ++j) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + n0 + j * 16 + lq * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j][i] = bb;
+    }
+    for (int s = 0; s < nsteps; ++s) {
+      // hipcc does not reliably order an LDS-DMA before a barrier (seen: no vmcnt wait in this loop): wait explicitly
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // step s landed in every wave; the other stage (and the epilogue scratch in it) is free
+      if (s + 1 < nsteps) issue(s + 1, (st0 + s + 1) & 1);
+      compute((st0 + s) & 1);
+    }
+    mfma_epilogue_fence<T>();
+    const int last = (st0 + nsteps - 1) & 1;  // stage read by the final compute
+    const int next = tile + G;
+    const bool more = next < p.nblk;
+    __syncthreads();  // every wave is done reading both stages
+    if (more) {
+      setup_tile(next, &tM, &tN);
+      issue(0, last);  // prefetch: lands while the epilogue below runs out of the OTHER stage
+    }
+    // ---- epilogue of the finished tile: 32 pixels per pass through the per-wave scratch in stage 1 - last ----
+    unsigned char* escr = smem + (1 - last) * STAGE + wave * (32 * EP_PITCH);
+#pragma unroll
+    for (int g = 0; g < NFR / EG; ++g) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int jj = 0; jj < EG; ++jj) {
+          const int j = g * EG + jj;
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii) {
+            const int i = half * 2 + ii;
+            float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
+            if (p.act == DY_ACT_SILU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
+            }
+            if (rg != nullptr) {
+              const int m = m0 + i * 16 + lr;
+              if (m < p.M) {
+                typedef __attribute__((ext_vector_type(4))) T t4;
+                const t4 rv = *reinterpret_cast<const t4*>(rg + (size_t)m * (size_t)p.ldres + (size_t)(n0 + j * 16 + lq * 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += Elem<T>::to_f32(rv[e]);
+              }
+            }
+            unsigned char* sp = escr + (ii * 16 + lr) * EP_PITCH + (jj * 16 + lq * 4) * (int)sizeof(T);
+            if constexpr (sizeof(T) == 4) {
+              *reinterpret_cast<f32x4*>(sp) = f32x4{v[0], v[1], v[2], v[3]};
+            } else {
+              typedef __attribute__((ext_vector_type(4))) T t4;
+              t4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f32(v[e]);
+              *reinterpret_cast<u32x2*>(sp) = __builtin_bit_cast(u32x2, o);
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = 0; k < (32 * CPP + 63) / 64; ++k) {  // 32 pixels x CPP chunks of 16 bytes
+          const int idx = k * 64 + lane;
+          const int px = idx / CPP, cc = idx % CPP;
+          const int m = m0 + half * 32 + px;
+          if (px < 32 && m < p.M) {
+            const u32x4 val = *reinterpret_cast<const u32x4*>(escr + px * EP_PITCH + cc * 16);
+            *reinterpret_cast<u32x4*>(yg + (size_t)m * (size_t)p.ldy + (size_t)(n0 + g * EG * 16 + cc * EPC)) = val;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+    if (!more) break;
+    tile = next;
+    st0 = last;
+  }
+}
+
+template <typename T, int BN>
+static int launch_glds_persist(const ConvArgs& a, hipStream_t st) {
+  ConvArgs p = a;
+  const int tilesM = (p.M + 127) / 128;
+  p.tilesN = p.Cout / BN;
+  p.nblk = tilesM * p.tilesN;
+  const int per_cu = (160 * 1024) / (2 * (128 + BN) * 128);  // 2 (BN = 128) or 3 (BN = 64) workgroups per CU
+  int grid = 256 * per_cu;
+  if (grid > p.nblk) grid = p.nblk;
+  hipLaunchKernelGGL((conv_gemm_glds_persist_kernel<T, BN>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  return check_launch("conv_gemm_glds_persist_kernel");
+}
+
 template <typename T, int BM, int BN, int STAGES>
 static int launch_glds(const ConvArgs& a, hipStream_t st) {
   ConvArgs p = a;
@@ -250,12 +472,15 @@ static int launch_glds(const ConvArgs& a, hipStream_t st) {
 
 template <typename T>
 static int launch_glds_dtype(const ConvArgs& a, hipStream_t st) {
-  static const int big = getenv("DYOLO_GLDS_BIG") ? atoi(getenv("DYOLO_GLDS_BIG")) : 0;
+  static const int big = getenv("DYOLO_GLDS_BIG") ? atoi(getenv("DYOLO_GLDS_BIG")) : 0;  // 1: 256x128 three-stage, 2: never persistent, 3: always persistent
+  // short K (<= 9 steps, the 64-channel stride-2 layers on 160x160 maps: thousands of tiles) measured faster one tile per
+  // workgroup; everything else gains 3-14 % from the persistent walk with the next tile's first K-step prefetched
+  const bool persist = big != 2 && (big == 3 || a.Kpad > 9 * 8 * (16 / (int)sizeof(T)));
   if (a.Cout % 128 == 0) {
-    if (big) return launch_glds<T, 256, 128, 3>(a, st);
-    return launch_glds<T, 128, 128, 2>(a, st);
+    if (big == 1) return launch_glds<T, 256, 128, 3>(a, st);
+    return persist ? launch_glds_persist<T, 128>(a, st) : launch_glds<T, 128, 128, 2>(a, st);
   }
-  return launch_glds<T, 128, 64, 2>(a, st);
+  return persist ? launch_glds_persist<T, 64>(a, st) : launch_glds<T, 128, 64, 2>(a, st);
 }
 
 int conv_gemm_glds_try(const ConvArgs& a, int dtype, bool out_f32, hipStream_t st) {
