@@ -40,15 +40,20 @@ struct Conv3Args {
   int Ho, Wo, Cout, ldy, ldres;
   int act;
   int tilesX, tilesY, tilesN, nTiles, nChunks;
-  unsigned x_bytes, w_bytes;  // extents of the x view and of the packed weights (buffer descriptors)
+  unsigned x_bytes, w_bytes, y_bytes;  // extents of the x / y views and of the packed weights (buffer descriptors)
   int dbg;  // ablation switches (DYOLO_DBG env): 1 skip global loads after the first item, 2 skip MFMAs,
             // 4 skip epilogue, 8 skip LDS staging writes, 16 force the streaming (non-WS) variant
 };
 
 constexpr int kHaloPixPitch = 80;  // bytes per halo pixel in LDS (64 data + 16 pad)
 
-template <typename T, int S, int MF, int NF, bool OUTF32, bool WS>
+// NCH > 0 = PIPE (weight-stationary, exactly NCH chunks per tile, 16-bit storage, SiLU, no residual): the epilogue of a
+// tile is deferred into the first item of the NEXT tile and interleaved in source order with that item's MFMAs (one
+// accumulator fragment's SiLU + scratch write after each tap), so its VALU / LDS / store work is issued in the shadow of
+// the matrix instructions instead of stalling all eight barrier-locked waves between tiles (64->64 @80x80: 151 -> 135 us).
+template <typename T, int S, int MF, int NF, bool OUTF32, bool WS, int NCH = 0>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
+  constexpr bool PIPE = NCH > 0;
   constexpr int NT = 512;
   constexpr int EPC = Elem<T>::EPC;
   constexpr int KCE = 4 * EPC;             // channels per chunk (one MFMA k-group)
@@ -76,8 +81,12 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
   // 8-byte stores straight from the accumulator layout are store-issue bound (~580 cycles per wave store).
   constexpr int EP_PITCH = BN * (int)sizeof(OutT) + 16;
   constexpr int EP_BYTES = MF * 16 * EP_PITCH;
-  unsigned char* const escr = const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(sbias)) +
-                              ((WS ? BN : p.tilesN * BN) * 4) + (threadIdx.x >> 6) * EP_BYTES;
+  // PIPE keeps the scratch in a SEPARATE LDS object: only then can the compiler prove that the epilogue's scratch
+  // writes do not alias the stage reads of the MFMAs that follow and interleave the two
+  __shared__ __attribute__((aligned(16))) unsigned char pipe_scr[PIPE ? 8 * EP_BYTES : 16];
+  unsigned char* const escr = PIPE ? pipe_scr + (threadIdx.x >> 6) * EP_BYTES
+                                   : const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(sbias)) +
+                                         ((WS ? BN : p.tilesN * BN) * 4) + (threadIdx.x >> 6) * EP_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane >> 4, lr = lane & 15;
@@ -86,6 +95,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
   // flight behind counted s_waitcnt vmcnt(N) (predicated global loads made it drain with vmcnt(0)).
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);  // PIPE: branch-free masked stores
   const u32x4* __restrict__ wg = reinterpret_cast<const u32x4*>(p.w);
   const int G = (int)gridDim.x;
 
@@ -203,29 +213,30 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
 
   // byte offset of this lane's fragment element for tap (0,0), row i = 0 inside a halo stage
   const int a_lane = ((wave * MF * S) * HWD + lr * S) * PP + lq * 16;
-  auto compute = [&](int stage, int chunk) {
+  auto compute_tap = [&](int stage, int chunk, int tap) {
     const unsigned char* sa = stage0 + stage * STAGE + a_lane;
     const unsigned char* sw = (WS ? dyn_smem + chunk * W_BYTES : stage0 + stage * STAGE + A_BYTES) + lane * 16;
+    const int r = tap / 3, q = tap % 3;
+    u32x4 a[MF], b[NF];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int r = tap / 3, q = tap % 3;
-      u32x4 a[MF], b[NF];
+    for (int i = 0; i < MF; ++i) a[i] = *reinterpret_cast<const u32x4*>(sa + ((i * S + r) * HWD + q) * PP);
 #pragma unroll
-      for (int i = 0; i < MF; ++i) a[i] = *reinterpret_cast<const u32x4*>(sa + ((i * S + r) * HWD + q) * PP);
+    for (int j = 0; j < NF; ++j) b[j] = *reinterpret_cast<const u32x4*>(sw + (tap * NF + j) * 1024);
 #pragma unroll
-      for (int j = 0; j < NF; ++j) b[j] = *reinterpret_cast<const u32x4*>(sw + (tap * NF + j) * 1024);
+    for (int i = 0; i < MF; ++i)
 #pragma unroll
-      for (int i = 0; i < MF; ++i)
+      for (int j = 0; j < NF; ++j) acc[i][j] = Elem<T>::mma(b[j], a[i], acc[i][j]);  // D[cout][pixel]
+  };
+  auto compute = [&](int stage, int chunk) {
 #pragma unroll
-        for (int j = 0; j < NF; ++j) acc[i][j] = Elem<T>::mma(b[j], a[i], acc[i][j]);  // D[cout][pixel]
-    }
+    for (int tap = 0; tap < 9; ++tap) compute_tap(stage, chunk, tap);
   };
 
   // ---- epilogue from registers: lane holds couts (lq*4 .. +3) of pixel lr for every (i, j) ------------
   OutT* __restrict__ yg = reinterpret_cast<OutT*>(p.y);
   const T* __restrict__ rg = reinterpret_cast<const T*>(p.res);
-  auto epilogue = [&](const TileIt& t) {
-    mfma_epilogue_fence<T>();
+  auto epilogue = [&](const TileIt& t, const f32x4 (&acc)[MF][NF], bool valid) {
+    if constexpr (!PIPE) mfma_epilogue_fence<T>();
     const int xx = t.tx * TW + lr;
     const int co0 = t.nt * BN + lq * 4;
     size_t m[MF];
@@ -233,12 +244,12 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
       const int yy = t.ty * TH + wave * MF + i;
-      rowok[i] = yy < p.Ho && xx < p.Wo;
+      rowok[i] = valid && yy < p.Ho && xx < p.Wo;
       m[i] = (size_t)(t.n * p.Ho + (rowok[i] ? yy : 0)) * p.Wo + (rowok[i] ? xx : 0);
     }
     // all residual loads first (one wait for the lot), then the arithmetic
     float rv[MF][NF][4];
-    if constexpr (!OUTF32) {
+    if constexpr (!OUTF32 && !PIPE) {
       if (rg != nullptr) {
 #pragma unroll
         for (int i = 0; i < MF; ++i)
@@ -265,11 +276,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
 #pragma unroll
       for (int i = 0; i < MF; ++i) {
         float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};  // bias is already inside
-        if (p.act == DY_ACT_SILU) {
+        if (PIPE || p.act == DY_ACT_SILU) {  // PIPE is only launched for SiLU layers without residual: no branches
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
         }
-        if constexpr (!OUTF32) {
+        if constexpr (!OUTF32 && !PIPE) {
           if (rg != nullptr) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += rv[i][j][e];
@@ -298,7 +309,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
       const int yy = t.ty * TH + wave * MF + i, xo = t.tx * TW + px;
       const int co = t.nt * BN + cc * VE;
       const u32x4 val = *reinterpret_cast<const u32x4*>(escr + pixl * EP_PITCH + cc * 16);
-      if (yy < p.Ho && xo < p.Wo && co < p.Cout) {
+      if constexpr (PIPE) {  // out-of-range offset: the store is dropped by the hardware (cout % VE == 0 on this path)
+        const bool ok = valid && yy < p.Ho && xo < p.Wo && co < p.Cout;
+        const unsigned off = ok ? (unsigned)((((size_t)(t.n * p.Ho + yy) * p.Wo + xo) * (size_t)p.ldy + co) * sizeof(OutT)) : 0xfffffff0u;
+        __builtin_amdgcn_raw_buffer_store_b128(val, yrs, off, 0, 0);
+      } else if (valid && yy < p.Ho && xo < p.Wo && co < p.Cout) {
         OutT* yp = yg + ((size_t)(t.n * p.Ho + yy) * p.Wo + xo) * (size_t)p.ldy + co;
         if (co + VE <= p.Cout) {
           *reinterpret_cast<u32x4*>(yp) = val;
@@ -307,6 +322,36 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
           *reinterpret_cast<u32x2*>(yp) = lo;
         }
       }
+    }
+  };
+
+  // PIPE pieces: one (i, j) accumulator fragment -> SiLU -> scratch; and the row-wise read-back + masked buffer stores
+  auto epi_pair = [&](const f32x4 (&accp)[MF][NF], int i, int j) {
+    float v[4] = {accp[i][j][0], accp[i][j][1], accp[i][j][2], accp[i][j][3]};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
+    if constexpr (sizeof(T) == 2) {  // PIPE exists for 16-bit storage only
+      typedef __attribute__((ext_vector_type(4))) T t4;
+      t4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f32(v[e]);
+      *reinterpret_cast<u32x2*>(escr + (i * 16 + lr) * EP_PITCH + (j * 16 + lq * 4) * (int)sizeof(T)) = __builtin_bit_cast(u32x2, o);
+    }
+  };
+  auto epi_store = [&](const TileIt& t, bool valid) {
+    constexpr int CPR = BN * (int)sizeof(OutT) / 16;
+    constexpr int VE = 16 / (int)sizeof(OutT);
+#pragma unroll
+    for (int k = 0; k < MF * 16 * CPR / 64; ++k) {
+      const int idx = k * 64 + lane;
+      const int pixl = idx / CPR, cc = idx - pixl * CPR;
+      const int i = pixl >> 4, px = pixl & 15;
+      const int yy = t.ty * TH + wave * MF + i, xo = t.tx * TW + px;
+      const int co = t.nt * BN + cc * VE;
+      const u32x4 val = *reinterpret_cast<const u32x4*>(escr + pixl * EP_PITCH + cc * 16);
+      const bool ok = valid && yy < p.Ho && xo < p.Wo && co < p.Cout;
+      const unsigned off = ok ? (unsigned)((((size_t)(t.n * p.Ho + yy) * p.Wo + xo) * (size_t)p.ldy + co) * sizeof(OutT)) : 0xfffffff0u;
+      __builtin_amdgcn_raw_buffer_store_b128(val, yrs, off, 0, 0);
     }
   };
 
@@ -331,11 +376,76 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
   init_acc(ct.nt);
 
   // ---- item pipeline: one barrier per (tile, chunk) item, prefetch depth two -------------------------
+  if constexpr (PIPE) {
+    f32x4 acc_prev[MF][NF];  // the previous tile's results wait here for their deferred epilogue
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) acc_prev[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    TileIt pt = ct;
+    bool pvalid = false;
+    // one (tile, chunk) item; FIRST / LAST of its tile are compile-time, items alternate stages and register sets
+    auto item = [&](auto first_c, auto last_c, int stage, int chunk, u32x4 (&ra_i)[NA], u32x4 (&rw_i)[NW], const u32x4 (&ra_s)[NA],
+                    const u32x4 (&rw_s)[NW]) {
+      issue_loads(ra_i, rw_i);
+      if constexpr (decltype(first_c)::value) {
+        // source-order interleave (the scheduler keeps it): after the MFMAs of tap k, the SiLU + scratch write of one
+        // accumulator fragment of the PREVIOUS tile issue while the matrix pipe works; the row stores follow the last tap
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          compute_tap(stage, chunk, tap);
+#pragma unroll
+          for (int k = tap; k < MF * NF; k += 8)  // 8 slots (taps 0..7) share the MF*NF fragments
+            if (tap < 8) epi_pair(acc_prev, k / NF, k % NF);
+        }
+        epi_store(pt, pvalid);
+      } else {
+        compute(stage, chunk);
+      }
+      store_lds(1 - stage, ra_s, rw_s);
+      if constexpr (decltype(last_c)::value) {
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+          for (int j = 0; j < NF; ++j) acc_prev[i][j] = acc[i][j];
+        pt = ct;
+        pvalid = true;
+        advance(ct);
+        init_acc(ct.nt);
+      }
+      __syncthreads();
+    };
+    using Tr = std::true_type;
+    using Fa = std::false_type;
+    if constexpr (NCH == 1) {
+      for (int it = 0; it < nItems; it += 2) {
+        item(Tr{}, Tr{}, 0, 0, ra0, rw0, ra1, rw1);
+        if (it + 1 < nItems) item(Tr{}, Tr{}, 1, 0, ra1, rw1, ra0, rw0);
+      }
+    } else if constexpr (NCH == 2) {
+      for (int it = 0; it < nItems; it += 2) {
+        item(Tr{}, Fa{}, 0, 0, ra0, rw0, ra1, rw1);
+        item(Fa{}, Tr{}, 1, 1, ra1, rw1, ra0, rw0);
+      }
+    } else {
+      static_assert(NCH == 4, "PIPE is built for 1, 2 or 4 chunks per tile");
+      for (int it = 0; it < nItems; it += 4) {
+        item(Tr{}, Fa{}, 0, 0, ra0, rw0, ra1, rw1);
+        item(Fa{}, Fa{}, 1, 1, ra1, rw1, ra0, rw0);
+        item(Fa{}, Fa{}, 0, 2, ra0, rw0, ra1, rw1);
+        item(Fa{}, Tr{}, 1, 3, ra1, rw1, ra0, rw0);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < MF * NF; ++k) epi_pair(acc_prev, k / NF, k % NF);
+    epi_store(pt, pvalid);
+    return;
+  }
   int c_chunk = 0;
   auto tile_end = [&]() {
     if (++c_chunk == p.nChunks) {  // last chunk of a tile
       c_chunk = 0;
-      if (!(p.dbg & 4)) epilogue(ct);
+      if (!(p.dbg & 4)) epilogue(ct, acc, true);
       advance(ct);
       init_acc(ct.nt);
     }
@@ -395,6 +505,25 @@ static int launch_halo(const Conv3Args& a, int batch, hipStream_t st) {
   int grid = 256 * per_cu;
   if (grid > p.nTiles) grid = p.nTiles;
   if (ws && grid > p.tilesN) grid -= grid % p.tilesN;  // keep every block on one n-tile
+  static const int nopipe = getenv("DYOLO_NO_PIPE") ? atoi(getenv("DYOLO_NO_PIPE")) : 0;
+  if constexpr (sizeof(T) == 2 && !OUTF32 && S == 1) {
+    if (ws && (p.nChunks == 1 || p.nChunks == 2 || p.nChunks == 4) && !nopipe && !p.dbg && !p.res && p.act == DY_ACT_SILU && p.Cout % 8 == 0 &&
+        p.y_bytes) {
+      constexpr int ep_bytes = 8 * MF * 16 * (NF * 16 * (int)sizeof(T) + 16);  // a static LDS object in this variant
+#define DY_PIPE_LAUNCH(N)                                                                                                              \
+  do {                                                                                                                                 \
+    auto kern = conv3x3_halo_kernel<T, S, MF, NF, OUTF32, true, N>;                                                                    \
+    static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget - ep_bytes); \
+    (void)once;                                                                                                                        \
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem - ep_bytes, st, p);                                                 \
+  } while (0)
+      if (p.nChunks == 1) DY_PIPE_LAUNCH(1);
+      else if (p.nChunks == 2) DY_PIPE_LAUNCH(2);
+      else DY_PIPE_LAUNCH(4);
+#undef DY_PIPE_LAUNCH
+      return check_launch("conv3x3_halo_kernel");
+    }
+  }
   if (ws) {
     auto kern = conv3x3_halo_kernel<T, S, MF, NF, OUTF32, true>;
     static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
@@ -455,6 +584,10 @@ int conv3x3_halo_dispatch(const dy_conv_desc* d, hipStream_t st) {
   a.act = d->act;
   a.nChunks = (d->cin + 4 * epc - 1) / (4 * epc);
   a.x_bytes = (unsigned)((long long)d->batch * d->h * d->w_in * d->ld_x * es);
+  {
+    const long long yb = (long long)d->batch * d->ho * d->wo * d->ld_y * (d->out_f32 ? 4 : es);
+    a.y_bytes = yb < (1ll << 32) - 64 ? (unsigned)yb : 0u;  // 0: view too large for a buffer descriptor -> PIPE variant not used
+  }
   {
     const int bn = d->cout > 32 ? 64 : 32;
     a.w_bytes = (unsigned)((long long)((d->cout + bn - 1) / bn) * a.nChunks * 9 * (bn / 16) * 1024);
