@@ -506,7 +506,7 @@ static int launch_halo(const Conv3Args& a, int batch, hipStream_t st) {
   if (grid > p.nTiles) grid = p.nTiles;
   if (ws && grid > p.tilesN) grid -= grid % p.tilesN;  // keep every block on one n-tile
   static const int nopipe = getenv("DYOLO_NO_PIPE") ? atoi(getenv("DYOLO_NO_PIPE")) : 0;
-  if constexpr (sizeof(T) == 2 && !OUTF32 && S == 1) {
+  if constexpr (sizeof(T) == 2 && !OUTF32) {
     if (ws && (p.nChunks == 1 || p.nChunks == 2 || p.nChunks == 4) && !nopipe && !p.dbg && !p.res && p.act == DY_ACT_SILU && p.Cout % 8 == 0 &&
         p.y_bytes) {
       constexpr int ep_bytes = 8 * MF * 16 * (NF * 16 * (int)sizeof(T) + 16);  // a static LDS object in this variant
