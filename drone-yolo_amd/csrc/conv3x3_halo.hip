@@ -40,7 +40,7 @@ struct Conv3Args {
   int Ho, Wo, Cout, ldy, ldres;
   int act;
   int tilesX, tilesY, tilesN, nTiles, nChunks;
-  unsigned x_bytes, w_bytes, y_bytes;  // extents of the x / y views and of the packed weights (buffer descriptors)
+  unsigned x_bytes, w_bytes, y_bytes, r_bytes;  // extents of the x / y / residual views and of the packed weights (buffer descriptors)
   int dbg;  // ablation switches (DYOLO_DBG env): 1 skip global loads after the first item, 2 skip MFMAs,
             // 4 skip epilogue, 8 skip LDS staging writes, 16 force the streaming (non-WS) variant
 };
@@ -96,6 +96,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);  // PIPE: branch-free masked stores
+  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res ? p.res : p.y), 0, p.res ? p.r_bytes : 0u, 0x00020000);
   const u32x4* __restrict__ wg = reinterpret_cast<const u32x4*>(p.w);
   const int G = (int)gridDim.x;
 
@@ -326,12 +327,32 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
   };
 
   // PIPE pieces: one (i, j) accumulator fragment -> SiLU -> scratch; and the row-wise read-back + masked buffer stores
+  // residual of the PREVIOUS tile (Bottleneck shortcut): 8-byte raw buffer loads, zero when there is no residual (the
+  // descriptor then has zero records) or the pixel is outside the image — no branches
+  u32x2 rres[MF][NF];
+  auto load_residual = [&](const TileIt& t, bool valid) {
+    const int xx = t.tx * TW + lr;
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+      const int yy = t.ty * TH + wave * MF + i;
+      const bool ok = valid && yy < p.Ho && xx < p.Wo;
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const int co = t.nt * BN + j * 16 + lq * 4;
+        const unsigned off = (ok && co < p.Cout) ? (unsigned)((((size_t)(t.n * p.Ho + yy) * p.Wo + xx) * (size_t)p.ldres + co) * sizeof(T)) : 0xfffffff0u;
+        rres[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rrs, off, 0, 0);
+      }
+    }
+  };
   auto epi_pair = [&](const f32x4 (&accp)[MF][NF], int i, int j) {
     float v[4] = {accp[i][j][0], accp[i][j][1], accp[i][j][2], accp[i][j][3]};
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
     if constexpr (sizeof(T) == 2) {  // PIPE exists for 16-bit storage only
       typedef __attribute__((ext_vector_type(4))) T t4;
+      const t4 rr = __builtin_bit_cast(t4, rres[i][j]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += Elem<T>::to_f32(rr[e]);
       t4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f32(v[e]);
@@ -387,6 +408,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
     // one (tile, chunk) item; FIRST / LAST of its tile are compile-time, items alternate stages and register sets
     auto item = [&](auto first_c, auto last_c, int stage, int chunk, u32x4 (&ra_i)[NA], u32x4 (&rw_i)[NW], const u32x4 (&ra_s)[NA],
                     const u32x4 (&rw_s)[NW]) {
+      if constexpr (decltype(first_c)::value) load_residual(pt, pvalid);  // older than the halo prefetch: counted waits suffice
       issue_loads(ra_i, rw_i);
       if constexpr (decltype(first_c)::value) {
         // source-order interleave (the scheduler keeps it): after the MFMAs of tap k, the SiLU + scratch write of one
@@ -436,6 +458,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
         item(Fa{}, Tr{}, 1, 3, ra1, rw1, ra0, rw0);
       }
     }
+    load_residual(pt, pvalid);
 #pragma unroll
     for (int k = 0; k < MF * NF; ++k) epi_pair(acc_prev, k / NF, k % NF);
     epi_store(pt, pvalid);
@@ -507,8 +530,8 @@ static int launch_halo(const Conv3Args& a, int batch, hipStream_t st) {
   if (ws && grid > p.tilesN) grid -= grid % p.tilesN;  // keep every block on one n-tile
   static const int nopipe = getenv("DYOLO_NO_PIPE") ? atoi(getenv("DYOLO_NO_PIPE")) : 0;
   if constexpr (sizeof(T) == 2 && !OUTF32) {
-    if (ws && (p.nChunks == 1 || p.nChunks == 2 || p.nChunks == 4) && !nopipe && !p.dbg && !p.res && p.act == DY_ACT_SILU && p.Cout % 8 == 0 &&
-        p.y_bytes) {
+    if (ws && (p.nChunks == 1 || p.nChunks == 2 || p.nChunks == 4) && !nopipe && !p.dbg && p.act == DY_ACT_SILU && p.Cout % 8 == 0 &&
+        p.y_bytes && (!p.res || p.r_bytes)) {
       constexpr int ep_bytes = 8 * MF * 16 * (NF * 16 * (int)sizeof(T) + 16);  // a static LDS object in this variant
 #define DY_PIPE_LAUNCH(N)                                                                                                              \
   do {                                                                                                                                 \
@@ -587,6 +610,8 @@ int conv3x3_halo_dispatch(const dy_conv_desc* d, hipStream_t st) {
   {
     const long long yb = (long long)d->batch * d->ho * d->wo * d->ld_y * (d->out_f32 ? 4 : es);
     a.y_bytes = yb < (1ll << 32) - 64 ? (unsigned)yb : 0u;  // 0: view too large for a buffer descriptor -> PIPE variant not used
+    const long long rb = d->residual ? (long long)d->batch * d->ho * d->wo * d->ld_res * es : 0;
+    a.r_bytes = rb < (1ll << 32) - 64 ? (unsigned)rb : 0u;
   }
   {
     const int bn = d->cout > 32 ? 64 : 32;
