@@ -15,6 +15,7 @@
 // waves split the pixel range (WK = 4 / (WCO*WCI) independent 32-pixel steps per iteration).  Pixel slabs are spread
 // over gridDim.x; partial sums are added to dW with fp32 atomics (dW must be zero before the call).
 #include "common.cuh"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace dy {
@@ -31,7 +32,7 @@ struct WgradArgs {
 
 // The four 16-channel fragments of one operand for this lane: 8 transposed reads and their wait in ONE asm statement
 // (the compiler does not track asm loads, so results must not be touched before the s_waitcnt inside the statement).
-template <int PITCH>
+template <int PITCH, int ROW2 = 16 * PITCH>
 __device__ __forceinline__ void tr_read_frags(const void* base, u32x4 (&out)[4]) {
   u32x2 r0, r1, r2, r3, r4, r5, r6, r7;
   asm volatile(
@@ -45,8 +46,7 @@ __device__ __forceinline__ void tr_read_frags(const void* base, u32x4 (&out)[4])
       "ds_read_b64_tr_b16 %7, %8 offset:%16\n\t"
       "s_waitcnt lgkmcnt(0)"
       : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
-      : "v"((unsigned)(uintptr_t)base), "n"(0), "n"(16 * PITCH), "n"(32), "n"(32 + 16 * PITCH), "n"(64), "n"(64 + 16 * PITCH), "n"(96),
-        "n"(96 + 16 * PITCH)
+      : "v"((unsigned)(uintptr_t)base), "n"(0), "n"(ROW2), "n"(32), "n"(32 + ROW2), "n"(64), "n"(64 + ROW2), "n"(96), "n"(96 + ROW2)
       : "memory");
   out[0] = u32x4{r0[0], r0[1], r1[0], r1[1]};
   out[1] = u32x4{r2[0], r2[1], r3[0], r3[1]};
@@ -200,6 +200,150 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     }
 }
 
+// ---- 3x3 kernels, 16-bit storage: all nine taps from ONE staged halo --------------------------------------------------
+// The kernel above stages x once per tap (nine passes over dz and x: 32 flop per byte moved into LDS).  Here a workgroup
+// of three waves walks spatial steps of 2 output rows x 16 output columns; per step it stages the 32 dz pixels and the
+// (S+3) x (15*S+3)... halo of x they touch ONCE, wave r owns kernel row r (taps (r,0), (r,1), (r,2): three 64 x 64
+// accumulator tiles), the dz fragments are read once per step and every tap's x fragments are transposed reads at
+// lane base + compile-time offset of the same halo tile: ~180 flop per staged byte.
+struct Wgrad3Args {
+  const void* x;
+  const void* dz;
+  float* dw;
+  int H, W, Cin, ldx, Ho, Wo, Cout, lddz;
+  int tilesCo, tilesCi, stepsX, stepsY, nSteps, steps_per_block;
+};
+
+template <typename T, int S>
+__global__ __launch_bounds__(192) void conv_wgrad3x3_kernel(const Wgrad3Args p) {
+  constexpr int E = Elem<T>::EPC;                // 8
+  constexpr int PITCH = 64 * (int)sizeof(T) + 32;  // 160 B rows: 64 channels + pad (conflict-free transposed reads)
+  constexpr int HH = S + 3, HW = 15 * S + 3;     // x halo of a 2 x 16 output step: 4 x 18 (S = 1), 5 x 33 (S = 2)
+  constexpr int NPX = HH * HW;
+  constexpr int DZ_BYTES = 32 * PITCH, X_BYTES = NPX * PITCH, STAGE = DZ_BYTES + X_BYTES;
+  constexpr int NCHK = (32 + NPX) * 8;           // 16-byte chunks per step
+  constexpr int PER = (NCHK + 191) / 192;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, r_ = tid >> 6;  // wave = kernel row
+  const int lr = lane & 15, lq = lane >> 4;
+  int t = blockIdx.y;
+  const int tci = t % p.tilesCi, tco = t / p.tilesCi;
+  const int co0 = tco * 64, ci0 = tci * 64;
+  const int s_begin = blockIdx.x * p.steps_per_block;
+  int s_end = s_begin + p.steps_per_block;
+  if (s_end > p.nSteps) s_end = p.nSteps;
+  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ dg = reinterpret_cast<const T*>(p.dz);
+
+  f32x4 acc[3][4][4];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 stage[PER];
+  auto load_step = [&](int step) {
+    const int bx = step % p.stepsX;
+    int rest = step / p.stepsX;
+    const int by = rest % p.stepsY, n = rest / p.stepsY;
+    const int y0 = by * 2, x0 = bx * 16;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int id = k * 192 + tid;
+      u32x4 v = zero_chunk();
+      if (id < 32 * 8) {  // dz: pixel (row id/128, col (id/8)%16), chunk id%8
+        const int px = id >> 3, ch = id & 7;
+        const int yy = y0 + (px >> 4), xx = x0 + (px & 15), co = co0 + ch * E;
+        if (yy < p.Ho && xx < p.Wo && co < p.Cout) v = *reinterpret_cast<const u32x4*>(dg + ((long long)(n * p.Ho + yy) * p.Wo + xx) * p.lddz + co);
+      } else if (id < NCHK) {
+        const int idx = id - 32 * 8;
+        const int px = idx >> 3, ch = idx & 7;
+        const int hy = px / HW, hx = px - hy * HW;
+        const int gy = y0 * S - 1 + hy, gx = x0 * S - 1 + hx, ci = ci0 + ch * E;
+        if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && ci < p.Cin)
+          v = *reinterpret_cast<const u32x4*>(xg + ((long long)(n * p.H + gy) * p.W + gx) * p.ldx + ci);
+      }
+      stage[k] = v;
+    }
+  };
+  auto store_step = [&](int buf) {
+    unsigned char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int id = k * 192 + tid;
+      if (id < NCHK) {
+        const int px = id >> 3, ch = id & 7;  // dz rows first, the halo rows follow in the same pitch
+        *reinterpret_cast<u32x4*>(base + px * PITCH + ch * 16) = stage[k];
+      }
+    }
+  };
+
+  // lane part of the transposed-read addresses: lane 4q+p of a 16-lane group addresses pixel row q of the 4-pixel block,
+  // channels 4p..4p+3; lane group lq takes output columns 4lq..4lq+3 of output row 0 (first read) and row 1 (second read)
+  const int q4 = lr >> 2, pp = lr & 3;
+  const int dz_lane = (lq * 4 + q4) * PITCH + pp * 8;
+  const int x_lane = ((lq * 4 + q4) * S) * PITCH + pp * 8;
+
+  if (s_begin < s_end) load_step(s_begin);
+  int buf = 0;
+  for (int st = s_begin; st < s_end; ++st, buf ^= 1) {
+    store_step(buf);  // stage `buf` was last read two steps ago: the barrier of the previous step covers it
+    __syncthreads();
+    if (st + 1 < s_end) load_step(st + 1);  // in flight during the MFMAs
+    const unsigned char* tdz = smem + buf * STAGE;
+    const unsigned char* tx = tdz + DZ_BYTES;
+    u32x4 a[4];
+    tr_read_frags<PITCH, 16 * PITCH>(tdz + dz_lane, a);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      u32x4 b[4];
+      // tap (r_, q): halo pixel of output (row, col) is ((row*S + r_) * HW + col*S + q); the second output row is S halo rows below
+      tr_read_frags<PITCH, S * HW * PITCH>(tx + x_lane + (r_ * HW + q) * PITCH, b);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[q][i][j] = Elem<T>::mma(a[i], b[j], acc[q][i][j]);
+    }
+  }
+
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int tap = r_ * 3 + q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ci = ci0 + j * 16 + lr;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int co = co0 + i * 16 + lq * 4 + e;
+          if (co < p.Cout && ci < p.Cin) atomicAdd(p.dw + ((size_t)co * 9 + tap) * p.Cin + ci, acc[q][i][j][e]);
+        }
+      }
+  }
+}
+
+template <typename T, int S>
+static int launch_wgrad3(const WgradArgs& a, int batch, hipStream_t st) {
+  Wgrad3Args p{};
+  p.x = a.x, p.dz = a.dz, p.dw = a.dw, p.H = a.H, p.W = a.W, p.Cin = a.Cin, p.ldx = a.ldx, p.Ho = a.Ho, p.Wo = a.Wo, p.Cout = a.Cout, p.lddz = a.lddz;
+  p.tilesCo = (p.Cout + 63) / 64, p.tilesCi = (p.Cin + 63) / 64;
+  p.stepsX = (p.Wo + 15) / 16, p.stepsY = (p.Ho + 1) / 2;
+  p.nSteps = batch * p.stepsY * p.stepsX;
+  const int ny = p.tilesCo * p.tilesCi;
+  int slabs = (768 + ny - 1) / ny;  // ~3 workgroups of 3 waves per CU overall
+  const int max_slabs = (p.nSteps + 7) / 8;
+  if (slabs > max_slabs) slabs = max_slabs;
+  if (slabs < 1) slabs = 1;
+  p.steps_per_block = (p.nSteps + slabs - 1) / slabs;
+  const unsigned gx = (unsigned)((p.nSteps + p.steps_per_block - 1) / p.steps_per_block);
+  hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, S>), dim3(gx, (unsigned)ny), dim3(192), 0, st, p);
+  return check_launch("conv_wgrad3x3_kernel");
+}
+
 template <typename T, int WCO, int WCI>
 static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
   WgradArgs p = a;
@@ -270,6 +414,11 @@ extern "C" int32_t dy_conv2d_wgrad_nhwc(const dy_conv_desc* d, const void* dz, i
   a.div_howo = make_fastdiv((unsigned)a.HoWo);
   a.div_wo = make_fastdiv((unsigned)wo);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  static const int no3 = getenv("DYOLO_NO_WGRAD3") ? atoi(getenv("DYOLO_NO_WGRAD3")) : 0;
+  if (!no3 && d->ksize == 3 && d->pad == 1 && (d->stride == 1 || d->stride == 2) && es == 2) {  // all nine taps from one staged halo
+    if (d->dtype == DY_BF16) return d->stride == 1 ? launch_wgrad3<bf16_t, 1>(a, d->batch, st) : launch_wgrad3<bf16_t, 2>(a, d->batch, st);
+    return d->stride == 1 ? launch_wgrad3<f16_t, 1>(a, d->batch, st) : launch_wgrad3<f16_t, 2>(a, d->batch, st);
+  }
   switch (d->dtype) {
     case DY_BF16: return launch_wgrad_dtype<bf16_t>(a, st);
     case DY_F16: return launch_wgrad_dtype<f16_t>(a, st);
