@@ -327,3 +327,32 @@ def test_tiled_inference_matches_oracle_chain(device):
     assert res.orig_shape == (200, 300) and 0 < len(exp) < len(allr)  # the merge removed cross-tile duplicates
     assert got.shape == exp.shape, (got.shape, exp.shape)
     assert torch.equal(got[:, 5], exp[:, 5]) and torch.allclose(got[:, :5], exp[:, :5], atol=3e-2, rtol=1e-4)
+
+
+def test_two_batches_in_flight_on_two_streams(device):
+    """bench.py keeps two batches in flight on two HIP streams (separate predictor state and hipGraph each): the results
+    must be exactly what the same batches give one after the other on one stream."""
+    g = golden("e2e.npz")
+    m, d, sd, model, _ = _build("n128", g, device)
+    xs = [torch.rand(4, 3, 128, 96, generator=torch.Generator().manual_seed(40 + j)).to(device) for j in range(2)]
+    serial = D.engine.predictor.DetectionPredictor(model, dict(conf=0.25, iou=0.7, dtype=torch.bfloat16, device=0, graph=True))
+    ref = []
+    for x in xs:
+        cf = serial.forward_device(x)
+        torch.cuda.synchronize()
+        ref.append((cf.pred.clone(), cf.nms.out.clone(), cf.nms.count.clone()))
+    streams = [torch.cuda.Stream(device=device) for _ in range(2)]
+    preds, cfs = [], []
+    for j in range(2):
+        with torch.cuda.stream(streams[j]):
+            pj = D.engine.predictor.DetectionPredictor(model, dict(conf=0.25, iou=0.7, dtype=torch.bfloat16, device=0, graph=True))
+            cfs.append(pj.forward_device(xs[j]))
+            preds.append(pj)
+    torch.cuda.synchronize()
+    for _ in range(6):  # interleaved replays
+        for j in range(2):
+            with torch.cuda.stream(streams[j]):
+                preds[j].forward_device(xs[j])
+    torch.cuda.synchronize()
+    for j in range(2):
+        assert torch.equal(cfs[j].pred, ref[j][0]) and torch.equal(cfs[j].nms.out, ref[j][1]) and torch.equal(cfs[j].nms.count, ref[j][2])
