@@ -129,6 +129,34 @@ def _launch(fn, args: tuple, keep: Sequence[object] = ()) -> None:
 # ---- convolution --------------------------------------------------------------------------------
 
 
+def _pad_to(t: torch.Tensor, shape) -> torch.Tensor:
+    """``t`` (fp32) zero-padded at the end of every dim to ``shape``; ``t`` itself when nothing is to pad (no kernel)."""
+    if tuple(t.shape) == tuple(shape):
+        return t
+    out = torch.zeros(shape, dtype=t.dtype, device=t.device)
+    out[tuple(slice(0, n) for n in t.shape)] = t
+    return out
+
+
+def _permute_cast(view: torch.Tensor, dtype: torch.dtype, device) -> torch.Tensor:
+    """Contiguous copy of a permuted view in ``dtype`` — one copy kernel for layout change + cast."""
+    out = torch.empty(view.shape, dtype=dtype, device=view.device)
+    out.copy_(view)
+    return out.view(-1).to(device)
+
+
+_ZERO_BIAS = {}
+
+
+def zero_bias(n: int, device) -> torch.Tensor:
+    """Cached fp32 zeros(n) on ``device`` (BatchNorm-ed and gradient convolutions carry no bias); never written to."""
+    key = (n, str(device))
+    z = _ZERO_BIAS.get(key)
+    if z is None:
+        z = _ZERO_BIAS[key] = torch.zeros(n, dtype=torch.float32, device=device)
+    return z
+
+
 class PackedConv:
     """Folded + packed weights of one convolution in the layout ``dy_conv2d_nhwc`` expects.
 
@@ -169,14 +197,10 @@ class PackedConv:
             e = elems_per_chunk(dtype)
             kc, bn = 4 * e, (64 if cout > 32 else 32)
             nt, nch = -(-cout // bn), -(-self.cin // kc)
-            wpad = torch.zeros((nt * bn, nch * kc, 3, 3), dtype=torch.float32, device=wdev)
-            wpad[:cout, : self.cin] = weight.detach().to(torch.float32)
-            wp = wpad.view(nt, bn // 16, 16, nch, 4, e, 3, 3).permute(0, 3, 6, 7, 1, 4, 2, 5).contiguous().view(-1)
+            wpad = _pad_to(weight.detach().to(torch.float32), (nt * bn, nch * kc, 3, 3))
             self.k_pad, self.cout_pad = 0, L.dy_conv_cout_pad(cout)
-            bp = torch.zeros((self.cout_pad,), dtype=torch.float32, device=wdev)
-            bp[:cout] = bias.detach().to(torch.float32).to(wdev)
-            self.w = wp.to(dtype).contiguous().to(device)
-            self.b = bp.contiguous().to(device)
+            self.w = _permute_cast(wpad.reshape(nt, bn // 16, 16, nch, 4, e, 3, 3).permute(0, 3, 6, 7, 1, 4, 2, 5), dtype, device)
+            self.b = _pad_to(bias.detach().to(torch.float32).to(wdev), (self.cout_pad,)).to(device)
             return
         e = elems_per_chunk(dtype)
         nkg = -(-self.cin // (4 * e))
@@ -202,15 +226,20 @@ class PackedConv:
             self.w = wp.to(dtype).contiguous().to(device)
             self.b = bp.contiguous().to(device)
             return
-        w = weight.detach().to(torch.float32).permute(0, 2, 3, 1).reshape(cout, k * k * cin_g)
         if groups == 1:
             self.k_pad = L.dy_conv_k_pad(self.cin, k, dy_dtype(dtype))
             self.cout_pad = L.dy_conv_cout_pad(cout)
+            if self.k_pad == k * k * cin_g and self.cout_pad == cout:  # nothing to pad: one permute + cast kernel
+                self.w = _permute_cast(weight.detach().permute(0, 2, 3, 1), dtype, device)
+                self.b = bias.detach().to(torch.float32).to(device)
+                return
+            w = weight.detach().to(torch.float32).permute(0, 2, 3, 1).reshape(cout, k * k * cin_g)
             wp = torch.zeros((self.cout_pad, self.k_pad), dtype=torch.float32, device=wdev)
             wp[:cout, : w.shape[1]] = w
             bp = torch.zeros((self.cout_pad,), dtype=torch.float32, device=wdev)
             bp[:cout] = bias.detach().to(torch.float32).to(wdev)
         else:
+            w = weight.detach().to(torch.float32).permute(0, 2, 3, 1).reshape(cout, k * k * cin_g)
             self.k_pad, self.cout_pad = w.shape[1], cout
             wp, bp = w, bias.detach().to(torch.float32)
         self.w = wp.to(dtype).contiguous().to(device)
@@ -659,9 +688,11 @@ def pack_dgrad(weight: torch.Tensor, stride: int, dtype: torch.dtype, device) ->
     """Weights of the convolution that computes dx from dz: w'[ci][co][r][q] = w[co][ci][k-1-r][k-1-q], stride 1,
     pad k-1-pad (= pad for the 'same' convolutions of this model); stride-2 layers run on the generic / LDS-DMA kernels
     (zero-dilated gather), stride-1 3x3 layers may take the halo kernel."""
-    wt = weight.detach().flip(2, 3).permute(1, 0, 2, 3).contiguous()
     k = weight.shape[2]
-    return PackedConv(wt, torch.zeros(wt.shape[0], device=wt.device), 1, k // 2, 1, False, dtype, device,
+    wt = weight.detach().permute(1, 0, 2, 3)  # a view: the packing copy below does the layout change
+    if k > 1:
+        wt = wt.flip(2, 3)
+    return PackedConv(wt, zero_bias(wt.shape[0], wt.device), 1, k // 2, 1, False, dtype, device,
                       halo=None if (stride == 1 and k == 3) else False)  # the streaming 1x1 kernel has no residual (accumulate) input
 
 

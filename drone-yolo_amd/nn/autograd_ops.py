@@ -36,7 +36,7 @@ class ConvBnAct(torch.autograd.Function):
     def forward(ctx, x, weight, gamma, beta, bn, stride, pad, act, need_dx):
         dtype, dev = x.dtype, x.device
         cin_pad = x.shape[1] if x.shape[1] != weight.shape[1] else None  # image padded to one chunk
-        pc = H.PackedConv(weight, torch.zeros(weight.shape[0], device=dev), stride, pad, 1, False, dtype, dev, cin_pad=cin_pad)
+        pc = H.PackedConv(weight, H.zero_bias(weight.shape[0], dev), stride, pad, 1, False, dtype, dev, cin_pad=cin_pad)
         z = H.conv2d(x, pc)
         st = H.BnState(weight.shape[0], dev)
         y = H.bn_train_fwd(z, gamma, beta, st, act, eps=bn.eps, momentum=bn.momentum, running_mean=bn.running_mean, running_var=bn.running_var)
@@ -62,7 +62,7 @@ class RepVGGTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w3, g3, b3, w1, g1, b1, bn3, bn1, stride):
         dtype, dev = x.dtype, x.device
-        zero = lambda w: torch.zeros(w.shape[0], device=dev)  # noqa: E731
+        zero = lambda w: H.zero_bias(w.shape[0], dev)  # noqa: E731
         z3 = H.conv2d(x, H.PackedConv(w3, zero(w3), stride, 1, 1, False, dtype, dev))
         z1 = H.conv2d(x, H.PackedConv(w1, zero(w1), stride, 0, 1, False, dtype, dev, halo=False))
         s3, s1 = H.BnState(w3.shape[0], dev), H.BnState(w1.shape[0], dev)
