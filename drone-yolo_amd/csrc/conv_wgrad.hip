@@ -373,16 +373,37 @@ static int launch_wgrad_dtype(const WgradArgs& a, hipStream_t st) {
   return launch_wgrad<T, 1, 1>(a, st);
 }
 
-// column sums of a (rows, c) view: the bias gradient of the plain Detect convolutions (head.py:43-57)
+// column sums of a (rows, c) view: the bias gradient of the plain Detect convolutions (head.py:43-57).
+// 256 threads = R rows x NCH 16-byte chunks; every thread sums its chunk over its rows of the slab (coalesced 16-byte
+// loads), the R partials meet in LDS, one fp32 atomic per channel and workgroup.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* z, float* out, long long rows, int c, int ld, int rows_per_block) {
-  const long long r0 = (long long)blockIdx.x * rows_per_block;
-  long long r1 = r0 + rows_per_block;
-  if (r1 > rows) r1 = rows;
-  for (int cc = threadIdx.x; cc < c; cc += 256) {
-    float s = 0.f;
-    for (long long r = r0; r < r1; ++r) s += Elem<T>::to_f32(z[r * ld + cc]);
-    atomicAdd(out + cc, s);
+__global__ __launch_bounds__(256) void colsum_kernel(const T* z, float* out, long long rows, int c, int ld, int rows_per_block, int nch, int R) {
+  constexpr int E = Elem<T>::EPC;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  float* red = reinterpret_cast<float*>(dyn_smem);  // [R][nch*E]
+  const int tid = threadIdx.x, ch = tid % nch, rr = tid / nch;
+  const int cw = nch * E;
+  if (rr < R) {
+    float s[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) s[e] = 0.f;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    for (long long r = r0 + rr; r < r1; r += R) {
+      float f[E];
+      Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(z + r * ld + ch * E), f);
+#pragma unroll
+      for (int e = 0; e < E; ++e) s[e] += f[e];
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) red[rr * cw + ch * E + e] = s[e];
+  }
+  __syncthreads();
+  for (int cc = tid; cc < c; cc += 256) {
+    float t = 0.f;
+    for (int k = 0; k < R; ++k) t += red[k * cw + cc];
+    atomicAdd(out + cc, t);
   }
 }
 
@@ -427,16 +448,23 @@ extern "C" int32_t dy_conv2d_wgrad_nhwc(const dy_conv_desc* d, const void* dz, i
 }
 
 extern "C" int32_t dy_colsum(const void* z, float* out, int64_t rows, int32_t c, int32_t ld, int32_t dtype, dy_stream_t stream) {
-  DY_REQUIRE(z && out && rows > 0 && c > 0 && ld >= c && dy_dtype_size(dtype), DY_ERR_INVALID_ARG, "dy_colsum: bad arguments");
+  const int es = dy_dtype_size(dtype);
+  DY_REQUIRE(z && out && rows > 0 && c > 0 && es, DY_ERR_INVALID_ARG, "dy_colsum: bad arguments");
+  const int epc = 16 / es, nch = (c + epc - 1) / epc;
+  // channels are read in whole 16-byte chunks: the pitch must cover c rounded up (the padding only reaches sums that are dropped)
+  DY_REQUIRE(aligned16(z) && (ld * es) % 16 == 0 && ld >= nch * epc && nch <= 256, DY_ERR_INVALID_ARG,
+             "dy_colsum: view must be 16-byte aligned with a pitch covering c rounded up to %d (c <= %d)", epc, 256 * epc);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  long long blocks = (rows + 255) / 256;
+  const int R = 256 / nch;
+  long long blocks = (rows + 8LL * R - 1) / (8LL * R);
   if (blocks > 1024) blocks = 1024;
   const int rpb = (int)((rows + blocks - 1) / blocks);
   const unsigned gx = (unsigned)((rows + rpb - 1) / rpb);
+  const size_t smem = (size_t)R * nch * epc * 4;
   switch (dtype) {
-    case DY_BF16: hipLaunchKernelGGL((colsum_kernel<bf16_t>), dim3(gx), dim3(256), 0, st, reinterpret_cast<const bf16_t*>(z), out, (long long)rows, c, ld, rpb); break;
-    case DY_F16: hipLaunchKernelGGL((colsum_kernel<f16_t>), dim3(gx), dim3(256), 0, st, reinterpret_cast<const f16_t*>(z), out, (long long)rows, c, ld, rpb); break;
-    default: hipLaunchKernelGGL((colsum_kernel<float>), dim3(gx), dim3(256), 0, st, reinterpret_cast<const float*>(z), out, (long long)rows, c, ld, rpb); break;
+    case DY_BF16: hipLaunchKernelGGL((colsum_kernel<bf16_t>), dim3(gx), dim3(256), smem, st, reinterpret_cast<const bf16_t*>(z), out, (long long)rows, c, ld, rpb, nch, R); break;
+    case DY_F16: hipLaunchKernelGGL((colsum_kernel<f16_t>), dim3(gx), dim3(256), smem, st, reinterpret_cast<const f16_t*>(z), out, (long long)rows, c, ld, rpb, nch, R); break;
+    default: hipLaunchKernelGGL((colsum_kernel<float>), dim3(gx), dim3(256), smem, st, reinterpret_cast<const float*>(z), out, (long long)rows, c, ld, rpb, nch, R); break;
   }
   return check_launch("dy_colsum");
 }

@@ -326,7 +326,8 @@ int32_t dy_detection_loss(const dy_loss_desc* d, dy_stream_t stream);
  *   16-byte chunk (the padding is read but only reaches entries that are never written).
  * Input gradient: dx = conv_transpose(dz, w) is run through dy_conv2d_nhwc itself on re-packed weights
  *   (w'[ci][2-r][2-q][co] = w[co][r][q][ci], stride 1; stride-2 layers read dz through `dil2`, a zero-dilated gather).
- * dy_colsum: out[c] += sum over rows of z[row][c] (bias gradient of the plain Detect convolutions); out zeroed by the caller. */
+ * dy_colsum: out[c] += sum over rows of z[row][c] (bias gradient of the plain Detect convolutions); out zeroed by the caller;
+ *   z 16-byte aligned, pitch a multiple of 16 bytes covering c rounded up to one chunk. */
 int32_t dy_conv2d_wgrad_nhwc(const dy_conv_desc* d, const void* dz, int32_t ld_dz, float* dw, dy_stream_t stream);
 int32_t dy_colsum(const void* z, float* out, int64_t rows, int32_t c, int32_t ld, int32_t dtype, dy_stream_t stream);
 
