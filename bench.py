@@ -293,6 +293,14 @@ def main():
                 "launches": len(work), "flops_per_image": round(flops / a.batch / 1e9, 3), "conv_ms_per_step": round(tconv * 1e3, 3),
                 "hbm_view": {"algorithmic_GB_per_step": round(nbytes / 1e9, 4), "achieved_GBs": round(nbytes / tconv / 1e9, 1),
                              "peak_GBs": HBM_PEAK_GBS, "frac": round(nbytes / tconv / 1e9 / HBM_PEAK_GBS, 4)}}
+        # the single dominant kernel symbol (largest share of GPU time in profiles/*kernel_stats.csv): the 3x3 halo kernel
+        # instantiation all 64->64 stride-1 layers run on; average over its launches, to be compared with the CSV's average
+        dom = [w for w in work if w[3].startswith("64->64 k3 s1")]
+        if dom and a.dtype == "bf16":
+            dfl, dt_ = sum(w[1] for w in dom), sum(times[w[0]] for w in dom)
+            roof["dominant_kernel"] = {"symbol": "dy::conv3x3_halo_kernel<bf16, S=1, MF=2, NF=4, OUTF32=false, WS=true, NCH=2>", "launches_per_pass": len(dom),
+                                       "avg_us": round(dt_ / len(dom) * 1e6, 1), "avg_gflop": round(dfl / len(dom) / 1e9, 2),
+                                       "achieved": round(dfl / dt_ / 1e12, 1), "unit": "TFLOP/s", "frac": round(dfl / dt_ / 1e12 / peak, 4)}
         if a.layers:
             os.makedirs(os.path.dirname(os.path.abspath(a.layers)), exist_ok=True)
             with open(a.layers, "w") as f:

@@ -9,9 +9,9 @@ O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cp -r $R /tmp/w && cd /tmp/w
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --batch $B --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_stats.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --batch $B --steps 2 --warmup 1 --no-cpu-baseline --no-graph > $O/bench_fetch.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --batch $B --steps 2 --warmup 1 --no-cpu-baseline --no-graph > $O/bench_write.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --batch $B --steps 30 --warmup 5 --streams 1 --no-cpu-baseline > $O/bench_stats.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --batch $B --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-graph > $O/bench_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --batch $B --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-graph > $O/bench_write.log 2>&1
 mkdir -p $O/pmc && cp -r $O/fetch $O/pmc/ && cp -r $O/write $O/pmc/
 python3 tools/traffic_summary.py $O/pmc $B 9 > $O/traffic.json
 python3 bench.py --batch $B --layers $O/layers_b$B.txt --no-cpu-baseline > $O/bench_layers.log 2>&1
