@@ -27,6 +27,27 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
   }
 }
 
+// ---- uint8 NCHW -> NHWC(T) with x * scale, zero-padded channels: DetectionTrainer.preprocess_batch's
+// `img.float() / 255` (models/yolo/detect/train.py:57-60) fused with the layout step of the training forward ----------
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_u8_to_nhwc_kernel(const uint8_t* __restrict__ src, T* __restrict__ dst, int n, int c, int hw, int c_pad, int ld,
+                                                              float scale) {
+  constexpr int EPC = Elem<T>::EPC;
+  const long long total = (long long)n * hw;
+  for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (long long)gridDim.x * 256) {
+    const int img = (int)(pix / hw);
+    const int p = (int)(pix - (long long)img * hw);
+    const uint8_t* s = src + (size_t)img * c * hw + p;
+    T* d = dst + (size_t)pix * ld;
+    for (int c0 = 0; c0 < c_pad; c0 += EPC) {
+      float f[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) f[e] = (c0 + e < c) ? (float)s[(size_t)(c0 + e) * hw] / scale : 0.f;
+      *reinterpret_cast<u32x4*>(d + c0) = Chunk<T>::pack(f);
+    }
+  }
+}
+
 // ---- NHWC(T) -> fp32 NCHW ---------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int n,
@@ -146,6 +167,25 @@ extern "C" int32_t dy_nchw_f32_to_nhwc(const float* src, void* dst, int32_t n, i
   else
     hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), dim3(grid), dim3(256), 0, st, src, (float*)dst, n, c, h * w, c_pad, ld_dst);
   return check_launch("nchw_to_nhwc_kernel");
+}
+
+extern "C" int32_t dy_nchw_u8_to_nhwc(const uint8_t* src, void* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t c_pad, int32_t ld_dst,
+                                      float divisor, int32_t dtype, dy_stream_t stream) {
+  const int es = dy_dtype_size(dtype);
+  DY_REQUIRE(src && dst && es && divisor != 0.f, DY_ERR_INVALID_ARG, "dy_nchw_u8_to_nhwc: null pointer, bad dtype or zero divisor");
+  DY_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0, DY_ERR_INVALID_ARG, "dy_nchw_u8_to_nhwc: bad dims");
+  const int epc = 16 / es;
+  DY_REQUIRE(c_pad >= c && c_pad % epc == 0 && ld_dst >= c_pad && (ld_dst * es) % 16 == 0 && aligned16(dst), DY_ERR_INVALID_ARG,
+             "dy_nchw_u8_to_nhwc: c_pad/ld_dst must be multiples of %d elements, dst 16B aligned", epc);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int grid = grid_for((long long)n * h * w);
+  if (dtype == DY_BF16)
+    hipLaunchKernelGGL((nchw_u8_to_nhwc_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, src, (bf16_t*)dst, n, c, h * w, c_pad, ld_dst, divisor);
+  else if (dtype == DY_F16)
+    hipLaunchKernelGGL((nchw_u8_to_nhwc_kernel<f16_t>), dim3(grid), dim3(256), 0, st, src, (f16_t*)dst, n, c, h * w, c_pad, ld_dst, divisor);
+  else
+    hipLaunchKernelGGL((nchw_u8_to_nhwc_kernel<float>), dim3(grid), dim3(256), 0, st, src, (float*)dst, n, c, h * w, c_pad, ld_dst, divisor);
+  return check_launch("nchw_u8_to_nhwc_kernel");
 }
 
 extern "C" int32_t dy_nhwc_to_nchw_f32(const void* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w,

@@ -357,6 +357,20 @@ def to_nhwc(src: torch.Tensor, dtype: torch.dtype, c_pad: Optional[int] = None, 
     return out
 
 
+def u8_to_nhwc(src: torch.Tensor, dtype: torch.dtype, divisor: float = 255.0) -> torch.Tensor:
+    """uint8 NCHW (contiguous) -> NHWC view of ``dtype`` holding src / divisor, channels zero-padded to one chunk."""
+    require_device(src, "input")
+    if src.dtype != torch.uint8 or not src.is_contiguous() or src.dim() != 4:
+        raise ValueError("u8_to_nhwc expects a contiguous uint8 NCHW tensor")
+    n, c, h, w = src.shape
+    epc = elems_per_chunk(dtype)
+    c_pad = (c + epc - 1) // epc * epc
+    out = alloc_nhwc(n, c_pad, h, w, dtype, src.device)
+    op, ld = view_params(out)
+    _launch(lib().dy_nchw_u8_to_nhwc, (src.data_ptr(), op, n, c, h, w, c_pad, ld, divisor, dy_dtype(dtype)), keep=(src, out))
+    return out
+
+
 def to_nchw_f32(x: torch.Tensor) -> torch.Tensor:
     """NHWC view -> contiguous fp32 NCHW tensor (module-level parity checks, user hand-back)."""
     require_device(x)

@@ -85,8 +85,10 @@ def module_train(m, x, first: bool = False):
 def model_train_forward(model, img: torch.Tensor, dtype: torch.dtype):
     """img: (N, 3, H, W) uint8 or float on the device -> Detect's per-level training outputs."""
     H.require_device(img, "training image")
-    x = img.float() / 255 if img.dtype == torch.uint8 else img.float()  # preprocess_batch, detect/train.py:59
-    x = H.to_nhwc(x.contiguous(), dtype)
+    if img.dtype == torch.uint8:
+        x = H.u8_to_nhwc(img.contiguous(), dtype)  # preprocess_batch's float() / 255 (detect/train.py:59) + layout, one kernel
+    else:
+        x = H.to_nhwc(img.float().contiguous(), dtype)
     ys = []
     for m in model.model:
         if m.f != -1:

@@ -166,6 +166,12 @@ int32_t dy_rows_to_pred(const float* rows, const int32_t* counts, const int32_t*
 int32_t dy_nchw_f32_to_nhwc(const float* src, void* dst, int32_t n, int32_t c, int32_t h, int32_t w,
                             int32_t c_pad, int32_t ld_dst, int32_t dtype, dy_stream_t stream);
 
+/* Training input: uint8 NCHW batch -> NHWC of `dtype`, every value divided by `divisor` (255), channels zero-padded to c_pad.
+ * Replaces DetectionTrainer.preprocess_batch's `batch["img"].float() / 255` (models/yolo/detect/train.py:57-60) + the
+ * layout step, in one pass (1 byte read per value). */
+int32_t dy_nchw_u8_to_nhwc(const uint8_t* src, void* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t c_pad,
+                           int32_t ld_dst, float divisor, int32_t dtype, dy_stream_t stream);
+
 /* Inverse, for handing activations back to NCHW callers: src NHWC view -> fp32 NCHW. */
 int32_t dy_nhwc_to_nchw_f32(const void* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w,
                             int32_t ld_src, int32_t src_dtype, dy_stream_t stream);
