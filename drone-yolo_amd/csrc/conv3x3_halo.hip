@@ -571,6 +571,13 @@ static int launch_halo_dtype(const Conv3Args& a, int batch, int stride, hipStrea
   if (big) big = (nf4 ? halo_smem<T, 1, 2, 4, OUTF32>(a, &ws) : halo_smem<T, 1, 2, 2, OUTF32>(a, &ws)) <= kLdsBudget;
   if (stride == 1) {
     if (nf4) return big ? launch_halo<T, 1, 2, 4, OUTF32>(a, batch, st) : launch_halo<T, 1, 1, 4, OUTF32>(a, batch, st);
+    // <= 32 couts: 36 MFMAs per wave and item at MF 2 drown in the per-item overhead; 32-row tiles (MF 4) when the map is
+    // tall enough, there are plenty of tiles and the bigger halo still fits LDS
+    static const int no_mf4 = getenv("DYOLO_NO_MF4") ? atoi(getenv("DYOLO_NO_MF4")) : 0;
+    const long long tiles32 = (long long)batch * ((a.Ho + 31) / 32) * ((a.Wo + 15) / 16) * ((a.Cout + 31) / 32);
+    bool ws4 = false;
+    if (!no_mf4 && big && a.Ho >= 32 && tiles32 >= 512 && halo_smem<T, 1, 4, 2, OUTF32>(a, &ws4) <= kLdsBudget && ws4)
+      return launch_halo<T, 1, 4, 2, OUTF32>(a, batch, st);
     return big ? launch_halo<T, 1, 2, 2, OUTF32>(a, batch, st) : launch_halo<T, 1, 1, 2, OUTF32>(a, batch, st);
   }
   if (nf4) return launch_halo<T, 2, 1, 4, OUTF32>(a, batch, st);
