@@ -232,6 +232,8 @@ def main():
 
     rank, local_rank, world = P.init_distributed()
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("DYOLO_FORCE_DEVICE"):  # rehearsal of N ranks on one GPU (with DYOLO_DIST_BACKEND=gloo)
+        local_rank = int(os.environ["DYOLO_FORCE_DEVICE"])
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 

@@ -171,7 +171,9 @@ class DetectionPredictor:
         cf.plan.rebind_input(cf.static_in.data_ptr())
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: HIP calls of OTHER host threads (e.g. RCCL's watchdog in a torch.distributed run) must not
+        # invalidate this capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             cf.plan.replay(torch.cuda.current_stream().cuda_stream)
         cf.graph = g
 

@@ -26,7 +26,8 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank, local_rank, world = dist_env()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # DYOLO_DIST_BACKEND=gloo: rehearse an N-rank run on fewer GPUs than ranks (RCCL refuses two ranks on one device)
+            backend = os.environ.get("DYOLO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
