@@ -177,6 +177,9 @@ def train_bench(a):
     from drone_yolo_amd.engine.trainer import DetectionTrainer
 
     rank, local_rank, world = P.init_distributed()
+    if os.environ.get("DYOLO_FORCE_DEVICE"):
+        local_rank = int(os.environ["DYOLO_FORCE_DEVICE"])
+        os.environ["LOCAL_RANK"] = str(local_rank)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     model = D.DetectionModel(a.model, nc=10, verbose=False)

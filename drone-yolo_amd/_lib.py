@@ -95,6 +95,16 @@ class LossDesc(C.Structure):
     ]  # fmt: skip
 
 
+class C2fDesc(C.Structure):
+    """Mirror of ``dy_c2f_desc``."""
+
+    _fields_ = [
+        ("x", _vp), ("y", _vp), ("w_cv1", _vp), ("w_m_cv1", _vp), ("w_m_cv2", _vp), ("w_cv2", _vp), ("bias", _vp),
+        ("batch", _i32), ("h", _i32), ("w", _i32), ("cin", _i32), ("hidden", _i32), ("cout", _i32), ("ld_x", _i32), ("ld_y", _i32),
+        ("shortcut", _i32), ("dtype", _i32),
+    ]  # fmt: skip
+
+
 class BnDesc(C.Structure):
     """Mirror of ``dy_bn_desc``."""
 
@@ -117,6 +127,8 @@ SIGNATURES = {
     "dy_conv_k_pad": (_i32, [_i32, _i32, _i32]),
     "dy_conv_cout_pad": (_i32, [_i32]),
     "dy_conv2d_nhwc": (_i32, [C.POINTER(ConvDesc), _vp]),
+    "dy_c2f_fused_supported": (_i32, [_i32, _i32, _i32, _i32, _i32]),
+    "dy_c2f_fused": (_i32, [C.POINTER(C2fDesc), _vp]),
     "dy_stem_conv3x3s2_nchw": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dy_nchw_f32_to_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dy_nhwc_to_nchw_f32": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import DY_ACT_NONE, DY_ACT_SILU, BnDesc, ConvDesc, DecodeDesc, HeadDecodeDesc, LossDesc, NmsDesc, check, lib
+from ._lib import DY_ACT_NONE, DY_ACT_SILU, BnDesc, C2fDesc, ConvDesc, DecodeDesc, HeadDecodeDesc, LossDesc, NmsDesc, check, lib
 
 _DTYPES = {torch.bfloat16: _lib.DY_BF16, torch.float16: _lib.DY_F16, torch.float32: _lib.DY_F32}
 
@@ -780,4 +780,45 @@ def letterbox(frames: torch.Tensor, new_w: int, new_h: int, top: int, left: int,
         out = torch.empty((n, 3, hn, wn), dtype=torch.float32, device=frames.device)
     _launch(lib().dy_letterbox_u8_to_nchw_f32, (frames.data_ptr(), out.data_ptr(), n, h0, w0, new_w, new_h, top, left, hn, wn, int(swap_rb), pad_value),
             keep=(frames, out))
+    return out
+
+
+# ---- fused C2f block ------------------------------------------------------------------------------------------------------
+
+
+class PackedC2f:
+    """Folded + packed weights of a whole C2f (n = 1) for ``dy_c2f_fused``: (w, b) pairs of cv1, m[0].cv1, m[0].cv2, cv2."""
+
+    def __init__(self, cv1, mcv1, mcv2, cv2, shortcut: bool, dtype: torch.dtype, device):
+        (w1, b1), (wa, ba), (wb, bb), (w2, b2) = cv1, mcv1, mcv2, cv2
+        self.cin, self.hidden, self.cout = w1.shape[1], wa.shape[0], w2.shape[0]
+        self.w1, _ = pack_frag1x1(w1, b1, dtype, device)
+        self.w2, _ = pack_frag1x1(w2, b2, dtype, device)
+        pa = PackedConv(wa, ba, 1, 1, 1, True, dtype, device, halo=True)
+        pb = PackedConv(wb, bb, 1, 1, 1, True, dtype, device, halo=True)
+        if pa.layout != _lib.DY_WLAYOUT_HALO3X3 or pb.layout != _lib.DY_WLAYOUT_HALO3X3:
+            raise ValueError("PackedC2f: the Bottleneck convolutions did not pack as DY_WLAYOUT_HALO3X3")
+        self.wa, self.wb = pa.w, pb.w
+        self.bias = torch.cat([t.detach().float().reshape(-1).cpu() for t in (b1, ba, bb, b2)]).contiguous().to(device)
+        self.shortcut, self.dtype = bool(shortcut), dtype
+
+
+def c2f_fused_supported(cin: int, hidden: int, cout: int, n: int, dtype: torch.dtype) -> bool:
+    return bool(lib().dy_c2f_fused_supported(cin, hidden, cout, n, dy_dtype(dtype)))
+
+
+def c2f_fused(x: torch.Tensor, pk: PackedC2f, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Whole C2f block in one ``dy_c2f_fused`` launch; x: NHWC view (N, cin, H, W) of pk.dtype."""
+    require_device(x, "c2f input")
+    n, c, h, w = x.shape
+    if c != pk.cin or x.dtype != pk.dtype:
+        raise ValueError("c2f_fused: input channels / dtype do not match the packed block")
+    if out is None:
+        out = alloc_nhwc(n, pk.cout, h, w, x.dtype, x.device)
+    d = C2fDesc()
+    (d.x, d.ld_x), (d.y, d.ld_y) = view_params(x), view_params(out)
+    d.w_cv1, d.w_m_cv1, d.w_m_cv2, d.w_cv2, d.bias = pk.w1.data_ptr(), pk.wa.data_ptr(), pk.wb.data_ptr(), pk.w2.data_ptr(), pk.bias.data_ptr()
+    d.batch, d.h, d.w, d.cin, d.hidden, d.cout = n, h, w, pk.cin, pk.hidden, pk.cout
+    d.shortcut, d.dtype = int(pk.shortcut), dy_dtype(x.dtype)
+    _launch(lib().dy_c2f_fused, (C.byref(d),), keep=(d, x, out, pk))
     return out

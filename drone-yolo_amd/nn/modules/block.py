@@ -57,12 +57,27 @@ class C2f(nn.Module):
         self.cv2 = Conv((2 + n) * self.c, c2, 1)
         self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, g, k=((3, 3), (3, 3)), e=1.0) for _ in range(n))
 
+    fuse_block = True  # one-kernel execution where dy_c2f_fused is built for the shape (the stride-4 backbone block)
+
+    def _packed_block(self, dtype, device):
+        convs = (self.cv1, self.m[0].cv1, self.m[0].cv2, self.cv2)
+        key = (dtype, str(device), tuple((c.conv.weight.data_ptr(), c.conv.weight._version, c.bn.weight._version, c.bn.running_var._version) for c in convs))
+        cache = self.__dict__.get("_block_cache")
+        if cache is None or cache[0] != key:
+            folded = [fold_conv_bn(c.conv.weight, c.conv.bias, c.bn) for c in convs]
+            cache = (key, H.PackedC2f(*folded, shortcut=self.m[0].add, dtype=dtype, device=device))
+            self.__dict__["_block_cache"] = cache
+        return cache[1]
+
     def forward(self, x, out=None, **kw):
         """cv1 -> [y0 | y1]; y_{i+2} = m_i(y_{i+1}); cv2(cat(y)).  One buffer holds every y_i.
 
         ``kw`` (x2= / up2x=) is forwarded to cv1 so that a Concat(+Upsample) in front of this block
         can be folded into cv1's gather.
         """
+        if not kw and self.fuse_block and len(self.m) == 1 and H.c2f_fused_supported(
+                x.shape[1], self.c, self.cv2.conv.out_channels, 1, x.dtype) and not self.training:
+            return H.c2f_fused(x, self._packed_block(x.dtype, x.device), out=out)
         n, _, hb, wb = x.shape
         h, w = (2 * hb, 2 * wb) if kw.get("up2x") else (hb, wb)
         c = self.c

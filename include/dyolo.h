@@ -122,6 +122,30 @@ int32_t dy_conv_k_pad(int32_t cin, int32_t ksize, int32_t dtype);
 int32_t dy_conv_cout_pad(int32_t cout);
 int32_t dy_conv2d_nhwc(const dy_conv_desc* d, dy_stream_t stream);
 
+/* ---- fused C2f block (n = 1, hidden 32) -------------------------------------------------------------
+ * Replaces in ONE kernel: C2f.forward (nn/modules/block.py:237-242) = cv1 (Conv 1x1 cin -> 2*hidden) -> chunk(2) ->
+ * Bottleneck(hidden, hidden, shortcut, k = (3,3), e = 1.0) (block.py:337-350) -> cat -> cv2 (Conv 1x1 3*hidden -> cout), each
+ * Conv = SiLU(conv + folded BatchNorm bias) (conv.py:53-55), for the stride-4 C2f of the Drone-YOLO-s backbone
+ * (yolov8-p2-repvgg.yaml layer 2).  Intermediates stay in LDS, rounded to `dtype` where the layer-by-layer path rounds.
+ * x: NHWC (batch, h, w, cin) pitch ld_x; y: NHWC (batch, h, w, cout) pitch ld_y.  Weights (BatchNorm folded):
+ *   w_cv1   DY_WLAYOUT_FRAG1X1 of (2*hidden, cin);      w_cv2   DY_WLAYOUT_FRAG1X1 of (cout, 3*hidden);
+ *   w_m_cv1, w_m_cv2   DY_WLAYOUT_HALO3X3 of (hidden, hidden, 3, 3);
+ *   bias    fp32: cv1 [2*hidden] | m.cv1 [hidden] | m.cv2 [hidden] | cv2 [cout].
+ * Built for cin 64, hidden 32, cout 64, DY_BF16 / DY_F16 (dy_c2f_fused_supported tells); other shapes: run the four
+ * dy_conv2d_nhwc calls. */
+typedef struct dy_c2f_desc {
+  const void* x;
+  void* y;
+  const void* w_cv1;
+  const void* w_m_cv1;
+  const void* w_m_cv2;
+  const void* w_cv2;
+  const float* bias;
+  int32_t batch, h, w, cin, hidden, cout, ld_x, ld_y, shortcut, dtype;
+} dy_c2f_desc;
+int32_t dy_c2f_fused_supported(int32_t cin, int32_t hidden, int32_t cout, int32_t n_bottlenecks, int32_t dtype);
+int32_t dy_c2f_fused(const dy_c2f_desc* d, dy_stream_t stream);
+
 /* Fused stem.  Replaces in one pass: the predictor's dtype/layout step for tensor sources
  * (engine/predictor.py:118-136) AND the model's first layer Conv(cin<=3, cout, 3, 2) (nn/modules/conv.py:37-55,
  * yolov8-p2-repvgg.yaml layer 0), so the image is never materialised in NHWC.

@@ -59,11 +59,11 @@ def test_struct_layout_matches_header():
 
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "s.c")
-        open(src, "w").write('#include <stdio.h>\n#include "dyolo.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", '
+        open(src, "w").write('#include <stdio.h>\n#include "dyolo.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", '
                              "sizeof(dy_conv_desc), sizeof(dy_decode_desc), sizeof(dy_nms_desc), sizeof(dy_loss_desc), "
-                             "sizeof(dy_head_decode_desc), sizeof(dy_bn_desc));return 0;}\n")
+                             "sizeof(dy_head_decode_desc), sizeof(dy_bn_desc), sizeof(dy_c2f_desc));return 0;}\n")
         exe = os.path.join(td, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
     assert sizes == [ctypes.sizeof(L.ConvDesc), ctypes.sizeof(L.DecodeDesc), ctypes.sizeof(L.NmsDesc), ctypes.sizeof(L.LossDesc),
-                     ctypes.sizeof(L.HeadDecodeDesc), ctypes.sizeof(L.BnDesc)]
+                     ctypes.sizeof(L.HeadDecodeDesc), ctypes.sizeof(L.BnDesc), ctypes.sizeof(L.C2fDesc)]
