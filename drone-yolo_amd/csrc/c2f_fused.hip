@@ -202,6 +202,9 @@ __global__ __launch_bounds__(512) void c2f_fused_kernel(const C2fArgs p) {
     __syncthreads();  // B2: T complete
 
     // ---- phase 4: m.cv2 3x3 32 -> 32 on T over the 16 x 16 tile (+ y1 when the Bottleneck has a shortcut) -> Y2 ----
+    // ---- phase 5: cv2 1x1 96 -> 64 on [y0 | y1 | y2] -> global.  A wave owns the ADJACENT rows 2w, 2w+1 in both phases, so
+    // phase 5 only reads y2 rows the wave itself wrote: no workgroup barrier between them, and once its six A fragments
+    // are in registers the wave's two y2 rows (2560 B) are dead and serve as its store-transpose scratch (2304 B).
     {
       f32x4 acc[2][2];
 #pragma unroll
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(512) void c2f_fused_kernel(const C2fArgs p) {
         for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const u32x4*>(smem + kC2fWM2 + ((tap * 2 + j) * 64 + lane) * 16);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const int row = wave + 8 * i;
+          const int row = 2 * wave + i;
           const u32x4 a = *reinterpret_cast<const u32x4*>(smem + kC2fT + ((row + r) * 18 + lr + q) * 80 + lq * 16);
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = Elem<T>::mma(b[j], a, acc[i][j]);
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(512) void c2f_fused_kernel(const C2fArgs p) {
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int row = wave + 8 * i;
+        const int row = 2 * wave + i;
         const int pin = (row + 2) * 20 + lr + 2;  // this pixel in the 20 x 20 region
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -242,35 +245,41 @@ __global__ __launch_bounds__(512) void c2f_fused_kernel(const C2fArgs p) {
         }
       }
     }
-    __syncthreads();  // B3: Y2 complete, T dead (becomes the store scratch)
-
-    // ---- phase 5: cv2 1x1 96 -> 64 on [y0 | y1 | y2] of the 16 x 16 tile -> global ----
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     {
       f32x4 acc[2][4];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = *reinterpret_cast<const f32x4*>(sbias + 128 + j * 16 + lq * 4);
+      u32x4 a[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = 2 * wave + i;
+        const int pin = (row + 2) * 20 + lr + 2;
+        a[i][0] = *reinterpret_cast<const u32x4*>(smem + kC2fY + pin * 128 + (((0 + lq) ^ ((pin >> 1) & 7)) * 16));
+        a[i][1] = *reinterpret_cast<const u32x4*>(smem + kC2fY + pin * 128 + (((4 + lq) ^ ((pin >> 1) & 7)) * 16));
+        a[i][2] = *reinterpret_cast<const u32x4*>(smem + kC2fY2 + (row * 16 + lr) * 80 + lq * 16);
+      }
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         u32x4 b[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const u32x4*>(smem + kC2fW2 + ((c * 4 + j) * 64 + lane) * 16);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int row = wave + 8 * i;
-          const int pin = (row + 2) * 20 + lr + 2;
-          const unsigned char* ap = (c < 2) ? smem + kC2fY + pin * 128 + (((c * 4 + lq) ^ ((pin >> 1) & 7)) * 16)
-                                            : smem + kC2fY2 + (row * 16 + lr) * 80 + lq * 16;
-          const u32x4 a = *reinterpret_cast<const u32x4*>(ap);
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = Elem<T>::mma(b[j], a, acc[i][j]);
-        }
+          for (int j = 0; j < 4; ++j) acc[i][j] = Elem<T>::mma(b[j], a[i][c], acc[i][j]);
       }
-      unsigned char* escr = smem + kC2fT + wave * (16 * 144);  // one 16-pixel row at a time: 16 px x (128 + 16) B per wave
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the y2 rows were read above; they become the scratch
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      unsigned char* escr = smem + kC2fY2 + (2 * wave * 16) * 80;  // this wave's two y2 rows: 2560 B >= 16 px x 144 B
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int row = wave + 8 * i;
+        const int row = 2 * wave + i;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float v[4];
