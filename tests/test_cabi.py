@@ -67,3 +67,25 @@ def test_struct_layout_matches_header():
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
     assert sizes == [ctypes.sizeof(L.ConvDesc), ctypes.sizeof(L.DecodeDesc), ctypes.sizeof(L.NmsDesc), ctypes.sizeof(L.LossDesc),
                      ctypes.sizeof(L.HeadDecodeDesc), ctypes.sizeof(L.BnDesc), ctypes.sizeof(L.C2fDesc)]
+
+
+def test_new_entry_points_validate_without_gpu():
+    """The training / fusion / preprocessing entry points refuse null or inconsistent descriptors before touching HIP."""
+    import drone_yolo_amd._lib as L
+
+    h = L.lib()
+    null = None
+    assert h.dy_c2f_fused(ctypes.byref(L.C2fDesc()), null) == -1 and b"null" in h.dy_last_error_string()
+    assert h.dy_detect_head_decode(ctypes.byref(L.HeadDecodeDesc()), null) == -1
+    assert h.dy_detection_loss(ctypes.byref(L.LossDesc()), null) == -1
+    assert h.dy_bn_train_fwd(ctypes.byref(L.BnDesc()), null) == -1 and h.dy_bn_train_bwd(ctypes.byref(L.BnDesc()), null) == -1
+    assert h.dy_conv2d_wgrad_nhwc(ctypes.byref(L.ConvDesc()), null, 0, null, null) == -1
+    assert h.dy_letterbox_u8_to_nchw_f32(null, null, 1, 8, 8, 8, 8, 0, 0, 8, 8, 1, 114.0, null) == -1
+    assert h.dy_sgd_step(null, null, null, 10, 0.1, 0.9, 0.0, 1, 1, null, 10.0, null) == -1
+    assert h.dy_adamw_step(null, null, null, null, 10, 0.1, 0.9, 0.999, 1e-8, 0.0, 0, null, 10.0, null) == -1
+    # shape support queries are pure host functions
+    assert h.dy_c2f_fused_supported(64, 32, 64, 1, L.DY_BF16) == 1 and h.dy_c2f_fused_supported(64, 32, 64, 2, L.DY_BF16) == 0
+    assert h.dy_c2f_fused_supported(64, 32, 64, 1, L.DY_F32) == 0 and h.dy_c2f_fused_supported(192, 32, 64, 1, L.DY_BF16) == 0
+    assert h.dy_detect_head_decode_supported(64, 64, 10, 16, L.DY_BF16) == 1 and h.dy_detect_head_decode_supported(64, 80, 80, 16, L.DY_BF16) == 0
+    assert h.dy_bn_workspace_bytes(64) == 2 * 64 * 8 and h.dy_bn_workspace_bytes(0) == -1
+    assert h.dy_detection_loss_workspace_bytes(2, 340, 7, 10) > 0 and h.dy_detection_loss_workspace_bytes(0, 340, 7, 10) == -1
