@@ -25,4 +25,7 @@ struct ConvArgs {
 // (the caller then runs the generic kernel), else the launch status.
 int conv_gemm_glds_try(const ConvArgs& a, int dtype, bool out_f32, hipStream_t st);
 
+// conv3x3_vgemm.hip: 3x3 stride-1, Cin >= 128, Cout % 128 == 0 over the virtual flat pixel index.  Same return convention.
+int conv3x3_vgemm_try(const ConvArgs& a, int dtype, bool out_f32, hipStream_t st);
+
 }  // namespace dy

@@ -438,6 +438,8 @@ extern "C" int32_t dy_conv2d_nhwc(const dy_conv_desc* d, dy_stream_t stream) {
   a.vec_store = (aligned16(d->y) && (d->ld_y * oes) % 16 == 0) ? 1 : 0;
 
   {
+    const int rv = conv3x3_vgemm_try(a, d->dtype, d->out_f32 != 0, st);  // deep 3x3 stride-1 layers: halo staged once per chunk
+    if (rv <= 0) return rv;
     const int rc = conv_gemm_glds_try(a, d->dtype, d->out_f32 != 0, st);  // big-tile LDS-DMA kernel where it is built
     if (rc <= 0) return rc;
   }

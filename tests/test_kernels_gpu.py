@@ -95,6 +95,13 @@ GLDS_CASES = [
     (768, 512, 1, 1, 24, 20, 20, "1x1 wide K"),
     (64, 192, 1, 1, 3, 64, 63, "1x1 cout=192 (BN=64), M tail"),
     (256, 256, 3, 1, 22, 20, 20, "3x3 on 20x20 maps"),
+    # deep 3x3 stride-1: the virtual-flat-index kernel (conv3x3_vgemm.hip) — one tile, odd maps, the widest map it
+    # takes (94), a map too wide for it (falls through to the per-tap gather), and more tiles than workgroups
+    (128, 128, 3, 1, 3, 5, 7, "vgemm single tile 5x7"),
+    (192, 128, 3, 1, 2, 33, 47, "vgemm cin=192 odd map"),
+    (128, 256, 3, 1, 1, 9, 94, "vgemm widest map"),
+    (128, 128, 3, 1, 1, 9, 96, "3x3 s1 too wide for vgemm"),
+    (128, 128, 3, 1, 80, 40, 40, "vgemm persistent, 526 tiles"),
 ]
 
 
