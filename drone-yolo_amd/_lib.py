@@ -105,6 +105,15 @@ class C2fDesc(C.Structure):
     ]  # fmt: skip
 
 
+class Stem2Desc(C.Structure):
+    """Mirror of ``dy_stem2_desc``."""
+
+    _fields_ = [
+        ("x", _vp), ("w0", _vp), ("b0", _vp), ("w1", _vp), ("b1", _vp), ("y", _vp),
+        ("n", _i32), ("h", _i32), ("w", _i32), ("ld_y", _i32), ("act0", _i32), ("act1", _i32), ("dtype", _i32),
+    ]  # fmt: skip
+
+
 class BnDesc(C.Structure):
     """Mirror of ``dy_bn_desc``."""
 
@@ -129,6 +138,8 @@ SIGNATURES = {
     "dy_conv2d_nhwc": (_i32, [C.POINTER(ConvDesc), _vp]),
     "dy_c2f_fused_supported": (_i32, [_i32, _i32, _i32, _i32, _i32]),
     "dy_c2f_fused": (_i32, [C.POINTER(C2fDesc), _vp]),
+    "dy_stem2_fused_supported": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32]),
+    "dy_stem2_fused": (_i32, [C.POINTER(Stem2Desc), _vp]),
     "dy_stem_conv3x3s2_nchw": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dy_nchw_f32_to_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dy_nhwc_to_nchw_f32": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

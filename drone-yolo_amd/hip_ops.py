@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import DY_ACT_NONE, DY_ACT_SILU, BnDesc, C2fDesc, ConvDesc, DecodeDesc, HeadDecodeDesc, LossDesc, NmsDesc, check, lib
+from ._lib import DY_ACT_NONE, DY_ACT_SILU, BnDesc, C2fDesc, ConvDesc, DecodeDesc, HeadDecodeDesc, LossDesc, NmsDesc, Stem2Desc, check, lib
 
 _DTYPES = {torch.bfloat16: _lib.DY_BF16, torch.float16: _lib.DY_F16, torch.float32: _lib.DY_F32}
 
@@ -86,6 +86,9 @@ class LaunchPlan:
     def rebind_input(self, ptr: int) -> None:
         i, j = self.input_slot
         fn, args, d = self.ops[i]
+        if j < 0:  # the input pointer is field ``x`` of the descriptor passed by reference
+            args[0]._obj.x = ptr
+            return
         args = list(args)
         args[j] = ptr
         self.ops[i] = (fn, tuple(args), d)
@@ -334,6 +337,41 @@ def stem_conv(src: torch.Tensor, ps: PackedStem, out: Optional[torch.Tensor] = N
         _recording.input_slot = (len(_recording.ops) - 1, 0)
     return out
 
+
+
+class PackedStem2:
+    """Weights of layers 0 + 1 for ``dy_stem2_fused``: the stem rows as in :class:`PackedStem` and the stride-2 3x3
+    layer as [64][288] rows with k = (r*3 + q)*32 + c (include/dyolo.h)."""
+
+    def __init__(self, w0, b0, act0: bool, w1, b1, act1: bool, dtype: torch.dtype, device):
+        if tuple(w0.shape) != (32, 3, 3, 3) or tuple(w1.shape) != (64, 32, 3, 3):
+            raise ValueError("PackedStem2: built for Conv(3, 32, 3, 2) followed by a 3x3 stride-2 32 -> 64 layer")
+        self.stem = PackedStem(w0, b0, act0, dtype, device)
+        self.dtype = dtype
+        self.act1 = DY_ACT_SILU if act1 else DY_ACT_NONE
+        self.w1 = w1.detach().to(torch.float32).cpu().permute(0, 2, 3, 1).reshape(64, 288).to(dtype).contiguous().to(device)
+        self.b1 = b1.detach().to(torch.float32).cpu().contiguous().to(device)
+
+
+def stem2_fused_supported(cin: int, c0: int, c1: int, h: int, w: int, dtype: torch.dtype) -> bool:
+    return bool(lib().dy_stem2_fused_supported(cin, c0, c1, h, w, dy_dtype(dtype)))
+
+
+def stem2_fused(src: torch.Tensor, ps: PackedStem2, out: Optional[torch.Tensor] = None, mark_input: bool = False) -> torch.Tensor:
+    """fp32 NCHW image -> layers 0 and 1 (two stride-2 3x3 convolutions with SiLU) as an NHWC view at 1/4 resolution."""
+    require_device(src, "input")
+    if src.dtype != torch.float32 or not src.is_contiguous() or src.dim() != 4 or src.shape[1] != 3:
+        raise ValueError("stem2_fused expects a contiguous fp32 (N,3,H,W) tensor")
+    n, _, h, w = src.shape
+    if out is None:
+        out = alloc_nhwc(n, 64, h // 4, w // 4, ps.dtype, src.device)
+    op, ld = view_params(out)
+    d = Stem2Desc(x=src.data_ptr(), w0=ps.stem.w.data_ptr(), b0=ps.stem.b.data_ptr(), w1=ps.w1.data_ptr(), b1=ps.b1.data_ptr(), y=op,
+                  n=n, h=h, w=w, ld_y=ld, act0=ps.stem.act, act1=ps.act1, dtype=dy_dtype(ps.dtype))
+    _launch(lib().dy_stem2_fused, (C.byref(d),), keep=(d, out, ps))
+    if mark_input and _recording is not None:
+        _recording.input_slot = (len(_recording.ops) - 1, -1)
+    return out
 
 # ---- layout ops -------------------------------------------------------------------------------------
 

@@ -160,6 +160,7 @@ class BaseModel(nn.Module):
             for s in srcs:
                 if i > 0:
                     consumers[s].append(i)
+        self._consumers0 = list(consumers[0])
         self._virtual: Dict[int, tuple] = {}  # concat layer index -> (lowres_src, skip_src) folded into next C2f
         self._skip: set = set()  # layers that launch nothing (folded Upsample / Concat)
         self._place: Dict[int, tuple] = {}  # producer layer -> (concat layer, channel offset)
@@ -200,6 +201,7 @@ class BaseModel(nn.Module):
                 x = H.to_nhwc(x, image_dtype, mark_input=True)
         y: List[Optional[torch.Tensor]] = []
         cat_bufs: Dict[int, torch.Tensor] = {}
+        fused_stem2 = None
         for m in self.model:
             i = m.i
             if i in self._skip:
@@ -224,11 +226,45 @@ class BaseModel(nn.Module):
             if isinstance(m, Concat) and i in cat_bufs:
                 kw["out"] = cat_bufs[i]
             if i == 0 and stem_image is not None:
+                pk2 = self._stem2_pack(stem_image, image_dtype, consumers0=self._consumers0)
+                if pk2 is not None:  # layers 0 + 1 in one kernel: the half-resolution map never reaches HBM
+                    y.append(None)
+                    fused_stem2 = H.stem2_fused(stem_image, pk2, mark_input=True)
+                    continue
                 out = m.forward_stem(stem_image, image_dtype, mark_input=True, **kw)
+            elif i == 1 and fused_stem2 is not None:
+                out = fused_stem2
             else:
                 out = m(xin, **kw)
             y.append(out)
         return y[-1]
+
+    fuse_stem2 = True  # layers 0 + 1 in one kernel where dy_stem2_fused is built for the shapes
+
+    def _stem2_pack(self, image, dtype, consumers0):
+        """Packed weights for ``dy_stem2_fused`` when layers 0 / 1 are Conv(3, 32, 3, 2) -> RepVGGBlock(32, 64, stride 2),
+        layer 0 feeds nothing else and neither output is a Concat slice; else None (layer-by-layer path)."""
+        if not self.fuse_stem2 or len(self.model) < 2 or consumers0 != [1] or 0 in self._place or 1 in self._place:
+            return None
+        m0, m1 = self.model[0], self.model[1]
+        if not (isinstance(m1, RepVGGBlock) and isinstance(m1.se, nn.Identity) and m1.stride == 2 and m1.groups == 1
+                and m0.conv.out_channels == 32 and m1.in_channels == 32 and isinstance(m0.act, nn.SiLU)):
+            return None
+        c1 = (m1.rbr_reparam if hasattr(m1, "rbr_reparam") else m1.rbr_dense.conv).out_channels
+        n, c, h, w = image.shape
+        if not H.stem2_fused_supported(c, 32, c1, h, w, dtype):
+            return None
+        srcs = [m0.conv.weight, m0.bn.weight, m0.bn.bias, m0.bn.running_mean, m0.bn.running_var] + list(m1.parameters()) + list(m1.buffers())
+        key = (dtype, str(image.device), tuple((t.data_ptr(), t._version) for t in srcs))
+        cache = self.__dict__.get("_stem2_cache")
+        if cache is None or cache[0] != key:
+            from .modules.conv import fold_conv_bn
+
+            w0, b0 = fold_conv_bn(m0.conv.weight, m0.conv.bias, m0.bn)
+            w1, b1 = (m1.rbr_reparam.weight, m1.rbr_reparam.bias) if hasattr(m1, "rbr_reparam") else m1.get_equivalent_kernel_bias()
+            cache = (key, H.PackedStem2(w0, b0, True, w1, b1, True, dtype, image.device))
+            self.__dict__["_stem2_cache"] = cache
+        return cache[1]
 
     def _out_hw(self, i: int, h: int, w: int):
         s = self._cum_stride[i]

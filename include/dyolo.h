@@ -156,6 +156,26 @@ int32_t dy_stem_conv3x3s2_nchw(const float* x, const void* w, const float* bias,
                                int32_t h, int32_t w_in, int32_t cout, int32_t ld_y, int32_t act, int32_t dtype,
                                dy_stream_t stream);
 
+/* Fused first TWO layers.  Replaces in one kernel: the layout step + Conv(3, 32, 3, 2) (yolov8-p2-repvgg.yaml layer 0,
+ * nn/modules/conv.py:37-55) + RepVGGBlock(32, 64, stride 2) in deploy form (layer 1, nn/modules/block.py:1393-1490:
+ * get_equivalent_kernel_bias folds the three branches into one 3x3 kernel), each followed by SiLU.  The 1/2-resolution
+ * 32-channel intermediate stays in LDS, rounded to `dtype` exactly where the layer-by-layer path rounds it.
+ * x: fp32 NCHW (n, 3, h, w) contiguous.  w0/b0: as dy_stem_conv3x3s2_nchw ([32][32], k = c*9 + r*3 + q; fp32[32]).
+ * w1: [64][288] of `dtype`, k = (r*3 + q)*32 + c (BatchNorm and branches folded); b1: fp32[64].
+ * y: NHWC view (n, h/4, w/4, 64) of `dtype`, pitch ld_y.  Built for DY_BF16 / DY_F16 and h, w multiples of 4
+ * (dy_stem2_fused_supported tells); otherwise run dy_stem_conv3x3s2_nchw and dy_conv2d_nhwc. */
+typedef struct dy_stem2_desc {
+  const float* x;
+  const void* w0;
+  const float* b0;
+  const void* w1;
+  const float* b1;
+  void* y;
+  int32_t n, h, w, ld_y, act0, act1, dtype;
+} dy_stem2_desc;
+int32_t dy_stem2_fused_supported(int32_t cin, int32_t c0, int32_t c1, int32_t h, int32_t w, int32_t dtype);
+int32_t dy_stem2_fused(const dy_stem2_desc* d, dy_stream_t stream);
+
 /* ---- image sources: LetterBox + BGR->RGB + HWC->CHW + /255 ------------------------------------------
  * Replaces: LetterBox.__call__ (ultralytics/data/augment.py:1545-1608: cv2.resize INTER_LINEAR to (new_w, new_h), then
  * cv2.copyMakeBorder with 114) and the non-tensor branch of BasePredictor.preprocess (engine/predictor.py:125-135:

@@ -59,14 +59,14 @@ def test_struct_layout_matches_header():
 
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "s.c")
-        open(src, "w").write('#include <stdio.h>\n#include "dyolo.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", '
+        open(src, "w").write('#include <stdio.h>\n#include "dyolo.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", '
                              "sizeof(dy_conv_desc), sizeof(dy_decode_desc), sizeof(dy_nms_desc), sizeof(dy_loss_desc), "
-                             "sizeof(dy_head_decode_desc), sizeof(dy_bn_desc), sizeof(dy_c2f_desc));return 0;}\n")
+                             "sizeof(dy_head_decode_desc), sizeof(dy_bn_desc), sizeof(dy_c2f_desc), sizeof(dy_stem2_desc));return 0;}\n")
         exe = os.path.join(td, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
     assert sizes == [ctypes.sizeof(L.ConvDesc), ctypes.sizeof(L.DecodeDesc), ctypes.sizeof(L.NmsDesc), ctypes.sizeof(L.LossDesc),
-                     ctypes.sizeof(L.HeadDecodeDesc), ctypes.sizeof(L.BnDesc), ctypes.sizeof(L.C2fDesc)]
+                     ctypes.sizeof(L.HeadDecodeDesc), ctypes.sizeof(L.BnDesc), ctypes.sizeof(L.C2fDesc), ctypes.sizeof(L.Stem2Desc)]
 
 
 def test_new_entry_points_validate_without_gpu():
@@ -87,5 +87,8 @@ def test_new_entry_points_validate_without_gpu():
     assert h.dy_c2f_fused_supported(64, 32, 64, 1, L.DY_BF16) == 1 and h.dy_c2f_fused_supported(64, 32, 64, 2, L.DY_BF16) == 0
     assert h.dy_c2f_fused_supported(64, 32, 64, 1, L.DY_F32) == 0 and h.dy_c2f_fused_supported(192, 32, 64, 1, L.DY_BF16) == 0
     assert h.dy_detect_head_decode_supported(64, 64, 10, 16, L.DY_BF16) == 1 and h.dy_detect_head_decode_supported(64, 80, 80, 16, L.DY_BF16) == 0
+    assert h.dy_stem2_fused(ctypes.byref(L.Stem2Desc()), null) == -1
+    assert h.dy_stem2_fused_supported(3, 32, 64, 640, 640, L.DY_BF16) == 1 and h.dy_stem2_fused_supported(3, 32, 64, 642, 640, L.DY_BF16) == 0
+    assert h.dy_stem2_fused_supported(3, 48, 96, 640, 640, L.DY_BF16) == 0 and h.dy_stem2_fused_supported(3, 32, 64, 640, 640, L.DY_F32) == 0
     assert h.dy_bn_workspace_bytes(64) == 2 * 64 * 8 and h.dy_bn_workspace_bytes(0) == -1
     assert h.dy_detection_loss_workspace_bytes(2, 340, 7, 10) > 0 and h.dy_detection_loss_workspace_bytes(0, 340, 7, 10) == -1

@@ -202,6 +202,37 @@ def test_conv_dual_source_upsample_gather(dtype, device):
     check_close(back(y3), F.conv2d(F.interpolate(a, scale_factor=2.0, mode="nearest"), w3, None, 1, 1), dtype, "up2x 3x3 conv")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 36, 44), (3, 4, 4), (1, 132, 68), (2, 640, 640)],
+                         ids=["64x96", "36x44 partial tiles", "4x4", "132x68", "640"])
+def test_fused_stem2_matches_cpu(shape, dtype, device):
+    """dy_stem2_fused: image -> SiLU(conv s2) -> round -> SiLU(conv s2), vs the two F.conv2d with the same rounding points;
+    and bit-identical to the two-kernel path it replaces (same operands, same accumulation order per output)."""
+    n, h, w = shape
+    g = torch.Generator().manual_seed(h * 3 + w)
+    img = torch.rand(n, 3, h, w, generator=g)
+    w0 = quantize(torch.randn(32, 3, 3, 3, generator=g) * 0.4, dtype)
+    b0 = torch.randn(32, generator=g) * 0.2
+    w1 = quantize(torch.randn(64, 32, 3, 3, generator=g) * (2.0 / 288) ** 0.5, dtype)
+    b1 = torch.randn(64, generator=g) * 0.2
+    assert H.stem2_fused_supported(3, 32, 64, h, w, dtype) and not H.stem2_fused_supported(3, 32, 64, h + 2, w, dtype)
+    ps = H.PackedStem2(w0, b0, True, w1, b1, True, dtype, device)
+    out = torch.full((n, h // 4, w // 4, 80), 3.0, dtype=dtype, device=device).permute(0, 3, 1, 2)  # a slice of a wider buffer
+    y = H.stem2_fused(img.to(device), ps, out=out[:, 8:72])
+    torch.cuda.synchronize()
+    mid = quantize(F.silu(F.conv2d(quantize(img, dtype), w0, b0, 2, 1)), dtype)
+    ref = F.silu(F.conv2d(mid, w1, b1, 2, 1))
+    assert tuple(y.shape) == tuple(ref.shape)
+    check_close(back(y), ref, dtype, f"stem2 {shape}", extra=1.5)
+    assert float((out[:, :8].float() - 3.0).abs().max()) == 0.0 and float((out[:, 72:].float() - 3.0).abs().max()) == 0.0
+    t = H.stem_conv(img.to(device), ps.stem)
+    y2 = H.conv2d(t, H.PackedConv(w1, b1, 2, 1, 1, True, dtype, device))
+    torch.cuda.synchronize()
+    d = (back(y) - back(y2)).abs()
+    assert float(d.max()) <= RTOL[dtype] * float(ref.abs().max()), "fused and layer-by-layer paths disagree beyond one rounding"
+    assert float((d > 0).float().mean()) < 0.02, "fused path should reproduce the layer-by-layer result almost everywhere"
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("shape", [(2, 3, 64, 96, 32), (1, 3, 50, 70, 16), (3, 3, 33, 31, 48), (1, 1, 40, 40, 80), (2, 3, 640, 640, 32)],
                          ids=["64x96->32", "odd 50x70->16", "odd 33x31->48", "cin1 ->80", "640 ->32"])
