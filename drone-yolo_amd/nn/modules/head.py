@@ -94,10 +94,54 @@ class Detect(nn.Module):
             self._tail_cache = cache
         return cache[1], cache[2]
 
+    fuse_first = True  # run cv2[i][0] and cv3[i][0] (same input, both 3x3) as ONE convolution on the deep levels
+
+    def _packed_first(self, i, dtype, device):
+        """cv2[i][0] and cv3[i][0] stacked along cout, or None when the level is not one the stacking pays for.
+
+        Both read the same feature map; stacked they make a cin -> c2 + c3 3x3 layer that reads it once and, from 128
+        input channels up, runs in the deep-layer GEMM kernel (conv3x3_vgemm.hip) instead of two 64-cout launches.
+        Same operands and fp32 accumulation per output; only the summation order over K differs from the two-launch path.
+        """
+        a, b = self.cv2[i][0], self.cv3[i][0]
+        if not (self.fuse_first and isinstance(a, Conv) and isinstance(b, Conv) and not isinstance(a, DWConv) and not isinstance(b, DWConv)):
+            return None
+        ca, cb = a.conv, b.conv
+        if not (ca.kernel_size == cb.kernel_size == (3, 3) and ca.stride == cb.stride == (1, 1) and ca.groups == cb.groups == 1
+                and ca.in_channels == cb.in_channels and ca.in_channels >= 128 and (ca.out_channels + cb.out_channels) % 128 == 0
+                and ca.out_channels % 8 == 0 and isinstance(a.act, nn.SiLU) and isinstance(b.act, nn.SiLU)):
+            return None
+        srcs = [ca.weight, a.bn.weight, a.bn.bias, a.bn.running_mean, a.bn.running_var, cb.weight, b.bn.weight, b.bn.bias, b.bn.running_mean, b.bn.running_var]
+        key = (dtype, str(device), tuple((t.data_ptr(), t._version) for t in srcs))
+        cache = self.__dict__.setdefault("_first_cache", {})
+        hit = cache.get(i)
+        if hit is None or hit[0] != key:
+            from .conv import fold_conv_bn
+
+            wa, ba = fold_conv_bn(ca.weight, ca.bias, a.bn)
+            wb, bb = fold_conv_bn(cb.weight, cb.bias, b.bn)
+            hit = (key, H.PackedConv(torch.cat((wa, wb), 0), torch.cat((ba, bb), 0), 1, 1, 1, True, dtype, device), ca.out_channels)
+            cache[i] = hit
+        return hit[1], hit[2]
+
+    def _trunks(self, i, x):
+        """Outputs of the two branch trunks (all but the last 1x1 conv) of level i."""
+        pf = self._packed_first(i, x.dtype, x.device)
+        if pf is None:
+            return self._run_trunk(self.cv2[i], x), self._run_trunk(self.cv3[i], x)
+        pc, c2 = pf
+        both = H.conv2d(x, pc)
+        tb, tc = both[:, :c2], both[:, c2:]
+        for m in list(self.cv2[i])[1:-1]:
+            tb = m(tb)
+        for m in list(self.cv3[i])[1:-1]:
+            tc = m(tc)
+        return tb, tc
+
     def _forward_fused(self, x):
         """Inference with the branch tails, decode and NMS filter in one launch (dy_detect_head_decode)."""
-        xb = [self._run_trunk(self.cv2[i], x[i]) for i in range(self.nl)]
-        xc = [self._run_trunk(self.cv3[i], x[i]) for i in range(self.nl)]
+        tr = [self._trunks(i, x[i]) for i in range(self.nl)]
+        xb, xc = [t[0] for t in tr], [t[1] for t in tr]
         pb, pc = self._packed_tail(xb[0].dtype, xb[0].device)
         fused = getattr(self, "fused_nms", None)
         kw = {}

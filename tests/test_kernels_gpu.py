@@ -530,3 +530,32 @@ def test_c2f_fused_block_matches_layerwise(shape, shortcut, dtype, device):
     torch.cuda.synchronize()
     check_close(back(got), ref, dtype, "fused C2f vs CPU chain", extra=3.0)
     check_close(back(got), back(layerwise), dtype, "fused C2f vs layer-by-layer device path", extra=3.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_detect_stacked_first_convs_match_separate(dtype, device):
+    """Detect._trunks: cv2[i][0] / cv3[i][0] stacked into one conv on the deep levels == the two separate branches."""
+    from drone_yolo_amd.nn.modules import Detect
+
+    g = torch.Generator().manual_seed(5)
+    class LegacyDetect(Detect):  # the v8 head of the Drone-YOLO YAMLs: two 3x3 convs per branch (nn/tasks.py sets legacy)
+        legacy = True
+
+    det = LegacyDetect(nc=10, ch=(64, 128, 256)).eval()
+    for prm in det.parameters():
+        prm.data = torch.randn(prm.shape, generator=g) * (0.05 if prm.dim() > 1 else 0.2) + (1.0 if prm.dim() == 1 else 0.0)
+    for m in det.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+    det = det.to(device)
+    xs = [nhwc(quantize(torch.randn(2, c, s, s, generator=g), dtype), dtype, device) for c, s in ((64, 40), (128, 20), (256, 10))]
+    assert det._packed_first(0, dtype, device) is None and det._packed_first(1, dtype, device) is not None
+    for i, x in enumerate(xs):
+        det.fuse_first = True
+        tb, tc = det._trunks(i, x)
+        det.fuse_first = False
+        sb, sc = det._trunks(i, x)
+        torch.cuda.synchronize()
+        check_close(back(tb), back(sb), dtype, f"stacked box trunk level {i}", extra=3.0)
+        check_close(back(tc), back(sc), dtype, f"stacked class trunk level {i}", extra=3.0)
