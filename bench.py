@@ -89,6 +89,20 @@ def conv_work(plan):
             out.append((i, 2.0 * n * ho * wo * cout * cin * 9, n * cin * h * w * 4 + n * ho * wo * cout * es + cout * cin * 9 * es,
                         f"{cin}->{cout} k3 s2 {h}x{w} (stem, fp32 NCHW in)"))
             continue
+        if fn.__name__ == "dy_stem2_fused":  # layers 0 + 1 in one launch; the half-resolution map never reaches HBM
+            d = args[0]._obj
+            es = 2
+            h0, w0, h1, w1 = d.h // 2, d.w // 2, d.h // 4, d.w // 4
+            out.append((i, 2.0 * d.n * (h0 * w0 * 32 * 27 + h1 * w1 * 64 * 288), d.n * 3 * d.h * d.w * 4 + d.n * h1 * w1 * 64 * es + (32 * 27 + 64 * 288) * es,
+                        f"3->32 k3 s2 + 32->64 k3 s2 {d.h}x{d.w} (fused stem + layer 1, fp32 NCHW in)"))
+            continue
+        if fn.__name__ == "dy_c2f_fused":  # whole C2f block (cv1, Bottleneck 3x3 3x3, cv2) in one launch
+            d = args[0]._obj
+            es, c = 2, d.hidden
+            px = d.batch * d.h * d.w
+            out.append((i, 2.0 * px * (d.cin * 2 * c + 2 * 9 * c * c + 3 * c * d.cout), px * (d.cin + d.cout) * es + (d.cin * 2 * c + 18 * c * c + 3 * c * d.cout) * es,
+                        f"C2f {d.cin}->{d.cout} (hidden {c}: 1x1, 3x3, 3x3, 1x1 fused) {d.h}x{d.w}"))
+            continue
         if fn.__name__ == "dy_detect_head_decode":  # fused tail: both 1x1 convs of every level + decode in one launch
             d = args[0]._obj
             es = 4 if d.dtype == _lib.DY_F32 else 2
@@ -291,7 +305,7 @@ def main():
             tj = json.load(open(tfile))
             if tj.get("batch") == a.batch and a.dtype == "bf16":
                 traffic = round((tj["families"]["conv"]["hbm_bytes_per_step"] + tj["families"].get("head", {}).get("hbm_bytes_per_step", 0.0)) / 1e9, 3)
-        roof = {"bound": "mfma", "kernel": "conv family: conv3x3_halo + conv1x1_stream + conv_igemm + conv_stem + detect_head kernels (every launch that convolves, one pass)",
+        roof = {"bound": "mfma", "kernel": "conv family: conv3x3_halo + conv3x3_vgemm + conv_gemm_glds + conv1x1_stream + stem2_fused + c2f_fused + detect_head kernels (every launch that convolves, one pass)",
                 "achieved": round(flops / tconv / 1e12, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(flops / tconv / 1e12 / peak, 4), "traffic": traffic,
                 "traffic_unit": f"GB of HBM traffic per pass (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic_b{a.batch}.json)",

@@ -5,7 +5,7 @@ root, batch, passes_per_run = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        fam = "head" if "detect_head" in r["Kernel_Name"] else "conv" if ("conv" in r["Kernel_Name"] or "c2f_fused" in r["Kernel_Name"]) else ("nms" if "nms" in r["Kernel_Name"] else ("decode" if "decode" in r["Kernel_Name"] else
+        fam = "head" if "detect_head" in r["Kernel_Name"] else "conv" if ("conv" in r["Kernel_Name"] or "c2f_fused" in r["Kernel_Name"] or "stem2_fused" in r["Kernel_Name"]) else ("nms" if "nms" in r["Kernel_Name"] else ("decode" if "decode" in r["Kernel_Name"] else
               ("layout" if ("nchw" in r["Kernel_Name"] or "sppf" in r["Kernel_Name"] or "copy_chunks" in r["Kernel_Name"]) else "other")))
         acc[fam][r["Counter_Name"]] += float(r["Counter_Value"])
 out = {"round": 1, "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph  (bf16)",
