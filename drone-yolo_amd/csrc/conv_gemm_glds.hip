@@ -476,6 +476,13 @@ static int launch_glds_dtype(const ConvArgs& a, hipStream_t st) {
   // short K (<= 9 steps, the 64-channel stride-2 layers on 160x160 maps: thousands of tiles) measured faster one tile per
   // workgroup; everything else gains 3-14 % from the persistent walk with the next tile's first K-step prefetched
   const bool persist = big != 2 && (big == 3 || a.Kpad > 9 * 8 * (16 / (int)sizeof(T)));
+  // 256 x 256 tiles (8 waves of 64 x 128, one workgroup per CU) halve the gathered-operand bytes per flop: 4-19 % faster on
+  // the wide 1x1 layers and the 256-cout stride-2 layers at throughput batch sizes (512->256 @40x40: 241 -> 204 us); slower on
+  // 256->512 stride 2 (measured 2x) and pointless when the tile count cannot fill the CUs.  Every output element is still
+  // accumulated over K in the same order, so the choice does not change results.  DYOLO_GLDS_BIG=5 turns it off.
+  if (big != 5 && big != 2 && big != 3 && a.Cout % 256 == 0 && (a.ks == 1 || (a.stride == 2 && a.Cout == 256)) &&
+      (long long)a.M * a.Cout >= 256ll * 256 * 512)
+    return launch_glds<T, 256, 256, 2>(a, st);
   if (a.Cout % 128 == 0) {
     if (big == 1) return launch_glds<T, 256, 128, 3>(a, st);
     return persist ? launch_glds_persist<T, 128>(a, st) : launch_glds<T, 128, 128, 2>(a, st);
