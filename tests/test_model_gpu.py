@@ -356,3 +356,43 @@ def test_two_batches_in_flight_on_two_streams(device):
     torch.cuda.synchronize()
     for j in range(2):
         assert torch.equal(cfs[j].pred, ref[j][0]) and torch.equal(cfs[j].nms.out, ref[j][1]) and torch.equal(cfs[j].nms.count, ref[j][2])
+
+
+def test_fusions_agree_with_layer_by_layer_path(device):
+    """Drone-YOLO-s 640x640 bf16: the one-launch forms (layers 0 + 1 fused, stride-4 C2f fused, Detect first convs stacked)
+    against the same model run layer by layer.  Same operands and rounding points, different K summation order: raw
+    predictions agree to a few bf16 roundings of the deepest activations and the kept detections match."""
+    g = golden("e2e.npz")
+    m, d, sd, model, _ = _build("s640", g, device)
+    pred = D.engine.predictor.DetectionPredictor(model, dict(conf=0.25, iou=0.7, dtype=torch.bfloat16, device=0))
+    x = torch.rand(2, 3, 640, 640, generator=torch.Generator().manual_seed(11)).to(device)
+    det = model.model[-1]
+    cf = pred.forward_device(x)
+    torch.cuda.synchronize()
+    y1, o1, c1 = cf.pred.clone(), cf.nms.out.clone(), cf.nms.count.clone()
+    model.fuse_stem2 = False
+    det.fuse_first = False
+    for mod in model.modules():
+        if isinstance(mod, M.C2f):
+            mod.fuse_block = False
+    pred2 = D.engine.predictor.DetectionPredictor(model, dict(conf=0.25, iou=0.7, dtype=torch.bfloat16, device=0))
+    cf2 = pred2.forward_device(x)
+    torch.cuda.synchronize()
+    y2, o2, c2 = cf2.pred, cf2.nms.out, cf2.nms.count
+    box_err = float((y1[:, :4] - y2[:, :4]).abs().max())
+    cls_err = float((y1[:, 4:] - y2[:, 4:]).abs().max())
+    matched = 0
+    total = 0
+    for i in range(2):
+        a, b = o1[i, : int(c1[i])], o2[i, : int(c2[i])]
+        total += max(len(a), len(b))
+        if len(a) and len(b):
+            an, bn = a.float().cpu().numpy(), b.float().cpu().numpy()
+            iou = box_iou_pairs(np.repeat(an[:, :4], len(bn), 0), np.tile(bn[:, :4], (len(an), 1))).reshape(len(an), len(bn))
+            same = an[:, None, 5] == bn[None, :, 5]
+            matched += int(((iou > 0.95) & same).any(1).sum())
+    _report("fused_vs_layerwise_s640", {"box_max_abs_px": box_err, "cls_max_abs": cls_err, "matched": matched, "total": total})
+    assert box_err < 8.0 and cls_err < 0.08, (box_err, cls_err)
+    assert total > 0 and matched >= 0.9 * total, (matched, total)
+    model.fuse_stem2 = True
+    det.fuse_first = True
