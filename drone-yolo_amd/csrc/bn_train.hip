@@ -14,6 +14,8 @@
 
 namespace dy {
 
+constexpr int kBnMaxSlabs = 1024;  // workgroups of a reduction pass (dy_bn_workspace_bytes reserves one partial each)
+
 struct BnArgs {
   const void* z;
   void* y;
@@ -64,15 +66,15 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const BnArgs p) {
     if (r1 > p.rows) r1 = p.rows;
     const T* zb = reinterpret_cast<const T*>(p.z) + ch * E;
     const T* db = reinterpret_cast<const T*>(p.dy) + ch * E;
-    for (long long r = r0 + rr; r < r1; r += p.R) {
+    auto accumulate = [&](const u32x4 zraw, const u32x4 draw) {
       float zf[E];
-      Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(zb + r * p.ld_z), zf);
+      Chunk<T>::unpack(zraw, zf);
       if (MODE == 0) {
 #pragma unroll
         for (int e = 0; e < E; ++e) s0[e] += zf[e], s1[e] += zf[e] * zf[e];
       } else {
         float df[E];
-        Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(db + r * p.ld_dy), df);
+        Chunk<T>::unpack(draw, df);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
           const float xh = (zf[e] - mu[e]) * rs[e];
@@ -81,7 +83,22 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const BnArgs p) {
           s0[e] += du, s1[e] += du * xh;
         }
       }
+    };
+    // UNR rows in flight per thread: with one load per iteration the pass ran at 1.2 TB/s (latency bound)
+    constexpr int UNR = MODE == 0 ? 8 : 4;
+    long long r = r0 + rr;
+    for (; r + (long long)(UNR - 1) * p.R < r1; r += (long long)UNR * p.R) {
+      u32x4 zr[UNR], dr[UNR];
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {
+        zr[k] = *reinterpret_cast<const u32x4*>(zb + (r + (long long)k * p.R) * p.ld_z);
+        if (MODE == 1) dr[k] = *reinterpret_cast<const u32x4*>(db + (r + (long long)k * p.R) * p.ld_dy);
+      }
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) accumulate(zr[k], MODE == 1 ? dr[k] : zr[k]);
     }
+    for (; r < r1; r += p.R)
+      accumulate(*reinterpret_cast<const u32x4*>(zb + r * p.ld_z), MODE == 1 ? *reinterpret_cast<const u32x4*>(db + r * p.ld_dy) : u32x4{0u, 0u, 0u, 0u});
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       red[(0 * p.R + rr) * p.c + ch * E + e] = s0[e];
@@ -93,7 +110,30 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const BnArgs p) {
     const int which = i / p.c, cc = i - which * p.c;
     double t = 0.0;
     for (int k = 0; k < p.R; ++k) t += (double)red[(which * p.R + k) * p.c + cc];
-    atomicAdd(p.acc + which * p.c + cc, t);
+    p.acc[(size_t)(1 + blockIdx.x) * 2 * p.c + i] = t;  // this slab's partial; summed by bn_sum_partials_kernel
+  }
+}
+
+// acc[0 .. 2c) += sum over slabs of their partials (slab b at acc[(1 + b) * 2c ...)).  The first version had every slab end
+// with 2c double atomics on the same addresses (1024 slabs x 128 atomics queued on 128 addresses per launch: the reduce
+// pass ran at 1.2 TB/s).  Here 16 x 8 threads share the slabs of an output: 16 atomics per address.
+constexpr int kBnSumY = 16;
+__global__ __launch_bounds__(256) void bn_sum_partials_kernel(const BnArgs p, int slabs) {
+  __shared__ double red[8][32];
+  const int il = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + il;
+  const int chunk = (slabs + kBnSumY - 1) / kBnSumY;
+  const int b0 = blockIdx.y * chunk, b1 = (b0 + chunk < slabs) ? b0 + chunk : slabs;
+  double t = 0.0;
+  if (i < 2 * p.c)
+    for (int b = b0 + g; b < b1; b += 8) t += p.acc[(size_t)(1 + b) * 2 * p.c + i];
+  red[g][il] = t;
+  __syncthreads();
+  if (g == 0 && i < 2 * p.c) {
+    double u = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) u += red[k][il];
+    atomicAdd(p.acc + i, u);
   }
 }
 
@@ -221,8 +261,8 @@ static int bn_prepare(const dy_bn_desc* d, BnArgs* a, const char* who, bool bwd)
   const int epc = 16 / es;
   DY_REQUIRE(d->c % epc == 0 && d->c <= 8192, DY_ERR_UNSUPPORTED, "%s: c %d must be a multiple of %d (one 16-byte chunk) and <= 8192", who, d->c, epc);
   DY_REQUIRE(aligned16(d->z) && d->ld_z >= d->c && (d->ld_z * es) % 16 == 0, DY_ERR_INVALID_ARG, "%s: z view misaligned", who);
-  DY_REQUIRE(d->workspace_bytes >= (int64_t)(2 * d->c * 8) && (reinterpret_cast<uintptr_t>(d->workspace) & 7) == 0, DY_ERR_WORKSPACE,
-             "%s: workspace needs %d bytes", who, 2 * d->c * 8);
+  DY_REQUIRE(d->workspace_bytes >= dy_bn_workspace_bytes(d->c) && (reinterpret_cast<uintptr_t>(d->workspace) & 7) == 0, DY_ERR_WORKSPACE,
+             "%s: workspace needs %lld bytes (dy_bn_workspace_bytes)", who, (long long)dy_bn_workspace_bytes(d->c));
   if (bwd) {
     DY_REQUIRE(d->dy && d->dz && aligned16(d->dy) && aligned16(d->dz) && d->ld_dy >= d->c && d->ld_dz >= d->c && (d->ld_dy * es) % 16 == 0 &&
                    (d->ld_dz * es) % 16 == 0, DY_ERR_INVALID_ARG, "%s: dy/dz views null or misaligned", who);
@@ -241,9 +281,9 @@ static int bn_prepare(const dy_bn_desc* d, BnArgs* a, const char* who, bool bwd)
   if (R < 1) R = 1;
   a->R = R;
   DY_REQUIRE(a->nch <= 256, DY_ERR_UNSUPPORTED, "%s: c %d too wide for one workgroup row (max %d)", who, d->c, 256 * epc);
-  // slabs: enough workgroups to fill the chip, at least 4 passes of R rows each
+  // slabs: enough workgroups to fill the chip (four per CU), at least 4 passes of R rows each
   long long blocks = (d->rows + 4LL * R - 1) / (4LL * R);
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > kBnMaxSlabs) blocks = kBnMaxSlabs;
   a->rows_per_block = (int)((d->rows + blocks - 1) / blocks);
   return 0;
 }
@@ -254,6 +294,7 @@ static int bn_fwd_t(const BnArgs& a, hipStream_t st) {
   const unsigned blocks = (unsigned)((a.rows + a.rows_per_block - 1) / a.rows_per_block);
   const size_t smem = (size_t)2 * a.R * a.c * 4;
   hipLaunchKernelGGL((bn_reduce_kernel<T, 0>), dim3(blocks), dim3(256), smem, st, a);
+  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((unsigned)((2 * a.c + 31) / 32), kBnSumY), dim3(256), 0, st, a, (int)blocks);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((a.c + 255) / 256)), dim3(256), 0, st, a);
   const long long nb = (a.rows + a.R - 1) / a.R;
   const unsigned ab = (unsigned)(nb < 4096 ? nb : 4096);
@@ -267,6 +308,7 @@ static int bn_bwd_t(const BnArgs& a, hipStream_t st) {
   const unsigned blocks = (unsigned)((a.rows + a.rows_per_block - 1) / a.rows_per_block);
   const size_t smem = (size_t)2 * a.R * a.c * 4;
   hipLaunchKernelGGL((bn_reduce_kernel<T, 1>), dim3(blocks), dim3(256), smem, st, a);
+  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((unsigned)((2 * a.c + 31) / 32), kBnSumY), dim3(256), 0, st, a, (int)blocks);
   const long long nb = (a.rows + a.R - 1) / a.R;
   const unsigned ab = (unsigned)(nb < 4096 ? nb : 4096);
   hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ab), dim3(256), 0, st, a);
@@ -277,7 +319,7 @@ static int bn_bwd_t(const BnArgs& a, hipStream_t st) {
 
 using namespace dy;
 
-extern "C" int64_t dy_bn_workspace_bytes(int32_t c) { return c <= 0 ? -1 : (int64_t)2 * c * 8; }
+extern "C" int64_t dy_bn_workspace_bytes(int32_t c) { return c <= 0 ? -1 : (int64_t)(1 + kBnMaxSlabs) * 2 * c * 8; }  // sums + one partial per slab
 
 extern "C" int32_t dy_bn_train_fwd(const dy_bn_desc* d, dy_stream_t stream) {
   BnArgs a{};

@@ -392,7 +392,8 @@ int32_t dy_colsum(const void* z, float* out, int64_t rows, int32_t c, int32_t ld
  *   does: r = (1 - momentum) * r + momentum * stat, the variance unbiased.
  * Backward: dy = gradient w.r.t. y; dz = gradient w.r.t. z; dgamma / dbeta fp32[c] (optional).  With act = SILU the
  *   pre-activation is recomputed from z.  `addend` is not used (its gradient is dy * act'(u): dy_silu_bwd).
- * workspace: dy_bn_workspace_bytes(c) bytes, 8-byte aligned.  Sums are accumulated in double. */
+ * workspace: dy_bn_workspace_bytes(c) bytes (the 2c sums + one partial per reduction slab), 8-byte aligned.  Sums are
+ *   accumulated in double. */
 typedef struct dy_bn_desc {
   const void* z;
   void* y;

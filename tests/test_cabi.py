@@ -90,5 +90,5 @@ def test_new_entry_points_validate_without_gpu():
     assert h.dy_stem2_fused(ctypes.byref(L.Stem2Desc()), null) == -1
     assert h.dy_stem2_fused_supported(3, 32, 64, 640, 640, L.DY_BF16) == 1 and h.dy_stem2_fused_supported(3, 32, 64, 642, 640, L.DY_BF16) == 0
     assert h.dy_stem2_fused_supported(3, 48, 96, 640, 640, L.DY_BF16) == 0 and h.dy_stem2_fused_supported(3, 32, 64, 640, 640, L.DY_F32) == 0
-    assert h.dy_bn_workspace_bytes(64) == 2 * 64 * 8 and h.dy_bn_workspace_bytes(0) == -1
+    assert h.dy_bn_workspace_bytes(64) == (1 + 1024) * 2 * 64 * 8 and h.dy_bn_workspace_bytes(0) == -1
     assert h.dy_detection_loss_workspace_bytes(2, 340, 7, 10) > 0 and h.dy_detection_loss_workspace_bytes(0, 340, 7, 10) == -1
