@@ -29,12 +29,12 @@ __device__ __attribute__((aligned(256))) const unsigned int g_zero_page[64] = {0
 // BM x BN tile, WM x 2 waves (wave tile 64 x BN/2), STAGES LDS stages.  STAGES == 2: plain barrier per K-step, one step of
 // DMA in flight (2 workgroups per CU cover for each other).  STAGES == 3: two steps in flight behind a counted
 // s_waitcnt vmcnt(N) and a raw s_barrier (a __syncthreads() would drain the DMA), one 8-wave workgroup per CU.
-template <typename T, int BM, int BN, int STAGES>
-__global__ __launch_bounds__(BM * 2) void conv_gemm_glds_kernel(const ConvArgs p) {
+template <typename T, int BM, int BN, int STAGES, int WN = 2>
+__global__ __launch_bounds__(BM * WN) void conv_gemm_glds_kernel(const ConvArgs p) {
   constexpr int EPC = Elem<T>::EPC;
-  constexpr int NW = BM / 64 * 2;       // waves: BM/64 along M x 2 along N
+  constexpr int NW = BM / 64 * WN;      // waves: BM/64 along M x WN along N (WN = 4: 64 x BN/4 wave tiles, twice the waves per SIMD)
   constexpr int BKE = 8 * EPC;          // K elements per step (128 bytes)
-  constexpr int NFR = BN / 32;          // cout fragments per wave (wave tile 64 x BN/2)
+  constexpr int NFR = BN / WN / 16;     // cout fragments per wave (wave tile 64 x BN/WN)
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int PA = BM / 8 / NW;       // A pieces per wave per step
   constexpr int PB = BN / 8 / NW;       // W pieces per wave per step
@@ -43,12 +43,14 @@ __global__ __launch_bounds__(BM * 2) void conv_gemm_glds_kernel(const ConvArgs p
   constexpr int EG = NFR < EG0 ? NFR : EG0;          // fragments per epilogue group
   constexpr int CPP = EG * (int)sizeof(T);           // 16-byte chunks per pixel and group
   constexpr int EP_PITCH = 128 + 16;
-  static_assert(64 * EP_PITCH * NW <= STAGES * STAGE, "epilogue scratch must fit the stage memory");
+  constexpr int NH = (64 * EP_PITCH * NW <= STAGES * STAGE) ? 1 : 2;  // epilogue passes per wave tile (64 / NH pixels each)
+  constexpr int PXP = 64 / NH;
+  static_assert(PXP * EP_PITCH * NW <= STAGES * STAGE, "epilogue scratch must fit the stage memory");
 
   __shared__ __attribute__((aligned(1024))) unsigned char smem[STAGES * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;  // BM/64 x 2 wave grid
+  const int wm = wave / WN, wn = wave % WN;  // BM/64 x WN wave grid
   const int lq = lane >> 4, lr = lane & 15;
   const unsigned L = xcd_remap(blockIdx.x, (unsigned)p.nblk);
   const int tileN = (int)(L % (unsigned)p.tilesN);
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(BM * 2) void conv_gemm_glds_kernel(const ConvArgs p
   f32x4 acc[NFR][4];
 #pragma unroll
   for (int j = 0; j < NFR; ++j) {
-    const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + tileN * BN + wn * (BN / 2) + j * 16 + lq * 4);
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + tileN * BN + wn * (BN / WN) + j * 16 + lq * 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[j][i] = bb;
   }
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(BM * 2) void conv_gemm_glds_kernel(const ConvArgs p
   const int swz = lr >> 1;  // (row >> 1) & 7 of every fragment row this lane reads (fragment bases are multiples of 16)
   auto compute = [&](int stage) {
     const unsigned char* sa = smem + stage * STAGE + (wm * 64 + lr) * 128;
-    const unsigned char* sb = smem + stage * STAGE + A_BYTES + (wn * (BN / 2) + lr) * 128;
+    const unsigned char* sb = smem + stage * STAGE + A_BYTES + (wn * (BN / WN) + lr) * 128;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int slot = ((s * 4 + lq) ^ swz) * 16;
@@ -181,60 +183,64 @@ __global__ __launch_bounds__(BM * 2) void conv_gemm_glds_kernel(const ConvArgs p
   __syncthreads();  // stage memory becomes the per-wave transpose scratch
 
   // ---- epilogue ----
-  unsigned char* escr = smem + wave * (64 * EP_PITCH);
+  unsigned char* escr = smem + wave * (PXP * EP_PITCH);
   T* __restrict__ yg = reinterpret_cast<T*>(p.y);
   const T* __restrict__ rg = reinterpret_cast<const T*>(p.res);
   const int m0 = tileM * BM + wm * 64;
-  const int n0 = tileN * BN + wn * (BN / 2);
+  const int n0 = tileN * BN + wn * (BN / WN);
 #pragma unroll
   for (int g = 0; g < NFR / EG; ++g) {
 #pragma unroll
-    for (int jj = 0; jj < EG; ++jj) {
-      const int j = g * EG + jj;
+    for (int half = 0; half < NH; ++half) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-        if (p.act == DY_ACT_SILU) {
+      for (int jj = 0; jj < EG; ++jj) {
+        const int j = g * EG + jj;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
-        }
-        if (rg != nullptr) {
-          const int m = m0 + i * 16 + lr;
-          if (m < p.M) {
+        for (int ii = 0; ii < 4 / NH; ++ii) {
+          const int i = half * (4 / NH) + ii;
+          float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
+          if (p.act == DY_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
+          }
+          if (rg != nullptr) {
+            const int m = m0 + i * 16 + lr;
+            if (m < p.M) {
+              typedef __attribute__((ext_vector_type(4))) T t4;
+              const t4 rv = *reinterpret_cast<const t4*>(rg + (size_t)m * (size_t)p.ldres + (size_t)(n0 + j * 16 + lq * 4));
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += Elem<T>::to_f32(rv[e]);
+            }
+          }
+          unsigned char* sp = escr + (ii * 16 + lr) * EP_PITCH + (jj * 16 + lq * 4) * (int)sizeof(T);
+          if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<f32x4*>(sp) = f32x4{v[0], v[1], v[2], v[3]};
+          } else {
             typedef __attribute__((ext_vector_type(4))) T t4;
-            const t4 rv = *reinterpret_cast<const t4*>(rg + (size_t)m * (size_t)p.ldres + (size_t)(n0 + j * 16 + lq * 4));
+            t4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += Elem<T>::to_f32(rv[e]);
+            for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f32(v[e]);
+            *reinterpret_cast<u32x2*>(sp) = __builtin_bit_cast(u32x2, o);
           }
         }
-        unsigned char* sp = escr + (i * 16 + lr) * EP_PITCH + (jj * 16 + lq * 4) * (int)sizeof(T);
-        if constexpr (sizeof(T) == 4) {
-          *reinterpret_cast<f32x4*>(sp) = f32x4{v[0], v[1], v[2], v[3]};
-        } else {
-          typedef __attribute__((ext_vector_type(4))) T t4;
-          t4 o;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f32(v[e]);
-          *reinterpret_cast<u32x2*>(sp) = __builtin_bit_cast(u32x2, o);
+      for (int k = 0; k < (PXP * CPP + 63) / 64; ++k) {  // PXP pixels x CPP chunks of 16 bytes
+        const int idx = k * 64 + lane;
+        const int px = idx / CPP, cc = idx % CPP;
+        const int m = m0 + half * PXP + px;
+        if (px < PXP && m < p.M) {
+          const u32x4 val = *reinterpret_cast<const u32x4*>(escr + px * EP_PITCH + cc * 16);
+          *reinterpret_cast<u32x4*>(yg + (size_t)m * (size_t)p.ldy + (size_t)(n0 + g * EG * 16 + cc * EPC)) = val;
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int k = 0; k < CPP; ++k) {  // 64 pixels x CPP chunks of 16 bytes
-      const int idx = k * 64 + lane;
-      const int px = idx / CPP, cc = idx % CPP;
-      const int m = m0 + px;
-      if (m < p.M) {
-        const u32x4 val = *reinterpret_cast<const u32x4*>(escr + px * EP_PITCH + cc * 16);
-        *reinterpret_cast<u32x4*>(yg + (size_t)m * (size_t)p.ldy + (size_t)(n0 + g * EG * 16 + cc * EPC)) = val;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
@@ -459,14 +465,14 @@ static int launch_glds_persist(const ConvArgs& a, hipStream_t st) {
   return check_launch("conv_gemm_glds_persist_kernel");
 }
 
-template <typename T, int BM, int BN, int STAGES>
+template <typename T, int BM, int BN, int STAGES, int WN = 2>
 static int launch_glds(const ConvArgs& a, hipStream_t st) {
   ConvArgs p = a;
   const int tilesM = (p.M + BM - 1) / BM;
   p.tilesN = p.Cout / BN;
   p.nblk = tilesM * p.tilesN;
-  auto kern = conv_gemm_glds_kernel<T, BM, BN, STAGES>;
-  hipLaunchKernelGGL(kern, dim3((unsigned)p.nblk), dim3(BM * 2), 0, st, p);  // static LDS only (up to 144 KiB)
+  auto kern = conv_gemm_glds_kernel<T, BM, BN, STAGES, WN>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)p.nblk), dim3(BM * WN), 0, st, p);  // static LDS only (up to 144 KiB)
   return check_launch("conv_gemm_glds_kernel");
 }
 
@@ -476,13 +482,14 @@ static int launch_glds_dtype(const ConvArgs& a, hipStream_t st) {
   // short K (<= 9 steps, the 64-channel stride-2 layers on 160x160 maps: thousands of tiles) measured faster one tile per
   // workgroup; everything else gains 3-14 % from the persistent walk with the next tile's first K-step prefetched
   const bool persist = big != 2 && (big == 3 || a.Kpad > 9 * 8 * (16 / (int)sizeof(T)));
-  // 256 x 256 tiles (8 waves of 64 x 128, one workgroup per CU) halve the gathered-operand bytes per flop: 4-19 % faster on
+  // 256 x 256 tiles (one workgroup per CU; sixteen waves of 64 x 64 = four per SIMD measured 5-14 % faster than eight of 64 x 128:
+  // the kernels are wait-bound, not LDS-bound) halve the gathered-operand bytes per flop: 4-19 % faster on
   // the wide 1x1 layers and the 256-cout stride-2 layers at throughput batch sizes (512->256 @40x40: 241 -> 204 us); slower on
   // 256->512 stride 2 (measured 2x) and pointless when the tile count cannot fill the CUs.  Every output element is still
   // accumulated over K in the same order, so the choice does not change results.  DYOLO_GLDS_BIG=5 turns it off.
   if (big != 5 && big != 2 && big != 3 && a.Cout % 256 == 0 && (a.ks == 1 || (a.stride == 2 && a.Cout == 256)) &&
       (long long)a.M * a.Cout >= 256ll * 256 * 512)
-    return launch_glds<T, 256, 256, 2>(a, st);
+    return big == 7 ? launch_glds<T, 256, 256, 2>(a, st) : launch_glds<T, 256, 256, 2, 4>(a, st);  // 16 waves of 64 x 64 (7: 8 waves of 64 x 128)
   if (a.Cout % 128 == 0) {
     if (big == 1) return launch_glds<T, 256, 128, 3>(a, st);
     return persist ? launch_glds_persist<T, 128>(a, st) : launch_glds<T, 128, 128, 2>(a, st);
