@@ -492,6 +492,10 @@ static int launch_glds_dtype(const ConvArgs& a, hipStream_t st) {
     return big == 7 ? launch_glds<T, 256, 256, 2>(a, st) : launch_glds<T, 256, 256, 2, 4>(a, st);  // 16 waves of 64 x 64 (7: 8 waves of 64 x 128)
   if (a.Cout % 128 == 0) {
     if (big == 1) return launch_glds<T, 256, 128, 3>(a, st);
+    // eight waves of 64 x 32 (two workgroups per CU = four waves per SIMD) measured 5-12 % faster than the persistent
+    // four-wave 64 x 64 kernel with its cross-tile prefetch (256->512 stride 2 @40x40: 360 -> 315 us): wait-bound kernels
+    // gain more from waves to switch to than from fewer LDS reads per MFMA.  DYOLO_GLDS_BIG=9: the four-wave kernels.
+    if (big != 9 && big != 2 && big != 3) return launch_glds<T, 128, 128, 2, 4>(a, st);
     return persist ? launch_glds_persist<T, 128>(a, st) : launch_glds<T, 128, 128, 2>(a, st);
   }
   return persist ? launch_glds_persist<T, 64>(a, st) : launch_glds<T, 128, 64, 2>(a, st);
