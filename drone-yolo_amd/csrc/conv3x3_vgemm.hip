@@ -579,7 +579,7 @@ static int launch_vgemm(const ConvArgs& a, hipStream_t st) {
   p.nblk = g.tilesM * p.tilesN;
   int grid = 256;
   if (grid > p.nblk) grid = p.nblk;
-  // DYOLO_VGEMM_VAR (experiments): 16 / 8 = always / never the 16-wave variant, 1 = prefetch the next step's pixel fragments into registers (measured +-2 %),
+  // DYOLO_VGEMM_VAR (experiments): 8 = the 8-wave kernel instead of the 16-wave one, 1 = prefetch the next step's pixel fragments into registers (measured +-2 %),
   // 11 / 12 = timing probes without MFMAs / without LDS reads (wrong results)
   static const int var = getenv("DYOLO_VGEMM_VAR") ? atoi(getenv("DYOLO_VGEMM_VAR")) : 0;
   const bool narrow = g.S <= 6 * 64;  // maps up to 62 wide: 48 KiB halo stages leave room for a third weight stage
@@ -595,9 +595,9 @@ static int launch_vgemm(const ConvArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((conv3x3_vgemm_kernel<T, 6, 3, false, 1>), gr, bl, 0, st, p, g);
   } else if (var == 12) {
     hipLaunchKernelGGL((conv3x3_vgemm_kernel<T, 6, 3, false, 2>), gr, bl, 0, st, p, g);
-  } else if (var == 16 || (var != 8 && sizeof(T) == 2 && g.nchunk >= 4)) {
-    // deep K (cin >= 256): sixteen waves of 32 x 64 hide more of the per-step waits (256->128 @40x40 280 -> 259 us,
-    // 256->256 @20x20 147 -> 139 us); with two chunks the longer epilogue eats the gain (128->128 @40x40 155 -> 160 us)
+  } else if (var != 8 && sizeof(T) == 2) {
+    // sixteen waves of 32 x 64 hide more of the per-step waits than eight of 64 x 64: 3-5 % faster on every shape in an
+    // alternating A/B (tools/ab_conv.sh; 128->128 @40x40 160 -> 151 us, 256->256 @20x20 145 -> 138 us)
     hipLaunchKernelGGL((conv3x3_vgemm16_kernel<T, 3, 3>), gr, dim3(1024), 0, st, p, g);
   } else {
     hipLaunchKernelGGL((conv3x3_vgemm_kernel<T, 6, 3, false>), gr, bl, 0, st, p, g);
