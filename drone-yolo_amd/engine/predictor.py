@@ -46,6 +46,7 @@ class CompiledForward:
         self.nms: Optional[H.NmsBuffers] = None
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.static_in: Optional[torch.Tensor] = None
+        self.weights_sig = None  # BaseModel.weights_signature() of the weights this plan baked in
 
 
 class DetectionPredictor:
@@ -146,6 +147,12 @@ class DetectionPredictor:
         """Run one batch; outputs stay on the device in the returned object's ``nms`` buffers."""
         key = (tuple(im.shape), self.dtype)
         cf = self._compiled.get(key)
+        sig = self.model.weights_signature()
+        if cf is not None and cf.weights_sig != sig:
+            # the recorded plan (and its hipGraph) holds device pointers to the weight packs as they were at record time;
+            # the reference predictor always runs the live model, so re-record after load_state_dict / training / .to()
+            self._compiled.pop(key)
+            cf = None
         if cf is not None:  # the recorded dy_scale_boxes launch reads this device tensor: refresh it when the source geometry changed
             bp = self._box_params(im.shape[2], im.shape[3])
             if bp != cf.box_key:
@@ -153,6 +160,7 @@ class DetectionPredictor:
                 cf.box_key = bp
         if cf is None:
             cf = self._compiled[key] = self._record(im)  # recording also executes the launches
+            cf.weights_sig = self.model.weights_signature()  # after recording: packing may itself touch caches
             if self.args["graph"]:
                 self._capture(cf, im)
             return cf

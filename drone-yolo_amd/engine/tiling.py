@@ -56,6 +56,7 @@ class TiledPredictor:
         tiles = torch.empty((k, 3, self.tile, self.tile), dtype=torch.float32, device=self.device)
         H.check(lib().dy_tiles_u8_to_nchw_f32(frame.data_ptr(), offs_d.data_ptr(), tiles.data_ptr(), k, hf, wf, self.tile, self.tile, 1, 114.0, stream))
         self.pred.letterbox_info = None
+        self.last_tiles = tiles  # the tile batch of the last frame (tests re-run the per-tile pass on it)
         cf = self.pred.forward_device(tiles)
         md = cf.nms.out.shape[1]
         merged_in = torch.empty((1, 4 + self.nc, k * md), dtype=torch.float32, device=self.device)

@@ -6,15 +6,15 @@ Reference: ``torch_safe_load`` / ``attempt_load_one_weight`` (ultralytics/nn/tas
 unpickler resolves every ``ultralytics.*`` class name to the same-named class of this package when it has one (Conv,
 C2f, SPPF, RepVGGBlock, Detect, DetectionModel ... keep the reference's attribute and child names, so the restored objects
 are ordinary ``nn.Module``s whose ``state_dict()`` has the reference's keys) and to an inert placeholder otherwise
-(trainer arguments, loss objects, callbacks).  Only ``torch``, ``collections``, ``numpy`` reconstruction helpers and those
-classes can be instantiated: stricter than the reference's own ``torch.load``.
+(trainer arguments, loss objects, callbacks).  Globals are resolved through an EXACT (module, name) allow-list — tensor /
+storage / parameter rebuild helpers, ``OrderedDict``, numpy array reconstruction, ``torch.nn.modules.*`` layer classes and
+a few builtin containers; dotted names (``torch`` + ``serialization.os.system``) are refused, as is everything else.
 
 The result is turned into THIS package's ``DetectionModel`` built from the pickled model's ``yaml`` dict and loaded with
 the pickled weights (fp32); BatchNorm eps / momentum are set by ``initialize_weights`` as in the reference.
 """
 from __future__ import annotations
 
-import importlib
 import pickle
 import types
 from typing import Any, Dict, Tuple
@@ -36,9 +36,22 @@ class _Placeholder:
         return self
 
 
-_ALLOWED_PREFIXES = ("torch", "collections", "numpy", "_codecs", "builtins", "pathlib", "argparse", "copyreg", "types")
-_BUILTINS_OK = {"set", "frozenset", "dict", "list", "tuple", "int", "float", "bool", "str", "bytes", "bytearray", "complex", "slice", "range", "object",
-                "getattr"}
+# EXACT (module, name) pairs that may be resolved while reading a checkpoint.  A prefix allow-list is not enough: pickle
+# resolves dotted names attribute by attribute, so ("torch", "serialization.os.system") would walk out of torch; every
+# name with a "." in it is refused outright, and nothing callable beyond tensor / container reconstruction is reachable.
+_TORCH_STORAGES = ("FloatStorage", "HalfStorage", "BFloat16Storage", "DoubleStorage", "LongStorage", "IntStorage", "ShortStorage", "CharStorage",
+                   "ByteStorage", "BoolStorage")
+_TORCH_DTYPES = ("float16", "float32", "float64", "bfloat16", "int8", "uint8", "int16", "int32", "int64", "bool", "half", "float", "double", "long", "int")
+_EXACT = {("collections", "OrderedDict"), ("torch", "Size"), ("torch", "device"),
+          ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_parameter"), ("torch._utils", "_rebuild_parameter_with_state"),
+          ("torch._utils", "_rebuild_tensor"), ("torch.nn.parameter", "Parameter"),
+          ("numpy", "ndarray"), ("numpy", "dtype"),
+          ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+          ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"),
+          ("pathlib", "PosixPath"), ("pathlib", "PurePosixPath"), ("_codecs", "encode")}
+_EXACT |= {("torch", n) for n in _TORCH_STORAGES} | {("torch", n) for n in _TORCH_DTYPES}
+_INERT = {("argparse", "Namespace"), ("pathlib", "WindowsPath"), ("pathlib", "PureWindowsPath")}  # restored as placeholders, never instantiated
+_BUILTINS_OK = {"set", "frozenset", "dict", "list", "tuple", "int", "float", "bool", "str", "bytes", "bytearray", "complex", "slice", "range", "object"}
 
 
 def _own_classes() -> Dict[str, type]:
@@ -53,16 +66,22 @@ def _own_classes() -> Dict[str, type]:
 
 class RefUnpickler(pickle.Unpickler):
     def find_class(self, module: str, name: str):
-        if module.startswith("ultralytics") or module.startswith("models.") or module == "models":
-            own = _own_classes()
-            return own.get(name.split(".")[-1], type(name.split(".")[-1], (_Placeholder,), {}))
-        root = module.split(".")[0]
-        if root in ("builtins", "__builtin__"):  # torch.save writes protocol-2 pickles: builtins appear as __builtin__
+        if "." in name or not name.isidentifier():
+            raise pickle.UnpicklingError(f"refusing dotted / malformed global {module}.{name} in a checkpoint")
+        if module.startswith("ultralytics.") or module == "ultralytics" or module.startswith("models.") or module == "models":
+            return _own_classes().get(name, type(name, (_Placeholder,), {}))
+        if module in ("builtins", "__builtin__"):  # torch.save writes protocol-2 pickles: builtins appear as __builtin__
             if name not in _BUILTINS_OK:
                 raise pickle.UnpicklingError(f"refusing builtins.{name} in a checkpoint")
             return super().find_class("builtins", name)
-        if root in _ALLOWED_PREFIXES:
+        if (module, name) in _INERT:
+            return type(name, (_Placeholder,), {})
+        if (module, name) in _EXACT:
             return super().find_class(module, name)
+        if module.startswith("torch.nn.modules."):  # layer classes of the pickled module graph (Conv2d, BatchNorm2d, SiLU, Sequential ...)
+            obj = super().find_class(module, name)
+            if isinstance(obj, type) and issubclass(obj, nn.Module):
+                return obj
         raise pickle.UnpicklingError(f"refusing to import {module}.{name} while reading a checkpoint")
 
 

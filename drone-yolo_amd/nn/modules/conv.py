@@ -58,7 +58,8 @@ class _PackedMixin:
         self.__dict__.pop("_packed", None)
 
     def train(self, mode: bool = True):
-        self.invalidate_packed()
+        if mode != self.training:  # a training phase writes the parameters through raw pointers: packs made before it are stale
+            self.invalidate_packed()
         return super().train(mode)
 
     def _load_from_state_dict(self, *args, **kwargs):
@@ -66,8 +67,11 @@ class _PackedMixin:
         return super()._load_from_state_dict(*args, **kwargs)
 
     def _apply(self, fn, *args, **kwargs):
-        self.invalidate_packed()
-        return super()._apply(fn, *args, **kwargs)
+        before = [(t.data_ptr(), t.dtype, t.device) for t in list(self.parameters()) + list(self.buffers())]
+        out = super()._apply(fn, *args, **kwargs)
+        if before != [(t.data_ptr(), t.dtype, t.device) for t in list(self.parameters()) + list(self.buffers())]:
+            self.invalidate_packed()  # .to(device) / .half(): a no-op move (second predictor on the same model) keeps the packs
+        return out
 
 
 def _require_eval(m: nn.Module) -> None:

@@ -270,12 +270,42 @@ class BaseModel(nn.Module):
         s = self._cum_stride[i]
         return int(round(h / s)), int(round(w / s))
 
+    _PACK_CACHES = ("_packed", "_block_cache", "_tail_cache", "_first_cache", "_stem2_cache")
+
+    def drop_packed(self) -> None:
+        """Forget every packed (BatchNorm-folded, device-layout) copy of the weights and advance the weights epoch that
+        recorded launch plans are keyed on (``weights_signature``)."""
+        self.__dict__["_weights_epoch"] = self.__dict__.get("_weights_epoch", 0) + 1
+        self.__dict__.pop("_sig_tensors", None)
+        for m in self.modules():
+            for k in self._PACK_CACHES:
+                m.__dict__.pop(k, None)
+
+    def weights_signature(self):
+        """Changes whenever the weights a recorded pass baked in may have changed: storage identity and torch's in-place
+        version counter of every parameter / buffer (load_state_dict, .to(), in-place edits) plus the weights epoch
+        (train() <-> eval() transitions: the trainer's kernels write parameters through raw pointers, which torch's
+        version counters cannot see)."""
+        ts = self.__dict__.get("_sig_tensors")
+        if ts is None:  # the module walk costs ~1 ms; the cached list ~60 us per pass
+            ts = self.__dict__["_sig_tensors"] = list(self.parameters()) + list(self.buffers())
+        return (self.__dict__.get("_weights_epoch", 0), tuple((t.data_ptr(), t._version) for t in ts))
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop("_sig_tensors", None)
+        return super()._apply(fn, *args, **kwargs)
+
+    def train(self, mode: bool = True):
+        changed = mode != self.training
+        super().train(mode)
+        if changed:
+            self.drop_packed()
+        return self
+
     def fuse(self, verbose=True):
         """Reference tasks.py:193-221 folds Conv+BN in place; here folding happens when weights are
         packed for the device, so this only drops stale packs and reports."""
-        for m in self.modules():
-            if hasattr(m, "invalidate_packed"):
-                m.invalidate_packed()
+        self.drop_packed()
         return self
 
     def is_fused(self, thresh=10):

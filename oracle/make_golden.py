@@ -467,7 +467,8 @@ def train_vectors(R):
 
     out = {}
     for tag, yname, scale, nc, (b, h, w), seed in [("tn64", "yolov8-p2-repvgg.yaml", "n", 10, (2, 64, 64), 201),
-                                                   ("tn96", "yolov8-p2-repvgg.yaml", "n", 10, (3, 96, 128), 202)]:
+                                                   ("tn96", "yolov8-p2-repvgg.yaml", "n", 10, (3, 96, 128), 202),
+                                                   ("ts160", "yolov8-p2-repvgg.yaml", "s", 10, (2, 160, 160), 203)]:  # config 3's model at a reduced size
         torch.manual_seed(0)
         model, _ = build_reference_model(R, yname, scale, nc)
         d = our_yaml(yname, scale, nc)
@@ -537,6 +538,100 @@ def train_vectors(R):
     np.savez_compressed(OUT / "train.npz", **out)
 
 
+
+# ---- full-size configurations (BASELINE.json configs 2, 4, 5): reference outputs at the sizes the device tests run -----------------
+def _ref_model(R, yname, scale, nc):
+    torch.manual_seed(0)
+    model, _ = build_reference_model(R, yname, scale, nc)
+    return model, our_yaml(yname, scale, nc), {k: v for k, v in model.state_dict().items()}
+
+
+def big_vectors(R):
+    """tests/golden/big.npz — (a) s640b4 / s640b4lo: Drone-YOLO-s with EXACTLY the weights and input recipe bench.py times
+    (bench.synthetic_state_dict seed 0 + the calibrated BatchNorm statistics of bench_data/, torch.rand seed 1000), four
+    640x640 images: the parity gate bench.py prints next to its throughput ("lo": class bias 1.5 lower, so that the kept
+    counts stay below max_det); (b) l1280t8: BASELINE config 4, Drone-YOLO-l on the eight 1280x1280 tiles of a seeded
+    3840x2160 uint8 frame (A = 136,000 per tile): per-tile rows of the REAL reference + the merge the build defines,
+    restated by the oracle chain; (c) x1536: BASELINE config 5's shape, Drone-YOLO-x 1536x1536 (A = 195,840) in fp32 —
+    the expectation the fp8 path's stated tolerance is measured against.  Weights: random conv weights from the seed with
+    BatchNorm statistics calibrated to the activations (oracle/calibrate_synthetic.py), i.e. a network whose scores depend
+    on the input the way a trained one's do; inputs are regenerated from seeds on both sides."""
+    import bench
+
+    out = {}
+
+    def run(tag, yname, scale, nc, x, input_seed=None, bias_shift=0.0, check_oracle=True):
+        model, d, template = _ref_model(R, yname, scale, nc)
+        name = yname.replace("yolov8", f"yolov8{scale}")
+        shim = types.SimpleNamespace(yaml={"yaml_file": name, "nc": nc}, state_dict=lambda: template)
+        sd = bench.synthetic_state_dict(shim, 0)
+        bias = float(np.load(ROOT / "bench_data" / f"{os.path.splitext(name)[0]}_nc{nc}_seed0_bn.npz")["__cls_bias__"]) + bias_shift
+        if bias_shift:
+            sd = bench.synthetic_state_dict(shim, 0, cls_bias=bias)
+        model.load_state_dict(sd)
+        R.tu.initialize_weights(model)
+        model.eval()
+        model.fuse(verbose=False)
+        ys = []
+        with torch.no_grad():
+            for i in range(len(x)):  # one image at a time: bounded memory at 1280 / 1536
+                ys.append(model(x[i : i + 1])[0])
+            y = torch.cat(ys)
+            if check_oracle:
+                oy, _ = O.forward(d, sd, x[:1], fused=True)
+                rel_tol_check(f"{tag} decoded y image 0 (fused)", oy, y[:1], tol=5e-5)
+        # max_time_img: the reference breaks out of its per-image loop on a wall-clock limit (ops.py:328-330); the stub NMS
+        # primitive under it is a slow numpy loop, so give it time — a fixture must not depend on the clock
+        ref_det = R.ops.non_max_suppression(y.clone(), 0.25, 0.7, max_det=300, nc=nc, max_time_img=60.0)
+        our_det, our_idx = O.non_max_suppression(y.clone(), 0.25, 0.7, max_det=300, nc=nc, return_index=True)
+        for a_, b_ in zip(our_det, ref_det):
+            assert torch.equal(a_, b_), f"{tag}: oracle NMS rows differ from the reference's"
+        frac = float((y[:, 4:].amax(1) > 0.25).float().mean())
+        print(f"[{tag}] {name} input={tuple(x.shape)} A={y.shape[2]} cls_bias={bias:.3f} candidates {frac * 100:.2f} %  kept {[len(r) for r in ref_det]}")
+        out[f"{tag}__meta"] = np.array(repr(dict(yaml=yname, scale=scale, nc=nc, shape=(x.shape[0], x.shape[2], x.shape[3]), weights="bench.synthetic_state_dict seed 0",
+                                                 **({"seed": input_seed} if input_seed is not None else {}),
+                                                 cls_bias=round(bias, 4), bias_shift=bias_shift, params=sum(p.numel() for p in model.parameters()))))
+        out[f"{tag}__n"] = np.array([len(r) for r in ref_det])
+        out[f"{tag}__det"] = np.concatenate([tnp(r) for r in ref_det], 0)
+        out[f"{tag}__det_idx"] = np.concatenate([tnp(r) for r in our_idx], 0)
+        out[f"{tag}__y_sub"] = tnp(y[:, :, ::199])
+        out[f"{tag}__y_sum"] = np.array([float(y.double().sum()), float(y.double().abs().sum()), float((y.double() ** 2).sum())])
+        return ref_det
+
+    # (a) the metric's own configuration: bench.py's rank-0 input recipe
+    x = torch.rand(4, 3, 640, 640, generator=torch.Generator().manual_seed(1000))
+    run("s640b4", "yolov8-p2-repvgg.yaml", "s", 10, x, input_seed=1000)  # meta seed = the seed of torch.rand(shape) that makes the input
+    run("s640b4lo", "yolov8-p2-repvgg.yaml", "s", 10, x, input_seed=1000, bias_shift=-1.5, check_oracle=False)
+
+    # (b) config 4: tiles of a 3840x2160 BGR uint8 frame, stride 1024 / last tile clamped (engine/tiling.py::tile_offsets)
+    tile, hf, wf = 1280, 2160, 3840
+    frame = np.random.default_rng(107).integers(0, 256, (hf, wf, 3), dtype=np.uint8)
+    offs = [(y, xx) for y in (0, 880) for xx in (0, 1024, 2048, 2560)]
+    xt = torch.stack([torch.from_numpy(np.ascontiguousarray(frame[y : y + tile, xx : xx + tile, ::-1].transpose(2, 0, 1))).float() / 255 for y, xx in offs])
+    det = run("l1280t8", "yolov8-p2-repvgg.yaml", "l", 10, xt)
+    rows = []
+    for (oy, ox), r in zip(offs, det):
+        r = r.clone()
+        r[:, :4] = O.clip_boxes(r[:, :4], (tile, tile))
+        r[:, [0, 2]] += ox
+        r[:, [1, 3]] += oy
+        rows.append(r)
+    allr = torch.cat(rows)
+    pred = torch.zeros(1, 14, len(allr))
+    pred[0, 0], pred[0, 1] = (allr[:, 0] + allr[:, 2]) / 2, (allr[:, 1] + allr[:, 3]) / 2
+    pred[0, 2], pred[0, 3] = allr[:, 2] - allr[:, 0], allr[:, 3] - allr[:, 1]
+    pred[0, 4 + allr[:, 5].long(), torch.arange(len(allr))] = allr[:, 4]
+    merged, _ = O.non_max_suppression(pred, 0.0, 0.7, max_det=1000, nc=10, return_index=True)
+    out["l1280t8__merged"] = tnp(merged[0])
+    out["l1280t8__frame"] = np.array(repr(dict(rng_seed=107, hw=(hf, wf), tile=tile, overlap=0.2, offsets=offs, merge_iou=0.7, merge_max_det=1000)))
+    print(f"  tiles -> {len(allr)} rows, merged {len(merged[0])}")
+
+    # (c) config 5's shape in fp32
+    x = torch.rand(1, 3, 1536, 1536, generator=torch.Generator().manual_seed(108))
+    run("x1536", "yolov8-p2-repvgg.yaml", "x", 10, x, input_seed=108)
+    np.savez_compressed(OUT / "big.npz", **out)
+
+
 def checkpoint_fixture(R):
     """A checkpoint exactly as the reference's trainer writes it (engine/trainer.py:514-545: pickled module graph, fp16,
     under 'ema'), for a tiny custom scale so that the fixture stays small; plus the outputs the reference computes from it."""
@@ -587,6 +682,8 @@ if __name__ == "__main__":
         train_vectors(R)
     elif "--loss-only" in sys.argv:
         loss_vectors(R)
+    elif "--big-only" in sys.argv:
+        big_vectors(R)
     else:
         per_op(R)
         nms_cases(R)
@@ -594,5 +691,6 @@ if __name__ == "__main__":
         loss_vectors(R)
         train_vectors(R)
         checkpoint_fixture(R)
+        big_vectors(R)
     for f in sorted(OUT.glob("*.npz")):
         print(f"wrote {f.relative_to(ROOT)}  {f.stat().st_size / 1024:.1f} KiB")

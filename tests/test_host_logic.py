@@ -171,3 +171,32 @@ def test_reference_checkpoint_reader():
             return (os.system, ("true",))
     with pytest.raises(pickle.UnpicklingError):
         RefUnpickler(io.BytesIO(pickle.dumps(_E()))).load()
+
+
+def test_checkpoint_unpickler_refuses_bypass_payloads():
+    """a prefix allow-list let protocol-4 dotted globals walk out of torch / numpy
+    (('torch', 'serialization.os.getcwd') resolved to os.getcwd).  The allow-list is exact now: each of the three verified
+    payloads, builtins.getattr and types.FunctionType must raise UnpicklingError without running anything."""
+    import io
+    import pickle
+
+    import pytest
+
+    from drone_yolo_amd.nn.checkpoint import RefUnpickler
+
+    def stack_global(module: str, name: str, call: bool = True) -> bytes:
+        def s(x):
+            b = x.encode()
+            return b"\x8c" + bytes([len(b)]) + b
+        return b"\x80\x04" + s(module) + s(name) + b"\x93" + (b")R" if call else b"") + b"."
+
+    for module, name in [("torch", "serialization.os.getcwd"), ("numpy", "testing._private.utils.runstring"), ("types", "FunctionType"),
+                         ("builtins", "getattr"), ("torch", "load"), ("torch.serialization", "os"), ("copyreg", "_reconstructor"),
+                         ("torch.nn.modules.module", "torch"), ("torch.nn.modules.conv", "F"), ("argparse", "ArgumentParser"), ("os", "system")]:
+        with pytest.raises(pickle.UnpicklingError):
+            RefUnpickler(io.BytesIO(stack_global(module, name))).load()
+    # what a checkpoint legitimately needs still resolves
+    import collections
+
+    assert RefUnpickler(io.BytesIO(stack_global("collections", "OrderedDict"))).load() == collections.OrderedDict()
+    assert RefUnpickler(io.BytesIO(stack_global("torch.nn.modules.conv", "Conv2d", call=False))).load() is __import__("torch").nn.Conv2d

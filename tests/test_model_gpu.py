@@ -154,10 +154,142 @@ def test_end_to_end_against_reference_vectors(tag, dtype, device):
                 assert abs(score_of[int(got_idx[k])] - float(exp_rows[i][k, 4])) < 2e-6, f"{tag} image {i}: order differs at rank {k}"
         assert iou_min >= 0.999, iou_min
     else:
-        # reduced-precision storage: scores near conf / near-ties may flip; demand that the bulk agrees
-        floor = 0.80 if dtype == torch.bfloat16 else 0.93
-        assert match >= floor, f"{tag} [{dtype}]: only {match:.3f} of the reference detections reproduced"
-        assert iou_min >= (0.80 if dtype == torch.bfloat16 else 0.95), iou_min
+        # reduced-precision storage: a score within rounding of conf or of a neighbour may flip.  Floors = the measured level
+        # (profiles/r01_parity_report.jsonl, r02) minus a margin: bf16 may lose 3 % of the reference detections (at least one:
+        # the small cases keep 2..17 boxes), fp16 1 %; matched boxes IoU >= 0.998 (bf16) / 0.9995 (fp16)
+        tol, iou_floor = (0.03, 0.998) if dtype == torch.bfloat16 else (0.01, 0.9995)
+        for i, st in enumerate(stats):
+            n_ref = max(len(exp_idx[i]), 1)
+            allowed = max(1, int(tol * n_ref))
+            assert st[0] >= 1.0 - allowed / n_ref - 1e-9, f"{tag} [{dtype}] image {i}: only {st[0]:.4f} of {n_ref} reference detections reproduced"
+        assert iou_min >= iou_floor, f"{tag} [{dtype}]: min IoU {iou_min:.5f} < {iou_floor}"
+
+
+def _bench_model(meta, device):
+    """The model bench.py times: Drone-YOLO of the fixture's scale with bench.synthetic_state_dict(seed 0) weights."""
+    import bench
+
+    d = load_yaml(meta["yaml"], meta["scale"], meta["nc"])
+    d["yaml_file"] = meta["yaml"].replace("yolov8", f"yolov8{meta['scale']}")
+    model = D.DetectionModel(dict(d), nc=meta["nc"], verbose=False)
+    model.load_state_dict(bench.synthetic_state_dict(model, seed=0, cls_bias=meta["cls_bias"] if meta.get("bias_shift") else None))
+    return model
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("tag", ["s640b4", "s640b4lo"])
+def test_bench_configuration_against_reference_rows(tag, dtype, device):
+    """BASELINE config 2 exactly as bench.py runs it (its weights, its input recipe, 4 images of 640x640) against the rows the
+    REAL reference computed on CPU in fp32 (tests/golden/big.npz).  This is the gate bench.py prints as `parity`; the bar
+    (class / index exact, IoU >= 0.999) is asserted for fp32 and for the headline dtype fp16; bf16 is held to its measured level."""
+    from drone_yolo_amd.utils import parity as PR
+
+    meta, x, exp_rows, exp_idx = PR.golden_case("big.npz", tag)
+    model = _bench_model(meta, device)
+    pred = D.engine.predictor.DetectionPredictor(model, dict(conf=0.25, iou=0.7, max_det=300, dtype=dtype, device=0))
+    cf = pred.forward_device(pred.preprocess(x))
+    torch.cuda.synchronize()
+    g = golden("big.npz")
+    y_sub = cf.pred[:, :, ::199].cpu()
+    box_err = float((y_sub[:, :4] - torch.from_numpy(g[f"{tag}__y_sub"])[:, :4]).abs().max())
+    cls_err = float((y_sub[:, 4:] - torch.from_numpy(g[f"{tag}__y_sub"])[:, 4:]).abs().max())
+    par = PR.detection_parity(cf.nms, exp_rows, exp_idx)
+    _report(f"bench-config {tag}", {"dtype": str(dtype), "box_max_err_px": box_err, "cls_max_err": cls_err, **par})
+    if dtype == torch.float32:
+        assert box_err < 2e-2 and cls_err < 1e-4, (box_err, cls_err)
+        assert par["counts_equal"] and par["kept_sets_identical"] and par["match_rate"] == 1.0 and par["iou_min"] >= 0.999, par
+    elif dtype == torch.float16:  # the headline dtype: IoU bar met, at most 1 % of the reference detections lost to score near-ties
+        assert par["match_rate"] >= 0.99 and par["iou_min"] >= 0.999, par
+    else:
+        assert par["match_rate"] >= 0.97 and par["iou_min"] >= 0.998, par
+
+
+def test_plan_follows_the_live_weights(device):
+    """a recorded LaunchPlan / hipGraph bakes in pointers to the weight packs.  After load_state_dict (and after a
+    train() <-> eval() round trip) the predictor must re-record instead of replaying stale weights: its output equals a
+    fresh predictor's, as the reference predictor always runs the live model."""
+    g = golden("e2e.npz")
+    m, d, sd, model, x = _build("n128", g, device)
+    x = x.to(device)
+    pred = D.engine.predictor.DetectionPredictor(model, dict(conf=0.25, iou=0.7, dtype=torch.bfloat16, device=0, graph=True))
+    y0 = pred.forward_device(x).pred.clone()
+    assert torch.equal(pred.forward_device(x).pred, y0)  # replay path
+    sd2 = O.seeded_state_dict(model.state_dict(), m["seed"] + 1, cls_bias=m["cls_bias"])
+    model.load_state_dict(sd2)
+    y1 = pred.forward_device(x).pred.clone()
+    fresh = D.engine.predictor.DetectionPredictor(model, dict(conf=0.25, iou=0.7, dtype=torch.bfloat16, device=0)).forward_device(x).pred
+    torch.cuda.synchronize()
+    assert not torch.equal(y1, y0) and torch.equal(y1, fresh)
+    with torch.no_grad():  # raw in-place edit of one parameter (what an optimizer kernel does, seen through torch)
+        model.model[0].conv.weight.mul_(0.5)
+    y2 = pred.forward_device(x).pred.clone()
+    fresh2 = D.engine.predictor.DetectionPredictor(model, dict(conf=0.25, iou=0.7, dtype=torch.bfloat16, device=0)).forward_device(x).pred
+    assert torch.equal(y2, fresh2) and not torch.equal(y2, y1)
+    model.train()
+    model.eval()  # a training phase happened in between as far as the predictor can tell: packs dropped, plan re-recorded
+    assert torch.equal(pred.forward_device(x).pred, fresh2)
+
+
+def test_config4_tiled_scale_l_against_reference_rows(device):
+    """BASELINE config 4 at its real size: Drone-YOLO-l, a 3840x2160 uint8 frame, eight 1280x1280 tiles (A = 136,000 per tile,
+    ~13k candidates per tile through decode, filter and NMS), cross-tile merge.  Expectation: per-tile rows of the REAL
+    reference + the oracle's merge (tests/golden/big.npz::l1280t8, computed once in the build container, 6.6 TFLOP of CPU work).
+    fp32 storage: kept sets identical per tile and after the merge; fp16: the measured level."""
+    import ast
+
+    from drone_yolo_amd.engine.tiling import TiledPredictor, tile_offsets
+    from drone_yolo_amd.utils import parity as PR
+
+    g = golden("big.npz")
+    meta, _, exp_rows, exp_idx = PR.golden_case("big.npz", "l1280t8")
+    fr = ast.literal_eval(str(g["l1280t8__frame"]))
+    hf, wf = fr["hw"]
+    assert tile_offsets(hf, wf, fr["tile"], fr["overlap"]) == [tuple(o) for o in fr["offsets"]]
+    frame = np.random.default_rng(fr["rng_seed"]).integers(0, 256, (hf, wf, 3), dtype=np.uint8)
+    model = _bench_model(meta, device)
+    exp_merged = g["l1280t8__merged"]
+    for dtype in (torch.float32, torch.float16):
+        tp = TiledPredictor(model, tile=fr["tile"], overlap=fr["overlap"], merge_iou=fr["merge_iou"], merge_max_det=fr["merge_max_det"], conf=0.25, iou=0.7,
+                            dtype=dtype, device=0)
+        res = tp(frame)
+        cf = tp.pred.forward_device(tp.last_tiles)  # the per-tile pass the merge consumed (replay of the recorded plan)
+        torch.cuda.synchronize()
+        par = PR.detection_parity(cf.nms, exp_rows, exp_idx)
+        got = res.boxes.data.cpu().numpy()
+        key = lambda r: {(round(float(b[4]), 4), int(b[5])) for b in r}  # noqa: E731
+        merged_common = len(key(got) & key(exp_merged)) / len(exp_merged)
+        _report("config4 l1280t8", {"dtype": str(dtype), **par, "merged": int(len(got)), "merged_ref": int(len(exp_merged)), "merged_common": merged_common})
+        assert res.orig_shape == (hf, wf)
+        if dtype == torch.float32:
+            assert par["counts_equal"] and par["kept_sets_identical"] and par["iou_min"] >= 0.999, par
+            assert got.shape == exp_merged.shape and np.array_equal(got[:, 5], exp_merged[:, 5])
+            assert np.allclose(got[:, :5], exp_merged[:, :5], atol=5e-2, rtol=1e-4)
+        else:
+            assert par["match_rate"] >= 0.97 and par["iou_min"] >= 0.998, par
+            assert merged_common >= 0.90, merged_common
+        del tp, cf, res
+        torch.cuda.empty_cache()
+
+
+def test_config5_shape_scale_x_1536_against_reference_rows(device):
+    """BASELINE config 5's model and shape (Drone-YOLO-x, 1536x1536, A = 195,840) in fp32 and fp16 storage against the rows the
+    REAL reference computed in fp32 (tests/golden/big.npz::x1536): the expectation the fp8 path's tolerance is stated against."""
+    from drone_yolo_amd.utils import parity as PR
+
+    meta, x, exp_rows, exp_idx = PR.golden_case("big.npz", "x1536")
+    model = _bench_model(meta, device)
+    for dtype in (torch.float32, torch.float16):
+        pred = D.engine.predictor.DetectionPredictor(model, dict(conf=0.25, iou=0.7, max_det=300, dtype=dtype, device=0))
+        cf = pred.forward_device(pred.preprocess(x))
+        torch.cuda.synchronize()
+        par = PR.detection_parity(cf.nms, exp_rows, exp_idx)
+        _report("config5-shape x1536", {"dtype": str(dtype), **par})
+        if dtype == torch.float32:
+            assert par["counts_equal"] and par["kept_sets_identical"] and par["iou_min"] >= 0.999, par
+        else:
+            assert par["match_rate"] >= 0.97 and par["iou_min"] >= 0.998, par
+        del pred, cf
+        torch.cuda.empty_cache()
 
 
 def test_replay_graph_and_api(device):

@@ -111,7 +111,7 @@ def test_e2e_vectors():
     import drone_yolo_amd as D
 
     g = golden("e2e.npz")
-    for tag in ("n64", "n128", "sf_n64", "v8n320"):
+    for tag in ("n64", "n128", "sf_n64", "v8n320", "s640"):  # s640: the one full-size fixture, re-checked here too (0.3 s of CPU)
         m = meta(g, tag)
         d = load_yaml(m["yaml"], m["scale"], m["nc"])
         model = D.DetectionModel(dict(d), nc=m["nc"], verbose=False)
@@ -132,6 +132,37 @@ def test_e2e_vectors():
         assert [len(r) for r in det] == list(g[f"{tag}__n"]), tag
         assert np.array_equal(np.concatenate([i.numpy() for i in idx]), g[f"{tag}__det_idx"]), tag
         assert np.allclose(np.concatenate([r.numpy() for r in det]), g[f"{tag}__det"], atol=2e-3), tag
+
+
+def test_bench_configuration_vectors():
+    """tests/golden/big.npz::s640b4 / s640b4lo (BASELINE config 2 with the weights and inputs bench.py times, rows computed by the
+    REAL reference): the oracle reproduces them here, and the package's seeded weight generator equals the oracle's.  The scale-l
+    1280x1280 tiles and the scale-x 1536x1536 case of the same file cost minutes of CPU each: their oracle == reference
+    check ran when make_golden.py wrote them (max |err| 0)."""
+    import bench
+    import drone_yolo_amd as D
+    from drone_yolo_amd.utils import parity as PR
+
+    g = golden("big.npz")
+    for tag in ("s640b4", "s640b4lo"):
+        m, x, exp_rows, exp_idx = PR.golden_case("big.npz", tag)
+        assert x.shape == (4, 3, 640, 640)
+        d = load_yaml(m["yaml"], m["scale"], m["nc"])
+        d["yaml_file"] = m["yaml"].replace("yolov8", f"yolov8{m['scale']}")
+        model = D.DetectionModel(dict(d), nc=m["nc"], verbose=False)
+        sd = bench.synthetic_state_dict(model, seed=0, cls_bias=m["cls_bias"] if m.get("bias_shift") else None)
+        with torch.no_grad():
+            y, _ = O.forward(d, sd, x[:2])
+        assert torch.allclose(y[:, :, ::199], torch.from_numpy(g[f"{tag}__y_sub"][:2]), atol=2e-3, rtol=1e-4), tag
+        det, idx = O.non_max_suppression(y, 0.25, 0.7, max_det=300, nc=m["nc"], return_index=True)
+        for i in range(2):
+            assert np.array_equal(idx[i].numpy(), exp_idx[i]), tag
+            assert np.allclose(PR.clip_rows(det[i].numpy(), (640, 640)), exp_rows[i], atol=2e-3), tag
+    tmpl = {"a.conv.weight": torch.zeros(8, 4, 3, 3), "a.bn.weight": torch.zeros(8), "a.bn.bias": torch.zeros(8), "a.bn.running_mean": torch.zeros(8),
+            "a.bn.running_var": torch.zeros(8), "a.bn.num_batches_tracked": torch.zeros((), dtype=torch.long), "m.cv3.0.2.bias": torch.zeros(10),
+            "m.dfl.conv.weight": torch.zeros(1, 16, 1, 1)}
+    a, b = PR.seeded_state_dict(tmpl, 9, cls_bias=-2.0), O.seeded_state_dict(tmpl, 9, cls_bias=-2.0)
+    assert all(torch.equal(a[k], b[k]) for k in tmpl)
 
 
 def test_loss_stack_vectors():
