@@ -58,8 +58,16 @@ class Model(nn.Module):
         self.overrides["model"] = weights
 
     def save(self, filename: Union[str, Path] = "saved_model.pt") -> None:
-        yaml_d = {k: v for k, v in self.model.yaml.items()}
-        torch.save({"yaml": yaml_d, "model": self.model.state_dict()}, filename)
+        """Reference engine/model.py:366-395: a checkpoint with the trainer's key layout ({epoch, ema / model, optimizer,
+        train_args, date, version ...}); the module graph is pickled in fp16 under the reference's class paths
+        (nn/checkpoint.py::save_reference_checkpoint), so both this package and the reference itself can load it."""
+        from datetime import datetime
+
+        from ..nn.checkpoint import save_reference_checkpoint
+
+        extra = {k: v for k, v in (self.ckpt or {}).items() if k in ("epoch", "best_fitness", "updates", "train_args", "train_metrics", "train_results")}
+        extra["date"] = datetime.now().isoformat()
+        save_reference_checkpoint(filename, self.model, self.model.state_dict(), extra=extra)
 
     def __call__(self, source=None, stream: bool = False, **kwargs):
         return self.predict(source, stream, **kwargs)
@@ -76,9 +84,34 @@ class Model(nn.Module):
         return self.predictor(source, stream=stream)
 
     def train(self, trainer=None, **kwargs):
-        """Reference engine/model.py:744-817. The device training step (conv dgrad/wgrad, BN batch stats,
-        TaskAlignedAssigner + v8DetectionLoss, RCCL gradient all-reduce) is SURVEY §8 a28-a36 and not built yet."""
-        raise NotImplementedError("train(): the HIP training path is not built yet; no eager-PyTorch fallback exists")
+        """Reference engine/model.py:744-817: build the trainer from the model + overrides, train, then continue with the
+        trained weights.  ``data``: a tensor dataset (.pt / dict) or "synthetic[:N]" (engine/trainer.py::load_dataset);
+        ``device="0,1,.."`` trains with one rank per GPU (child processes under torch.distributed.run, RCCL all-reduce),
+        after which rank-less this process reloads ``weights/last.pt`` — as the reference does (model.py:806-813)."""
+        from .trainer import DetectionTrainer
+
+        args = {**{k: v for k, v in self.overrides.items() if k not in ("task", "mode")}, **kwargs}
+        devs = [x for x in str(args.get("device", "")).replace("cuda:", "").split(",") if x.strip() != ""]
+        multi = len(devs) > 1
+        if multi:
+            # the ranks rebuild the model from a file: hand them the current weights
+            import tempfile
+
+            start = Path(tempfile.mkdtemp(prefix="dyolo_train_")) / "start.pt"
+            self.save(start)
+            args["model"] = str(start)
+            self.trainer = (trainer or DetectionTrainer)(overrides=args)
+        else:
+            args.setdefault("model", self.overrides.get("model"))
+            self.trainer = (trainer or DetectionTrainer)(self.model, overrides=args)
+        out = self.trainer.train()
+        last = self.trainer.last
+        if multi and last.exists():
+            self._load(str(last))
+        elif not multi:
+            self.model.eval()  # the live model carries the trained weights (flat-buffer views); packs are dropped by train() -> eval()
+        self.predictor = None
+        return out
 
     def fuse(self):
         self.model.fuse()

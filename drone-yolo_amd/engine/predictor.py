@@ -20,6 +20,7 @@ import torch
 from .. import hip_ops as H
 from ..utils import LOGGER, ops
 from ..utils.torch_utils import select_device
+from ..nn.autobackend import AutoBackend
 from .results import Results
 
 _DTYPE_NAMES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "half": torch.float16,
@@ -59,8 +60,9 @@ class DetectionPredictor:
         self.args = a
         self.device = select_device(a["device"])
         self.dtype = resolve_dtype(a["dtype"], a["half"])
-        self.model = model.to(self.device).eval()
-        self.model.requires_grad_(False)
+        # setup_model (predictor.py:300-323): AutoBackend moves the graph to the device, fuses, picks the precision and freezes it
+        self.backend = AutoBackend(model, device=self.device, fp16=bool(a["half"]), dtype=self.dtype, fuse=False, verbose=bool(a["verbose"]))
+        self.model = self.backend.model
         self._compiled: Dict[Tuple, CompiledForward] = {}
         self._classes_mask = None
         if a["classes"] is not None:

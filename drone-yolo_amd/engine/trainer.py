@@ -2,36 +2,46 @@
 models/yolo/detect/train.py ``DetectionTrainer``).
 
 What is kept from the reference, with the place it comes from:
-  * one process per GPU, batch // world_size images per rank (trainer.py:286), loss * world_size followed by DDP's
-    mean == a SUM all-reduce of the per-rank gradients (trainer.py:382-383 + DDP) — here ONE flat fp32 gradient buffer
-    is all-reduced over RCCL/xGMI after backward (43 MB for Drone-YOLO-s; no SyncBN, as in the reference);
+  * ``train()`` (trainer.py:171-207): ``device="0,1,.."`` with no LOCAL_RANK in the environment makes this process the
+    launcher — it writes a temp script that rebuilds the trainer from its arguments and runs it under
+    ``torch.distributed.run`` with one rank per GPU (utils/dist.py:25-66), as a CHILD process; otherwise ``_do_train``;
+  * ``_do_train`` (trainer.py:319-476): epochs x batches, warm-up by batch counter ``ni = i + nb * epoch`` (accumulate ramped
+    from 1 to nbs / batch, bias lr from ``warmup_bias_lr``, other lrs from 0, SGD momentum from ``warmup_momentum`` to
+    ``momentum``), optimizer step every ``accumulate`` batches, linear lr schedule per epoch (trainer.py:214-216),
+    ``results.csv`` (trainer.py:700-708), ``last.pt`` (trainer.py:514-545);
+  * one process per GPU, batch // world_size images per rank (trainer.py:286), loss * world_size followed by DDP's mean == a
+    SUM all-reduce of the per-rank gradients (trainer.py:382-383 + DDP): the flat fp32 gradient buffer is all-reduced over
+    RCCL/xGMI in buckets (reverse layer order), each bucket issued as soon as backward has produced its last gradient, so
+    the ring runs under the remaining backward kernels (parallel.GradBuckets); no SyncBN, as in the reference;
   * build_optimizer (trainer.py:764-825): three groups — biases (no decay), BatchNorm weights (no decay), other weights
-    (decay); optimizer 'auto' = SGD(lr0, momentum, nesterov) beyond 10,000 iterations else AdamW(0.002*5/(4+nc), betas
-    (momentum, 0.999)); weight_decay scaled by batch*accumulate/nbs (trainer.py:254-256);
-  * warm-up of lr / momentum per iteration and the linear lr schedule (trainer.py:361-372, 214-216);
-  * gradient clipping max_norm 10 (trainer.py:594), ModelEMA (utils/torch_utils.py:515-545) on rank 0's replica (every
-    rank keeps it here: replicas are identical, so no broadcast is needed).
+    (decay); optimizer 'auto' = SGD(0.01, 0.9, nesterov) beyond 10,000 iterations else AdamW(0.002*5/(4+nc), betas
+    (0.9, 0.999)) with ``warmup_bias_lr`` forced to 0; weight_decay scaled by batch*accumulate/nbs (trainer.py:254-256);
+  * gradient clipping max_norm 10 (trainer.py:594), ModelEMA (utils/torch_utils.py:515-545).
 Parameters, gradients, BatchNorm buffers and the EMA copy live in FLAT fp32 buffers (the module parameters are views), so
-the clip norm is one reduction, each optimizer group one kernel launch, the EMA one launch and the all-reduce one call.
+the clip norm is one reduction, each optimizer group one kernel launch and the EMA one launch.
+Out of scope: dataset files, augmentation, validation / fitness, callbacks, plots.  The loader here serves
+tensor datasets (uint8 images + labels in the reference's collate layout) or the synthetic VisDrone-shaped set of SURVEY §8(d).
 """
 from __future__ import annotations
 
+import csv
 import math
-from typing import Dict, List, Optional, Tuple
+import os
+import subprocess
+import time
+from pathlib import Path
+from typing import Dict, Iterator, List, Optional, Tuple
 
 import numpy as np
 import torch
-import torch.distributed as dist
 import torch.nn as nn
 
-from .. import hip_ops as H
 from .. import parallel as P
+from ..utils import LOGGER
 
 
 def get_cfg(overrides: Optional[dict] = None) -> dict:
     """cfg/default.yaml (the reference's key names and values, ultralytics/cfg/default.yaml) updated with overrides."""
-    import os
-
     import yaml
 
     with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cfg", "default.yaml")) as f:
@@ -72,6 +82,9 @@ class FlatState:
         n = sum(self.sizes)
         self.P = torch.empty(n, dtype=torch.float32, device=device)
         self.G = torch.zeros(n, dtype=torch.float32, device=device)
+        self.offsets: Dict[str, Tuple[int, int]] = {}  # name -> (offset, numel) in P / G
+        self.reg_order = [k for k in params if params[k].requires_grad]  # registration (= forward execution) order
+        self.params: Dict[str, nn.Parameter] = {}
         off = 0
         for k in order:
             p = params[k]
@@ -79,6 +92,8 @@ class FlatState:
             self.P[off : off + c].copy_(p.detach().reshape(-1))
             p.data = self.P[off : off + c].view_as(p)
             p.grad = self.G[off : off + c].view_as(p)
+            self.offsets[k] = (off, c)
+            self.params[k] = p
             off += c
         bufs = [(k, b) for k, b in model.named_buffers() if b.is_floating_point()]
         nb = sum(b.numel() for _, b in bufs)
@@ -106,40 +121,225 @@ class ModelEMA:
         self.flat, self.decay, self.tau, self.updates = flat, decay, tau, updates
 
     def update(self) -> None:
+        from .. import hip_ops as H
+
         self.updates += 1
         d = self.decay * (1 - math.exp(-self.updates / self.tau))
         H.ema_update_(self.P, self.flat.P, d)
         if self.flat.nb:
             H.ema_update_(self.B, self.flat.B, d)
 
+    def state_dict(self, model: nn.Module) -> Dict[str, torch.Tensor]:
+        """The EMA weights under the model's state-dict keys (what ``deepcopy(self.ema.ema)`` holds in the reference)."""
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        for k, (off, c) in self.flat.offsets.items():
+            sd[k] = self.P[off : off + c].view_as(sd[k]).clone()
+        off = 0
+        for k, b in model.named_buffers():
+            if b.is_floating_point():
+                c = b.numel()
+                sd[k] = self.B[off : off + c].view_as(b).clone()
+                off += c
+        return sd
 
+
+# ---- data ----------------------------------------------------------------------------------------------------------------
+def synthetic_dataset(n: int, imgsz: int, seed: int, nc: int = 10) -> Dict[str, torch.Tensor]:
+    """uint8 images randint(0, 256); per image n ~ Poisson(50) clipped to [1, 300] boxes (VisDrone-like
+    density), class uniform, centres uniform(0.05, 0.95), wh lognormal(median 0.03, sigma 0.6) clipped to [0.004, 0.5]."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randint(0, 256, (n, 3, imgsz, imgsz), generator=g, dtype=torch.uint8)
+    counts = torch.poisson(torch.full((n,), 50.0), generator=g).clamp(1, 300).long()
+    m = int(counts.sum())
+    bi = torch.repeat_interleave(torch.arange(n), counts).float()
+    cls = torch.randint(0, nc, (m, 1), generator=g).float()
+    cxy = torch.rand(m, 2, generator=g) * 0.9 + 0.05
+    wh = (torch.randn(m, 2, generator=g) * 0.6 + math.log(0.03)).exp().clamp(0.004, 0.5)
+    return dict(img=img, batch_idx=bi, cls=cls, bboxes=torch.cat((cxy, wh), 1))
+
+
+def load_dataset(data, imgsz: int, nc: int, seed: int) -> Dict[str, torch.Tensor]:
+    """``data``: a dict / a ``.pt`` file of tensors ``img`` (N,3,H,W) uint8, ``batch_idx`` (M,), ``cls`` (M,1), ``bboxes`` (M,4
+    normalised xywh) — the reference's collate layout (data/dataset.py:232-248) over the whole set — or ``"synthetic[:N]"``."""
+    if isinstance(data, dict):
+        d = data
+    elif isinstance(data, str) and data.startswith("synthetic"):
+        n = int(data.split(":")[1]) if ":" in data else 128
+        d = synthetic_dataset(n, imgsz, seed=1000 + seed, nc=nc)
+    elif isinstance(data, (str, Path)) and str(data).endswith(".pt"):
+        d = torch.load(str(data), map_location="cpu", weights_only=True)
+    else:
+        raise NotImplementedError(f"data={data!r}: tensor datasets (.pt / dict) and 'synthetic[:N]' are built; image folders and dataset YAMLs "
+                                  "(decoding, mosaic, augmentation) are outside the accelerated path")
+    missing = {"img", "batch_idx", "cls", "bboxes"} - set(d)
+    if missing:
+        raise KeyError(f"dataset lacks {sorted(missing)}")
+    if d["img"].dtype != torch.uint8 or d["img"].dim() != 4:
+        raise ValueError("dataset 'img' must be uint8 (N, 3, H, W)")
+    return d
+
+
+class TensorLoader:
+    """Batches of a tensor dataset with ``DistributedSampler`` semantics (data/build.py:144: shuffle by seed + epoch, pad to a
+    multiple of world size by wrapping around, rank r takes indices r::world); labels re-indexed per batch as the reference's
+    collate_fn does (``batch_idx`` = position in the batch)."""
+
+    def __init__(self, data: Dict[str, torch.Tensor], batch: int, rank: int = 0, world: int = 1, seed: int = 0, shuffle: bool = True):
+        self.d, self.batch, self.rank, self.world, self.seed, self.shuffle, self.epoch = data, max(int(batch), 1), rank, world, seed, shuffle, 0
+        self.n = data["img"].shape[0]
+        self.per_rank = -(-self.n // world)
+        bi = data["batch_idx"].long()
+        order = torch.argsort(bi, stable=True)
+        self._rows = order
+        counts = torch.bincount(bi, minlength=self.n)
+        self._start = torch.cat((torch.zeros(1, dtype=torch.long), counts.cumsum(0)))
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = epoch
+
+    def __len__(self) -> int:
+        return -(-self.per_rank // self.batch)
+
+    def indices(self) -> List[int]:
+        if self.shuffle:
+            idx = torch.randperm(self.n, generator=torch.Generator().manual_seed(self.seed + self.epoch)).tolist()
+        else:
+            idx = list(range(self.n))
+        total = self.per_rank * self.world
+        idx += idx[: total - len(idx)]
+        return idx[self.rank : total : self.world]
+
+    def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
+        idx = self.indices()
+        for s in range(0, len(idx), self.batch):
+            take = idx[s : s + self.batch]
+            rows, bi = [], []
+            for j, i in enumerate(take):
+                r = self._rows[self._start[i] : self._start[i + 1]]
+                rows.append(r)
+                bi.append(torch.full((len(r),), float(j)))
+            rows = torch.cat(rows) if rows else torch.zeros(0, dtype=torch.long)
+            yield dict(img=self.d["img"][take], batch_idx=torch.cat(bi) if bi else torch.zeros(0), cls=self.d["cls"][rows].view(-1, 1).float(),
+                       bboxes=self.d["bboxes"][rows].float())
+
+
+# ---- optimizer selection and schedules (host logic only) -------------------------------------------------------------------
+def resolve_optimizer(args: dict, nc: int, iterations: float) -> Tuple[str, float, float, float]:
+    """(name, lr0, momentum, warmup_bias_lr) — build_optimizer's 'auto' rule (trainer.py:784-793): SGD(0.01, 0.9) beyond 10,000
+    iterations, else AdamW(round(0.002 * 5 / (4 + nc), 6), 0.9); either way warmup_bias_lr is forced to 0."""
+    name = args.get("optimizer", "auto")
+    if name == "auto":
+        name, lr0, mom = ("SGD", 0.01, 0.9) if iterations > 10000 else ("AdamW", round(0.002 * 5 / (4 + nc), 6), 0.9)
+        return name, lr0, mom, 0.0
+    return name, args["lr0"], args["momentum"], args["warmup_bias_lr"]
+
+
+class OptimSchedule:
+    """What the reference keeps in ``optimizer.param_groups`` between iterations and how its loop mutates it: LambdaLR at the
+    top of an epoch (trainer.py:349, lr = lr0 * lf(epoch) for every group) and the per-batch warm-up (trainer.py:362-377).
+    Group order here is (decay weights, norm weights, biases); the reference's is (biases, decay weights, norm weights)."""
+
+    def __init__(self, args: dict, opt_name: str, lr0: float, momentum: float, warmup_bias_lr: float, batch_size: int, epochs: int):
+        self.args, self.opt_name, self.lr0, self.momentum, self.warmup_bias_lr = args, opt_name, lr0, momentum, warmup_bias_lr
+        self.batch_size, self.epochs = batch_size, epochs
+        self.accumulate = max(round(args["nbs"] / max(batch_size, 1)), 1)  # trainer.py:254
+        self.cur_lrs = [lr0] * 3
+        self.cur_momentum = momentum  # SGD's; AdamW groups have no 'momentum' key, so its beta1 is never warmed up
+        lrf = args["lrf"]
+        self.lf = lambda x: max(1 - x / self.epochs, 0) * (1.0 - lrf) + lrf  # linear, trainer.py:214-216
+
+    def warmup_iters(self, nb: int) -> int:
+        return max(round(self.args["warmup_epochs"] * nb), 100) if self.args["warmup_epochs"] > 0 else -1
+
+    def scheduler_step(self, epoch: int) -> None:
+        self.cur_lrs = [self.lr0 * self.lf(epoch)] * 3
+
+    def warmup(self, ni: int, epoch: int, nb: int) -> None:
+        nw = self.warmup_iters(nb)
+        if ni > nw:
+            return
+        xi, a = [0, nw], self.args
+        self.accumulate = max(1, int(np.interp(ni, xi, [1, a["nbs"] / self.batch_size]).round()))
+        target = self.lr0 * self.lf(epoch)
+        self.cur_lrs = [float(np.interp(ni, xi, [0.0, target])), float(np.interp(ni, xi, [0.0, target])),
+                        float(np.interp(ni, xi, [self.warmup_bias_lr, target]))]
+        if self.opt_name == "SGD":
+            self.cur_momentum = float(np.interp(ni, xi, [a["warmup_momentum"], a["momentum"]]))
+
+
+# ---- trainer -------------------------------------------------------------------------------------------------------------
 class DetectionTrainer:
-    """Minimal trainer for tensor batches: ``step(batch)`` = forward, loss, backward, all-reduce, clip, optimizer, EMA."""
+    """``DetectionTrainer(model, overrides)`` for tensor batches (``step``) or ``DetectionTrainer(overrides=...)`` +
+    ``train()`` for the whole loop (model from ``overrides['model']``, data from ``overrides['data']``)."""
 
-    def __init__(self, model: nn.Module, overrides: Optional[dict] = None, iterations_hint: int = 0):
+    def __init__(self, model: Optional[nn.Module] = None, overrides: Optional[dict] = None, iterations_hint: int = 0):
         self.args = a = get_cfg(overrides or {})
+        data = a.get("data")
+        if isinstance(data, (str, Path)) and not (str(data).startswith("synthetic") or str(data).endswith(".pt")):
+            load_dataset(data, 0, 0, 0)  # raises NotImplementedError naming what is built, before any device work
+        if not torch.cuda.is_available():
+            raise RuntimeError("training needs an MI355X: no HIP device visible and this path has no CPU fallback")
         self.rank, self.local_rank, self.world = P.dist_env()
-        self.device = torch.device("cuda", self.local_rank if a.get("device", "") in ("", None) else int(str(a["device"]).split(",")[0]))
-        self.model = model.to(self.device).train()
+        self.model = model
+        self.iterations_hint = iterations_hint
+        self.save_dir = Path(a.get("project") or "runs/detect") / (a.get("name") or "train")
+        self.wdir = self.save_dir / "weights"
+        self.last, self.csv = self.wdir / "last.pt", self.save_dir / "results.csv"
+        self.epochs = int(a["epochs"])
+        self.start_epoch, self.epoch = 0, 0
+        self.loss_names = ("box_loss", "cls_loss", "dfl_loss")
+        self.flat = None
+        self.tloss = None
+        self.train_loader = None
+        if model is not None:
+            self._setup_model_state()
+
+    # ---- setup -----------------------------------------------------------------------------------------------------------
+    def _device_list(self) -> List[int]:
+        dev = self.args.get("device", "")
+        if dev in ("", None):
+            return [self.local_rank]
+        if isinstance(dev, (list, tuple)):
+            return [int(x) for x in dev]
+        return [int(x) for x in str(dev).replace("cuda:", "").split(",") if x.strip() != ""]
+
+    def _setup_model_state(self) -> None:
+        """Model onto this rank's GPU, flat buffers, optimizer state, EMA — the device part of _setup_train (trainer.py:231-317)."""
+        a = self.args
+        devs = self._device_list()
+        index = self.local_rank if (self.world > 1 and "LOCAL_RANK" in os.environ) else devs[0]
+        if os.environ.get("DYOLO_FORCE_DEVICE"):  # N-rank rehearsal on one GPU (gloo)
+            index = int(os.environ["DYOLO_FORCE_DEVICE"])
+        self.device = torch.device("cuda", index)
+        if self.model is None:
+            from ..nn.tasks import DetectionModel
+
+            src = str(a.get("model") or "yolov8s-p2-repvgg.yaml")
+            if src.endswith(".pt"):
+                from ..nn.checkpoint import load_reference_checkpoint
+
+                self.model, _ = load_reference_checkpoint(src)
+            else:
+                self.model = DetectionModel(src, nc=a.get("nc") or None, verbose=False)
+        torch.manual_seed(int(a.get("seed", 0)))  # trainer.py:121 init_seeds: replicas start identical
+        self.model = self.model.to(self.device).train()
         self.model.train_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[a.get("dtype", "bf16")] if a.get("amp", True) \
             else torch.float32
         self.model.args = type("Args", (), dict(box=a["box"], cls=a["cls"], dfl=a["dfl"]))()
         self.batch_size = int(a["batch"])  # GLOBAL batch, as in the reference; each rank sees batch // world
-        self.accumulate = max(round(a["nbs"] / max(self.batch_size, 1)), 1)
-        self.weight_decay = a["weight_decay"] * self.batch_size * self.accumulate / a["nbs"]
+        self.weight_decay = a["weight_decay"] * self.batch_size * max(round(a["nbs"] / max(self.batch_size, 1)), 1) / a["nbs"]  # trainer.py:254-256
         self.flat = FlatState(self.model, self.device)
+        if self.world > 1 and torch.distributed.is_initialized():
+            # DDP broadcasts rank 0's parameters and buffers at construction; so do we (replicas must not rely on equal seeds)
+            torch.distributed.broadcast(self.flat.P, 0)
+            torch.distributed.broadcast(self.flat.B, 0)
         nc = self.model.yaml["nc"]
-        name = a.get("optimizer", "auto")
-        if name == "auto":  # trainer.py:784-793
-            if iterations_hint > 10000:
-                name, self.lr0, self.momentum = "SGD", 0.01, 0.9
-            else:
-                name, self.lr0, self.momentum = "AdamW", round(0.002 * 5 / (4 + nc), 6), 0.9
-        else:
-            self.lr0, self.momentum = a["lr0"], a["momentum"]
+        name, self.lr0, self.momentum, self.warmup_bias_lr = resolve_optimizer(a, nc, self.iterations_hint)
         if name not in ("SGD", "AdamW"):
             raise NotImplementedError(f"optimizer {name}: SGD and AdamW are built")
         self.opt_name = name
+        self.sched = OptimSchedule(a, name, self.lr0, self.momentum, self.warmup_bias_lr, self.batch_size, self.epochs)
+        self.lf = self.sched.lf
         n = self.flat.P.numel()
         self.buf1 = torch.zeros(n, dtype=torch.float32, device=self.device)  # momentum / first moment
         self.buf2 = torch.zeros(n, dtype=torch.float32, device=self.device) if name == "AdamW" else None
@@ -147,50 +347,206 @@ class DetectionTrainer:
         self.ema = ModelEMA(self.flat)
         self.opt_steps = 0
         self.iters = 0
-        self.epochs = int(a["epochs"])
-        self.lf = lambda x: max(1 - x / self.epochs, 0) * (1.0 - a["lrf"]) + a["lrf"]  # linear schedule, trainer.py:214-216
+        self.last_opt_step = -1
+        self.buckets = P.GradBuckets(self.flat, n_buckets=int(os.environ.get("DYOLO_GRAD_BUCKETS", 4))) if self.world > 1 else None
 
-    # ---- schedules -----------------------------------------------------------------------------------------------------
+    # ---- schedules (state lives in self.sched) ------------------------------------------------------------------------------
+    cur_lrs = property(lambda self: self.sched.cur_lrs)
+    cur_momentum = property(lambda self: self.sched.cur_momentum)
+    accumulate = property(lambda self: self.sched.accumulate)
+
+    def warmup_iters(self, nb: int) -> int:
+        return self.sched.warmup_iters(nb)
+
+    def scheduler_step(self, epoch: int) -> None:
+        self.sched.scheduler_step(epoch)
+
+    def warmup(self, ni: int, epoch: int, nb: int) -> None:
+        self.sched.warmup(ni, epoch, nb)
+
     def lr_momentum(self, ni: int, epoch: int, nb: int) -> Tuple[List[float], float]:
-        """Per-group lr (decay weights, norm weights, biases) and momentum at iteration ni — trainer.py:361-372."""
-        a = self.args
-        nw = max(round(a["warmup_epochs"] * nb), 100) if a["warmup_epochs"] > 0 else -1
-        target = self.lr0 * self.lf(epoch)
-        if ni <= nw:
-            xi = [0, nw]
-            lrs = [float(np.interp(ni, xi, [0.0, target])), float(np.interp(ni, xi, [0.0, target])),
-                   float(np.interp(ni, xi, [a["warmup_bias_lr"], target]))]
-            mom = float(np.interp(ni, xi, [a["warmup_momentum"], self.momentum]))
-            return lrs, mom
-        return [target] * 3, self.momentum
+        """Per-group lr and momentum the optimizer uses at batch counter ``ni`` of ``epoch`` (stateless view of the above)."""
+        self.scheduler_step(epoch)
+        self.warmup(ni, epoch, nb)
+        return list(self.cur_lrs), self.cur_momentum
 
     # ---- one iteration ---------------------------------------------------------------------------------------------------
     def step(self, batch: Dict[str, torch.Tensor], epoch: int = 0, nb: int = 1000):
-        """batch: img (N_local, 3, H, W) uint8/float on the device, batch_idx / cls / bboxes as the reference's collate gives
-        them (data/dataset.py:232-248).  Returns (loss, loss_items) of this rank."""
-        if self.iters % self.accumulate == 0:
-            self.flat.G.zero_()
+        """One batch outside the epoch loop (tests, bench): warm-up by this trainer's own batch counter, optimizer step when
+        ``accumulate`` batches have been seen.  batch: img (N_local, 3, H, W) uint8/float on the device, batch_idx / cls /
+        bboxes as the reference's collate gives them.  Returns (loss, loss_items) of this rank."""
+        ni = self.iters
+        self.scheduler_step(epoch)
+        return self.train_batch(batch, ni, epoch, nb)
+
+    def train_batch(self, batch: Dict[str, torch.Tensor], ni: int, epoch: int, nb: int):
+        """Warm-up, forward, loss * world (folded into the SUM all-reduce), backward, optimizer step — trainer.py:362-399."""
+        self.warmup(ni, epoch, nb)
+        will_step = ni - self.last_opt_step >= self.accumulate
+        if self.buckets is not None:
+            self.buckets.arm(will_step)  # the backward that precedes an optimizer step all-reduces its buckets as they fill
         loss, items = self.model(batch)
-        # the reference multiplies by world_size and lets DDP average: the net effect is the plain SUM below
         loss.backward()
         self.iters += 1
-        if self.iters % self.accumulate == 0:
-            self.optimizer_step(epoch, nb)
-        return loss.detach(), items
+        if will_step:
+            self.optimizer_step()
+            self.last_opt_step = ni
+        return loss.detach() * self.world, items  # the reference reports loss * world_size (trainer.py:382-383)
 
-    def optimizer_step(self, epoch: int = 0, nb: int = 1000) -> None:
+    def optimizer_step(self) -> None:
+        """unscale (no scaler: bf16 / fp32), clip 10, step, zero_grad, EMA — trainer.py:591-599."""
+        from .. import hip_ops as H
+
         G, Pm = self.flat.G, self.flat.P
-        P.allreduce_gradients(G)  # RCCL ring over xGMI: one 4*n_params-byte bucket (no-op in a single process)
+        if self.buckets is not None:
+            self.buckets.finish()  # wait for the in-flight bucket all-reduces, reduce whatever backward did not reach
         self.sumsq.zero_()
         H.sumsq_into(self.sumsq, G)
-        lrs, mom = self.lr_momentum(self.iters // self.accumulate - 1, epoch, nb)
         self.opt_steps += 1
         for gi, sl in enumerate(self.flat.group_slices()):
             if sl.stop == sl.start:
                 continue
             wd = self.weight_decay if gi == 0 else 0.0
             if self.opt_name == "SGD":
-                H.sgd_step_(Pm[sl], G[sl], self.buf1[sl], lrs[gi], mom, wd, True, self.opt_steps == 1, self.sumsq, 10.0)
+                H.sgd_step_(Pm[sl], G[sl], self.buf1[sl], self.cur_lrs[gi], self.cur_momentum, wd, True, self.opt_steps == 1, self.sumsq, 10.0)
             else:
-                H.adamw_step_(Pm[sl], G[sl], self.buf1[sl], self.buf2[sl], lrs[gi], (mom, 0.999), 1e-8, wd, self.opt_steps, self.sumsq, 10.0)
+                H.adamw_step_(Pm[sl], G[sl], self.buf1[sl], self.buf2[sl], self.cur_lrs[gi], (self.momentum, 0.999), 1e-8, wd, self.opt_steps, self.sumsq, 10.0)
+        G.zero_()
         self.ema.update()
+
+    # ---- the loop --------------------------------------------------------------------------------------------------------
+    def train(self):
+        """trainer.py:171-207: launch one rank per GPU when several devices are asked for and we are not a rank yet."""
+        devs = self._device_list()
+        world = len(devs) if len(devs) > 1 else 1
+        if world > 1 and "LOCAL_RANK" not in os.environ:
+            from ..utils.dist import ddp_cleanup, generate_ddp_command, rank_env, visible_gpu_count
+
+            rehearsal = bool(os.environ.get("DYOLO_FORCE_DEVICE"))
+            if not rehearsal and visible_gpu_count() < world:
+                raise RuntimeError(f"device={self.args['device']!r} asks for {world} GPUs, this node has {visible_gpu_count()}")
+            overrides = {k: v for k, v in self.args.items()}
+            cmd, file = generate_ddp_command(world, overrides)
+            try:
+                LOGGER.info(f"DDP: debug command {' '.join(cmd)}")
+                subprocess.run(cmd, check=True, env=rank_env())
+            finally:
+                ddp_cleanup(file)
+            return None
+        return self._do_train(world)
+
+    def _setup_train(self, world: int) -> None:
+        a = self.args
+        nc_hint = int(a.get("nc") or (self.model.yaml["nc"] if self.model is not None else 10))
+        data = load_dataset(a.get("data") or "synthetic", int(a["imgsz"]), nc_hint, int(a.get("seed", 0)))
+        if self.flat is None:
+            # build_optimizer's 'auto' rule looks at the planned number of iterations (trainer.py:309-310)
+            self.iterations_hint = math.ceil(data["img"].shape[0] / max(int(a["batch"]), a["nbs"])) * self.epochs
+            self._setup_model_state()
+        per_rank = max(self.batch_size // max(world, 1), 1)  # trainer.py:286
+        self.train_loader = TensorLoader(data, per_rank, self.rank if world > 1 else 0, max(world, 1), seed=int(a.get("seed", 0)))
+        if self.rank == 0:
+            self.wdir.mkdir(parents=True, exist_ok=True)
+
+    def _do_train(self, world: int = 1):
+        if world > 1:
+            P.init_distributed()  # _setup_ddp (trainer.py:218-229): RCCL, one rank per GPU
+            self.rank, self.local_rank, self.world = P.dist_env()
+        self._setup_train(world)
+        nb = len(self.train_loader)
+        nw = self.warmup_iters(nb)
+        self.last_opt_step = -1
+        self.flat.G.zero_()
+        t_start = time.time()
+        LOGGER.info(f"Image sizes {self.args['imgsz']} train\\nLogging results to {self.save_dir}\\nStarting training for {self.epochs} epochs...") if self.rank == 0 else None
+        epoch = self.start_epoch
+        while True:
+            self.epoch = epoch
+            self.scheduler_step(epoch)
+            self.model.train()
+            self.train_loader.set_epoch(epoch)
+            self.tloss = None
+            for i, batch in enumerate(self.train_loader):
+                ni = i + nb * epoch
+                batch = self.preprocess_batch(batch)
+                self.loss, self.loss_items = self.train_batch(batch, ni, epoch, nb)
+                self.tloss = (self.tloss * i + self.loss_items) / (i + 1) if self.tloss is not None else self.loss_items
+            final_epoch = epoch + 1 >= self.epochs
+            if self.rank == 0:
+                self.lr = {f"lr/pg{ir}": x for ir, x in enumerate((self.cur_lrs[2], self.cur_lrs[0], self.cur_lrs[1]))}  # reference group order
+                self.save_metrics({"time": time.time() - t_start, **self.label_loss_items(self.tloss), **self.lr})
+                if self.args.get("save", True) or final_epoch:
+                    self.save_model()
+                LOGGER.info(f"{epoch + 1}/{self.epochs}  " + "  ".join(f"{k} {float(v):.4g}" for k, v in self.label_loss_items(self.tloss).items()))
+            if final_epoch:
+                break
+            epoch += 1
+        torch.cuda.synchronize(self.device)
+        if self.rank == 0:
+            LOGGER.info(f"{epoch - self.start_epoch + 1} epochs completed in {(time.time() - t_start) / 3600:.3f} hours.")
+        if world > 1 and torch.distributed.is_initialized():
+            torch.distributed.barrier()
+        return {**self.label_loss_items(self.tloss), "save_dir": str(self.save_dir)}
+
+    def preprocess_batch(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """detect/train.py:57-74: images to the device (the /255 and the layout change ride in the first kernel)."""
+        batch["img"] = batch["img"].to(self.device, non_blocking=True)
+        return batch
+
+    def label_loss_items(self, loss_items=None, prefix: str = "train") -> Dict[str, float]:
+        """detect/train.py:107-118."""
+        keys = [f"{prefix}/{x}" for x in self.loss_names]
+        if loss_items is None:
+            return keys
+        return dict(zip(keys, [round(float(x), 5) for x in loss_items]))
+
+    def save_metrics(self, metrics: Dict[str, float]) -> None:
+        """results.csv, one row per epoch — trainer.py:700-708."""
+        keys, vals = list(metrics.keys()), list(metrics.values())
+        new = not self.csv.exists()
+        with open(self.csv, "a", newline="") as f:
+            w = csv.writer(f)
+            if new:
+                w.writerow(["epoch"] + keys)
+            w.writerow([self.epoch + 1] + [f"{v:.6g}" for v in vals])
+
+    def read_results_csv(self) -> Dict[str, list]:
+        if not self.csv.exists():
+            return {}
+        with open(self.csv) as f:
+            rows = list(csv.DictReader(f))
+        return {k: [float(r[k]) for r in rows] for k in (rows[0] if rows else {})}
+
+    def optimizer_state_dict(self) -> dict:
+        """``torch.optim`` state-dict layout of the reference's optimizer (param_groups: biases, decay weights, norm weights —
+        trainer.py:810-819), built from the flat moment buffers."""
+        g0, g1, g2 = self.flat.groups
+        order = list(g2) + list(g0) + list(g1)
+        state = {}
+        for i, k in enumerate(order):
+            off, c = self.flat.offsets[k]
+            shape = self.flat.params[k].shape
+            if self.opt_name == "SGD":
+                state[i] = {"momentum_buffer": self.buf1[off : off + c].view(shape).clone()}
+            else:
+                state[i] = {"step": torch.tensor(float(self.opt_steps)), "exp_avg": self.buf1[off : off + c].view(shape).clone(),
+                            "exp_avg_sq": self.buf2[off : off + c].view(shape).clone()}
+        groups, s = [], 0
+        for names, lr, wd in ((g2, self.cur_lrs[2], 0.0), (g0, self.cur_lrs[0], self.weight_decay), (g1, self.cur_lrs[1], 0.0)):
+            grp = {"lr": lr, "initial_lr": self.lr0, "weight_decay": wd, "params": list(range(s, s + len(names)))}
+            grp.update({"momentum": self.cur_momentum, "nesterov": True, "dampening": 0} if self.opt_name == "SGD" else {"betas": (self.momentum, 0.999), "eps": 1e-8})
+            groups.append(grp)
+            s += len(names)
+        return {"state": state, "param_groups": groups}
+
+    def save_model(self) -> None:
+        """last.pt with the reference's keys (trainer.py:514-545): epoch, best_fitness, model None, ema = the EMA weights as a
+        pickled fp16 module graph under the reference's class paths, updates, optimizer (fp16 state), train_args, ..."""
+        from datetime import datetime
+
+        from ..nn.checkpoint import save_reference_checkpoint
+
+        save_reference_checkpoint(self.last, self.model, self.ema.state_dict(self.model), extra={
+            "epoch": self.epoch, "best_fitness": None, "updates": self.ema.updates, "optimizer": self.optimizer_state_dict(),
+            "train_args": dict(self.args), "train_metrics": {**self.label_loss_items(self.tloss), "fitness": None},
+            "train_results": self.read_results_csv(), "date": datetime.now().isoformat()})

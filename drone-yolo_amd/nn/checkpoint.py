@@ -128,3 +128,109 @@ def load_reference_checkpoint(path: str, verbose: bool = False):
     if isinstance(meta.get("names"), dict):
         model.names = meta["names"]
     return model, meta
+
+
+# ---- writing: a checkpoint the reference itself can torch.load (engine/trainer.py:514-545) ------------------------------------
+_REF_PATHS = {"Conv": "ultralytics.nn.modules.conv", "DWConv": "ultralytics.nn.modules.conv", "Concat": "ultralytics.nn.modules.conv",
+              "DFL": "ultralytics.nn.modules.block", "SPPF": "ultralytics.nn.modules.block", "C2f": "ultralytics.nn.modules.block",
+              "Bottleneck": "ultralytics.nn.modules.block", "RepVGGBlock": "ultralytics.nn.modules.block", "SEBlock": "ultralytics.nn.modules.block",
+              "Detect": "ultralytics.nn.modules.head", "DetectionModel": "ultralytics.nn.tasks", "BaseModel": "ultralytics.nn.tasks"}
+_DROP_ATTRS = ("_packed", "_block_cache", "_tail_cache", "_first_cache", "_stem2_cache", "_sig_tensors", "_weights_epoch", "_place", "_srcs", "_virtual", "_skip",
+               "_consumers0", "_out_ch", "_cum_stride", "criterion", "train_dtype", "args", "fused_nms", "fuse_tail")
+
+
+class _reference_class_paths:
+    """While active, this package's module classes present themselves to ``pickle`` under the reference's import paths
+    (``ultralytics.nn.modules.conv.Conv`` ...): throw-away entries in ``sys.modules`` that hold OUR classes, and the classes'
+    ``__module__`` pointed at them, so ``save_global`` writes the reference's names.  Everything is restored on exit."""
+
+    def __enter__(self):
+        import sys
+
+        self._saved_modules, self._saved_attr = {}, []
+        own = _own_classes()
+        for name, path in _REF_PATHS.items():
+            cls = own.get(name)
+            if cls is None:
+                continue
+            parts = path.split(".")
+            for i in range(1, len(parts) + 1):
+                mod_name = ".".join(parts[:i])
+                if mod_name not in self._saved_modules:
+                    self._saved_modules[mod_name] = sys.modules.get(mod_name)
+                    if not isinstance(sys.modules.get(mod_name), types.ModuleType) or not getattr(sys.modules[mod_name], "__dyolo_fake__", False):
+                        fake = types.ModuleType(mod_name)
+                        fake.__dyolo_fake__ = True
+                        sys.modules[mod_name] = fake
+            setattr(sys.modules[path], name, cls)
+            self._saved_attr.append((cls, cls.__module__, cls.__qualname__))
+            cls.__module__, cls.__qualname__ = path, name
+        return self
+
+    def __exit__(self, *exc):
+        import sys
+
+        for cls, mod, qual in self._saved_attr:
+            cls.__module__, cls.__qualname__ = mod, qual
+        for mod_name, old in self._saved_modules.items():
+            if old is None:
+                sys.modules.pop(mod_name, None)
+            else:
+                sys.modules[mod_name] = old
+        return False
+
+
+def reference_module_graph(model: nn.Module, state_dict: Dict[str, torch.Tensor], half: bool = True) -> nn.Module:
+    """A CPU deep copy of ``model`` carrying ``state_dict``, shaped the way the reference expects its own pickled module graph:
+    caches and planner state dropped, the plain last conv of each Detect branch and the Upsample layers turned back into
+    ``torch.nn`` instances, ``.type`` strings as the reference's ``parse_model`` writes them, fp16 like ``ema.half()``."""
+    from copy import deepcopy
+
+    from .modules.conv import PlainConv2d, Upsample
+
+    live = {id(m): {k: m.__dict__.pop(k) for k in _DROP_ATTRS if k in m.__dict__} for m in model.modules()}  # do not deep-copy device caches
+    try:
+        cp = deepcopy(model).cpu()
+    finally:
+        for m in model.modules():
+            m.__dict__.update(live[id(m)])
+    cp.load_state_dict({k: v.detach().cpu().float() if v.is_floating_point() else v.detach().cpu() for k, v in state_dict.items()})
+    for m in cp.modules():
+        for k in _DROP_ATTRS:
+            m.__dict__.pop(k, None)
+        if isinstance(m, PlainConv2d):
+            m.__class__ = nn.Conv2d
+        elif isinstance(m, Upsample):
+            m.__class__ = nn.Upsample
+            m.__dict__.setdefault("name", "Upsample")
+            m.scale_factor = float(m.scale_factor)
+            m.__dict__.setdefault("align_corners", None)
+            m.__dict__.setdefault("recompute_scale_factor", None)
+        t = getattr(m, "type", None)
+        if isinstance(t, str) and "." not in t:
+            m.type = "torch.nn.modules.upsampling.Upsample" if t == "nn.Upsample" else f"{_REF_PATHS.get(t, 'ultralytics.nn.modules')}.{t}"
+    cp.eval()
+    for p in cp.parameters():
+        p.requires_grad_(False)
+    return cp.half() if half else cp
+
+
+def save_reference_checkpoint(path, model: nn.Module, state_dict: Dict[str, torch.Tensor], extra: Dict[str, Any] = None) -> None:
+    """Write ``path`` with the keys of ``BaseTrainer.save_model`` (engine/trainer.py:514-545): ``model`` None, ``ema`` the module
+    graph in fp16 — pickled under the reference's class paths, so the reference's own ``torch.load`` / ``attempt_load_one_weight``
+    (nn/tasks.py:786-926) restore it as ITS classes — optimizer state in fp16 (torch_utils.py:553-566), train_args as a dict."""
+    ck = {"epoch": -1, "best_fitness": None, "model": None, "ema": reference_module_graph(model, state_dict), "updates": 0, "optimizer": None,
+          "train_args": {}, "train_metrics": {}, "train_results": {}, "date": None, "version": "8.3.0", "license": "AGPL-3.0 (https://ultralytics.com/license)",
+          "docs": "https://docs.ultralytics.com"}
+    ck.update(extra or {})
+    opt = ck.get("optimizer")
+    if isinstance(opt, dict):  # convert_optimizer_state_dict_to_fp16: every fp32 state tensor except 'step'
+        for st in opt.get("state", {}).values():
+            for k, v in st.items():
+                if k != "step" and isinstance(v, torch.Tensor) and v.dtype == torch.float32:
+                    st[k] = v.detach().cpu().half()
+                elif isinstance(v, torch.Tensor):
+                    st[k] = v.detach().cpu()
+    ck["train_args"] = {k: (str(v) if isinstance(v, (torch.dtype, torch.device)) else v) for k, v in dict(ck.get("train_args") or {}).items()}
+    with _reference_class_paths():
+        torch.save(ck, str(path))

@@ -103,3 +103,57 @@ def ema_update(ema_sd, sd, updates: int, decay: float = 0.9999, tau: float = 200
         if v.is_floating_point():
             ema_sd[k] = v * dcy + (1 - dcy) * sd[k].detach()
     return updates
+
+
+def reference_schedule(args: dict, nb: int, batch_size: int, epochs: int, iterations: float, nc: int = 10):
+    """The reference's optimizer construction and per-batch schedule, restated around REAL ``torch.optim`` objects: build_optimizer
+    (engine/trainer.py:764-825: 'auto' rule, group order biases / decay weights / norm weights), ``_setup_scheduler``
+    (:209-216, LambdaLR with ``last_epoch = start_epoch - 1``, :317) and the loop of ``_do_train`` (:345-390: ``scheduler.step()``
+    per epoch, warm-up of accumulate / lr / momentum by ``ni = i + nb * epoch``, optimizer step when ``ni - last_opt_step >=
+    accumulate``).  Returns one row per batch: (ni, lr of [biases, decay weights, norm weights], momentum or None, beta1 or
+    None, accumulate, stepped)."""
+    import numpy as np
+    from torch import optim
+
+    a = dict(args)
+    name, lr, momentum = a["optimizer"], a["lr0"], a["momentum"]
+    if name == "auto":
+        lr_fit = round(0.002 * 5 / (4 + nc), 6)
+        name, lr, momentum = ("SGD", 0.01, 0.9) if iterations > 10000 else ("AdamW", lr_fit, 0.9)
+        a["warmup_bias_lr"] = 0.0
+    g = [[torch.nn.Parameter(torch.zeros(1))] for _ in range(3)]  # decay weights, norm weights, biases
+    accumulate = max(round(a["nbs"] / batch_size), 1)
+    decay = a["weight_decay"] * batch_size * accumulate / a["nbs"]
+    if name == "AdamW":
+        opt = optim.AdamW(g[2], lr=lr, betas=(momentum, 0.999), weight_decay=0.0)
+    else:
+        opt = optim.SGD(g[2], lr=lr, momentum=momentum, nesterov=True)
+    opt.add_param_group({"params": g[0], "weight_decay": decay})
+    opt.add_param_group({"params": g[1], "weight_decay": 0.0})
+    lf = lambda x: max(1 - x / epochs, 0) * (1.0 - a["lrf"]) + a["lrf"]  # noqa: E731
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        scheduler = optim.lr_scheduler.LambdaLR(opt, lr_lambda=lf)
+        scheduler.last_epoch = -1
+        nw = max(round(a["warmup_epochs"] * nb), 100) if a["warmup_epochs"] > 0 else -1
+        last_opt_step, rows = -1, []
+        for epoch in range(epochs):
+            scheduler.step()
+            for i in range(nb):
+                ni = i + nb * epoch
+                if ni <= nw:
+                    xi = [0, nw]
+                    accumulate = max(1, int(np.interp(ni, xi, [1, a["nbs"] / batch_size]).round()))
+                    for j, x in enumerate(opt.param_groups):
+                        x["lr"] = np.interp(ni, xi, [a["warmup_bias_lr"] if j == 0 else 0.0, x["initial_lr"] * lf(epoch)])
+                        if "momentum" in x:
+                            x["momentum"] = np.interp(ni, xi, [a["warmup_momentum"], a["momentum"]])
+                stepped = ni - last_opt_step >= accumulate
+                if stepped:
+                    last_opt_step = ni
+                pg = opt.param_groups
+                rows.append((ni, [float(x["lr"]) for x in pg], float(pg[0]["momentum"]) if "momentum" in pg[0] else None,
+                             float(pg[0]["betas"][0]) if "betas" in pg[0] else None, accumulate, stepped))
+    return name, decay, rows

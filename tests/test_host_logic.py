@@ -95,8 +95,11 @@ def test_no_cpu_fallback():
 
     with pytest.raises(RuntimeError):
         select_device("cpu")
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):  # dataset YAMLs / image folders: the loader side is out of scope
         D.YOLO("yolov8n-p2-repvgg.yaml").train(data="x.yaml")
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            D.YOLO("yolov8n-p2-repvgg.yaml").train(data="synthetic:4", epochs=1)
     m.train()
     with pytest.raises(NotImplementedError):
         m.model[0](torch.zeros(1, 8, 8, 8))
@@ -200,3 +203,67 @@ def test_checkpoint_unpickler_refuses_bypass_payloads():
 
     assert RefUnpickler(io.BytesIO(stack_global("collections", "OrderedDict"))).load() == collections.OrderedDict()
     assert RefUnpickler(io.BytesIO(stack_global("torch.nn.modules.conv", "Conv2d", call=False))).load() is __import__("torch").nn.Conv2d
+
+
+def test_optimizer_schedule_matches_reference_loop():
+    """warm-up and optimizer selection against the reference's loop restated around real torch.optim
+    objects (oracle/train_oracle.py::reference_schedule; trainer.py:362-377, 784-793): per batch the three group lrs, SGD
+    momentum (AdamW's beta1 untouched), the accumulate ramp and which batches step the optimizer — with warmup_epochs > 0,
+    for explicit SGD / AdamW and for optimizer='auto' on both sides of its 10,000-iteration rule."""
+    from drone_yolo_amd.engine.trainer import OptimSchedule, get_cfg, resolve_optimizer
+    from oracle import train_oracle as TO
+
+    for opt, batch, iters in [("SGD", 16, 50), ("AdamW", 16, 50), ("auto", 16, 50), ("auto", 64, 20000), ("SGD", 64, 50)]:
+        a = get_cfg(dict(optimizer=opt, batch=batch, epochs=4, warmup_epochs=3.0))
+        nb, epochs = 40, 4
+        name, lr0, mom, wbl = resolve_optimizer(a, 10, iters)
+        ref_name, ref_decay, rows = TO.reference_schedule(a, nb, batch, epochs, iters, nc=10)
+        assert name == ref_name
+        s = OptimSchedule(a, name, lr0, mom, wbl, batch, epochs)
+        assert abs(a["weight_decay"] * batch * s.accumulate / a["nbs"] - ref_decay) < 1e-15
+        last = -1
+        for epoch in range(epochs):
+            s.scheduler_step(epoch)
+            for i in range(nb):
+                ni = i + nb * epoch
+                s.warmup(ni, epoch, nb)
+                stepped = ni - last >= s.accumulate
+                if stepped:
+                    last = ni
+                r_ni, r_lrs, r_mom, r_b1, r_acc, r_step = rows[ni]
+                assert r_ni == ni and stepped == r_step and s.accumulate == r_acc, (opt, ni)
+                # reference group order: biases, decay weights, norm weights
+                got = [s.cur_lrs[2], s.cur_lrs[0], s.cur_lrs[1]]
+                assert all(abs(g - r) <= 1e-12 + 1e-9 * abs(r) for g, r in zip(got, r_lrs)), (opt, ni, got, r_lrs)
+                if name == "SGD":
+                    assert abs(s.cur_momentum - r_mom) < 1e-12, (opt, ni)
+                else:
+                    assert r_mom is None and abs(s.momentum - r_b1) < 1e-12  # beta1 never warmed up
+
+
+def test_tensor_loader_is_a_distributed_sampler():
+    """TensorLoader == torch's DistributedSampler (data/build.py:144) + the reference's collate: same indices per rank and
+    epoch, ranks cover the padded set exactly once, labels re-indexed by position in the batch."""
+    from torch.utils.data.distributed import DistributedSampler
+
+    from drone_yolo_amd.engine.trainer import TensorLoader, synthetic_dataset
+
+    d = synthetic_dataset(11, 16, seed=3)
+    for epoch in (0, 2):
+        seen = []
+        for rank in range(2):
+            ld = TensorLoader(d, 4, rank, 2, seed=5)
+            ld.set_epoch(epoch)
+            ds = DistributedSampler(range(11), num_replicas=2, rank=rank, shuffle=True, seed=5)
+            ds.set_epoch(epoch)
+            assert ld.indices() == list(ds)
+            assert len(ld) == 2
+            seen += ld.indices()
+            batches = list(ld)
+            take = ld.indices()[:4]
+            b = batches[0]
+            assert torch.equal(b["img"], d["img"][take])
+            for j, i in enumerate(take):
+                m_src, m_dst = d["batch_idx"] == i, b["batch_idx"] == j
+                assert torch.equal(b["bboxes"][m_dst], d["bboxes"][m_src]) and torch.equal(b["cls"][m_dst], d["cls"][m_src])
+        assert sorted(set(seen)) == list(range(11)) and len(seen) == 12
