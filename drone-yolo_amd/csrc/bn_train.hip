@@ -10,7 +10,7 @@
 // accumulators with atomics (sum and sum of squares in double: var = E[z^2] - mean^2 stays accurate at 3.3 M rows).
 // All kernels are bandwidth bound: forward reads z twice (stats, apply) and writes y once; backward reads dy and z
 // twice and writes dz once.
-#include "common.cuh"
+#include "common_hip.h"
 
 namespace dy {
 

@@ -14,7 +14,7 @@
 // cv1; its space then holds t (324 px x 80 B), y2 (256 px x 80 B) and the store scratch.  128-byte pixel rows of X / Y use the
 // chunk ^ ((px >> 1) & 7) swizzle (conflict-free ds_read_b128 fragments); t / y2 use the 80-byte pitch of the halo kernel.
 // The next tile's input is fetched into registers during phases 3-5 and written to LDS after the tile's last barrier.
-#include "common.cuh"
+#include "common_hip.h"
 
 namespace dy {
 

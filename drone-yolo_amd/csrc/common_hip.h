@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <stdarg.h>
 #include "dyolo.h"
 
@@ -18,6 +19,18 @@ typedef __bf16 bf16_t;
 typedef _Float16 f16_t;
 
 constexpr int kWave = 64;
+
+// Ablation switches (kernel variants / timing probes picked by DYOLO_* environment variables) exist only in builds made with
+// -DDYOLO_ABLATE (tools/ab_conv.sh, `make ABLATE=1`).  The product library never reads the environment: a stray variable
+// cannot select another kernel or skip work.
+#ifdef DYOLO_ABLATE
+static inline int dy_ablate(const char* name) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : 0;
+}
+#else
+static constexpr int dy_ablate(const char*) { return 0; }
+#endif
 
 // ---- element traits -----------------------------------------------------------
 // EPC = elements per 16-byte chunk.  A "k-group" is 4 chunks (the K extent one

@@ -17,7 +17,7 @@
 //
 // Reference semantics: Conv k=1 (nn/modules/conv.py:37-55), the plain nn.Conv2d heads of Detect
 // (head.py:43-57, fp32 output), C2f.cv1 after Concat(+Upsample) (block.py:237-242, conv.py:323-333).
-#include "common.cuh"
+#include "common_hip.h"
 #include <type_traits>
 
 namespace dy {

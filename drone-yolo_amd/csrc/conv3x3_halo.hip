@@ -24,7 +24,7 @@
 //     registers and stores 8 (bf16/f16) or 16 (f32) contiguous bytes per lane, no LDS round trip.
 //
 // Reference semantics: Conv / RepVGGBlock (folded) / Bottleneck residual, as conv_igemm.hip.
-#include "common.cuh"
+#include "common_hip.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -528,7 +528,7 @@ static int launch_halo(const Conv3Args& a, int batch, hipStream_t st) {
   int grid = 256 * per_cu;
   if (grid > p.nTiles) grid = p.nTiles;
   if (ws && grid > p.tilesN) grid -= grid % p.tilesN;  // keep every block on one n-tile
-  static const int nopipe = getenv("DYOLO_NO_PIPE") ? atoi(getenv("DYOLO_NO_PIPE")) : 0;
+  static const int nopipe = dy_ablate("DYOLO_NO_PIPE");
   if constexpr (sizeof(T) == 2 && !OUTF32) {
     if (ws && (p.nChunks == 1 || p.nChunks == 2 || p.nChunks == 4) && !nopipe && !p.dbg && p.act == DY_ACT_SILU && p.Cout % 8 == 0 &&
         p.y_bytes && (!p.res || p.r_bytes)) {
@@ -573,7 +573,7 @@ static int launch_halo_dtype(const Conv3Args& a, int batch, int stride, hipStrea
     if (nf4) return big ? launch_halo<T, 1, 2, 4, OUTF32>(a, batch, st) : launch_halo<T, 1, 1, 4, OUTF32>(a, batch, st);
     // <= 32 couts: 36 MFMAs per wave and item at MF 2 drown in the per-item overhead; 32-row tiles (MF 4) when the map is
     // tall enough, there are plenty of tiles and the bigger halo still fits LDS
-    static const int no_mf4 = getenv("DYOLO_NO_MF4") ? atoi(getenv("DYOLO_NO_MF4")) : 0;
+    static const int no_mf4 = dy_ablate("DYOLO_NO_MF4");
     const long long tiles32 = (long long)batch * ((a.Ho + 31) / 32) * ((a.Wo + 15) / 16) * ((a.Cout + 31) / 32);
     bool ws4 = false;
     if (!no_mf4 && big && a.Ho >= 32 && tiles32 >= 512 && halo_smem<T, 1, 4, 2, OUTF32>(a, &ws4) <= kLdsBudget && ws4)
@@ -625,7 +625,7 @@ int conv3x3_halo_dispatch(const dy_conv_desc* d, hipStream_t st) {
     a.w_bytes = (unsigned)((long long)((d->cout + bn - 1) / bn) * a.nChunks * 9 * (bn / 16) * 1024);
   }
   {
-    static const int dbg = getenv("DYOLO_DBG") ? atoi(getenv("DYOLO_DBG")) : 0;
+    static const int dbg = dy_ablate("DYOLO_DBG");
     a.dbg = dbg;
   }
   switch (d->dtype) {

@@ -19,7 +19,7 @@
 // conv_gemm_glds.hip, + 3 weight stages x 16 KiB = 144 / 160 KiB.
 // One continuous software pipeline across K-steps AND tiles (persistent grid): weights run two steps ahead, the halo one
 // chunk ahead, behind counted s_waitcnt vmcnt(N) and raw s_barriers; the only bubble is the epilogue.
-#include "common.cuh"
+#include "common_hip.h"
 #include "conv_args.h"
 
 namespace dy {
@@ -581,7 +581,7 @@ static int launch_vgemm(const ConvArgs& a, hipStream_t st) {
   if (grid > p.nblk) grid = p.nblk;
   // DYOLO_VGEMM_VAR (experiments): 8 = the 8-wave kernel instead of the 16-wave one, 1 = prefetch the next step's pixel fragments into registers (measured +-2 %),
   // 11 / 12 = timing probes without MFMAs / without LDS reads (wrong results)
-  static const int var = getenv("DYOLO_VGEMM_VAR") ? atoi(getenv("DYOLO_VGEMM_VAR")) : 0;
+  static const int var = dy_ablate("DYOLO_VGEMM_VAR");
   const bool narrow = g.S <= 6 * 64;  // maps up to 62 wide: 48 KiB halo stages leave room for a third weight stage
   const dim3 gr((unsigned)grid), bl(512);
   if (!narrow) {
@@ -607,7 +607,7 @@ static int launch_vgemm(const ConvArgs& a, hipStream_t st) {
 
 // Returns 1 when the shape is not one this kernel is built for, else the launch status.
 int conv3x3_vgemm_try(const ConvArgs& a, int dtype, bool out_f32, hipStream_t st) {
-  static const int off = getenv("DYOLO_NO_VGEMM") ? atoi(getenv("DYOLO_NO_VGEMM")) : 0;
+  static const int off = dy_ablate("DYOLO_NO_VGEMM");
   const int es = dy_dtype_size(dtype);
   const int bke = 8 * (16 / es);
   if (off || out_f32 || !a.vec_store) return 1;

@@ -19,7 +19,7 @@
 // Two LDS stages; the DMA of step s+1 is issued right after the barrier that publishes step s and runs under its MFMAs.
 // Epilogue: weights are the MFMA A operand, so a lane holds 4 consecutive couts of one pixel: bias (accumulator
 // init), SiLU, residual, per-wave LDS transpose, 16-byte row stores.
-#include "common.cuh"
+#include "common_hip.h"
 #include "conv_args.h"
 
 namespace dy {
@@ -478,7 +478,7 @@ static int launch_glds(const ConvArgs& a, hipStream_t st) {
 
 template <typename T>
 static int launch_glds_dtype(const ConvArgs& a, hipStream_t st) {
-  static const int big = getenv("DYOLO_GLDS_BIG") ? atoi(getenv("DYOLO_GLDS_BIG")) : 0;  // 1: 256x128 three-stage, 2: never persistent, 3: always persistent
+  static const int big = dy_ablate("DYOLO_GLDS_BIG");  // 1: 256x128 three-stage, 2: never persistent, 3: always persistent
   // short K (<= 9 steps, the 64-channel stride-2 layers on 160x160 maps: thousands of tiles) measured faster one tile per
   // workgroup; everything else gains 3-14 % from the persistent walk with the next tile's first K-step prefetched
   const bool persist = big != 2 && (big == 3 || a.Kpad > 9 * 8 * (16 / (int)sizeof(T)));
@@ -502,7 +502,7 @@ static int launch_glds_dtype(const ConvArgs& a, hipStream_t st) {
 }
 
 int conv_gemm_glds_try(const ConvArgs& a, int dtype, bool out_f32, hipStream_t st) {
-  static const int off = getenv("DYOLO_NO_GLDS") ? atoi(getenv("DYOLO_NO_GLDS")) : 0;
+  static const int off = dy_ablate("DYOLO_NO_GLDS");
   const int es = dy_dtype_size(dtype);
   const int bke = 8 * (16 / es);
   if (off || out_f32 || !a.vec_store) return 1;

@@ -20,7 +20,7 @@
 //
 // Reference semantics: nn/modules/conv.py:37-55 (Conv), block.py:337-350 (Bottleneck
 // residual), block.py:1480-1490 (RepVGGBlock, folded), head.py:43-57 (Detect convs).
-#include "common.cuh"
+#include "common_hip.h"
 #include "conv_args.h"
 #include <type_traits>
 

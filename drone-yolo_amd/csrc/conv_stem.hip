@@ -14,7 +14,7 @@
 //     4 consecutive output channels of one pixel; bias + SiLU on registers, per-wave LDS transpose,
 //     16-byte stores of whole pixel rows.
 // fp32 storage uses two 16-wide k-groups of the fp32 MFMA with the same gather.
-#include "common.cuh"
+#include "common_hip.h"
 #include <type_traits>
 
 namespace dy {

@@ -14,7 +14,7 @@
 // Workgroup = 4 waves, each wave owns a 64 (cout) x 64 (cin) tile: 2 x 2 waves when cout and cin >= 128, otherwise the
 // waves split the pixel range (WK = 4 / (WCO*WCI) independent 32-pixel steps per iteration).  Pixel slabs are spread
 // over gridDim.x; partial sums are added to dW with fp32 atomics (dW must be zero before the call).
-#include "common.cuh"
+#include "common_hip.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -435,7 +435,7 @@ extern "C" int32_t dy_conv2d_wgrad_nhwc(const dy_conv_desc* d, const void* dz, i
   a.div_howo = make_fastdiv((unsigned)a.HoWo);
   a.div_wo = make_fastdiv((unsigned)wo);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  static const int no3 = getenv("DYOLO_NO_WGRAD3") ? atoi(getenv("DYOLO_NO_WGRAD3")) : 0;
+  static const int no3 = dy_ablate("DYOLO_NO_WGRAD3");
   if (!no3 && d->ksize == 3 && d->pad == 1 && (d->stride == 1 || d->stride == 2) && es == 2) {  // all nine taps from one staged halo
     if (d->dtype == DY_BF16) return d->stride == 1 ? launch_wgrad3<bf16_t, 1>(a, d->batch, st) : launch_wgrad3<bf16_t, 2>(a, d->batch, st);
     return d->stride == 1 ? launch_wgrad3<f16_t, 1>(a, d->batch, st) : launch_wgrad3<f16_t, 2>(a, d->batch, st);

@@ -8,7 +8,7 @@
 // copied to LDS with lane-linear 16-byte loads (every fetched byte is used once; a lane-per-row
 // float4 read pattern fetched ~4x the bytes) and each lane then reads its own row from LDS.
 // Writes: out[b][ch][a] — consecutive lanes are consecutive anchors, every channel row a coalesced store.
-#include "common.cuh"
+#include "common_hip.h"
 #include "nms_ws.h"
 
 namespace dy {

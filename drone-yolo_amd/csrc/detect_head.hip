@@ -13,7 +13,7 @@
 //    of one pixel -> one 16-byte LDS write into that pixel's logit row (pitch chosen bank-conflict free);
 //  * the next tile's inputs are requested right after the last MFMA, then the decode phase (one lane per anchor,
 //    identical arithmetic to detect_decode.hip) runs from LDS while those loads are in flight.
-#include "common.cuh"
+#include "common_hip.h"
 #include "nms_ws.h"
 
 namespace dy {

@@ -1,6 +1,6 @@
 // Bandwidth-bound layout kernels: input layout conversion, 2x nearest upsample, strided
 // NHWC copy and the SPPF triple max-pool.  All move 16-byte chunks per lane (guide G13).
-#include "common.cuh"
+#include "common_hip.h"
 
 namespace dy {
 

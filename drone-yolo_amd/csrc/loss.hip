@@ -17,7 +17,7 @@
 //   K6 loss_final_kernel    loss_cls = (sum softplus - sum x_cls t)/tss etc., gains, total.
 // Deviation (documented in DESIGN.md): picks with metric == 0 are never taken.  torch.topk may return such ties in
 // unspecified order; they carry target score 0 and weight 0, so they do not change any loss term.
-#include "common.cuh"
+#include "common_hip.h"
 
 namespace dy {
 

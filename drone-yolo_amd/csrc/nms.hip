@@ -22,7 +22,7 @@
 // inputs:  xyxy = xy -/+ wh/2 (ops.py:432-449); boxes + cls*max_wh (ops.py:305,311);
 // area = (x2-x1)*(y2-y1); inter = max(0,xx2-xx1)*max(0,yy2-yy1);
 // suppress iff inter / (area_i + area_j - inter) > iou_thres.
-#include "common.cuh"
+#include "common_hip.h"
 #include "nms_ws.h"
 
 #pragma clang fp contract(off)

@@ -6,7 +6,7 @@
 // oracle/letterbox_oracle.py (11-bit fixed-point coefficients, source coordinate (d + 0.5) * scale - 0.5 clamped at the
 // borders, vertical pass (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2), so the uint8 image equals the oracle's bit
 // for bit.  One thread per output pixel: three planes written with lane-contiguous stores.
-#include "common.cuh"
+#include "common_hip.h"
 
 namespace dy {
 

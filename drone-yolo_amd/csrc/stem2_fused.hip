@@ -21,7 +21,7 @@
 // the 16 pixels of a stride-2 fragment are CONSECUTIVE entries of one plane; the four 16-byte chunks of an entry are
 // XOR-swizzled by (index >> 2) & 3: conflict-free ds_read_b128 operand reads.
 // LDS 64 KiB -> two workgroups per CU: one loads its patch while the other computes.
-#include "common.cuh"
+#include "common_hip.h"
 
 namespace dy {
 

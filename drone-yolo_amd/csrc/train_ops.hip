@@ -2,7 +2,7 @@
 // (yolov8-p2-repvgg.yaml:30,34,38), of SPPF's MaxPool2d(k, 1, k//2) (nn/modules/block.py:185-191), the element-wise add
 // of Bottleneck's shortcut (block.py:348-350), and the optimizer / EMA / clipping updates of the trainer
 // (engine/trainer.py:591-599, 764-825; utils/torch_utils.py:515-545).
-#include "common.cuh"
+#include "common_hip.h"
 
 namespace dy {
 

@@ -560,14 +560,18 @@ def big_vectors(R):
 
     out = {}
 
-    def run(tag, yname, scale, nc, x, input_seed=None, bias_shift=0.0, check_oracle=True):
+    def run(tag, yname, scale, nc, x, input_seed=None, bias_shift=0.0, check_oracle=True, seeded=None):
         model, d, template = _ref_model(R, yname, scale, nc)
         name = yname.replace("yolov8", f"yolov8{scale}")
-        shim = types.SimpleNamespace(yaml={"yaml_file": name, "nc": nc}, state_dict=lambda: template)
-        sd = bench.synthetic_state_dict(shim, 0)
-        bias = float(np.load(ROOT / "bench_data" / f"{os.path.splitext(name)[0]}_nc{nc}_seed0_bn.npz")["__cls_bias__"]) + bias_shift
-        if bias_shift:
-            sd = bench.synthetic_state_dict(shim, 0, cls_bias=bias)
+        if seeded is not None:  # the e2e fixtures' recipe: seeded_state_dict(weights seed, cls_bias)
+            wseed, bias = seeded
+            sd = O.seeded_state_dict(template, wseed, cls_bias=bias)
+        else:
+            shim = types.SimpleNamespace(yaml={"yaml_file": name, "nc": nc}, state_dict=lambda: template)
+            sd = bench.synthetic_state_dict(shim, 0)
+            bias = float(np.load(ROOT / "bench_data" / f"{os.path.splitext(name)[0]}_nc{nc}_seed0_bn.npz")["__cls_bias__"]) + bias_shift
+            if bias_shift:
+                sd = bench.synthetic_state_dict(shim, 0, cls_bias=bias)
         model.load_state_dict(sd)
         R.tu.initialize_weights(model)
         model.eval()
@@ -588,7 +592,9 @@ def big_vectors(R):
             assert torch.equal(a_, b_), f"{tag}: oracle NMS rows differ from the reference's"
         frac = float((y[:, 4:].amax(1) > 0.25).float().mean())
         print(f"[{tag}] {name} input={tuple(x.shape)} A={y.shape[2]} cls_bias={bias:.3f} candidates {frac * 100:.2f} %  kept {[len(r) for r in ref_det]}")
-        out[f"{tag}__meta"] = np.array(repr(dict(yaml=yname, scale=scale, nc=nc, shape=(x.shape[0], x.shape[2], x.shape[3]), weights="bench.synthetic_state_dict seed 0",
+        out[f"{tag}__meta"] = np.array(repr(dict(yaml=yname, scale=scale, nc=nc, shape=(x.shape[0], x.shape[2], x.shape[3]),
+                                                 weights=f"seeded_state_dict seed {seeded[0]}" if seeded else "bench.synthetic_state_dict seed 0",
+                                                 **({"weights_seed": seeded[0]} if seeded else {}),
                                                  **({"seed": input_seed} if input_seed is not None else {}),
                                                  cls_bias=round(bias, 4), bias_shift=bias_shift, params=sum(p.numel() for p in model.parameters()))))
         out[f"{tag}__n"] = np.array([len(r) for r in ref_det])
@@ -598,10 +604,16 @@ def big_vectors(R):
         out[f"{tag}__y_sum"] = np.array([float(y.double().sum()), float(y.double().abs().sum()), float((y.double() ** 2).sum())])
         return ref_det
 
-    # (a) the metric's own configuration: bench.py's rank-0 input recipe
+    # (a) the metric's own model and shape, four images.  s640b4 / s640b4lo: the weights of the e2e fixture "s640"
+    # (seeded_state_dict seed 104) — the parity gate bench.py prints.  s640bench: bench.py's own weights and rank-0 input
+    # recipe; that random network with activation-calibrated BatchNorm is chaotic (1e-4 of input noise moves its fp32 boxes by
+    # more than a pixel), so it pins the fp32 kernels under maximal error amplification but is no yardstick for 16-bit storage.
+    e2e_meta = eval(str(np.load(OUT / "e2e.npz")["s640__meta"]))  # noqa: S307 - our own fixture
+    x = torch.rand(4, 3, 640, 640, generator=torch.Generator().manual_seed(1104))
+    run("s640b4", "yolov8-p2-repvgg.yaml", "s", 10, x, input_seed=1104, seeded=(e2e_meta["seed"], e2e_meta["cls_bias"]))
+    run("s640b4lo", "yolov8-p2-repvgg.yaml", "s", 10, x, input_seed=1104, seeded=(e2e_meta["seed"], e2e_meta["cls_bias"] - 0.08), check_oracle=False)
     x = torch.rand(4, 3, 640, 640, generator=torch.Generator().manual_seed(1000))
-    run("s640b4", "yolov8-p2-repvgg.yaml", "s", 10, x, input_seed=1000)  # meta seed = the seed of torch.rand(shape) that makes the input
-    run("s640b4lo", "yolov8-p2-repvgg.yaml", "s", 10, x, input_seed=1000, bias_shift=-1.5, check_oracle=False)
+    run("s640bench", "yolov8-p2-repvgg.yaml", "s", 10, x, input_seed=1000)
 
     # (b) config 4: tiles of a 3840x2160 BGR uint8 frame, stride 1024 / last tile clamped (engine/tiling.py::tile_offsets)
     tile, hf, wf = 1280, 2160, 3840

@@ -144,20 +144,20 @@ def test_bench_configuration_vectors():
     from drone_yolo_amd.utils import parity as PR
 
     g = golden("big.npz")
-    for tag in ("s640b4", "s640b4lo"):
+    for tag in ("s640b4", "s640bench"):
         m, x, exp_rows, exp_idx = PR.golden_case("big.npz", tag)
         assert x.shape == (4, 3, 640, 640)
         d = load_yaml(m["yaml"], m["scale"], m["nc"])
         d["yaml_file"] = m["yaml"].replace("yolov8", f"yolov8{m['scale']}")
         model = D.DetectionModel(dict(d), nc=m["nc"], verbose=False)
-        sd = bench.synthetic_state_dict(model, seed=0, cls_bias=m["cls_bias"] if m.get("bias_shift") else None)
+        sd = bench.fixture_weights(model, m)
         with torch.no_grad():
             y, _ = O.forward(d, sd, x[:2])
         assert torch.allclose(y[:, :, ::199], torch.from_numpy(g[f"{tag}__y_sub"][:2]), atol=2e-3, rtol=1e-4), tag
         det, idx = O.non_max_suppression(y, 0.25, 0.7, max_det=300, nc=m["nc"], return_index=True)
         for i in range(2):
             assert np.array_equal(idx[i].numpy(), exp_idx[i]), tag
-            assert np.allclose(PR.clip_rows(det[i].numpy(), (640, 640)), exp_rows[i], atol=2e-3), tag
+            assert np.allclose(PR.clip_rows(det[i].numpy(), (640, 640)), exp_rows[i], atol=2e-3 if tag == "s640b4" else 5e-2), tag
     tmpl = {"a.conv.weight": torch.zeros(8, 4, 3, 3), "a.bn.weight": torch.zeros(8), "a.bn.bias": torch.zeros(8), "a.bn.running_mean": torch.zeros(8),
             "a.bn.running_var": torch.zeros(8), "a.bn.num_batches_tracked": torch.zeros((), dtype=torch.long), "m.cv3.0.2.bias": torch.zeros(10),
             "m.dfl.conv.weight": torch.zeros(1, 16, 1, 1)}
