@@ -36,7 +36,7 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense, MI3
 HBM_PEAK_GBS = 8000.0
 
 
-def synthetic_state_dict(model, seed: int, cls_bias=None, bn_stats="file"):
+def synthetic_state_dict(model, seed: int, cls_bias=None, bn_stats="file", gamma_scale=None, variant=""):
     """Random-init weights of the architecture (no checkpoints exist offline): conv ~ N(0, 2/fan_in), BN affine
     near identity.  BatchNorm running statistics and the class-branch bias come from
     bench_data/<model>_nc<nc>_seed<seed>_bn.npz, calibrated offline by oracle/calibrate_synthetic.py so that
@@ -47,12 +47,13 @@ def synthetic_state_dict(model, seed: int, cls_bias=None, bn_stats="file"):
     g = torch.Generator().manual_seed(seed)
     if bn_stats == "file":
         name = os.path.splitext(os.path.basename(model.yaml.get("yaml_file", "model")))[0]
-        path = os.path.join(ROOT, "bench_data", f"{name}_nc{model.yaml['nc']}_seed{seed}_bn.npz")
+        path = os.path.join(ROOT, "bench_data", f"{name}_nc{model.yaml['nc']}_seed{seed}{variant}_bn.npz")
         if not os.path.exists(path):
             raise FileNotFoundError(f"{path} missing: run `python oracle/calibrate_synthetic.py --model {name}.yaml --seed {seed}`")
         z = np.load(path)
         bn_stats = {k: torch.from_numpy(z[k]) for k in z.files if not k.startswith("__")}
         cls_bias = float(z["__cls_bias__"]) if cls_bias is None else cls_bias
+        gamma_scale = float(z["__gamma_scale__"]) if "__gamma_scale__" in z.files and gamma_scale is None else gamma_scale
     sd = {}
     for k, t in sorted(model.state_dict().items()):
         shape = tuple(t.shape)
@@ -65,7 +66,7 @@ def synthetic_state_dict(model, seed: int, cls_bias=None, bn_stats="file"):
         elif k.endswith("running_var"):
             sd[k] = bn_stats[k].clone() if bn_stats else torch.ones(shape)
         elif k.endswith("weight") and len(shape) == 1:
-            sd[k] = torch.rand(shape, generator=g) * 0.4 + 0.8
+            sd[k] = (torch.rand(shape, generator=g) * 0.4 + 0.8) * (gamma_scale or 1.0)
         elif k.endswith("bias"):
             sd[k] = torch.randn(shape, generator=g) * 0.1
         else:
@@ -201,7 +202,7 @@ def fixture_weights(model, meta):
 
     if "weights_seed" in meta:
         return PR.seeded_state_dict(model.state_dict(), meta["weights_seed"], cls_bias=meta["cls_bias"])
-    return synthetic_state_dict(model, seed=0, cls_bias=meta["cls_bias"] if meta.get("bias_shift") else None)
+    return synthetic_state_dict(model, seed=0, cls_bias=meta["cls_bias"] if meta.get("bias_shift") else None, variant=meta.get("variant", ""))
 
 
 def parity_gate(dtype: str, device_index: int, npz: str = "big.npz", tag: str = "s640b4"):

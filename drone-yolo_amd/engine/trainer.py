@@ -331,8 +331,13 @@ class DetectionTrainer:
         self.flat = FlatState(self.model, self.device)
         if self.world > 1 and torch.distributed.is_initialized():
             # DDP broadcasts rank 0's parameters and buffers at construction; so do we (replicas must not rely on equal seeds)
-            torch.distributed.broadcast(self.flat.P, 0)
-            torch.distributed.broadcast(self.flat.B, 0)
+            for t in (self.flat.P, self.flat.B):
+                if torch.distributed.get_backend() == "nccl":
+                    torch.distributed.broadcast(t, 0)
+                else:  # gloo rehearsal on fewer GPUs than ranks: through host memory
+                    h = t.cpu()
+                    torch.distributed.broadcast(h, 0)
+                    t.copy_(h)
         nc = self.model.yaml["nc"]
         name, self.lr0, self.momentum, self.warmup_bias_lr = resolve_optimizer(a, nc, self.iterations_hint)
         if name not in ("SGD", "AdamW"):

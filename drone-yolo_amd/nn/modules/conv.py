@@ -43,8 +43,17 @@ def fold_conv_bn(conv_weight: torch.Tensor, conv_bias: Optional[torch.Tensor], b
 class _PackedMixin:
     """Lazy per-dtype cache of packed weights; dropped whenever parameters may have changed."""
 
+    def _pack_cache(self) -> dict:
+        """The per-dtype pack cache, emptied when any parameter / buffer of this module was re-homed or edited in place
+        (storage identity + torch's version counter) since the packs were made."""
+        sig = tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        cache = self.__dict__.get("_packed")
+        if cache is None or cache.get("__sig__") != sig:
+            cache = self.__dict__["_packed"] = {"__sig__": sig}
+        return cache
+
     def _packed_for(self, x: torch.Tensor) -> H.PackedConv:
-        cache = self.__dict__.setdefault("_packed", {})
+        cache = self._pack_cache()
         key = (x.dtype, x.device, x.shape[1])
         pc = cache.get(key)
         if pc is None:
@@ -119,7 +128,7 @@ class Conv(_PackedMixin, nn.Module):
     def forward_stem(self, im, dtype, out=None, mark_input=False):
         """fp32 NCHW image -> this layer's NHWC output in ``dtype`` (layout cast + conv + BN + SiLU in one kernel)."""
         _require_eval(self)
-        cache = self.__dict__.setdefault("_packed", {})
+        cache = self._pack_cache()
         key = ("stem", dtype, im.device)
         ps = cache.get(key)
         if ps is None:

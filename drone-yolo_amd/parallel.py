@@ -81,7 +81,12 @@ def allreduce_gradients(flat_grad: torch.Tensor) -> torch.Tensor:
     then DistributedDataParallel's gradient mean — the product is the plain sum).  One bucket: for Drone-YOLO-s 43 MB fp32,
     a single ring pass over the xGMI links; BatchNorm statistics stay per rank (no SyncBN in the reference)."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+        if flat_grad.is_cuda and dist.get_backend() != "nccl":  # gloo rehearsal: through host memory
+            h = flat_grad.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            flat_grad.copy_(h)
+        else:
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return flat_grad
 
 
@@ -148,7 +153,14 @@ class GradBuckets:
 
     def _issue(self, bi: int) -> None:
         for lo, hi in self.buckets[bi]["ranges"]:
-            self.works.append(dist.all_reduce(self.flat.G[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            g = self.flat.G[lo:hi]
+            if g.is_cuda and dist.get_backend() != "nccl":
+                # rehearsal of N ranks on fewer GPUs (DYOLO_DIST_BACKEND=gloo): the exchange goes through host memory
+                h = g.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                g.copy_(h)
+            else:
+                self.works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
 
     def _ready(self, bi: int) -> None:
         if not self.armed:

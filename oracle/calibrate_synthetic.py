@@ -38,10 +38,13 @@ def main():
     ap.add_argument("--images", type=int, default=2)
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--target", type=float, default=0.02)
+    ap.add_argument("--gamma", type=float, default=1.0, help="scale of every BatchNorm weight: < 1 keeps SiLU near its linear range, which takes a deep RANDOM "
+                                                             "network out of the chaotic regime (rounding noise is no longer amplified layer by layer)")
+    ap.add_argument("--variant", default="", help="suffix of the output file name")
     a = ap.parse_args()
     torch.set_num_threads(8)
     model = D.DetectionModel(a.model, nc=a.nc, verbose=False)
-    sd = bench.synthetic_state_dict(model, a.seed, cls_bias=0.0, bn_stats=None)
+    sd = bench.synthetic_state_dict(model, a.seed, cls_bias=0.0, bn_stats=None, gamma_scale=a.gamma)
     x = torch.rand(a.images, 3, a.size, a.size, generator=torch.Generator().manual_seed(12345))
 
     def bn_calibrating(t, sd_, p):
@@ -62,7 +65,7 @@ def main():
         y, feats = O.forward(model.yaml, sd, x, fused=True)
     logits = torch.logit(y[:, 4:].amax(1).clamp(1e-6, 1 - 1e-6)).flatten()
     bias = round(float(math.log(0.25 / 0.75) - torch.quantile(logits, 1 - a.target)), 3)
-    sd = bench.synthetic_state_dict(model, a.seed, cls_bias=bias, bn_stats={k: v for k, v in sd.items() if "running_" in k})
+    sd = bench.synthetic_state_dict(model, a.seed, cls_bias=bias, bn_stats={k: v for k, v in sd.items() if "running_" in k}, gamma_scale=a.gamma)
     with torch.no_grad():
         y, feats = O.forward(model.yaml, sd, x, fused=True)
     frac = float((y[:, 4:].amax(1) > 0.25).float().mean())
@@ -71,8 +74,9 @@ def main():
           f"raw logit std {[round(float(f.std()), 2) for f in feats]}")
     out = {k: v.numpy() for k, v in sd.items() if "running_" in k}
     out["__cls_bias__"] = np.array(bias, dtype=np.float32)
+    out["__gamma_scale__"] = np.array(a.gamma, dtype=np.float32)
     os.makedirs(os.path.join(ROOT, "bench_data"), exist_ok=True)
-    path = os.path.join(ROOT, "bench_data", f"{os.path.splitext(a.model)[0]}_nc{a.nc}_seed{a.seed}_bn.npz")
+    path = os.path.join(ROOT, "bench_data", f"{os.path.splitext(a.model)[0]}_nc{a.nc}_seed{a.seed}{a.variant}_bn.npz")
     np.savez_compressed(path, **out)
     print("wrote", os.path.relpath(path, ROOT), f"{os.path.getsize(path) / 1024:.1f} KiB")
 

@@ -546,7 +546,7 @@ def _ref_model(R, yname, scale, nc):
     return model, our_yaml(yname, scale, nc), {k: v for k, v in model.state_dict().items()}
 
 
-def big_vectors(R):
+def big_vectors(R, only=None):
     """tests/golden/big.npz — (a) s640b4 / s640b4lo: Drone-YOLO-s with EXACTLY the weights and input recipe bench.py times
     (bench.synthetic_state_dict seed 0 + the calibrated BatchNorm statistics of bench_data/, torch.rand seed 1000), four
     640x640 images: the parity gate bench.py prints next to its throughput ("lo": class bias 1.5 lower, so that the kept
@@ -559,8 +559,13 @@ def big_vectors(R):
     import bench
 
     out = {}
+    if only and (OUT / "big.npz").exists():  # recompute a subset of the cases, keep the rest
+        old = np.load(OUT / "big.npz")
+        out = {k: old[k] for k in old.files}
 
-    def run(tag, yname, scale, nc, x, input_seed=None, bias_shift=0.0, check_oracle=True, seeded=None):
+    def run(tag, yname, scale, nc, x, input_seed=None, bias_shift=0.0, check_oracle=True, seeded=None, variant=""):
+        if only and tag not in only:
+            return None
         model, d, template = _ref_model(R, yname, scale, nc)
         name = yname.replace("yolov8", f"yolov8{scale}")
         if seeded is not None:  # the e2e fixtures' recipe: seeded_state_dict(weights seed, cls_bias)
@@ -568,10 +573,10 @@ def big_vectors(R):
             sd = O.seeded_state_dict(template, wseed, cls_bias=bias)
         else:
             shim = types.SimpleNamespace(yaml={"yaml_file": name, "nc": nc}, state_dict=lambda: template)
-            sd = bench.synthetic_state_dict(shim, 0)
-            bias = float(np.load(ROOT / "bench_data" / f"{os.path.splitext(name)[0]}_nc{nc}_seed0_bn.npz")["__cls_bias__"]) + bias_shift
+            sd = bench.synthetic_state_dict(shim, 0, variant=variant)
+            bias = float(np.load(ROOT / "bench_data" / f"{os.path.splitext(name)[0]}_nc{nc}_seed0{variant}_bn.npz")["__cls_bias__"]) + bias_shift
             if bias_shift:
-                sd = bench.synthetic_state_dict(shim, 0, cls_bias=bias)
+                sd = bench.synthetic_state_dict(shim, 0, cls_bias=bias, variant=variant)
         model.load_state_dict(sd)
         R.tu.initialize_weights(model)
         model.eval()
@@ -594,7 +599,7 @@ def big_vectors(R):
         print(f"[{tag}] {name} input={tuple(x.shape)} A={y.shape[2]} cls_bias={bias:.3f} candidates {frac * 100:.2f} %  kept {[len(r) for r in ref_det]}")
         out[f"{tag}__meta"] = np.array(repr(dict(yaml=yname, scale=scale, nc=nc, shape=(x.shape[0], x.shape[2], x.shape[3]),
                                                  weights=f"seeded_state_dict seed {seeded[0]}" if seeded else "bench.synthetic_state_dict seed 0",
-                                                 **({"weights_seed": seeded[0]} if seeded else {}),
+                                                 **({"weights_seed": seeded[0]} if seeded else {"variant": variant}),
                                                  **({"seed": input_seed} if input_seed is not None else {}),
                                                  cls_bias=round(bias, 4), bias_shift=bias_shift, params=sum(p.numel() for p in model.parameters()))))
         out[f"{tag}__n"] = np.array([len(r) for r in ref_det])
@@ -614,6 +619,7 @@ def big_vectors(R):
     run("s640b4lo", "yolov8-p2-repvgg.yaml", "s", 10, x, input_seed=1104, seeded=(e2e_meta["seed"], e2e_meta["cls_bias"] - 0.08), check_oracle=False)
     x = torch.rand(4, 3, 640, 640, generator=torch.Generator().manual_seed(1000))
     run("s640bench", "yolov8-p2-repvgg.yaml", "s", 10, x, input_seed=1000)
+    run("s640g025", "yolov8-p2-repvgg.yaml", "s", 10, x, input_seed=1000, variant="_g025")
 
     # (b) config 4: tiles of a 3840x2160 BGR uint8 frame, stride 1024 / last tile clamped (engine/tiling.py::tile_offsets)
     tile, hf, wf = 1280, 2160, 3840
@@ -622,21 +628,24 @@ def big_vectors(R):
     xt = torch.stack([torch.from_numpy(np.ascontiguousarray(frame[y : y + tile, xx : xx + tile, ::-1].transpose(2, 0, 1))).float() / 255 for y, xx in offs])
     det = run("l1280t8", "yolov8-p2-repvgg.yaml", "l", 10, xt)
     rows = []
+    if det is None:
+        offs = []
     for (oy, ox), r in zip(offs, det):
         r = r.clone()
         r[:, :4] = O.clip_boxes(r[:, :4], (tile, tile))
         r[:, [0, 2]] += ox
         r[:, [1, 3]] += oy
         rows.append(r)
-    allr = torch.cat(rows)
+    allr = torch.cat(rows) if rows else torch.zeros(0, 6)
     pred = torch.zeros(1, 14, len(allr))
     pred[0, 0], pred[0, 1] = (allr[:, 0] + allr[:, 2]) / 2, (allr[:, 1] + allr[:, 3]) / 2
     pred[0, 2], pred[0, 3] = allr[:, 2] - allr[:, 0], allr[:, 3] - allr[:, 1]
     pred[0, 4 + allr[:, 5].long(), torch.arange(len(allr))] = allr[:, 4]
-    merged, _ = O.non_max_suppression(pred, 0.0, 0.7, max_det=1000, nc=10, return_index=True)
-    out["l1280t8__merged"] = tnp(merged[0])
-    out["l1280t8__frame"] = np.array(repr(dict(rng_seed=107, hw=(hf, wf), tile=tile, overlap=0.2, offsets=offs, merge_iou=0.7, merge_max_det=1000)))
-    print(f"  tiles -> {len(allr)} rows, merged {len(merged[0])}")
+    if det is not None:
+        merged, _ = O.non_max_suppression(pred, 0.0, 0.7, max_det=1000, nc=10, return_index=True)
+        out["l1280t8__merged"] = tnp(merged[0])
+        out["l1280t8__frame"] = np.array(repr(dict(rng_seed=107, hw=(hf, wf), tile=tile, overlap=0.2, offsets=offs, merge_iou=0.7, merge_max_det=1000)))
+        print(f"  tiles -> {len(allr)} rows, merged {len(merged[0])}")
 
     # (c) config 5's shape in fp32
     x = torch.rand(1, 3, 1536, 1536, generator=torch.Generator().manual_seed(108))
@@ -695,7 +704,8 @@ if __name__ == "__main__":
     elif "--loss-only" in sys.argv:
         loss_vectors(R)
     elif "--big-only" in sys.argv:
-        big_vectors(R)
+        only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--cases=")]
+        big_vectors(R, only=only[0] if only else None)
     else:
         per_op(R)
         nms_cases(R)

@@ -157,7 +157,7 @@ def _train_case(tag):
     return g, m, d, model, sd, img, labels
 
 
-@pytest.mark.parametrize("tag", ["tn64", "tn96"])
+@pytest.mark.parametrize("tag", ["tn64", "tn96", "ts160"])  # ts160: config 3's model (scale s) at a reduced size
 def test_model_train_step_gradients_fp32(tag, device):
     """module.train() forward + v8DetectionLoss + backward on the device in fp32 storage against autograd through the
     oracle (bit-identical to the real reference, oracle/make_golden.py::train_vectors) and the reference's golden norms.
@@ -315,3 +315,109 @@ def test_optimizer_kernels_match_torch_optim(device):
     H.ema_update_(ed, p0.to(device), 0.37)
     torch.cuda.synchronize()
     assert torch.allclose(ed.cpu(), e * 0.37 + 0.63 * p0, rtol=1e-6, atol=1e-6)
+
+
+def test_config3_full_size_step_properties(device):
+    """BASELINE config 3's model at its real size — Drone-YOLO-s, 640x640, B = 8, VisDrone-shaped labels (Poisson(50) per image)
+    — where the CPU oracle's autograd is too slow to be a per-test reference: size-independent properties of one step.
+    (1) loss and all 238 gradients finite and non-zero; (2) bf16 storage (what bench.py --mode train times) against fp32
+    storage of the same step: loss within 3 %, gradient norm within 10 %, head gradients' cosine > 0.98; (3) the loss is a sum
+    over images normalised by the batch's target-score sum, so permuting the images of the batch (labels re-indexed) leaves
+    loss, items and the gradient norm unchanged up to atomics / summation order."""
+    import bench
+    import drone_yolo_amd as D
+    from drone_yolo_amd.engine.trainer import synthetic_dataset
+
+    data = synthetic_dataset(8, 640, seed=1000)
+    model = D.DetectionModel("yolov8s-p2-repvgg.yaml", nc=10, verbose=False)
+    model.load_state_dict(bench.synthetic_state_dict(model, seed=0))
+    model = model.to(device).train()
+
+    def step(dtype, perm=None):
+        for p in model.parameters():
+            p.grad = None
+        model.train_dtype = dtype
+        img, bi, cls, bb = data["img"], data["batch_idx"], data["cls"], data["bboxes"]
+        if perm is not None:
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(len(perm))
+            img, bi = img[perm], inv[bi.long()].float()
+            order = torch.argsort(bi, stable=True)
+            bi, cls, bb = bi[order], cls[order], bb[order]
+        sd0 = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
+        loss, items = model(dict(img=img.to(device), batch_idx=bi, cls=cls, bboxes=bb))
+        loss.backward()
+        torch.cuda.synchronize()
+        model.load_state_dict(sd0, strict=False)  # every variant starts from the same BatchNorm buffers
+        grads = {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters() if p.grad is not None}
+        return float(loss), items.cpu().clone(), grads
+
+    def gnorm(g):
+        return float(torch.sqrt(sum((v.double() ** 2).sum() for v in g.values())))
+
+    l32, i32, g32 = step(torch.float32)
+    assert len(g32) == 238 and all(torch.isfinite(v).all() and float(v.abs().max()) > 0 for v in g32.values())
+    assert l32 > 0 and torch.isfinite(i32).all()
+    l16, i16, g16 = step(torch.bfloat16)
+    assert abs(l16 - l32) <= 0.03 * l32, (l16, l32)
+    assert abs(gnorm(g16) - gnorm(g32)) <= 0.10 * gnorm(g32), (gnorm(g16), gnorm(g32))
+    head = [k for k in g32 if k.startswith("model.28.") and (".2.weight" in k or ".2.bias" in k)]
+    a, b = torch.cat([g16[k].flatten().double() for k in head]), torch.cat([g32[k].flatten().double() for k in head])
+    assert float((a * b).sum() / (a.norm() * b.norm())) > 0.98
+    perm = torch.randperm(8, generator=torch.Generator().manual_seed(3))
+    lp, ip, gp = step(torch.float32, perm)
+    assert abs(lp - l32) <= 2e-4 * l32 and torch.allclose(ip, i32, rtol=2e-4, atol=1e-6), (lp, l32)
+    assert abs(gnorm(gp) - gnorm(g32)) <= 2e-3 * gnorm(g32)
+
+
+def test_yolo_train_api_end_to_end(device, tmp_path):
+    """``YOLO(...).train(...)`` (engine/model.py:744-817 / trainer.py:319-476): two epochs over a synthetic tensor dataset —
+    results.csv has one row per epoch with the reference's column names, weights/last.pt carries the reference's keys, loads
+    back through YOLO('last.pt') and predicts; the live model's weights moved and its predictor re-records."""
+    import csv
+
+    import drone_yolo_amd as D
+
+    yolo = D.YOLO("yolov8n-p2-repvgg.yaml")
+    w0 = yolo.model.model[0].conv.weight.detach().clone()
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(1))
+    before = yolo.predict(x, device=0, conf=0.001, dtype="fp32")
+    out = yolo.train(data="synthetic:16", epochs=2, imgsz=64, batch=8, device=0, dtype="fp32", optimizer="SGD", lr0=0.01, warmup_epochs=0.0,
+                     project=str(tmp_path), name="t")
+    rows = list(csv.DictReader(open(tmp_path / "t" / "results.csv")))
+    assert [r["epoch"] for r in rows] == ["1", "2"]
+    assert {"time", "train/box_loss", "train/cls_loss", "train/dfl_loss", "lr/pg0", "lr/pg1", "lr/pg2"} <= set(rows[0])
+    assert all(float(r["train/box_loss"]) > 0 for r in rows) and "train/box_loss" in out
+    ck = torch.load(tmp_path / "t" / "weights" / "last.pt", map_location="cpu", weights_only=False, pickle_module=__import__("drone_yolo_amd").nn.checkpoint._pickle_module())
+    assert {"epoch", "best_fitness", "model", "ema", "updates", "optimizer", "train_args", "train_metrics", "train_results", "date", "version"} <= set(ck)
+    assert ck["epoch"] == 1 and ck["model"] is None and ck["updates"] == 4 and len(ck["optimizer"]["param_groups"]) == 3
+    assert next(ck["ema"].parameters()).dtype == torch.float16
+    assert not torch.equal(yolo.model.model[0].conv.weight.detach().cpu(), w0.cpu())  # the live model trained
+    after = yolo.predict(x, device=0, conf=0.001, dtype="fp32")
+    assert len(after) == 2 and not yolo.model.training
+    again = D.YOLO(str(tmp_path / "t" / "weights" / "last.pt")).predict(x, device=0, conf=0.001, dtype="fp32")
+    assert len(again) == 2 and again[0].boxes.data.shape[1] == 6
+    assert len(before) == 2
+
+
+def test_two_rank_training_rehearsal_on_one_gpu(device, tmp_path):
+    """``YOLO.train(device="0,1")``: the launcher path (temp script -> python -m torch.distributed.run -> two ranks) rehearsed on
+    ONE GPU (DYOLO_FORCE_DEVICE=0, gloo for the exchange: RCCL refuses two ranks on a device).  Each rank takes batch // 2
+    images (trainer.py:286), gradients are summed in buckets during backward, rank 0 writes results.csv / last.pt."""
+    import csv
+    import os
+
+    import drone_yolo_amd as D
+
+    old = {k: os.environ.get(k) for k in ("DYOLO_FORCE_DEVICE", "DYOLO_DIST_BACKEND")}
+    os.environ.update(DYOLO_FORCE_DEVICE="0", DYOLO_DIST_BACKEND="gloo")
+    try:
+        yolo = D.YOLO("yolov8n-p2-repvgg.yaml")
+        yolo.train(data="synthetic:16", epochs=1, imgsz=64, batch=8, device="0,1", dtype="fp32", optimizer="SGD", warmup_epochs=0.0, project=str(tmp_path), name="ddp")
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    rows = list(csv.DictReader(open(tmp_path / "ddp" / "results.csv")))
+    assert len(rows) == 1 and float(rows[0]["train/box_loss"]) > 0
+    assert (tmp_path / "ddp" / "weights" / "last.pt").exists()
+    assert yolo.ckpt["epoch"] == 0 and yolo.ckpt["updates"] == 2  # 16 images / (8 per step over 2 ranks) = 2 optimizer steps
