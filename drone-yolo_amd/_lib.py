@@ -154,6 +154,7 @@ SIGNATURES = {
     "dy_scale_boxes": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "dy_detection_loss_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "dy_conv2d_wgrad_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _i32, _vp, _vp]),
+    "dy_conv2d_grouped_bwd_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
     "dy_colsum": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "dy_nchw_u8_to_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "dy_letterbox_u8_to_nchw_f32": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),

@@ -186,6 +186,86 @@ static inline unsigned grid1(long long items) {
   return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
+
+// ---- grouped convolution gradients (DWConv of the -sf YAML, nn/modules/conv.py:102-107: g = gcd(c1, c2), k 3, stride 2) ----------
+// Tiny (0.026 GFLOP / image forward) and bandwidth bound, so direct kernels.  Weights and their gradient are the fp32 master
+// tensors in torch's own (cout, cin/g, k, k) layout: no packing step, the gradient lands where the optimizer reads it.
+// wgrad: one thread per (pixel slab, output channel): consecutive lanes = consecutive channels, so the dz row (64 channels x 2 B) and
+// the x row of the matching groups are read as whole lines; CPG_IN*K*K partial sums in registers, added with fp32 atomics.
+template <typename T, int CPG_IN, int K>
+__global__ __launch_bounds__(256) void conv_grouped_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dz, float* __restrict__ dw, int n, int h, int w, int cin,
+                                                                 int ldx, int ho, int wo, int cout, int lddz, int stride, int pad, int groups, int slab) {
+  const int co = blockIdx.y * 64 + (threadIdx.x & 63);
+  const long long m_total = (long long)n * ho * wo;
+  const long long m0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * slab;
+  if (co >= cout || m0 >= m_total) return;
+  const int cpg_out = cout / groups;
+  const int cbase = (co / cpg_out) * CPG_IN;
+  float acc[K * K * CPG_IN];
+#pragma unroll
+  for (int i = 0; i < K * K * CPG_IN; ++i) acc[i] = 0.f;
+  const long long m1 = m0 + slab < m_total ? m0 + slab : m_total;
+  for (long long m = m0; m < m1; ++m) {
+    const int img = (int)(m / ((long long)ho * wo));
+    const int rem = (int)(m - (long long)img * ho * wo);
+    const int oy = rem / wo, ox = rem - oy * wo;
+    const float g = Elem<T>::to_f32(dz[(size_t)m * (size_t)lddz + co]);
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+      const int iy = oy * stride - pad + r;
+      if ((unsigned)iy >= (unsigned)h) continue;
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        const int ix = ox * stride - pad + q;
+        if ((unsigned)ix >= (unsigned)w) continue;
+        const T* xp = x + ((size_t)(img * h + iy) * w + ix) * (size_t)ldx + cbase;
+#pragma unroll
+        for (int c = 0; c < CPG_IN; ++c) acc[(c * K + r) * K + q] += g * Elem<T>::to_f32(xp[c]);
+      }
+    }
+  }
+  float* out = dw + (size_t)co * (CPG_IN * K * K);
+#pragma unroll
+  for (int i = 0; i < K * K * CPG_IN; ++i) atomicAdd(out + i, acc[i]);
+}
+
+// dgrad: one thread per (input pixel, input channel): dx = sum over the taps whose output pixel exists of dz[out pixel][co] * w[co][ci_local][r][q]
+template <typename T>
+__global__ __launch_bounds__(256) void conv_grouped_dgrad_kernel(const T* __restrict__ dz, const float* __restrict__ wt, const T* __restrict__ acc_in, T* __restrict__ dx, int n,
+                                                                 int h, int w, int cin, int lddx, int ldacc, int ho, int wo, int cout, int lddz, int k, int stride, int pad,
+                                                                 int groups) {
+  const long long total = (long long)n * h * w * cin;
+  const int cpg_in = cin / groups, cpg_out = cout / groups;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ci = (int)(i % cin);
+    long long t = i / cin;
+    const int ix = (int)(t % w);
+    t /= w;
+    const int iy = (int)(t % h);
+    const int img = (int)(t / h);
+    const int g = ci / cpg_in, cil = ci - g * cpg_in;
+    float acc = 0.f;
+    for (int r = 0; r < k; ++r) {
+      const int ty = iy + pad - r;
+      if (ty < 0 || ty % stride) continue;
+      const int oy = ty / stride;
+      if (oy >= ho) continue;
+      for (int q = 0; q < k; ++q) {
+        const int tx = ix + pad - q;
+        if (tx < 0 || tx % stride) continue;
+        const int ox = tx / stride;
+        if (ox >= wo) continue;
+        const T* gp = dz + ((size_t)(img * ho + oy) * wo + ox) * (size_t)lddz + g * cpg_out;
+        for (int j = 0; j < cpg_out; ++j)
+          acc += Elem<T>::to_f32(gp[j]) * wt[(((size_t)(g * cpg_out + j) * cpg_in + cil) * k + r) * k + q];
+      }
+    }
+    const size_t pix = ((size_t)(img * h + iy) * w + ix);
+    if (acc_in) acc += Elem<T>::to_f32(acc_in[pix * (size_t)ldacc + ci]);
+    dx[pix * (size_t)lddx + ci] = Elem<T>::from_f32(acc);
+  }
+}
+
 }  // namespace dy
 
 using namespace dy;
@@ -244,6 +324,56 @@ extern "C" int32_t dy_add_nhwc(const void* a, const void* b, void* out, int64_t 
   else if (dtype == DY_F16) hipLaunchKernelGGL((add_kernel<f16_t>), dim3(grid), dim3(256), 0, st, (const f16_t*)a, (const f16_t*)b, (f16_t*)out, (long long)rows, cch, ld_a, ld_b, ld_o);
   else hipLaunchKernelGGL((add_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, (long long)rows, cch, ld_a, ld_b, ld_o);
   return check_launch("dy_add_nhwc");
+}
+
+
+extern "C" int32_t dy_conv2d_grouped_bwd_nhwc(const dy_conv_desc* d, const void* dz, int32_t ld_dz, const float* w_oihw, float* dw_oihw, void* dx, int32_t ld_dx,
+                                              const void* dx_accumulate, int32_t ld_acc, dy_stream_t stream) {
+  DY_REQUIRE(d && dz && d->x && (dw_oihw || (dx && w_oihw)), DY_ERR_INVALID_ARG, "dy_conv2d_grouped_bwd_nhwc: null argument");
+  const int es = dy_dtype_size(d->dtype);
+  DY_REQUIRE(es && d->groups > 1 && d->cin % d->groups == 0 && d->cout % d->groups == 0, DY_ERR_INVALID_ARG, "dy_conv2d_grouped_bwd_nhwc: bad dtype / groups");
+  DY_REQUIRE(d->batch > 0 && d->h > 0 && d->w_in > 0 && d->ho == (d->h + 2 * d->pad - d->ksize) / d->stride + 1 && d->wo == (d->w_in + 2 * d->pad - d->ksize) / d->stride + 1,
+             DY_ERR_INVALID_ARG, "dy_conv2d_grouped_bwd_nhwc: geometry");
+  DY_REQUIRE(d->ld_x >= d->cin && ld_dz >= d->cout && (d->stride == 1 || d->stride == 2) && d->ksize >= 1 && d->ksize <= 7, DY_ERR_INVALID_ARG,
+             "dy_conv2d_grouped_bwd_nhwc: pitches / stride / kernel size");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int cpg_in = d->cin / d->groups;
+  if (dw_oihw) {
+    DY_REQUIRE((cpg_in == 1 || cpg_in == 2 || cpg_in == 4) && d->ksize == 3, DY_ERR_UNSUPPORTED,
+               "dy_conv2d_grouped_bwd_nhwc: weight gradient is built for 3x3 kernels with 1, 2 or 4 input channels per group (got k %d, %d)", d->ksize, cpg_in);
+    const long long m_total = (long long)d->batch * d->ho * d->wo;
+    const int slab = 128;
+    dim3 grid((unsigned)((m_total + 4LL * slab - 1) / (4LL * slab)), (unsigned)((d->cout + 63) / 64));
+#define DY_GW(T, CI)                                                                                                                                      \
+  hipLaunchKernelGGL((conv_grouped_wgrad_kernel<T, CI, 3>), grid, dim3(256), 0, st, (const T*)d->x, (const T*)dz, dw_oihw, d->batch, d->h, d->w_in, d->cin, d->ld_x, d->ho, \
+                     d->wo, d->cout, ld_dz, d->stride, d->pad, d->groups, slab)
+#define DY_GWT(T)                        \
+  do {                                   \
+    if (cpg_in == 1) DY_GW(T, 1);        \
+    else if (cpg_in == 2) DY_GW(T, 2);   \
+    else DY_GW(T, 4);                    \
+  } while (0)
+    if (d->dtype == DY_BF16) DY_GWT(bf16_t);
+    else if (d->dtype == DY_F16) DY_GWT(f16_t);
+    else DY_GWT(float);
+#undef DY_GWT
+#undef DY_GW
+    const int rc = check_launch("conv_grouped_wgrad_kernel");
+    if (rc) return rc;
+  }
+  if (dx) {
+    DY_REQUIRE(w_oihw && ld_dx >= d->cin && (!dx_accumulate || ld_acc >= d->cin), DY_ERR_INVALID_ARG, "dy_conv2d_grouped_bwd_nhwc: dx arguments");
+    const unsigned grid = grid1((long long)d->batch * d->h * d->w_in * d->cin);
+#define DY_GD(T)                                                                                                                                              \
+  hipLaunchKernelGGL((conv_grouped_dgrad_kernel<T>), dim3(grid), dim3(256), 0, st, (const T*)dz, w_oihw, (const T*)dx_accumulate, (T*)dx, d->batch, d->h, d->w_in, d->cin, ld_dx, \
+                     ld_acc, d->ho, d->wo, d->cout, ld_dz, d->ksize, d->stride, d->pad, d->groups)
+    if (d->dtype == DY_BF16) DY_GD(bf16_t);
+    else if (d->dtype == DY_F16) DY_GD(f16_t);
+    else DY_GD(float);
+#undef DY_GD
+    return check_launch("conv_grouped_dgrad_kernel");
+  }
+  return DY_OK;
 }
 
 extern "C" int32_t dy_sumsq_f32(const float* g, int64_t n, double* out, dy_stream_t stream) {

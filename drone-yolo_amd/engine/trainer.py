@@ -323,6 +323,8 @@ class DetectionTrainer:
                 self.model = DetectionModel(src, nc=a.get("nc") or None, verbose=False)
         torch.manual_seed(int(a.get("seed", 0)))  # trainer.py:121 init_seeds: replicas start identical
         self.model = self.model.to(self.device).train()
+        for k, v in self.model.named_parameters():  # _setup_train's freeze block (trainer.py:238-254): '.dfl' stays frozen, the rest trains
+            v.requires_grad_(".dfl" not in k and v.dtype.is_floating_point)  # (a predictor may have frozen the graph before)
         self.model.train_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[a.get("dtype", "bf16")] if a.get("amp", True) \
             else torch.float32
         self.model.args = type("Args", (), dict(box=a["box"], cls=a["cls"], dfl=a["dfl"]))()

@@ -728,6 +728,26 @@ def conv_wgrad(x: torch.Tensor, dz: torch.Tensor, ksize: int, stride: int, pad: 
     return dw.permute(0, 3, 1, 2)
 
 
+def conv_grouped_bwd(x: torch.Tensor, dz: torch.Tensor, weight: torch.Tensor, stride: int, pad: int, groups: int, need_dx: bool = True):
+    """(dw, dx) of z = conv2d(x, weight, stride, pad, groups=groups) given dz through ``dy_conv2d_grouped_bwd_nhwc``.
+    weight: the fp32 master tensor (cout, cin/groups, k, k) on the device; dw comes back in the same layout (fp32)."""
+    require_device(x, "grouped wgrad input")
+    n, cin, h, w = x.shape
+    cout, ho, wo = dz.shape[1], dz.shape[2], dz.shape[3]
+    k = weight.shape[2]
+    if (ho, wo) != conv_out_hw(h, w, k, stride, pad) or dz.shape[0] != n or dz.dtype != x.dtype or weight.dtype != torch.float32 or not weight.is_contiguous():
+        raise ValueError("conv_grouped_bwd: dz / weight do not match the forward geometry, dtype or layout")
+    d = ConvDesc()
+    (d.x, d.ld_x), (dzp, lddz) = view_params(x), view_params(dz)
+    d.batch, d.h, d.w_in, d.cin, d.ho, d.wo, d.cout = n, h, w, cin, ho, wo, cout
+    d.ksize, d.stride, d.pad, d.groups, d.dtype = k, stride, pad, groups, dy_dtype(x.dtype)
+    dw = torch.zeros_like(weight)
+    dx = alloc_nhwc(n, cin, h, w, x.dtype, x.device) if need_dx else None
+    dxp, lddx = view_params(dx) if need_dx else (None, 0)
+    _launch(lib().dy_conv2d_grouped_bwd_nhwc, (C.byref(d), dzp, lddz, weight.data_ptr(), dw.data_ptr(), dxp, lddx, None, 0), keep=(d, x, dz, weight, dw, dx))
+    return dw, dx
+
+
 def colsum(z: torch.Tensor) -> torch.Tensor:
     """Per-channel sum over (N, H, W) of an NHWC view: the bias gradient of a plain convolution."""
     zp, ld = view_params(z)

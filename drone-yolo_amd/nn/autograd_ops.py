@@ -56,6 +56,29 @@ class ConvBnAct(torch.autograd.Function):
         return dx, dw, dgamma, dbeta, None, None, None, None, None
 
 
+class GroupedConvBnAct(torch.autograd.Function):
+    """ConvBnAct for a grouped convolution (DWConv of the -sf YAML, conv.py:102-107): forward through the grouped kernel of
+    dy_conv2d_nhwc, both gradients through dy_conv2d_grouped_bwd_nhwc."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, bn, stride, pad, groups, act):
+        dtype, dev = x.dtype, x.device
+        pc = H.PackedConv(weight, H.zero_bias(weight.shape[0], dev), stride, pad, groups, False, dtype, dev)
+        z = H.conv2d(x, pc)
+        st = H.BnState(weight.shape[0], dev)
+        y = H.bn_train_fwd(z, gamma, beta, st, act, eps=bn.eps, momentum=bn.momentum, running_mean=bn.running_mean, running_var=bn.running_var)
+        ctx.save_for_backward(x, z, weight, gamma, beta)
+        ctx.st, ctx.stride, ctx.pad, ctx.groups, ctx.act = st, stride, pad, groups, act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z, weight, gamma, beta = ctx.saved_tensors
+        dz, dgamma, dbeta = H.bn_train_bwd(as_nhwc(dy), z, gamma, beta, ctx.st, ctx.act)
+        dw, dx = H.conv_grouped_bwd(x, dz, weight.detach().contiguous(), ctx.stride, ctx.pad, ctx.groups)
+        return dx, dw, dgamma, dbeta, None, None, None, None, None
+
+
 class RepVGGTrain(torch.autograd.Function):
     """y = SiLU(BN3(conv3x3 s(x)) + BN1(conv1x1 s(x))) (no identity branch: the model's RepVGG blocks are stride 2)."""
 

@@ -16,8 +16,8 @@ from . import autograd_ops as A
 
 def conv_train(m, x, need_dx: bool = True):
     c = m.conv
-    if c.groups != 1:
-        raise NotImplementedError("training of grouped convolutions (DWConv, the -sf YAML) is not built on the HIP path")
+    if c.groups != 1:  # DWConv of the -sf YAML
+        return A.GroupedConvBnAct.apply(x, c.weight, m.bn.weight, m.bn.bias, m.bn, c.stride[0], c.padding[0], c.groups, isinstance(m.act, nn.SiLU))
     return A.ConvBnAct.apply(x, c.weight, m.bn.weight, m.bn.bias, m.bn, c.stride[0], c.padding[0], isinstance(m.act, nn.SiLU), need_dx)
 
 

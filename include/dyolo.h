@@ -380,6 +380,14 @@ int32_t dy_detection_loss(const dy_loss_desc* d, dy_stream_t stream);
  *   z 16-byte aligned, pitch a multiple of 16 bytes covering c rounded up to one chunk. */
 int32_t dy_conv2d_wgrad_nhwc(const dy_conv_desc* d, const void* dz, int32_t ld_dz, float* dw, dy_stream_t stream);
 int32_t dy_colsum(const void* z, float* out, int64_t rows, int32_t c, int32_t ld, int32_t dtype, dy_stream_t stream);
+/* Grouped convolution (DWConv of yolov8-p2-repvgg-sf.yaml:32,38,44; nn/modules/conv.py:102-107, g = gcd(c1, c2)): both gradients
+ * of z = conv2d(x, w, stride, pad, groups) given dz — replaces autograd of F.conv2d for that layer.  d describes the FORWARD
+ * convolution (x, batch, h, w_in, cin, ld_x, ho, wo, cout, ksize, stride, pad, groups, dtype).  w_oihw / dw_oihw: the fp32 master
+ * weight and its gradient in torch's own (cout, cin/groups, k, k) layout; dw_oihw is ADDED to (zeroed or carrying an earlier
+ * micro-batch; fp32 atomics); built for 3x3 kernels with 1, 2 or 4 input channels per group.  dx (optional, with w_oihw): NHWC view
+ * (batch, h, w_in, cin) of `dtype`, pitch ld_dx, = conv_transpose(dz, w) (+ dx_accumulate when given).  Either output may be NULL. */
+int32_t dy_conv2d_grouped_bwd_nhwc(const dy_conv_desc* d, const void* dz, int32_t ld_dz, const float* w_oihw, float* dw_oihw, void* dx, int32_t ld_dx,
+                                   const void* dx_accumulate, int32_t ld_acc, dy_stream_t stream);
 
 /* ---- train-mode BatchNorm2d (+ SiLU) -----------------------------------------------------
  * Replaces: the BatchNorm2d + SiLU half of Conv.forward in training mode (nn/modules/conv.py:37-55; eps 1e-3 and

@@ -468,7 +468,8 @@ def train_vectors(R):
     out = {}
     for tag, yname, scale, nc, (b, h, w), seed in [("tn64", "yolov8-p2-repvgg.yaml", "n", 10, (2, 64, 64), 201),
                                                    ("tn96", "yolov8-p2-repvgg.yaml", "n", 10, (3, 96, 128), 202),
-                                                   ("ts160", "yolov8-p2-repvgg.yaml", "s", 10, (2, 160, 160), 203)]:  # config 3's model at a reduced size
+                                                   ("ts160", "yolov8-p2-repvgg.yaml", "s", 10, (2, 160, 160), 203),  # config 3's model at a reduced size
+                                                   ("tsf64", "yolov8-p2-repvgg-sf.yaml", "n", 10, (2, 64, 64), 204)]:  # sandwich-fusion YAML: DWConv trains
         torch.manual_seed(0)
         model, _ = build_reference_model(R, yname, scale, nc)
         d = our_yaml(yname, scale, nc)
@@ -628,9 +629,7 @@ def big_vectors(R, only=None):
     xt = torch.stack([torch.from_numpy(np.ascontiguousarray(frame[y : y + tile, xx : xx + tile, ::-1].transpose(2, 0, 1))).float() / 255 for y, xx in offs])
     det = run("l1280t8", "yolov8-p2-repvgg.yaml", "l", 10, xt)
     rows = []
-    if det is None:
-        offs = []
-    for (oy, ox), r in zip(offs, det):
+    for (oy, ox), r in zip(offs, det or []):
         r = r.clone()
         r[:, :4] = O.clip_boxes(r[:, :4], (tile, tile))
         r[:, [0, 2]] += ox

@@ -126,6 +126,26 @@ def test_conv_wgrad_dgrad_match_autograd(case, dtype, device):
         close(dx2, x.grad + prev, dtype, f"dgrad+accumulate {tag}")
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("cin,cout,b,h,w", [(128, 64, 2, 20, 24), (64, 32, 2, 17, 19), (32, 16, 3, 40, 40), (16, 16, 2, 12, 12)])
+def test_grouped_conv_gradients_match_autograd(cin, cout, b, h, w, dtype, device):
+    """DWConv(c1, c2, 3, 2) of yolov8-p2-repvgg-sf.yaml:32,38,44 (g = gcd(c1, c2): 2 input channels and 1 output channel per group at
+    the YAML's shapes; (16, 16) is the plain depth-wise case): dy_conv2d_grouped_bwd_nhwc against autograd of F.conv2d(groups=g)."""
+    import math
+
+    g_ = math.gcd(cin, cout)
+    g = torch.Generator().manual_seed(cin + cout)
+    x = quantize(torch.randn(b, cin, h, w, generator=g), dtype).requires_grad_(True)
+    wt = (torch.randn(cout, cin // g_, 3, 3, generator=g) * 0.3).requires_grad_(True)
+    z = F.conv2d(x, wt, None, 2, 1, groups=g_)
+    dz = quantize(torch.randn(z.shape, generator=g), dtype)
+    z.backward(dz)
+    dw, dx = H.conv_grouped_bwd(nhwc(x.detach(), dtype, device), nhwc(dz, dtype, device, ld=cout + 8), wt.detach().to(device).contiguous(), 2, 1, g_)
+    torch.cuda.synchronize()
+    close(dw, wt.grad, torch.float32, "grouped wgrad", extra=30.0)
+    close(dx, x.grad, dtype, "grouped dgrad")
+
+
 def test_colsum_bias_grad(device):
     g = torch.Generator().manual_seed(1)
     z = torch.randn(3, 10, 17, 19, generator=g)
@@ -157,7 +177,7 @@ def _train_case(tag):
     return g, m, d, model, sd, img, labels
 
 
-@pytest.mark.parametrize("tag", ["tn64", "tn96", "ts160"])  # ts160: config 3's model (scale s) at a reduced size
+@pytest.mark.parametrize("tag", ["tn64", "tn96", "ts160", "tsf64"])  # ts160: config 3's model (scale s) at a reduced size; tsf64: the -sf YAML (DWConv)
 def test_model_train_step_gradients_fp32(tag, device):
     """module.train() forward + v8DetectionLoss + backward on the device in fp32 storage against autograd through the
     oracle (bit-identical to the real reference, oracle/make_golden.py::train_vectors) and the reference's golden norms.
