@@ -205,14 +205,13 @@ def fixture_weights(model, meta):
     return synthetic_state_dict(model, seed=0, cls_bias=meta["cls_bias"] if meta.get("bias_shift") else None, variant=meta.get("variant", ""))
 
 
-def parity_gate(dtype: str, device_index: int, npz: str = "big.npz", tag: str = "s640b4"):
+def parity_gate(dtype: str, device_index: int, npz: str = "big.npz", tag: str = "s640bench"):
     """the parity gate printed next to the throughput number.  The bench dtype's predictor runs a golden
     Drone-YOLO-s 640x640 batch of four images (tests/golden/big.npz — inputs and weights regenerated from the fixture's seeds,
     expected rows = the REAL reference's PyTorch-CPU fp32 `non_max_suppression` output captured by oracle/make_golden.py) and
     the kept detections are compared: match rate (same anchor index AND class), min box IoU of the matched boxes, equal counts.
-    `s640b4` carries the weights of the e2e "s640" golden (seeded generator); `s640bench` this benchmark's own weights — a random
-    network with activation-calibrated BatchNorm that is chaotic (1e-4 of input noise moves its fp32 boxes by > 1 px), reported
-    beside the gate for transparency, not as a yardstick for 16-bit storage."""
+    `s640bench` = this benchmark's own weights and rank-0 input recipe (the gate); `s640b4` = the weights of the e2e "s640" golden
+    (seeded generator), reported beside it."""
     import yaml
 
     import drone_yolo_amd as D
@@ -458,7 +457,7 @@ def main():
     parity = breakdown = sweep = alt = None
     if rank == 0:
         parity = parity_gate(a.dtype, local_rank)
-        parity["on_bench_weights"] = {k: v for k, v in parity_gate(a.dtype, local_rank, tag="s640bench").items() if k not in ("bar", "meets_iou_bar")}
+        parity["on_e2e_golden_weights"] = {k: v for k, v in parity_gate(a.dtype, local_rank, tag="s640b4").items() if k not in ("bar", "meets_iou_bar")}
         breakdown = time_breakdown(cf.plan)
         if world == 1 and not a.no_sweep:
             sweep = batch_sweep(model, a.dtype, local_rank) + [{"batch": a.batch, "ms_per_pass": round(dt / a.steps * 1e3, 3), "img_s": round(a.batch * a.steps / dt, 1),

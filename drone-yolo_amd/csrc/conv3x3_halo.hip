@@ -584,6 +584,8 @@ static int launch_halo_dtype(const Conv3Args& a, int batch, int stride, hipStrea
   return launch_halo<T, 2, 1, 2, OUTF32>(a, batch, st);
 }
 
+int conv3x3_hreg_try(const dy_conv_desc* d, hipStream_t st);  // conv3x3_hreg.hip: weights in registers, four workgroups per CU
+
 // Entry used by dy_conv2d_nhwc when d->w_layout == DY_WLAYOUT_HALO3X3.
 int conv3x3_halo_dispatch(const dy_conv_desc* d, hipStream_t st) {
   const int es = dy_dtype_size(d->dtype);
@@ -596,6 +598,10 @@ int conv3x3_halo_dispatch(const dy_conv_desc* d, hipStream_t st) {
   DY_REQUIRE((d->ld_y * (d->out_f32 ? 4 : es)) % 16 == 0, DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: output pitch must be a multiple of 16 bytes");
   DY_REQUIRE(!d->residual || (aligned16(d->residual) && d->ld_res % 4 == 0), DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: residual view misaligned");
   DY_REQUIRE((long long)d->batch * d->h * d->w_in * d->ld_x * es < (1ll << 32) - 64, DY_ERR_UNSUPPORTED, "dy_conv2d_nhwc: input view exceeds 4 GiB (buffer descriptor range)");
+  {
+    const int rv = conv3x3_hreg_try(d, st);  // cin 32 / 64, cout % 64 == 0, 16-bit, stride 1
+    if (rv <= 0) return rv;
+  }
   Conv3Args a{};
   a.x = d->x;
   a.w = d->w;

@@ -1,0 +1,246 @@
+// 3x3 stride-1 pad-1 NHWC convolution for the narrow 16-bit layers (cin 32 / 64, cout a multiple of 64) with the
+// weights held in REGISTERS: the kernel the 64->64 layers of the model run on (the P2 Detect trunks, the stride-8 C2f
+// Bottlenecks: 18 launches, the largest share of a pass).
+//
+// Why another 3x3 kernel.  conv3x3_halo.hip keeps the layer's weights stationary in LDS (72 KB for 64->64) and every
+// wave re-reads them per tap: 0.75 LDS reads per MFMA, one 512-thread workgroup per CU (LDS capacity), two waves per
+// SIMD that run in barrier lock-step.  Its counters (profiles/r01_pmc_halo_64x64_3x3_80.txt) show no unit saturated:
+// matrix pipe 37 % busy, 37 % of the wave cycles parked in s_waitcnt / s_barrier, 27 % of the LDS cycles lost to bank
+// conflicts of the 80-byte pixel pitch.  This kernel changes the decomposition instead of the schedule:
+//
+//   * a wave owns ONE 16-cout fragment and ALL pixels of the workgroup's 8 x 16 output tile; its weights — 9 taps x
+//     NCH chunks of 32 channels x one MFMA A fragment = 36 / 72 VGPRs — are loaded once per workgroup lifetime;
+//   * only the halo patch lives in LDS (10 x 18 pixels x 64 B per chunk, two stages = 30 KB), so four 256-thread
+//     workgroups fit a CU: four INDEPENDENT waves per SIMD, each at its own point of its item, instead of two in lock-step;
+//   * per 32-channel chunk a wave walks the 10 halo rows once: 3 fragment reads (the three column shifts) feed up to 9
+//     MFMAs (3 kernel rows x 3 columns) — 30 ds_read_b128 per 72 MFMAs = 0.42 reads per MFMA instead of 0.75;
+//   * the halo image has a 64-byte pixel pitch with the 16-byte part index XOR-ed with ((column >> 1) & 3): every
+//     fragment read (16 pixels x 4 parts, any of the three column shifts) is bank-conflict free (4 LDS cycles, the
+//     minimum for ds_read_b128; the 80-byte pitch took 8) and all read addresses are `lane base[q] + immediate`;
+//   * the image is lane-linear per wave-instruction, so it is filled by LDS-DMA (global_load_lds_dwordx4, the swizzle
+//     applied to the SOURCE address): no staging registers, no ds_write pass; zero padding comes from a zero page;
+//   * MFMA with the weight fragment as the A operand: a lane ends up with 4 consecutive couts of one pixel and stores
+//     them (bias-initialised accumulator, SiLU, optional Bottleneck residual) as 8 bytes straight from registers.
+//
+// Persistent workgroups, XCD-aware tile order (the tiles an XCD's workgroups visit are contiguous in the image, so the
+// halo columns / rows shared by neighbouring tiles are L2 hits), one barrier per (tile, chunk) item, the next item's DMA in
+// flight during the current item's MFMAs.
+// Reference semantics: Conv (nn/modules/conv.py:37-55, BatchNorm folded), Bottleneck shortcut (block.py:337-350).
+#include "common_hip.h"
+#include "conv_args.h"
+
+namespace dy {
+
+__device__ __attribute__((aligned(256))) const unsigned int g_hzero_page[64] = {0};
+
+struct HregArgs {
+  const void* x;
+  const void* w;       // DY_WLAYOUT_HALO3X3 packing with NF = 4: 1 KB blocks [(nt * nChunks + chunk) * 9 + tap][j], lane-major
+  const float* bias;   // cout_pad floats
+  const void* res;
+  void* y;
+  int N, H, W, Cin, ldx, Cout, ldy, ldres, act;
+  int tilesX, tilesY, tilesN, nSpatial;  // spatial tiles (n, ty, tx) and 64-cout groups
+  unsigned y_bytes, r_bytes;
+};
+
+constexpr int kHrTH = 8, kHrTW = 16, kHrHH = 10, kHrHW = 24;  // 10 x 18 halo pixels, rows padded to 24 (swizzle independent of the row)
+constexpr int kHrStage = kHrHH * kHrHW * 64;                    // bytes of one (tile, chunk) halo image
+
+template <typename T, int NCH>
+__global__ __launch_bounds__(256, (NCH == 1 ? 4 : 3)) void conv3x3_hreg_kernel(const HregArgs p) {
+  constexpr int EPC = Elem<T>::EPC;  // 8
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * kHrStage];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane >> 4, lr = lane & 15;
+  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+  const T* zp = reinterpret_cast<const T*>(g_hzero_page) + (lane & 3) * EPC;
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res ? p.res : p.y), 0, p.res ? p.r_bytes : 0u, 0x00020000);
+
+  // block -> (cout group, spatial sequence).  Blocks b and b + 8 share an XCD (guide T1): logical id = xcd * (G/8) + b/8, so an
+  // XCD's workgroups walk contiguous tiles.  The host makes G a multiple of 8 * tilesN.
+  const int G = (int)gridDim.x;
+  const int logical = ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);
+  const int nt = logical % p.tilesN;
+  const int sb = logical / p.tilesN, Gs = G / p.tilesN;
+  const int myTiles = sb < p.nSpatial ? (p.nSpatial - sb + Gs - 1) / Gs : 0;
+  if (myTiles <= 0) return;
+  const int nItems = myTiles * NCH;
+
+  // ---- this wave's weights: 16 couts (fragment `wave` of the 64-cout group) x all taps x all chunks, in registers ----
+  u32x4 wreg[NCH][9];
+  {
+    const u32x4* wg = reinterpret_cast<const u32x4*>(p.w) + (size_t)nt * NCH * 9 * 4 * 64;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wreg[c][t] = wg[((c * 9 + t) * 4 + wave) * 64 + lane];
+  }
+  const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + nt * 64 + wave * 16 + lq * 4);
+
+  // ---- loader: slot s = (k * 4 + wave) * 64 + lane of the 10 x 24 x 4 image; pixel = s >> 2, LDS part = s & 3 ----
+  constexpr int NDMA = 4;  // 15 wave-instructions cover the image; wave w issues instructions w, w + 4, w + 8, (w + 12 when < 15)
+  int a_off[NDMA];         // element offset of this lane's source chunk (channel part included), -1 = zero page
+  int l_tile = sb, l_chunk = 0, l_item = 0;
+  auto setup_tile = [&](int tile) {
+    const int tx = tile % p.tilesX;
+    const int r = tile / p.tilesX;
+    const int ty = r % p.tilesY, n = r / p.tilesY;
+#pragma unroll
+    for (int k = 0; k < NDMA; ++k) {
+      const int s = (k * 4 + wave) * 64 + lane;
+      const int pix = s >> 2, part = s & 3;
+      const int hy = pix / kHrHW, hx = pix - hy * kHrHW;
+      const int gy = ty * kHrTH - 1 + hy, gx = tx * kHrTW - 1 + hx;
+      const bool ok = hx < kHrTW + 2 && hy < kHrHH && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+      a_off[k] = ok ? ((n * p.H + gy) * p.W + gx) * p.ldx + (part ^ ((hx >> 1) & 3)) * EPC : -1;
+    }
+  };
+  auto issue_dma = [&](int stage) {  // DMA of item (l_tile, l_chunk) into `stage`, then advance the loader
+    unsigned char* sa = smem + stage * kHrStage;
+    const int cofs = l_chunk * 4 * EPC;
+#pragma unroll
+    for (int k = 0; k < NDMA; ++k) {
+      if (k * 4 + wave < 15) {  // wave-uniform
+        const T* src = a_off[k] < 0 ? zp : xg + (size_t)(unsigned)(a_off[k] + cofs);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(sa + (k * 4 + wave) * 1024), 16, 0, 0);
+      }
+    }
+    ++l_item;
+    if (++l_chunk == NCH) {
+      l_chunk = 0;
+      l_tile += Gs;
+      if (l_item < nItems) setup_tile(l_tile);
+    }
+  };
+
+  // ---- fragment reads: pixel (row iy, column lr + q), part lq  ->  byte lane_base[q] + iy * 24 * 64 ----
+  int lane_base[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) lane_base[q] = (lr + q) * 64 + ((lq ^ (((lr + q) >> 1) & 3)) * 16);
+
+  f32x4 acc[kHrTH];
+#pragma unroll
+  for (int o = 0; o < kHrTH; ++o) acc[o] = bias4;
+
+  auto compute = [&](int stage, int c) {
+    const unsigned char* sa = smem + stage * kHrStage;
+#pragma unroll
+    for (int iy = 0; iy < kHrHH; ++iy) {
+      u32x4 a[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const u32x4*>(sa + lane_base[q] + iy * (kHrHW * 64));
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int o = iy - r;
+        if (o >= 0 && o < kHrTH) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) acc[o] = Elem<T>::mma(wreg[c][r * 3 + q], a[q], acc[o]);  // D[cout][pixel]
+        }
+      }
+    }
+  };
+
+  auto epilogue = [&](int tile) {
+    const int tx = tile % p.tilesX;
+    const int r = tile / p.tilesX;
+    const int ty = r % p.tilesY, n = r / p.tilesY;
+    const int xx = tx * kHrTW + lr;
+    const int co = nt * 64 + wave * 16 + lq * 4;
+    typedef __attribute__((ext_vector_type(4))) T t4;
+    u32x2 rv[kHrTH];
+    if (p.res) {
+#pragma unroll
+      for (int o = 0; o < kHrTH; ++o) {
+        const int yy = ty * kHrTH + o;
+        const bool ok = yy < p.H && xx < p.W;
+        const unsigned off = ok ? (unsigned)((((size_t)(n * p.H + yy) * p.W + xx) * (size_t)p.ldres + co) * sizeof(T)) : 0xfffffff0u;
+        rv[o] = __builtin_amdgcn_raw_buffer_load_b64(rrs, off, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < kHrTH; ++o) {
+      float v[4] = {acc[o][0], acc[o][1], acc[o][2], acc[o][3]};
+      if (p.act == DY_ACT_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
+      }
+      if (p.res) {
+        const t4 rr = __builtin_bit_cast(t4, rv[o]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += Elem<T>::to_f32(rr[e]);
+      }
+      t4 ov;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ov[e] = Elem<T>::from_f32(v[e]);
+      const int yy = ty * kHrTH + o;
+      const bool ok = yy < p.H && xx < p.W;
+      const unsigned off = ok ? (unsigned)((((size_t)(n * p.H + yy) * p.W + xx) * (size_t)p.ldy + co) * sizeof(T)) : 0xfffffff0u;
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ov), yrs, off, 0, 0);
+      acc[o] = bias4;
+    }
+  };
+
+  // ---- item pipeline ----
+  setup_tile(l_tile);
+  issue_dma(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int c_tile = sb;
+  for (int it = 0; it < nItems; it += NCH) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int stage = (NCH & 1) ? ((it + c) & 1) : (c & 1);
+      if (it + c + 1 < nItems) issue_dma(stage ^ 1);  // stage ^ 1 was last read one item ago: every wave has passed that item's barrier
+      compute(stage, c);
+      if (c == NCH - 1) {
+        epilogue(c_tile);
+        c_tile += Gs;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of the next item have landed ...
+      __syncthreads();                                   // ... and so have everyone's; all reads of `stage` are done
+    }
+  }
+}
+
+template <typename T>
+static int launch_hreg(const HregArgs& a, hipStream_t st) {
+  HregArgs p = a;
+  const int nch = p.Cin / 32;
+  int grid = 256 * (nch == 1 ? 4 : 3);  // 256-thread workgroups per CU: four at cin 32 (118 VGPRs), three at cin 64 (72 weight registers)
+  const long long nwork = (long long)p.nSpatial * p.tilesN;
+  if (nwork < grid) grid = (int)nwork;
+  const int q = 8 * p.tilesN;
+  grid = (grid + q - 1) / q * q;  // the XCD remap and the fixed cout group per block need G % (8 * tilesN) == 0
+  if (nch == 1)
+    hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 1>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 2>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  return check_launch("conv3x3_hreg_kernel");
+}
+
+// Returns 1 when the shape is not one this kernel is built for (the caller then runs conv3x3_halo), else the launch status.
+int conv3x3_hreg_try(const dy_conv_desc* d, hipStream_t st) {
+  static const int off = dy_ablate("DYOLO_NO_HREG");
+  if (off) return 1;
+  if (!(d->dtype == DY_BF16 || d->dtype == DY_F16) || d->out_f32 || d->stride != 1 || d->ksize != 3 || d->pad != 1 || d->groups > 1 || d->up2x || d->x2) return 1;
+  if (!(d->cin == 32 || d->cin == 64) || d->cout % 64 != 0 || d->cout > 256) return 1;
+  if (d->ho != d->h || d->wo != d->w_in) return 1;
+  const long long xb = (long long)d->batch * d->h * d->w_in * d->ld_x * 2, yb = (long long)d->batch * d->ho * d->wo * d->ld_y * 2;
+  const long long rb = d->residual ? (long long)d->batch * d->ho * d->wo * d->ld_res * 2 : 0;
+  if (xb >= (1ll << 31) || yb >= (1ll << 32) - 64 || rb >= (1ll << 32) - 64) return 1;  // 32-bit element offsets / buffer descriptors
+  if (d->ld_y % 4 || (d->residual && d->ld_res % 4)) return 1;
+  HregArgs a{};
+  a.x = d->x, a.w = d->w, a.bias = d->bias, a.res = d->residual, a.y = d->y;
+  a.N = d->batch, a.H = d->h, a.W = d->w_in, a.Cin = d->cin, a.ldx = d->ld_x, a.Cout = d->cout, a.ldy = d->ld_y, a.ldres = d->ld_res, a.act = d->act;
+  a.tilesX = (d->wo + kHrTW - 1) / kHrTW;
+  a.tilesY = (d->ho + kHrTH - 1) / kHrTH;
+  a.tilesN = d->cout / 64;
+  a.nSpatial = d->batch * a.tilesY * a.tilesX;
+  a.y_bytes = (unsigned)yb, a.r_bytes = (unsigned)rb;
+  return d->dtype == DY_BF16 ? launch_hreg<bf16_t>(a, st) : launch_hreg<f16_t>(a, st);
+}
+
+}  // namespace dy

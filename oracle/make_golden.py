@@ -610,17 +610,18 @@ def big_vectors(R, only=None):
         out[f"{tag}__y_sum"] = np.array([float(y.double().sum()), float(y.double().abs().sum()), float((y.double() ** 2).sum())])
         return ref_det
 
-    # (a) the metric's own model and shape, four images.  s640b4 / s640b4lo: the weights of the e2e fixture "s640"
-    # (seeded_state_dict seed 104) — the parity gate bench.py prints.  s640bench: bench.py's own weights and rank-0 input
-    # recipe; that random network with activation-calibrated BatchNorm is chaotic (1e-4 of input noise moves its fp32 boxes by
-    # more than a pixel), so it pins the fp32 kernels under maximal error amplification but is no yardstick for 16-bit storage.
+    # (a) the metric's own model and shape, four images.  s640bench: bench.py's own weights and rank-0 input recipe — the
+    # parity gate bench.py prints.  s640b4 / s640b4lo: the weights of the e2e fixture "s640" (seeded_state_dict seed 104).
+    # bench.py's weights are random conv weights with activation-calibrated BatchNorm statistics and BatchNorm weights scaled
+    # by 0.25: at scale 1 such a deep random network is chaotic (1e-4 of input noise moved its fp32 boxes by > 1 px, and bf16
+    # storage lost 17 % of the detections), which no trained detector is; at 0.25 SiLU works near its linear range and the
+    # network amplifies rounding noise about as the e2e fixtures' network does (oracle/calibrate_synthetic.py --gamma).
     e2e_meta = eval(str(np.load(OUT / "e2e.npz")["s640__meta"]))  # noqa: S307 - our own fixture
     x = torch.rand(4, 3, 640, 640, generator=torch.Generator().manual_seed(1104))
     run("s640b4", "yolov8-p2-repvgg.yaml", "s", 10, x, input_seed=1104, seeded=(e2e_meta["seed"], e2e_meta["cls_bias"]))
     run("s640b4lo", "yolov8-p2-repvgg.yaml", "s", 10, x, input_seed=1104, seeded=(e2e_meta["seed"], e2e_meta["cls_bias"] - 0.08), check_oracle=False)
     x = torch.rand(4, 3, 640, 640, generator=torch.Generator().manual_seed(1000))
     run("s640bench", "yolov8-p2-repvgg.yaml", "s", 10, x, input_seed=1000)
-    run("s640g025", "yolov8-p2-repvgg.yaml", "s", 10, x, input_seed=1000, variant="_g025")
 
     # (b) config 4: tiles of a 3840x2160 BGR uint8 frame, stride 1024 / last tile clamped (engine/tiling.py::tile_offsets)
     tile, hf, wf = 1280, 2160, 3840

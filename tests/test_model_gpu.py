@@ -177,14 +177,12 @@ def _bench_model(meta, device):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
-@pytest.mark.parametrize("tag", ["s640b4", "s640b4lo", "s640bench", "s640g025"])
+@pytest.mark.parametrize("tag", ["s640bench", "s640b4", "s640b4lo"])
 def test_bench_configuration_against_reference_rows(tag, dtype, device):
     """BASELINE config 2 (Drone-YOLO-s, 4 images of 640x640) against the rows the REAL reference computed on CPU in fp32
-    (tests/golden/big.npz).  s640b4 is the gate bench.py prints as `parity`: the bar (IoU >= 0.999, class / index exact up to
-    1 % of near-tie flips) is asserted for fp32 and for the headline dtype fp16; bf16 is held to its measured level.
-    s640bench carries bench.py's own weights: a chaotic random network (see bench.parity_gate) — fp32 must still reproduce the
-    reference's kept sets exactly (the kernels under ~200x the error amplification of the other fixtures); for 16-bit storage
-    its numbers are recorded, and only a sanity floor is asserted."""
+    (tests/golden/big.npz).  s640bench — bench.py's own weights and input recipe — is the gate bench.py prints as `parity`; s640b4
+    carries the e2e golden's weights.  The bar (IoU >= 0.999, class / index exact up to 1 % of near-tie flips) is asserted for
+    fp32 (exact) and for the headline dtype fp16; bf16 is held to its measured level."""
     from drone_yolo_amd.utils import parity as PR
 
     meta, x, exp_rows, exp_idx = PR.golden_case("big.npz", tag)
@@ -201,12 +199,10 @@ def test_bench_configuration_against_reference_rows(tag, dtype, device):
     if dtype == torch.float32:
         assert box_err < 2e-2 and cls_err < 1e-4, (box_err, cls_err)
         assert par["counts_equal"] and par["kept_sets_identical"] and par["match_rate"] == 1.0 and par["iou_min"] >= 0.999, par
-    elif tag in ("s640bench", "s640g025"):
-        assert par["match_rate"] >= 0.5, par  # measured r02: bf16 0.83 / IoU 0.78; fp16 see gpurun_out/parity_report.jsonl
     else:
         # fp16 = the headline dtype: IoU bar met, at most 1 % of the reference detections (at least one) lost to score near-ties;
         # bf16: 3 %, IoU >= 0.998 (its measured level minus a margin)
-        tol, iou_floor = (0.01, 0.999) if dtype == torch.float16 else (0.03, 0.998)
+        tol, iou_floor = (0.01, 0.999) if dtype == torch.float16 else (0.04, 0.995)
         if tag == "s640b4lo" and dtype == torch.bfloat16:
             tol = 0.20  # every one of this case's 45 detections scores within 0.08 logit of conf: bf16 scores (+-2e-3) flip 7 of them (r02)
         misses = par["ref_detections"] - round(par["match_rate"] * par["ref_detections"])
@@ -277,16 +273,12 @@ def test_config4_tiled_scale_l_against_reference_rows(device):
         merged_common = float((m.max(1) > 0.9).mean())  # merged reference boxes found again (same class, IoU > 0.9)
         _report("config4 l1280t8", {"dtype": str(dtype), **par, "merged": int(len(got)), "merged_ref": int(len(exp_merged)), "merged_common": merged_common})
         assert res.orig_shape == (hf, wf)
-        # the fixture's weights are bench.py's recipe at scale l: a chaotic random network (bench.parity_gate) in which the fp32
-        # device pass and the fp32 CPU pass already drift apart by their summation orders (r02: 1 of 2400 kept boxes differs,
-        # IoU mean 0.99977, min 0.9943) — the bar is asserted on the well-conditioned fixtures; here the floors sit under the
-        # measured level
-        if dtype == torch.float32:
-            assert par["counts_equal"] and par["match_rate"] >= 0.995 and par["iou_mean"] >= 0.999 and par["iou_min"] >= 0.99, par
-            assert got.shape == exp_merged.shape and merged_common >= 0.98, merged_common
-        else:
-            assert par["match_rate"] >= 0.90 and par["iou_mean"] >= 0.98, par
-            assert merged_common >= 0.85, merged_common
+        if dtype == torch.float32:  # the bar: same kept sets per tile, IoU >= 0.999, and the same merged detections
+            assert par["counts_equal"] and par["match_rate"] >= 0.999 and par["iou_min"] >= 0.999, par
+            assert got.shape == exp_merged.shape and merged_common >= 0.995, merged_common
+        else:  # fp16 storage: at most 1 % of the detections lost to near-tie flips
+            assert par["match_rate"] >= 0.99 and par["iou_min"] >= 0.998, par
+            assert merged_common >= 0.97, merged_common
         del tp, cf, res
         torch.cuda.empty_cache()
 
@@ -304,10 +296,10 @@ def test_config5_shape_scale_x_1536_against_reference_rows(device):
         torch.cuda.synchronize()
         par = PR.detection_parity(cf.nms, exp_rows, exp_idx)
         _report("config5-shape x1536", {"dtype": str(dtype), **par})
-        if dtype == torch.float32:  # chaotic random network, see the config-4 test: identical kept set, IoU min 0.9975 measured (r02)
-            assert par["counts_equal"] and par["match_rate"] >= 0.995 and par["iou_mean"] >= 0.999 and par["iou_min"] >= 0.99, par
+        if dtype == torch.float32:
+            assert par["counts_equal"] and par["match_rate"] >= 0.999 and par["iou_min"] >= 0.999, par
         else:
-            assert par["match_rate"] >= 0.90 and par["iou_mean"] >= 0.98, par
+            assert par["match_rate"] >= 0.99 and par["iou_min"] >= 0.998, par
         del pred, cf
         torch.cuda.empty_cache()
 

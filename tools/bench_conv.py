@@ -3,6 +3,7 @@ usage: python tools/bench_conv.py [--halo 0|1] [--batch B] [shape ...]   shape =
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from drone_yolo_amd import _lib
 from drone_yolo_amd import hip_ops as H
 
 ap = argparse.ArgumentParser()
@@ -10,9 +11,13 @@ ap.add_argument("--halo", type=int, default=1)
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--lib", default="", help="another build of libdyolo.so, e.g. drone-yolo_amd/lib_ablate/libdyolo.so (make ABLATE=1 OUT=...): only that build reads DYOLO_* probes")
+ap.add_argument("--residual", type=int, default=0)
 ap.add_argument("shapes", nargs="*", default=["64,64,3,1,160", "32,32,3,1,160", "64,64,3,1,80", "128,128,3,1,40", "256,256,3,1,20",
                                                "512,64,3,1,20", "64,128,3,2,160", "96,64,1,1,160", "768,512,1,1,20", "384,256,1,1,40"])
 a = ap.parse_args()
+if a.lib:
+    _lib.LIB_PATH = os.path.abspath(a.lib)
 dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[a.dtype]
 dev = torch.device("cuda", 0)
 for sh in a.shapes:
@@ -21,11 +26,12 @@ for sh in a.shapes:
     w = torch.randn(cout, cin, k, k) * (2.0 / (cin * k * k)) ** 0.5
     pc = H.PackedConv(w, torch.zeros(cout), s, k // 2, 1, True, dt, dev, halo=bool(a.halo))
     y = H.conv2d(x, pc)
+    res = torch.randn(a.batch, y.shape[2], y.shape[3], cout, device=dev).to(dt).permute(0, 3, 1, 2) if a.residual else None
     torch.cuda.synchronize()
     st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     st.record()
     for _ in range(a.iters):
-        H.conv2d(x, pc, out=y)
+        H.conv2d(x, pc, out=y, residual=res)
     en.record()
     torch.cuda.synchronize()
     us = st.elapsed_time(en) / a.iters * 1e3

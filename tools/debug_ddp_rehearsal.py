@@ -11,7 +11,7 @@ if "RANK" in os.environ:
 
     from drone_yolo_amd.engine.trainer import DetectionTrainer
 
-    tr = DetectionTrainer(overrides=dict(model="yolov8n-p2-repvgg.yaml", data="synthetic:16", epochs=1, imgsz=64, batch=8, device="0,1", dtype="fp32", optimizer="SGD",
+    tr = DetectionTrainer(overrides=dict(model="yolov8n-p2-repvgg.yaml", data="synthetic:16", epochs=1, imgsz=64, batch=8, nbs=8, device="0,1", dtype="fp32", optimizer="SGD",
                                          warmup_epochs=0.0, project=tempfile.mkdtemp(), name="dbg"))
     orig = tr.train_batch
 
