@@ -37,6 +37,8 @@ extern "C" int32_t dy_dtype_size(int32_t dtype) {
       return 2;
     case DY_F32:
       return 4;
+    case DY_FP8:
+      return 1;
     default:
       return 0;
   }

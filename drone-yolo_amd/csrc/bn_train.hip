@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void silu_kernel(const void* u_, const void* d
 
 static int bn_prepare(const dy_bn_desc* d, BnArgs* a, const char* who, bool bwd) {
   DY_REQUIRE(d && d->z && d->gamma && d->beta && d->mean && d->rstd && d->workspace, DY_ERR_INVALID_ARG, "%s: null pointer", who);
-  const int es = dy_dtype_size(d->dtype);
+  const int es = dtype_size_no_fp8(d->dtype);
   DY_REQUIRE(es != 0 && d->rows > 0 && d->c > 0, DY_ERR_INVALID_ARG, "%s: bad dtype/rows/c", who);
   const int epc = 16 / es;
   DY_REQUIRE(d->c % epc == 0 && d->c <= 8192, DY_ERR_UNSUPPORTED, "%s: c %d must be a multiple of %d (one 16-byte chunk) and <= 8192", who, d->c, epc);
@@ -349,7 +349,7 @@ extern "C" int32_t dy_bn_train_bwd(const dy_bn_desc* d, dy_stream_t stream) {
 template <bool BWD>
 static int silu_launch(const void* u, const void* dy, void* out, int64_t rows, int32_t c, int32_t ld_u, int32_t ld_dy, int32_t ld_o, int32_t dtype,
                        hipStream_t st, const char* who) {
-  const int es = dy_dtype_size(dtype);
+  const int es = dtype_size_no_fp8(dtype);
   DY_REQUIRE(es && u && out && (!BWD || dy) && rows > 0 && c > 0, DY_ERR_INVALID_ARG, "%s: null pointer or bad dims", who);
   const int epc = 16 / es;
   DY_REQUIRE(c % epc == 0 && aligned16(u) && aligned16(out) && (ld_u * es) % 16 == 0 && (ld_o * es) % 16 == 0 && ld_u >= c && ld_o >= c &&

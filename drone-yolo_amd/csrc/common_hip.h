@@ -17,6 +17,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 typedef __bf16 bf16_t;
 typedef _Float16 f16_t;
+struct fp8_t {  // OCP e4m3fn, one byte (gfx950's fp8; MI300's fnuz encoding is a different format)
+  unsigned char v;
+};
 
 constexpr int kWave = 64;
 
@@ -57,6 +60,25 @@ template <> struct Elem<f16_t> {
   static __device__ __forceinline__ f16_t from_f32(float v) { return (f16_t)v; }
 };
 
+// fp8 (e4m3fn): 16 elements per 16-byte chunk, so a k-group (4 lane quarters) is 64 channels and takes TWO
+// v_mfma_f32_16x16x32_fp8_fp8 (8 bytes per lane each): instruction j consumes bytes 8j..8j+7 of every quarter's chunk.
+// A and B agree on that (quarter, byte) -> k map, which is all a dot product needs.  Same cycles per MFMA as bf16.
+template <> struct Elem<fp8_t> {
+  static constexpr int EPC = 16;
+  static __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
+    typedef __attribute__((ext_vector_type(2))) long l2;
+    const l2 al = __builtin_bit_cast(l2, a), bl = __builtin_bit_cast(l2, b);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(al[0], bl[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(al[1], bl[1], c, 0, 0, 0);
+    return c;
+  }
+  static __device__ __forceinline__ float to_f32(fp8_t v) { return __builtin_amdgcn_cvt_f32_fp8((int)v.v, 0); }
+  static __device__ __forceinline__ fp8_t from_f32(float v) {  // saturating (|v| > 448 -> +-448), round to nearest even
+    v = __builtin_fminf(__builtin_fmaxf(v, -448.f), 448.f);
+    return fp8_t{(unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v, v, 0, false) & 0xff)};
+  }
+};
+
 template <> struct Elem<float> {
   static constexpr int EPC = 4;
   // Lane-quarter q holds k = 4q..4q+3 of the 16-k group in its chunk; instruction j
@@ -88,6 +110,32 @@ template <typename T> struct Chunk {
 #pragma unroll
     for (int i = 0; i < EPC; ++i) t[i] = Elem<T>::from_f32(f[i]);
     return __builtin_bit_cast(u32x4, t);
+  }
+};
+
+template <> struct Chunk<fp8_t> {
+  static constexpr int EPC = 16;
+  static __device__ __forceinline__ void unpack(u32x4 v, float (&f)[16]) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      f[4 * w + 0] = __builtin_amdgcn_cvt_f32_fp8((int)v[w], 0);
+      f[4 * w + 1] = __builtin_amdgcn_cvt_f32_fp8((int)v[w], 1);
+      f[4 * w + 2] = __builtin_amdgcn_cvt_f32_fp8((int)v[w], 2);
+      f[4 * w + 3] = __builtin_amdgcn_cvt_f32_fp8((int)v[w], 3);
+    }
+  }
+  static __device__ __forceinline__ u32x4 pack(const float (&f)[16]) {
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      float c[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) c[e] = __builtin_fminf(__builtin_fmaxf(f[4 * w + e], -448.f), 448.f);
+      int r = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false);
+      r = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], r, true);
+      o[w] = (unsigned)r;
+    }
+    return o;
   }
 };
 
@@ -140,6 +188,9 @@ __device__ __forceinline__ unsigned fastdiv(unsigned n, FastDiv f) {
   const unsigned t = __umulhi(f.m, n);
   return (t + ((n - t) >> 1)) >> (f.l - 1);
 }
+
+// element size for entry points that are NOT built for DY_FP8 (they then report "bad dtype")
+static inline int dtype_size_no_fp8(int dtype) { return dtype == DY_FP8 ? 0 : dy_dtype_size(dtype); }
 
 // ---- host-side error plumbing ----------------------------------------------------
 void set_error(const char* fmt, ...);

@@ -243,7 +243,7 @@ static int launch_1x1_dtype(const Conv1Args& a, bool out_f32, hipStream_t st) {
 
 // Entry used by dy_conv2d_nhwc when d->w_layout == DY_WLAYOUT_FRAG1X1.
 int conv1x1_stream_dispatch(const dy_conv_desc* d, hipStream_t st) {
-  const int es = dy_dtype_size(d->dtype);
+  const int es = dtype_size_no_fp8(d->dtype);
   const int epc = 16 / es;
   DY_REQUIRE(d->ksize == 1 && d->stride == 1 && d->pad == 0 && d->groups <= 1 && !d->residual, DY_ERR_UNSUPPORTED,
              "dy_conv2d_nhwc: FRAG1X1 layout needs a dense 1x1 stride-1 conv without residual");

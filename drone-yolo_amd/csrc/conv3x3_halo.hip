@@ -588,7 +588,7 @@ int conv3x3_hreg_try(const dy_conv_desc* d, hipStream_t st);  // conv3x3_hreg.hi
 
 // Entry used by dy_conv2d_nhwc when d->w_layout == DY_WLAYOUT_HALO3X3.
 int conv3x3_halo_dispatch(const dy_conv_desc* d, hipStream_t st) {
-  const int es = dy_dtype_size(d->dtype);
+  const int es = dtype_size_no_fp8(d->dtype);
   const int epc = 16 / es;
   DY_REQUIRE(d->ksize == 3 && d->pad == 1 && (d->stride == 1 || d->stride == 2) && d->groups <= 1 && !d->up2x && !d->x2,
              DY_ERR_UNSUPPORTED, "dy_conv2d_nhwc: HALO3X3 layout needs a dense 3x3 pad-1 stride-1/2 single-source conv");

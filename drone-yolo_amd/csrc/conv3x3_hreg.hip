@@ -10,8 +10,8 @@
 //
 //   * a wave owns ONE 16-cout fragment and ALL pixels of the workgroup's 8 x 16 output tile; its weights — 9 taps x
 //     NCH chunks of 32 channels x one MFMA A fragment = 36 / 72 VGPRs — are loaded once per workgroup lifetime;
-//   * only the halo patch lives in LDS (10 x 18 pixels x 64 B per chunk, two stages = 30 KB), so four 256-thread
-//     workgroups fit a CU: four INDEPENDENT waves per SIMD, each at its own point of its item, instead of two in lock-step;
+//   * only the halo patch lives in LDS (10 x 18 pixels x 64 B per chunk, a ring of three 16 KB stages), so three 256-thread
+//     workgroups fit a CU: three INDEPENDENT waves per SIMD, each at its own point of its item, instead of two in lock-step;
 //   * per 32-channel chunk a wave walks the 10 halo rows once: 3 fragment reads (the three column shifts) feed up to 9
 //     MFMAs (3 kernel rows x 3 columns) — 30 ds_read_b128 per 72 MFMAs = 0.42 reads per MFMA instead of 0.75;
 //   * the halo image has a 64-byte pixel pitch with the 16-byte part index XOR-ed with ((column >> 1) & 3): every
@@ -23,8 +23,9 @@
 //     them (bias-initialised accumulator, SiLU, optional Bottleneck residual) as 8 bytes straight from registers.
 //
 // Persistent workgroups, XCD-aware tile order (the tiles an XCD's workgroups visit are contiguous in the image, so the
-// halo columns / rows shared by neighbouring tiles are L2 hits), one barrier per (tile, chunk) item, the next item's DMA in
-// flight during the current item's MFMAs.
+// halo columns / rows shared by neighbouring tiles are L2 hits), one raw s_barrier per (tile, chunk) item.  TWO items' DMA
+// stay in flight per workgroup behind counted s_waitcnt vmcnt(N) (the first version had one and waited vmcnt(0), output
+// stores included: 46 KB in flight per CU made the kernel latency bound — 2.7 TB/s x 4.4 us = all that was in flight).
 // Reference semantics: Conv (nn/modules/conv.py:37-55, BatchNorm folded), Bottleneck shortcut (block.py:337-350).
 #include "common_hip.h"
 #include "conv_args.h"
@@ -42,15 +43,23 @@ struct HregArgs {
   int N, H, W, Cin, ldx, Cout, ldy, ldres, act;
   int tilesX, tilesY, tilesN, nSpatial;  // spatial tiles (n, ty, tx) and 64-cout groups
   unsigned y_bytes, r_bytes;
+  int dbg;  // -DDYOLO_ABLATE builds only (DYOLO_DBG): 1 no output stores, 2 no MFMAs, 4 no DMA after the prologue, 8 no fragment reads
 };
 
-constexpr int kHrTH = 8, kHrTW = 16, kHrHH = 10, kHrHW = 24;  // 10 x 18 halo pixels, rows padded to 24 (swizzle independent of the row)
-constexpr int kHrStage = kHrHH * kHrHW * 64;                    // bytes of one (tile, chunk) halo image
+#ifdef DYOLO_ABLATE
+#define HR_DBG(bit) (p.dbg & (bit))
+#else
+#define HR_DBG(bit) 0
+#endif
 
-template <typename T, int NCH>
-__global__ __launch_bounds__(256, (NCH == 1 ? 4 : 3)) void conv3x3_hreg_kernel(const HregArgs p) {
+constexpr int kHrTH = 8, kHrTW = 16, kHrHH = 10, kHrHW = 24;  // 10 x 18 halo pixels, rows padded to 24 (swizzle independent of the row)
+constexpr int kHrStage = 16 * 1024;  // one (tile, chunk) halo image: 10 x 24 x 64 = 15,360 B, padded to the 16 wave-instructions (4 per wave) that fill it
+constexpr int kHrStages = 3;
+
+template <typename T, int NCH, bool RES>
+__global__ __launch_bounds__(256, 3) void conv3x3_hreg_kernel(const HregArgs p) {
   constexpr int EPC = Elem<T>::EPC;  // 8
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * kHrStage];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[kHrStages * kHrStage];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane >> 4, lr = lane & 15;
   const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(256, (NCH == 1 ? 4 : 3)) void conv3x3_hreg_kernel(c
   const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + nt * 64 + wave * 16 + lq * 4);
 
   // ---- loader: slot s = (k * 4 + wave) * 64 + lane of the 10 x 24 x 4 image; pixel = s >> 2, LDS part = s & 3 ----
-  constexpr int NDMA = 4;  // 15 wave-instructions cover the image; wave w issues instructions w, w + 4, w + 8, (w + 12 when < 15)
+  constexpr int NDMA = 4;  // every wave issues exactly 4 wave-instructions per item (w, w + 4, w + 8, w + 12): the waits below are counted
   int a_off[NDMA];         // element offset of this lane's source chunk (channel part included), -1 = zero page
   int l_tile = sb, l_chunk = 0, l_item = 0;
   auto setup_tile = [&](int tile) {
@@ -93,26 +102,27 @@ __global__ __launch_bounds__(256, (NCH == 1 ? 4 : 3)) void conv3x3_hreg_kernel(c
       const int pix = s >> 2, part = s & 3;
       const int hy = pix / kHrHW, hx = pix - hy * kHrHW;
       const int gy = ty * kHrTH - 1 + hy, gx = tx * kHrTW - 1 + hx;
-      const bool ok = hx < kHrTW + 2 && hy < kHrHH && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+      const bool ok = hx < kHrTW + 2 && hy < kHrHH && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;  // (hy == 10: the stage's padding)
       a_off[k] = ok ? ((n * p.H + gy) * p.W + gx) * p.ldx + (part ^ ((hx >> 1) & 3)) * EPC : -1;
     }
   };
-  auto issue_dma = [&](int stage) {  // DMA of item (l_tile, l_chunk) into `stage`, then advance the loader
+  auto issue_dma = [&](int stage) {  // DMA of item (l_tile, l_chunk) into `stage`, then advance the loader; past the last item: zero page
     unsigned char* sa = smem + stage * kHrStage;
     const int cofs = l_chunk * 4 * EPC;
+    const bool live = l_item < nItems && !(HR_DBG(4) && l_item >= 2);
 #pragma unroll
     for (int k = 0; k < NDMA; ++k) {
-      if (k * 4 + wave < 15) {  // wave-uniform
-        const T* src = a_off[k] < 0 ? zp : xg + (size_t)(unsigned)(a_off[k] + cofs);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(sa + (k * 4 + wave) * 1024), 16, 0, 0);
-      }
+      const T* src = (!live || a_off[k] < 0) ? zp : xg + (size_t)(unsigned)(a_off[k] + cofs);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sa + (k * 4 + wave) * 1024), 16, 0, 0);
     }
-    ++l_item;
-    if (++l_chunk == NCH) {
-      l_chunk = 0;
-      l_tile += Gs;
-      if (l_item < nItems) setup_tile(l_tile);
+    if (live) {
+      ++l_item;
+      if (++l_chunk == NCH) {
+        l_chunk = 0;
+        l_tile += Gs;
+        if (l_item < nItems) setup_tile(l_tile);
+      }
     }
   };
 
@@ -125,41 +135,51 @@ __global__ __launch_bounds__(256, (NCH == 1 ? 4 : 3)) void conv3x3_hreg_kernel(c
 #pragma unroll
   for (int o = 0; o < kHrTH; ++o) acc[o] = bias4;
 
-  auto compute = [&](int stage, int c) {
-    const unsigned char* sa = smem + stage * kHrStage;
+  auto compute = [&](int stg, int c) {
+    const unsigned char* sa = smem + stg * kHrStage;
 #pragma unroll
     for (int iy = 0; iy < kHrHH; ++iy) {
       u32x4 a[3];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const u32x4*>(sa + lane_base[q] + iy * (kHrHW * 64));
+      for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const u32x4*>(sa + lane_base[q] + (HR_DBG(8) ? 0 : iy * (kHrHW * 64)));
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const int o = iy - r;
         if (o >= 0 && o < kHrTH) {
 #pragma unroll
-          for (int q = 0; q < 3; ++q) acc[o] = Elem<T>::mma(wreg[c][r * 3 + q], a[q], acc[o]);  // D[cout][pixel]
+          for (int q = 0; q < 3; ++q) {
+            if (HR_DBG(2)) asm volatile("" ::"v"(a[q]));
+            else acc[o] = Elem<T>::mma(wreg[c][r * 3 + q], a[q], acc[o]);  // D[cout][pixel]
+          }
         }
       }
     }
   };
 
+  // residual of the tile that ends with this item (Bottleneck shortcut): requested at the START of the item, BEFORE the next
+  // DMA is issued — the loads are then older than that DMA and their wait (at the epilogue) leaves it in flight
+  typedef __attribute__((ext_vector_type(4))) T t4;
+  u32x2 rv[kHrTH];
+  auto load_residual = [&](int tile) {
+    const int tx = tile % p.tilesX;
+    const int r = tile / p.tilesX;
+    const int ty = r % p.tilesY, n = r / p.tilesY;
+    const int xx = tx * kHrTW + lr;
+    const int co = nt * 64 + wave * 16 + lq * 4;
+#pragma unroll
+    for (int o = 0; o < kHrTH; ++o) {
+      const int yy = ty * kHrTH + o;
+      const bool ok = yy < p.H && xx < p.W;
+      const unsigned off = ok ? (unsigned)((((size_t)(n * p.H + yy) * p.W + xx) * (size_t)p.ldres + co) * sizeof(T)) : 0xfffffff0u;
+      rv[o] = __builtin_amdgcn_raw_buffer_load_b64(rrs, off, 0, 0);  // zero records without a residual: returns 0
+    }
+  };
   auto epilogue = [&](int tile) {
     const int tx = tile % p.tilesX;
     const int r = tile / p.tilesX;
     const int ty = r % p.tilesY, n = r / p.tilesY;
     const int xx = tx * kHrTW + lr;
     const int co = nt * 64 + wave * 16 + lq * 4;
-    typedef __attribute__((ext_vector_type(4))) T t4;
-    u32x2 rv[kHrTH];
-    if (p.res) {
-#pragma unroll
-      for (int o = 0; o < kHrTH; ++o) {
-        const int yy = ty * kHrTH + o;
-        const bool ok = yy < p.H && xx < p.W;
-        const unsigned off = ok ? (unsigned)((((size_t)(n * p.H + yy) * p.W + xx) * (size_t)p.ldres + co) * sizeof(T)) : 0xfffffff0u;
-        rv[o] = __builtin_amdgcn_raw_buffer_load_b64(rrs, off, 0, 0);
-      }
-    }
 #pragma unroll
     for (int o = 0; o < kHrTH; ++o) {
       float v[4] = {acc[o][0], acc[o][1], acc[o][2], acc[o][3]};
@@ -167,7 +187,7 @@ __global__ __launch_bounds__(256, (NCH == 1 ? 4 : 3)) void conv3x3_hreg_kernel(c
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
       }
-      if (p.res) {
+      if constexpr (RES) {
         const t4 rr = __builtin_bit_cast(t4, rv[o]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += Elem<T>::to_f32(rr[e]);
@@ -178,29 +198,40 @@ __global__ __launch_bounds__(256, (NCH == 1 ? 4 : 3)) void conv3x3_hreg_kernel(c
       const int yy = ty * kHrTH + o;
       const bool ok = yy < p.H && xx < p.W;
       const unsigned off = ok ? (unsigned)((((size_t)(n * p.H + yy) * p.W + xx) * (size_t)p.ldy + co) * sizeof(T)) : 0xfffffff0u;
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ov), yrs, off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ov), yrs, HR_DBG(1) ? 0xfffffff0u : off, 0, 0);
       acc[o] = bias4;
     }
   };
 
-  // ---- item pipeline ----
+  // ---- item pipeline: ring of three stages, two items' DMA in flight, counted waits, raw barriers ----
+  // Item i lives in stage i % 3.  At the start of item i the DMA of item i + 2 goes into stage (i + 2) % 3, last read in
+  // item i - 1 (every wave has passed the barrier that ended it).  At the end of item i the wave waits until ITS pieces of
+  // item i + 1 have landed: younger than those are only the 4 DMA instructions of item i + 2 and, when the item ended a
+  // tile, the tile's 8 output stores -> s_waitcnt vmcnt(4) / vmcnt(12); the barrier then publishes everyone's pieces.
   setup_tile(l_tile);
   issue_dma(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  issue_dma(1 % kHrStages);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
   int c_tile = sb;
+  int stage = 0;
   for (int it = 0; it < nItems; it += NCH) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      const int stage = (NCH & 1) ? ((it + c) & 1) : (c & 1);
-      if (it + c + 1 < nItems) issue_dma(stage ^ 1);  // stage ^ 1 was last read one item ago: every wave has passed that item's barrier
+      if constexpr (RES) {
+        if (c == NCH - 1) load_residual(c_tile);
+      }
+      issue_dma(stage + 2 >= kHrStages ? stage + 2 - kHrStages : stage + 2);
       compute(stage, c);
       if (c == NCH - 1) {
         epilogue(c_tile);
         c_tile += Gs;
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of the next item have landed ...
-      __syncthreads();                                   // ... and so have everyone's; all reads of `stage` are done
+      __builtin_amdgcn_s_barrier();
+      stage = stage + 1 == kHrStages ? 0 : stage + 1;
     }
   }
 }
@@ -209,15 +240,19 @@ template <typename T>
 static int launch_hreg(const HregArgs& a, hipStream_t st) {
   HregArgs p = a;
   const int nch = p.Cin / 32;
-  int grid = 256 * (nch == 1 ? 4 : 3);  // 256-thread workgroups per CU: four at cin 32 (118 VGPRs), three at cin 64 (72 weight registers)
+  int grid = 256 * 3;  // three 256-thread workgroups per CU (48 KB of LDS and <= 168 VGPRs each)
   const long long nwork = (long long)p.nSpatial * p.tilesN;
   if (nwork < grid) grid = (int)nwork;
   const int q = 8 * p.tilesN;
   grid = (grid + q - 1) / q * q;  // the XCD remap and the fixed cout group per block need G % (8 * tilesN) == 0
-  if (nch == 1)
-    hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 1>), dim3((unsigned)grid), dim3(256), 0, st, p);
-  else
-    hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 2>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  const bool res = p.res != nullptr;
+  if (nch == 1) {
+    if (res) hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 1, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 1, false>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  } else {
+    if (res) hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 2, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 2, false>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  }
   return check_launch("conv3x3_hreg_kernel");
 }
 
@@ -226,7 +261,10 @@ int conv3x3_hreg_try(const dy_conv_desc* d, hipStream_t st) {
   static const int off = dy_ablate("DYOLO_NO_HREG");
   if (off) return 1;
   if (!(d->dtype == DY_BF16 || d->dtype == DY_F16) || d->out_f32 || d->stride != 1 || d->ksize != 3 || d->pad != 1 || d->groups > 1 || d->up2x || d->x2) return 1;
-  if (!(d->cin == 32 || d->cin == 64) || d->cout % 64 != 0 || d->cout > 256) return 1;
+  // measured (B = 256, alternating A/B against conv3x3_halo, tools/bench_conv.py): 64->64 @160 650 -> 598 us, @80 150 -> 141, @40 55 -> 42,
+  // @20 29 -> 18, 64->128 @80 285 -> 268; cin 32 (one chunk per tile: an epilogue every item) 205-250 -> 227-252: no gain, stays on
+  // the halo kernel; with a Bottleneck residual (8-byte gathers of 32-byte segments) 210 -> 237 @80: stays there too
+  if (d->cin != 64 || d->cout % 64 != 0 || d->cout > 256 || d->residual) return 1;
   if (d->ho != d->h || d->wo != d->w_in) return 1;
   const long long xb = (long long)d->batch * d->h * d->w_in * d->ld_x * 2, yb = (long long)d->batch * d->ho * d->wo * d->ld_y * 2;
   const long long rb = d->residual ? (long long)d->batch * d->ho * d->wo * d->ld_res * 2 : 0;
@@ -240,6 +278,7 @@ int conv3x3_hreg_try(const dy_conv_desc* d, hipStream_t st) {
   a.tilesN = d->cout / 64;
   a.nSpatial = d->batch * a.tilesY * a.tilesX;
   a.y_bytes = (unsigned)yb, a.r_bytes = (unsigned)rb;
+  a.dbg = dy_ablate("DYOLO_DBG");
   return d->dtype == DY_BF16 ? launch_hreg<bf16_t>(a, st) : launch_hreg<f16_t>(a, st);
 }
 

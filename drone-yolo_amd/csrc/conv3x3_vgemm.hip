@@ -608,7 +608,8 @@ static int launch_vgemm(const ConvArgs& a, hipStream_t st) {
 // Returns 1 when the shape is not one this kernel is built for, else the launch status.
 int conv3x3_vgemm_try(const ConvArgs& a, int dtype, bool out_f32, hipStream_t st) {
   static const int off = dy_ablate("DYOLO_NO_VGEMM");
-  const int es = dy_dtype_size(dtype);
+  if (dtype == DY_FP8) return 1;  // not built for fp8: the generic kernel runs
+  const int es = dtype_size_no_fp8(dtype);
   const int bke = 8 * (16 / es);
   if (off || out_f32 || !a.vec_store) return 1;
   if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.up2x || a.split != a.Cin) return 1;

@@ -19,6 +19,8 @@ struct ConvArgs {
   int act, up2x;
   int tilesN, nblk;
   int vec_store;
+  const float* wscale;  // DY_FP8: per-output-channel dequantisation multiplier (act_scale * weight scale), else nullptr
+  float act_scale;      // DY_FP8: real value of one activation quantum (x, residual, y); 1 otherwise
 };
 
 // conv_gemm_glds.hip: LDS-DMA staged 128 x {64,128} tile.  Returns 1 when the shape is not one it is built for

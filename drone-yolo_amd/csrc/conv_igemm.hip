@@ -219,8 +219,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     float v[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; e += 4) {
-      const f32x4 t = *reinterpret_cast<const f32x4*>(cs + row * CLD + col + e);
+      f32x4 t = *reinterpret_cast<const f32x4*>(cs + row * CLD + col + e);
       const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + gcol + e);
+      if constexpr (std::is_same<T, fp8_t>::value) {  // integer-like products of quanta -> real units
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.wscale + gcol + e);
+        t = f32x4{t[0] * sc[0], t[1] * sc[1], t[2] * sc[2], t[3] * sc[3]};
+      }
       v[e + 0] = t[0] + bb[0];
       v[e + 1] = t[1] + bb[1];
       v[e + 2] = t[2] + bb[2];
@@ -237,10 +241,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         float rf[VEC];
         Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(rp), reinterpret_cast<float(&)[Elem<T>::EPC]>(rf));
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) v[e] += rf[e];
+        for (int e = 0; e < VEC; ++e) v[e] += rf[e] * (std::is_same<T, fp8_t>::value ? p.act_scale : 1.f);
       } else {
-        for (int e = 0; e < nvalid; ++e) v[e] += Elem<T>::to_f32(rp[e]);
+        for (int e = 0; e < nvalid; ++e) v[e] += Elem<T>::to_f32(rp[e]) * (std::is_same<T, fp8_t>::value ? p.act_scale : 1.f);
       }
+    }
+    if constexpr (std::is_same<T, fp8_t>::value && !OUTF32) {
+      const float inv = 1.f / p.act_scale;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] *= inv;
     }
     OutT* yp = yg + (size_t)m * (size_t)p.ldy + (size_t)gcol;
     if (p.vec_store && nvalid == VEC) {
@@ -384,6 +393,15 @@ extern "C" int32_t dy_conv2d_nhwc(const dy_conv_desc* d, dy_stream_t stream) {
   a.up2x = d->up2x;  // 0 plain, 1 nearest-upsampled source, 2 zero-dilated source (stride-2 transposed conv)
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
+  if (d->dtype == DY_FP8) {
+    DY_REQUIRE(d->w_layout == DY_WLAYOUT_ROWS && d->groups <= 1, DY_ERR_UNSUPPORTED, "dy_conv2d_nhwc: DY_FP8 is built for dense convolutions in DY_WLAYOUT_ROWS");
+    DY_REQUIRE(d->w_scale && d->act_scale > 0.f && aligned16(d->w_scale), DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: DY_FP8 needs w_scale (fp32[cout_pad], 16-byte aligned) and act_scale > 0");
+    a.wscale = d->w_scale;
+    a.act_scale = d->act_scale;
+  } else {
+    a.wscale = nullptr;
+    a.act_scale = 1.f;
+  }
   if (d->w_layout == DY_WLAYOUT_HALO3X3) return conv3x3_halo_dispatch(d, st);
   if (d->w_layout == DY_WLAYOUT_FRAG1X1) return conv1x1_stream_dispatch(d, st);
   DY_REQUIRE(d->w_layout == DY_WLAYOUT_ROWS, DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: unknown w_layout %d", d->w_layout);
@@ -448,6 +466,8 @@ extern "C" int32_t dy_conv2d_nhwc(const dy_conv_desc* d, dy_stream_t stream) {
       return d->out_f32 ? launch_dtype<bf16_t, true>(a, st) : launch_dtype<bf16_t, false>(a, st);
     case DY_F16:
       return d->out_f32 ? launch_dtype<f16_t, true>(a, st) : launch_dtype<f16_t, false>(a, st);
+    case DY_FP8:
+      return d->out_f32 ? launch_dtype<fp8_t, true>(a, st) : launch_dtype<fp8_t, false>(a, st);
     default:
       return launch_dtype<float, false>(a, st);
   }

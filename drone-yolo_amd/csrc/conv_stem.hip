@@ -210,7 +210,7 @@ using namespace dy;
 extern "C" int32_t dy_stem_conv3x3s2_nchw(const float* x, const void* w, const float* bias, void* y, int32_t n, int32_t cin,
                                           int32_t h, int32_t w_in, int32_t cout, int32_t ld_y, int32_t act, int32_t dtype,
                                           dy_stream_t stream) {
-  const int es = dy_dtype_size(dtype);
+  const int es = dtype_size_no_fp8(dtype);
   DY_REQUIRE(x && w && bias && y && es, DY_ERR_INVALID_ARG, "dy_stem_conv3x3s2_nchw: null pointer or bad dtype");
   DY_REQUIRE(n > 0 && h > 0 && w_in > 0 && cout > 0 && cin >= 1 && cin * 9 <= 32, DY_ERR_INVALID_ARG,
              "dy_stem_conv3x3s2_nchw: needs 1 <= cin <= 3 (K = 9*cin <= 32)");

@@ -413,7 +413,7 @@ using namespace dy;
 
 extern "C" int32_t dy_conv2d_wgrad_nhwc(const dy_conv_desc* d, const void* dz, int32_t ld_dz, float* dw, dy_stream_t stream) {
   DY_REQUIRE(d && d->x && dz && dw, DY_ERR_INVALID_ARG, "dy_conv2d_wgrad_nhwc: null pointer");
-  const int es = dy_dtype_size(d->dtype);
+  const int es = dtype_size_no_fp8(d->dtype);
   DY_REQUIRE(es != 0 && d->batch > 0 && d->h > 0 && d->w_in > 0 && d->cin > 0 && d->cout > 0 && d->ksize >= 1 && d->stride >= 1 && d->pad >= 0,
              DY_ERR_INVALID_ARG, "dy_conv2d_wgrad_nhwc: bad dims");
   DY_REQUIRE(d->groups <= 1 && !d->up2x && !d->x2, DY_ERR_UNSUPPORTED, "dy_conv2d_wgrad_nhwc: dense single-source convolutions only");
@@ -448,7 +448,7 @@ extern "C" int32_t dy_conv2d_wgrad_nhwc(const dy_conv_desc* d, const void* dz, i
 }
 
 extern "C" int32_t dy_colsum(const void* z, float* out, int64_t rows, int32_t c, int32_t ld, int32_t dtype, dy_stream_t stream) {
-  const int es = dy_dtype_size(dtype);
+  const int es = dtype_size_no_fp8(dtype);
   DY_REQUIRE(z && out && rows > 0 && c > 0 && es, DY_ERR_INVALID_ARG, "dy_colsum: bad arguments");
   const int epc = 16 / es, nch = (c + epc - 1) / epc;
   // channels are read in whole 16-byte chunks: the pitch must cover c rounded up (the padding only reaches sums that are dropped)

@@ -235,7 +235,7 @@ using namespace dy;
 
 extern "C" int32_t dy_detect_head_decode_supported(int32_t c_box, int32_t c_cls, int32_t nc, int32_t reg_max, int32_t dtype) {
   if (reg_max != 16 || nc < 1 || nc > 128) return 0;
-  const int esz = dy_dtype_size(dtype);
+  const int esz = dtype_size_no_fp8(dtype);
   if (esz == 0) return 0;
   const int kc = 4 * (16 / esz);
   if (c_box % kc || c_cls % kc) return 0;  // whole k-groups only: no reads past the channels (garbage * 0 could be NaN)
@@ -252,7 +252,7 @@ extern "C" int32_t dy_detect_head_decode(const dy_head_decode_desc* d, dy_stream
   DY_REQUIRE(dy_detect_head_decode_supported(d->c_box, d->c_cls, d->nc, d->reg_max, d->dtype), DY_ERR_UNSUPPORTED,
              "dy_detect_head_decode: shape c_box %d c_cls %d nc %d reg_max %d dtype %d not built (use dy_conv2d_nhwc + "
              "dy_detect_decode)", d->c_box, d->c_cls, d->nc, d->reg_max, d->dtype);
-  const int esz = dy_dtype_size(d->dtype), epc = 16 / esz, kc = 4 * epc;
+  const int esz = dtype_size_no_fp8(d->dtype), epc = 16 / esz, kc = 4 * epc;
   HeadArgs a{};
   int A = 0, G = 0;
   for (int i = 0; i < d->n_levels; ++i) {

@@ -141,6 +141,26 @@ __global__ __launch_bounds__(256) void sppf_maxpool3_kernel(const T* __restrict_
   }
 }
 
+// ---- 16-bit / fp32 NHWC -> fp8 (e4m3fn) NHWC, q = sat(x / act_scale): hand-over from the fp16 image stem to the fp8 layers ----
+template <typename T>
+__global__ __launch_bounds__(256) void quantize_fp8_kernel(const T* __restrict__ src, fp8_t* __restrict__ dst, long long rows, int c16, int lds, int ldd, float inv) {
+  constexpr int EPC = Elem<T>::EPC;  // source elements per 16-byte chunk; one destination chunk = 16 elements
+  const long long total = rows * c16;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cc = (int)(i % c16);
+    const long long r = i / c16;
+    float f[16];
+#pragma unroll
+    for (int k = 0; k < 16 / EPC; ++k) {
+      float t[EPC];
+      Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(src + (size_t)r * lds + cc * 16 + k * EPC), t);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) f[k * EPC + e] = t[e] * inv;
+    }
+    *reinterpret_cast<u32x4*>(dst + (size_t)r * ldd + cc * 16) = Chunk<fp8_t>::pack(f);
+  }
+}
+
 static inline int grid_for(long long items) {
   long long b = (items + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 2048 * 4 ? 2048 * 4 : b));
@@ -152,7 +172,7 @@ using namespace dy;
 
 extern "C" int32_t dy_nchw_f32_to_nhwc(const float* src, void* dst, int32_t n, int32_t c, int32_t h, int32_t w,
                                        int32_t c_pad, int32_t ld_dst, int32_t dtype, dy_stream_t stream) {
-  const int es = dy_dtype_size(dtype);
+  const int es = dtype_size_no_fp8(dtype);
   DY_REQUIRE(src && dst && es, DY_ERR_INVALID_ARG, "dy_nchw_f32_to_nhwc: null pointer or bad dtype");
   DY_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0, DY_ERR_INVALID_ARG, "dy_nchw_f32_to_nhwc: bad dims");
   const int epc = 16 / es;
@@ -171,7 +191,7 @@ extern "C" int32_t dy_nchw_f32_to_nhwc(const float* src, void* dst, int32_t n, i
 
 extern "C" int32_t dy_nchw_u8_to_nhwc(const uint8_t* src, void* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t c_pad, int32_t ld_dst,
                                       float divisor, int32_t dtype, dy_stream_t stream) {
-  const int es = dy_dtype_size(dtype);
+  const int es = dtype_size_no_fp8(dtype);
   DY_REQUIRE(src && dst && es && divisor != 0.f, DY_ERR_INVALID_ARG, "dy_nchw_u8_to_nhwc: null pointer, bad dtype or zero divisor");
   DY_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0, DY_ERR_INVALID_ARG, "dy_nchw_u8_to_nhwc: bad dims");
   const int epc = 16 / es;
@@ -190,7 +210,7 @@ extern "C" int32_t dy_nchw_u8_to_nhwc(const uint8_t* src, void* dst, int32_t n, 
 
 extern "C" int32_t dy_nhwc_to_nchw_f32(const void* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w,
                                        int32_t ld_src, int32_t src_dtype, dy_stream_t stream) {
-  const int es = dy_dtype_size(src_dtype);
+  const int es = dtype_size_no_fp8(src_dtype);
   DY_REQUIRE(src && dst && es, DY_ERR_INVALID_ARG, "dy_nhwc_to_nchw_f32: null pointer or bad dtype");
   DY_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0 && ld_src >= c, DY_ERR_INVALID_ARG, "dy_nhwc_to_nchw_f32: bad dims");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -261,8 +281,28 @@ extern "C" int32_t dy_sppf_maxpool3(const void* x, void* y1, void* y2, void* y3,
     DY_SPPF_LAUNCH(bf16_t);
   else if (dtype == DY_F16)
     DY_SPPF_LAUNCH(f16_t);
+  else if (dtype == DY_FP8)  // max commutes with the (monotonic) quantisation: exact in the quantised domain
+    DY_SPPF_LAUNCH(fp8_t);
   else
     DY_SPPF_LAUNCH(float);
 #undef DY_SPPF_LAUNCH
   return check_launch("sppf_maxpool3_kernel");
+}
+
+extern "C" int32_t dy_quantize_fp8_nhwc(const void* src, void* dst, int64_t rows, int32_t c, int32_t ld_src, int32_t ld_dst, int32_t src_dtype, float act_scale,
+                                        dy_stream_t stream) {
+  const int es = dtype_size_no_fp8(src_dtype);
+  DY_REQUIRE(src && dst && es && rows > 0 && c > 0 && act_scale > 0.f, DY_ERR_INVALID_ARG, "dy_quantize_fp8_nhwc: bad arguments");
+  DY_REQUIRE(c % 16 == 0 && ld_src >= c && ld_dst >= c && (ld_src * es) % 16 == 0 && ld_dst % 16 == 0 && aligned16(src) && aligned16(dst), DY_ERR_INVALID_ARG,
+             "dy_quantize_fp8_nhwc: c must be a multiple of 16 and both views whole 16-byte chunks");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int grid = grid_for((long long)rows * (c / 16));
+  const float inv = 1.f / act_scale;
+  if (src_dtype == DY_BF16)
+    hipLaunchKernelGGL((quantize_fp8_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (fp8_t*)dst, (long long)rows, c / 16, ld_src, ld_dst, inv);
+  else if (src_dtype == DY_F16)
+    hipLaunchKernelGGL((quantize_fp8_kernel<f16_t>), dim3(grid), dim3(256), 0, st, (const f16_t*)src, (fp8_t*)dst, (long long)rows, c / 16, ld_src, ld_dst, inv);
+  else
+    hipLaunchKernelGGL((quantize_fp8_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)src, (fp8_t*)dst, (long long)rows, c / 16, ld_src, ld_dst, inv);
+  return check_launch("quantize_fp8_kernel");
 }

@@ -274,7 +274,7 @@ using namespace dy;
 
 extern "C" int32_t dy_upsample2x_bwd_nhwc(const void* g, void* dx, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ld_g, int32_t ld_dx, int32_t dtype,
                                           dy_stream_t stream) {
-  const int es = dy_dtype_size(dtype);
+  const int es = dtype_size_no_fp8(dtype);
   DY_REQUIRE(es && g && dx && n > 0 && h > 0 && w > 0 && c > 0, DY_ERR_INVALID_ARG, "dy_upsample2x_bwd_nhwc: bad arguments");
   const int epc = 16 / es;
   DY_REQUIRE(c % epc == 0 && DY_VIEW_OK(g, ld_g, c, es) && DY_VIEW_OK(dx, ld_dx, c, es), DY_ERR_INVALID_ARG, "dy_upsample2x_bwd_nhwc: views must be whole 16-byte chunks");
@@ -289,7 +289,7 @@ extern "C" int32_t dy_upsample2x_bwd_nhwc(const void* g, void* dx, int32_t n, in
 
 extern "C" int32_t dy_maxpool_bwd_nhwc(const void* x, const void* g_out, void* g_in, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ld_x, int32_t ld_go,
                                        int32_t ld_gi, int32_t k, int32_t accumulate, int32_t dtype, dy_stream_t stream) {
-  const int es = dy_dtype_size(dtype);
+  const int es = dtype_size_no_fp8(dtype);
   DY_REQUIRE(es && x && g_out && g_in && n > 0 && h > 0 && w > 0 && c > 0 && k >= 1 && (k & 1) && k <= 15, DY_ERR_INVALID_ARG, "dy_maxpool_bwd_nhwc: bad arguments");
   const int epc = 16 / es;
   DY_REQUIRE(c % epc == 0 && DY_VIEW_OK(x, ld_x, c, es) && DY_VIEW_OK(g_out, ld_go, c, es) && DY_VIEW_OK(g_in, ld_gi, c, es), DY_ERR_INVALID_ARG,
@@ -312,7 +312,7 @@ extern "C" int32_t dy_maxpool_bwd_nhwc(const void* x, const void* g_out, void* g
 }
 
 extern "C" int32_t dy_add_nhwc(const void* a, const void* b, void* out, int64_t rows, int32_t c, int32_t ld_a, int32_t ld_b, int32_t ld_o, int32_t dtype, dy_stream_t stream) {
-  const int es = dy_dtype_size(dtype);
+  const int es = dtype_size_no_fp8(dtype);
   DY_REQUIRE(es && a && b && out && rows > 0 && c > 0, DY_ERR_INVALID_ARG, "dy_add_nhwc: bad arguments");
   const int epc = 16 / es;
   DY_REQUIRE(c % epc == 0 && DY_VIEW_OK(a, ld_a, c, es) && DY_VIEW_OK(b, ld_b, c, es) && DY_VIEW_OK(out, ld_o, c, es), DY_ERR_INVALID_ARG,
@@ -330,7 +330,7 @@ extern "C" int32_t dy_add_nhwc(const void* a, const void* b, void* out, int64_t 
 extern "C" int32_t dy_conv2d_grouped_bwd_nhwc(const dy_conv_desc* d, const void* dz, int32_t ld_dz, const float* w_oihw, float* dw_oihw, void* dx, int32_t ld_dx,
                                               const void* dx_accumulate, int32_t ld_acc, dy_stream_t stream) {
   DY_REQUIRE(d && dz && d->x && (dw_oihw || (dx && w_oihw)), DY_ERR_INVALID_ARG, "dy_conv2d_grouped_bwd_nhwc: null argument");
-  const int es = dy_dtype_size(d->dtype);
+  const int es = dtype_size_no_fp8(d->dtype);
   DY_REQUIRE(es && d->groups > 1 && d->cin % d->groups == 0 && d->cout % d->groups == 0, DY_ERR_INVALID_ARG, "dy_conv2d_grouped_bwd_nhwc: bad dtype / groups");
   DY_REQUIRE(d->batch > 0 && d->h > 0 && d->w_in > 0 && d->ho == (d->h + 2 * d->pad - d->ksize) / d->stride + 1 && d->wo == (d->w_in + 2 * d->pad - d->ksize) / d->stride + 1,
              DY_ERR_INVALID_ARG, "dy_conv2d_grouped_bwd_nhwc: geometry");

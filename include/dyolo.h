@@ -45,7 +45,10 @@ typedef enum dy_status {
   DY_ERR_WORKSPACE = -4      /* workspace too small */
 } dy_status;
 
-typedef enum dy_dtype { DY_BF16 = 0, DY_F16 = 1, DY_F32 = 2 } dy_dtype;
+/* DY_FP8 = OCP e4m3fn (gfx950's fp8, NOT MI300's fnuz): 1 byte per element, 16 per 16-byte chunk.  An fp8 activation or weight
+ * element q stands for the real value q * scale (dy_conv_desc.act_scale for activations, w_scale[co] / act_scale for the weights of
+ * output channel co).  Entry points that are not built for it return DY_ERR_INVALID_ARG ("bad dtype"). */
+typedef enum dy_dtype { DY_BF16 = 0, DY_F16 = 1, DY_F32 = 2, DY_FP8 = 3 } dy_dtype;
 typedef enum dy_act { DY_ACT_NONE = 0, DY_ACT_SILU = 1 } dy_act;
 /* Packed weight layouts of dy_conv2d_nhwc (see dy_conv_desc.w_layout). */
 typedef enum dy_wlayout { DY_WLAYOUT_ROWS = 0, DY_WLAYOUT_HALO3X3 = 1, DY_WLAYOUT_FRAG1X1 = 2 } dy_wlayout;
@@ -56,7 +59,7 @@ typedef enum dy_wlayout { DY_WLAYOUT_ROWS = 0, DY_WLAYOUT_HALO3X3 = 1, DY_WLAYOU
 int32_t dy_version(void);
 /* Message of the last error raised on this thread ("" if none). Host string. */
 const char* dy_last_error_string(void);
-/* Size in bytes of one element of `dtype` (2, 2, 4) or 0 if unknown. */
+/* Size in bytes of one element of `dtype` (2, 2, 4, 1) or 0 if unknown. */
 int32_t dy_dtype_size(int32_t dtype);
 
 /* ---- convolution ----------------------------------------------------------
@@ -116,8 +119,20 @@ typedef struct dy_conv_desc {
    * Built for ceil(cin/KC) in {2,3,4,6,8,12}; cout <= 16 and fp32 output (out_f32 with a 16-bit dtype) only
    * for 2 chunks; anything else returns DY_ERR_UNSUPPORTED (pack such layers with DY_WLAYOUT_ROWS). */
   int32_t w_layout;
+  /* DY_FP8 only (BASELINE config 5: fp8 weights / activations on the fp8 MFMA, fp32 accumulate).  Weights are quantised per OUTPUT
+   * channel, activations with ONE scale for the whole network (e4m3 is a floating format: a per-tensor scale only has to keep
+   * the values inside [2^-9, 448] * scale):
+   *   y_real[co] = act( (sum q_x * q_w[co]) * w_scale[co] + bias[co] ) (+ q_res * act_scale);   y_q = sat_e4m3(y_real / act_scale)
+   * w_scale: fp32[cout_pad], = act_scale * (weight scale of channel co); with out_f32 the result is y_real itself.
+   * DY_WLAYOUT_ROWS only.  Ignored (may be NULL / 0) for the other dtypes. */
+  const float* w_scale;
+  float act_scale;
 } dy_conv_desc;
 
+/* Quantise a 16-bit / fp32 NHWC view to DY_FP8: dst_q = sat_e4m3(src / act_scale).  c % 16 == 0, views 16-byte aligned.
+ * Replaces nothing in the reference (it has no fp8 path); it is the hand-over from the image stem (run in fp16) to the fp8 layers. */
+int32_t dy_quantize_fp8_nhwc(const void* src, void* dst, int64_t rows, int32_t c, int32_t ld_src, int32_t ld_dst, int32_t src_dtype, float act_scale,
+                             dy_stream_t stream);
 int32_t dy_conv_k_pad(int32_t cin, int32_t ksize, int32_t dtype);
 int32_t dy_conv_cout_pad(int32_t cout);
 int32_t dy_conv2d_nhwc(const dy_conv_desc* d, dy_stream_t stream);
