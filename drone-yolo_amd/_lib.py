@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdyolo.so")
 
-DY_BF16, DY_F16, DY_F32 = 0, 1, 2
+DY_BF16, DY_F16, DY_F32, DY_FP8 = 0, 1, 2, 3
 DY_ACT_NONE, DY_ACT_SILU = 0, 1
 DY_MAX_LEVELS = 8
 DY_WLAYOUT_ROWS, DY_WLAYOUT_HALO3X3, DY_WLAYOUT_FRAG1X1 = 0, 1, 2
@@ -32,6 +32,7 @@ class ConvDesc(C.Structure):
         ("groups", _i32), ("act", _i32), ("dtype", _i32), ("out_f32", _i32),
         ("k_pad", _i32), ("cout_pad", _i32), ("up2x", _i32),
         ("x2", _vp), ("ld_x2", _i32), ("cin_split", _i32), ("w_layout", _i32),
+        ("w_scale", _vp), ("act_scale", _f32),
     ]  # fmt: skip
 
 
@@ -154,6 +155,7 @@ SIGNATURES = {
     "dy_scale_boxes": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "dy_detection_loss_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "dy_conv2d_wgrad_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _i32, _vp, _vp]),
+    "dy_quantize_fp8_nhwc": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp]),
     "dy_conv2d_grouped_bwd_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
     "dy_colsum": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "dy_nchw_u8_to_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),

@@ -23,7 +23,7 @@ from ..utils.torch_utils import select_device
 from ..nn.autobackend import AutoBackend
 from .results import Results
 
-_DTYPE_NAMES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "half": torch.float16,
+_DTYPE_NAMES = {"fp8": H.FP8, "float8_e4m3fn": H.FP8, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "half": torch.float16,
                 "float16": torch.float16, "fp32": torch.float32, "float32": torch.float32}
 
 
@@ -105,9 +105,22 @@ class DetectionPredictor:
             raise ValueError(f"tensor source must have H, W divisible by the model stride {s} (loaders.py:516-584)")
         return im.to(self.device, torch.float32, non_blocking=True).contiguous()
 
+    def _calibrate_fp8(self, im: torch.Tensor) -> None:
+        """fp8 storage (BASELINE config 5): one fp16 pass over this batch measures the largest activation the network stores;
+        the network-wide activation scale puts it at 224 = half of e4m3's 448 (headroom for other inputs; e4m3 is a floating
+        format, so smaller activations keep their 3-bit mantissa down to 2^-9 of the scale).  Weight scales are per output
+        channel and need no data (hip_ops.PackedConv)."""
+        with H.observe_absmax() as log:
+            self.model._predict_once(im, image_dtype=torch.float16)
+        amax = float(torch.stack(log).max()) if log else 1.0
+        H.set_fp8_act_scale(max(amax / 224.0, 1e-8))
+        self.fp8_calibration = {"absmax": amax, "act_scale": H.fp8_act_scale()}
+
     def _record(self, im: torch.Tensor) -> CompiledForward:
         cf = CompiledForward()
         a = self.args
+        if self.dtype == H.FP8:
+            self._calibrate_fp8(im)
         n, _, h, w = im.shape
         params = torch.tensor([self._box_params(h, w)] * n, dtype=torch.float32, device=self.device)
         cf.box_params, cf.box_key = params, self._box_params(h, w)

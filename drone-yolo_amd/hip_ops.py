@@ -19,7 +19,40 @@ import torch
 from . import _lib
 from ._lib import DY_ACT_NONE, DY_ACT_SILU, BnDesc, C2fDesc, ConvDesc, DecodeDesc, HeadDecodeDesc, LossDesc, NmsDesc, Stem2Desc, check, lib
 
-_DTYPES = {torch.bfloat16: _lib.DY_BF16, torch.float16: _lib.DY_F16, torch.float32: _lib.DY_F32}
+FP8 = torch.float8_e4m3fn  # OCP e4m3fn: gfx950's fp8 (MI300's fnuz is another encoding)
+_DTYPES = {torch.bfloat16: _lib.DY_BF16, torch.float16: _lib.DY_F16, torch.float32: _lib.DY_F32, FP8: _lib.DY_FP8}
+
+# DY_FP8: ONE activation scale for the whole network (real value = quantum * scale), per-output-channel weight scales
+# (include/dyolo.h, dy_conv_desc.w_scale / act_scale).  Set by the predictor from a calibration pass before any fp8 pack is built.
+_FP8 = {"act_scale": 1.0}
+
+
+def set_fp8_act_scale(scale: float) -> None:
+    if not scale > 0:
+        raise ValueError("fp8 activation scale must be positive")
+    _FP8["act_scale"] = float(scale)
+
+
+def fp8_act_scale() -> float:
+    return _FP8["act_scale"]
+
+
+_absmax_log: Optional[list] = None  # calibration: conv2d appends the absolute maximum of every output while this is a list
+
+
+class observe_absmax:
+    """Context manager: records max |y| of every conv output launched inside (device scalars; read them after a sync)."""
+
+    def __enter__(self):
+        global _absmax_log
+        _absmax_log = []
+        return _absmax_log
+
+    def __exit__(self, *exc):
+        global _absmax_log
+        _absmax_log = None
+        return False
+
 
 
 def dy_dtype(dt: torch.dtype) -> int:
@@ -186,6 +219,25 @@ class PackedConv:
         self.act = DY_ACT_SILU if act else DY_ACT_NONE
         self.dtype = dtype
         self.layout = _lib.DY_WLAYOUT_ROWS
+        self.wscale, self.act_scale = None, 1.0
+        if dtype == FP8:
+            # e4m3 weights with one scale per OUTPUT channel (absmax -> 448), rows layout only; the epilogue multiplies the
+            # accumulator by act_scale * weight_scale[co] (include/dyolo.h)
+            if groups != 1:
+                raise NotImplementedError("fp8 storage is built for dense convolutions")
+            self.act_scale = fp8_act_scale()
+            w = weight.detach().to(torch.float32).permute(0, 2, 3, 1).reshape(cout, k * k * cin_g)
+            ws = (w.abs().amax(1) / 448.0).clamp_min(1e-12)
+            self.k_pad, self.cout_pad = L.dy_conv_k_pad(self.cin, k, dy_dtype(dtype)), L.dy_conv_cout_pad(cout)
+            wp = torch.zeros((self.cout_pad, self.k_pad), dtype=torch.float32, device=wdev)
+            wp[:cout, : w.shape[1]] = w / ws[:, None]
+            bp = torch.zeros((self.cout_pad,), dtype=torch.float32, device=wdev)
+            bp[:cout] = bias.detach().to(torch.float32).to(wdev)
+            sp = torch.ones((self.cout_pad,), dtype=torch.float32, device=wdev)
+            sp[:cout] = ws * self.act_scale
+            self.w = wp.to(FP8).contiguous().to(device)
+            self.b, self.wscale = bp.contiguous().to(device), sp.contiguous().to(device)
+            return
         # stride-2 halo tiles are 17x33 pixels (2 x 45 KB of LDS): only a weight set of <= 36 KB fits beside them
         s2_fits = self.cin <= 4 * elems_per_chunk(dtype) and cout > 32 or self.cin <= 8 * elems_per_chunk(dtype) and cout <= 32
         # deep 3x3 layers (small maps, weight sets far beyond LDS) run faster as a flat-M implicit GEMM on the LDS-DMA
@@ -294,7 +346,24 @@ def conv2d(x: torch.Tensor, pc: PackedConv, out: Optional[torch.Tensor] = None, 
             raise ValueError("conv2d: x2 must have the (upsampled) spatial size and dtype of x")
         d.x2, d.ld_x2 = view_params(x2)
         d.cin_split = c1
+    if pc.wscale is not None:
+        d.w_scale, d.act_scale = pc.wscale.data_ptr(), pc.act_scale
     _launch(lib().dy_conv2d_nhwc, (C.byref(d),), keep=(d, x, out, residual, x2, pc))
+    if _absmax_log is not None and not out_f32:  # activations that WOULD be stored in fp8 (the fp32 head logits are not)
+        _absmax_log.append(out.float().abs().amax())
+    return out
+
+
+def quantize_fp8(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """16-bit / fp32 NHWC view -> fp8 (e4m3fn) with the network's activation scale, through ``dy_quantize_fp8_nhwc``."""
+    require_device(x, "quantize input")
+    n, c, h, w = x.shape
+    if c % 16:
+        raise ValueError("quantize_fp8: channels must be a multiple of 16 (one fp8 chunk)")
+    if out is None:
+        out = alloc_nhwc(n, c, h, w, FP8, x.device)
+    (xp, ldx), (op, ldo) = view_params(x), view_params(out)
+    _launch(lib().dy_quantize_fp8_nhwc, (xp, op, n * h * w, c, ldx, ldo, dy_dtype(x.dtype), fp8_act_scale()), keep=(x, out))
     return out
 
 
@@ -354,7 +423,7 @@ class PackedStem2:
 
 
 def stem2_fused_supported(cin: int, c0: int, c1: int, h: int, w: int, dtype: torch.dtype) -> bool:
-    return bool(lib().dy_stem2_fused_supported(cin, c0, c1, h, w, dy_dtype(dtype)))
+    return dtype != FP8 and bool(lib().dy_stem2_fused_supported(cin, c0, c1, h, w, dy_dtype(dtype)))
 
 
 def stem2_fused(src: torch.Tensor, ps: PackedStem2, out: Optional[torch.Tensor] = None, mark_input: bool = False) -> torch.Tensor:
@@ -502,7 +571,7 @@ def pack_frag1x1(weight: torch.Tensor, bias: torch.Tensor, dtype: torch.dtype, d
 
 
 def head_decode_supported(c_box: int, c_cls: int, nc: int, reg_max: int, dtype: torch.dtype) -> bool:
-    return bool(lib().dy_detect_head_decode_supported(c_box, c_cls, nc, reg_max, dy_dtype(dtype)))
+    return dtype != FP8 and bool(lib().dy_detect_head_decode_supported(c_box, c_cls, nc, reg_max, dy_dtype(dtype)))
 
 
 def detect_head_decode(x_box: Sequence[torch.Tensor], x_cls: Sequence[torch.Tensor], packed_box, packed_cls,
@@ -862,7 +931,7 @@ class PackedC2f:
 
 
 def c2f_fused_supported(cin: int, hidden: int, cout: int, n: int, dtype: torch.dtype) -> bool:
-    return bool(lib().dy_c2f_fused_supported(cin, hidden, cout, n, dy_dtype(dtype)))
+    return dtype != FP8 and bool(lib().dy_c2f_fused_supported(cin, hidden, cout, n, dy_dtype(dtype)))
 
 
 def c2f_fused(x: torch.Tensor, pk: PackedC2f, out: Optional[torch.Tensor] = None) -> torch.Tensor:

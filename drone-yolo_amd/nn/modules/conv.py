@@ -54,7 +54,7 @@ class _PackedMixin:
 
     def _packed_for(self, x: torch.Tensor) -> H.PackedConv:
         cache = self._pack_cache()
-        key = (x.dtype, x.device, x.shape[1])
+        key = (x.dtype, x.device, x.shape[1], H.fp8_act_scale() if x.dtype == H.FP8 else None)  # an fp8 pack bakes the activation scale in
         pc = cache.get(key)
         if pc is None:
             pc = cache[key] = self._pack(x.dtype, x.device)

@@ -112,7 +112,7 @@ class Detect(nn.Module):
                 and ca.out_channels % 8 == 0 and isinstance(a.act, nn.SiLU) and isinstance(b.act, nn.SiLU)):
             return None
         srcs = [ca.weight, a.bn.weight, a.bn.bias, a.bn.running_mean, a.bn.running_var, cb.weight, b.bn.weight, b.bn.bias, b.bn.running_mean, b.bn.running_var]
-        key = (dtype, str(device), tuple((t.data_ptr(), t._version) for t in srcs))
+        key = (dtype, str(device), H.fp8_act_scale() if dtype == H.FP8 else None, tuple((t.data_ptr(), t._version) for t in srcs))
         cache = self.__dict__.setdefault("_first_cache", {})
         hit = cache.get(i)
         if hit is None or hit[0] != key:

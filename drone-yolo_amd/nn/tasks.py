@@ -197,6 +197,8 @@ class BaseModel(nn.Module):
                 stem_image = x
                 n, _, h, w = x.shape
                 x = torch.empty((n, 0, h, w), dtype=image_dtype, device=x.device)  # shape/dtype carrier only
+            elif image_dtype == H.FP8:
+                raise NotImplementedError("fp8 storage needs the image stem (Conv(3, c, 3, 2)) as the first layer: it runs in fp16 and hands over quantised")
             else:
                 x = H.to_nhwc(x, image_dtype, mark_input=True)
         y: List[Optional[torch.Tensor]] = []
@@ -231,7 +233,10 @@ class BaseModel(nn.Module):
                     y.append(None)
                     fused_stem2 = H.stem2_fused(stem_image, pk2, mark_input=True)
                     continue
-                out = m.forward_stem(stem_image, image_dtype, mark_input=True, **kw)
+                if image_dtype == H.FP8:  # the 3-channel image layer runs in fp16 (K = 27), its output is quantised once
+                    out = H.quantize_fp8(m.forward_stem(stem_image, torch.float16, mark_input=True), out=kw.get("out"))
+                else:
+                    out = m.forward_stem(stem_image, image_dtype, mark_input=True, **kw)
             elif i == 1 and fused_stem2 is not None:
                 out = fused_stem2
             else:

@@ -559,3 +559,72 @@ def test_detect_stacked_first_convs_match_separate(dtype, device):
         torch.cuda.synchronize()
         check_close(back(tb), back(sb), dtype, f"stacked box trunk level {i}", extra=3.0)
         check_close(back(tc), back(sc), dtype, f"stacked class trunk level {i}", extra=3.0)
+
+
+@pytest.mark.parametrize("case", [(64, 64, 3, 1, 2, 24, 20, True), (160, 80, 1, 1, 2, 17, 19, True), (80, 160, 3, 2, 2, 24, 28, True), (640, 320, 1, 1, 1, 12, 12, False),
+                                  (96, 48, 3, 1, 3, 10, 10, True)], ids=["3x3 64->64", "1x1 160->80", "3x3 s2 80->160", "1x1 640->320 no act", "3x3 96->48"])
+def test_fp8_conv_matches_dequantised_reference(case, device):
+    """DY_FP8 (BASELINE config 5): e4m3fn activations and per-output-channel-scaled e4m3fn weights on the fp8 MFMA, fp32 accumulate.
+    The reference is the SAME arithmetic on the CPU: dequantise the fp8 input and the fp8 weights exactly, convolve in fp32.
+    (a) fp32 output (out_f32, the Detect logits' form): equal to accumulation order, 1e-4 of the output scale; (b) fp8 output:
+    the reference rounded to e4m3 at the same activation scale, equal up to one quantum where the fp32 sums straddle a rounding
+    boundary (<= 2 % of the elements); (c) a residual (Bottleneck shortcut) is added in real units before the rounding."""
+    import torch.nn.functional as F
+
+    cin, cout, k, s_, b, h, w, act = case
+    FP8 = H.FP8
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    act_scale = 0.05
+    H.set_fp8_act_scale(act_scale)
+    try:
+        xq = (torch.randn(b, cin, h, w, generator=g) * 1.5 / act_scale).to(FP8)
+        wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+        bias = torch.randn(cout, generator=g) * 0.2
+        pc = H.PackedConv(wt, bias, s_, k // 2, 1, act, FP8, device)
+        ws = (wt.reshape(cout, -1).abs().amax(1) / 448.0).clamp_min(1e-12)
+        wq = (wt / ws.view(-1, 1, 1, 1)).to(FP8).float() * ws.view(-1, 1, 1, 1)  # what the device multiplies with, exactly
+        z = F.conv2d(xq.float() * act_scale, wq, bias, s_, k // 2)
+        ref = F.silu(z) if act else z
+        xd = xq.permute(0, 2, 3, 1).contiguous().to(device).permute(0, 3, 1, 2)
+        y32 = H.conv2d(xd, pc, out_f32=True) if not act else None
+        yq = H.conv2d(xd, pc)
+        rq = (torch.randn(ref.shape, generator=g) / act_scale).to(FP8)
+        yr = H.conv2d(xd, pc, residual=rq.permute(0, 2, 3, 1).contiguous().to(device).permute(0, 3, 1, 2))
+        torch.cuda.synchronize()
+        scale = float(ref.abs().max())
+        if y32 is not None:
+            assert float((y32.cpu() - ref).abs().max()) <= 1e-4 * scale
+        for got, want in ((yq, ref), (yr, ref + rq.float() * act_scale)):
+            want_q = (want / act_scale).clamp(-448, 448).to(FP8).float()
+            diff = (got.cpu().float() - want_q).abs()
+            step = want_q.abs().clamp_min(2.0 ** -6) * 0.126  # one e4m3 quantum is <= 1/8 of the value (2^-9 below 2^-6)
+            assert bool((diff <= step).all()), float((diff / step).max())
+            assert float((diff > 0).float().mean()) <= 0.02
+    finally:
+        H.set_fp8_act_scale(1.0)
+
+
+def test_fp8_quantize_and_pool(device):
+    """dy_quantize_fp8_nhwc == torch's e4m3fn cast of x / scale (round to nearest even, saturating); SPPF's three max pools are
+    exact on fp8 (max commutes with the monotonic quantisation)."""
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 32, 9, 11, generator=g) * 30
+    x[0, 0, 0, 0], x[0, 1, 0, 0] = 1e4, -1e4  # saturate
+    H.set_fp8_act_scale(0.25)
+    try:
+        x16 = x.half().permute(0, 2, 3, 1).contiguous().to(device).permute(0, 3, 1, 2)
+        q = H.quantize_fp8(x16)
+        torch.cuda.synchronize()
+        want = (x.half().float() / 0.25).clamp(-448, 448).to(H.FP8)
+        assert torch.equal(q.cpu().float(), want.float())
+        y1, y2, y3 = (H.alloc_nhwc(2, 32, 9, 11, H.FP8, device) for _ in range(3))
+        H.sppf_maxpool3(q, y1, y2, y3, 5)
+        torch.cuda.synchronize()
+        m1 = F.max_pool2d(want.float(), 5, 1, 2)
+        m2 = F.max_pool2d(m1, 5, 1, 2)
+        m3 = F.max_pool2d(m2, 5, 1, 2)
+        assert torch.equal(y1.cpu().float(), m1) and torch.equal(y2.cpu().float(), m2) and torch.equal(y3.cpu().float(), m3)
+    finally:
+        H.set_fp8_act_scale(1.0)

@@ -304,6 +304,33 @@ def test_config5_shape_scale_x_1536_against_reference_rows(device):
         torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("tag", ["s640bench", "x1536"])
+def test_config5_fp8_storage_against_reference_rows(tag, device):
+    """BASELINE config 5: fp8 (e4m3fn) weights and activations, fp8 MFMA with fp32 accumulate — Drone-YOLO-x at 1536x1536
+    (A = 195,840) and, for scale, Drone-YOLO-s at 640x640 — against the rows the REAL reference computed in fp32
+    (tests/golden/big.npz).  Bit-exact class / index parity is not expected under a 3-bit mantissa; the
+    tolerance of this configuration, stated here and in DESIGN §2: at least 70 % of the reference detections reproduced
+    (same anchor, same class), their boxes at mean IoU >= 0.97 / min IoU >= 0.80, and the decoded boxes of all anchors within
+    3 px RMS... measured values are written to gpurun_out/parity_report.jsonl."""
+    from drone_yolo_amd.utils import parity as PR
+
+    meta, x, exp_rows, exp_idx = PR.golden_case("big.npz", tag)
+    model = _bench_model(meta, device)
+    pred = D.engine.predictor.DetectionPredictor(model, dict(conf=0.25, iou=0.7, max_det=300, dtype="fp8", device=0))
+    cf = pred.forward_device(pred.preprocess(x))
+    torch.cuda.synchronize()
+    par = PR.detection_parity(cf.nms, exp_rows, exp_idx)
+    g = golden("big.npz")
+    y_sub = cf.pred[:, :, ::199].cpu()
+    ref_sub = torch.from_numpy(g[f"{tag}__y_sub"])
+    box_rms = float(((y_sub[:, :4] - ref_sub[:, :4]) ** 2).mean().sqrt())
+    cls_err = float((y_sub[:, 4:] - ref_sub[:, 4:]).abs().max())
+    _report(f"config5 fp8 {tag}", {"dtype": "fp8_e4m3fn", "box_rms_px": box_rms, "cls_max_err": cls_err, **par, **pred.fp8_calibration})
+    assert bool(torch.isfinite(cf.pred).all())
+    assert par["match_rate"] >= 0.70 and par["iou_mean"] >= 0.97 and par["iou_min"] >= 0.80 and box_rms <= 3.0, (par, box_rms, cls_err)
+    H.set_fp8_act_scale(1.0)
+
+
 def test_replay_graph_and_api(device):
     """LaunchPlan replay and hipGraph replay reproduce the recorded pass bit for bit; YOLO.predict API shape."""
     g = golden("e2e.npz")
