@@ -2,19 +2,19 @@
 # Run on the GPU box (gpurun -- 'bash tools/refresh_profiles.sh TAG'): kernel stats, HBM traffic counters and the
 # per-layer table for the default bench, written under gpurun_out/prof_TAG/ (copy what is judged into profiles/).
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 B=${2:-256}
 R=$PWD
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cp -r $R /tmp/w && cd /tmp/w
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --batch $B --steps 30 --warmup 5 --streams 1 --no-cpu-baseline > $O/bench_stats.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --batch $B --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-graph > $O/bench_fetch.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --batch $B --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-graph > $O/bench_write.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --batch $B --steps 30 --warmup 5 --streams 1 --bare > $O/bench_stats.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --batch $B --steps 2 --warmup 1 --streams 1 --bare --no-graph > $O/bench_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --batch $B --steps 2 --warmup 1 --streams 1 --bare --no-graph > $O/bench_write.log 2>&1
 mkdir -p $O/pmc && cp -r $O/fetch $O/pmc/ && cp -r $O/write $O/pmc/
 python3 tools/traffic_summary.py $O/pmc $B 9 > $O/traffic.json
-python3 bench.py --batch $B --layers $O/layers_b$B.txt --no-cpu-baseline > $O/bench_layers.log 2>&1
+python3 bench.py --batch $B --layers $O/layers_b$B.txt --bare > $O/bench_layers.log 2>&1
 find $O -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 # raw counter csvs are large; keep only the summaries
 rm -rf $O/fetch $O/write $O/pmc

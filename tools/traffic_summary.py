@@ -8,7 +8,7 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         fam = "head" if "detect_head" in r["Kernel_Name"] else "conv" if ("conv" in r["Kernel_Name"] or "c2f_fused" in r["Kernel_Name"] or "stem2_fused" in r["Kernel_Name"]) else ("nms" if "nms" in r["Kernel_Name"] else ("decode" if "decode" in r["Kernel_Name"] else
               ("layout" if ("nchw" in r["Kernel_Name"] or "sppf" in r["Kernel_Name"] or "copy_chunks" in r["Kernel_Name"]) else "other")))
         acc[fam][r["Counter_Name"]] += float(r["Counter_Value"])
-out = {"round": 1, "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph  (bf16)",
+out = {"round": 2, "dtype": "fp16", "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --streams 1 --bare --no-graph  (fp16, the default dtype)",
        "correction": "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); counters are KiB; "
                      "%d passes profiled (1 record + 1 warm-up + 2 steps + 5 event-timing passes of the conv launches)" % passes_per_run,
        "batch": batch, "families": {}}
