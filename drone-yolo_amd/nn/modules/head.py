@@ -99,8 +99,9 @@ class Detect(nn.Module):
     def _packed_first(self, i, dtype, device):
         """cv2[i][0] and cv3[i][0] stacked along cout, or None when the level is not one the stacking pays for.
 
-        Both read the same feature map; stacked they make a cin -> c2 + c3 3x3 layer that reads it once and, from 128
-        input channels up, runs in the deep-layer GEMM kernel (conv3x3_vgemm.hip) instead of two 64-cout launches.
+        Both read the same feature map; stacked they make a cin -> c2 + c3 3x3 layer that reads it once: from 128 input
+        channels up it runs in the deep-layer GEMM kernel (conv3x3_vgemm.hip), at 64 (the P2 level, the largest map of the
+        model) in the register-weight kernel (conv3x3_hreg.hip, cout 128 = two 64-cout groups that share the halo through L2).
         Same operands and fp32 accumulation per output; only the summation order over K differs from the two-launch path.
         """
         a, b = self.cv2[i][0], self.cv3[i][0]
@@ -108,7 +109,7 @@ class Detect(nn.Module):
             return None
         ca, cb = a.conv, b.conv
         if not (ca.kernel_size == cb.kernel_size == (3, 3) and ca.stride == cb.stride == (1, 1) and ca.groups == cb.groups == 1
-                and ca.in_channels == cb.in_channels and ca.in_channels >= 128 and (ca.out_channels + cb.out_channels) % 128 == 0
+                and ca.in_channels == cb.in_channels and ca.in_channels >= 64 and (ca.out_channels + cb.out_channels) % 128 == 0
                 and ca.out_channels % 8 == 0 and isinstance(a.act, nn.SiLU) and isinstance(b.act, nn.SiLU)):
             return None
         srcs = [ca.weight, a.bn.weight, a.bn.bias, a.bn.running_mean, a.bn.running_var, cb.weight, b.bn.weight, b.bn.bias, b.bn.running_mean, b.bn.running_var]
