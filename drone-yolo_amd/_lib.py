@@ -36,6 +36,18 @@ class ConvDesc(C.Structure):
     ]  # fmt: skip
 
 
+class BranchDesc(C.Structure):
+    """Mirror of ``dy_branch_desc``."""
+
+    _fields_ = [
+        ("x", _vp), ("w3", _vp), ("b3", _vp), ("w1", _vp), ("b1", _vp), ("out", _vp),
+        ("batch", _i32), ("h", _i32), ("w", _i32), ("ld_x", _i32), ("c_in", _i32), ("c_mid", _i32), ("nc", _i32), ("reg_max", _i32),
+        ("kind", _i32), ("dtype", _i32), ("anchors", _i32), ("anchor0", _i32),
+        ("stride", _f32),
+        ("nms_workspace", _vp), ("nms_workspace_bytes", _i64), ("conf_thres", _f32), ("classes_mask", _vp),
+    ]  # fmt: skip
+
+
 class DecodeDesc(C.Structure):
     """Mirror of ``dy_decode_desc``."""
 
@@ -156,6 +168,9 @@ SIGNATURES = {
     "dy_detection_loss_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "dy_conv2d_wgrad_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _i32, _vp, _vp]),
     "dy_quantize_fp8_nhwc": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "dy_detect_branch_fused_supported": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
+    "dy_detect_branch_fused": (_i32, [C.POINTER(BranchDesc), _vp]),
+    "dy_nms_reset_counts": (_i32, [_vp, _i32, _vp]),
     "dy_conv2d_grouped_bwd_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
     "dy_colsum": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "dy_nchw_u8_to_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),

@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import DY_ACT_NONE, DY_ACT_SILU, BnDesc, C2fDesc, ConvDesc, DecodeDesc, HeadDecodeDesc, LossDesc, NmsDesc, Stem2Desc, check, lib
+from ._lib import DY_ACT_NONE, DY_ACT_SILU, BnDesc, BranchDesc, C2fDesc, ConvDesc, DecodeDesc, HeadDecodeDesc, LossDesc, NmsDesc, Stem2Desc, check, lib
 
 FP8 = torch.float8_e4m3fn  # OCP e4m3fn: gfx950's fp8 (MI300's fnuz is another encoding)
 _DTYPES = {torch.bfloat16: _lib.DY_BF16, torch.float16: _lib.DY_F16, torch.float32: _lib.DY_F32, FP8: _lib.DY_FP8}
@@ -553,6 +553,40 @@ def detect_decode(levels: Sequence[torch.Tensor], strides: Sequence[float], nc: 
         d.classes_mask = classes_mask.data_ptr() if classes_mask is not None else None
     _launch(lib().dy_detect_decode, (C.byref(d),), keep=(d, out, nms_bufs, classes_mask, *levels))
     return out
+
+
+def branch_fused_supported(c_in: int, c_mid: int, c_out: int, kind: int, nc: int, reg_max: int, dtype: torch.dtype) -> bool:
+    return dtype in (torch.bfloat16, torch.float16) and bool(lib().dy_detect_branch_fused_supported(c_in, c_mid, c_out, kind, nc, reg_max, dy_dtype(dtype)))
+
+
+def nms_reset_counts(bufs: "NmsBuffers") -> None:
+    """Zero the per-image candidate counts: once per pass, before the first class branch appends candidates."""
+    _launch(lib().dy_nms_reset_counts, (bufs.workspace.data_ptr(), bufs.batch), keep=(bufs,))
+
+
+def detect_branch_fused(x: torch.Tensor, pc3: "PackedConv", w1: torch.Tensor, b1: torch.Tensor, kind: int, nc: int, reg_max: int, stride: float, pred: torch.Tensor,
+                        anchor0: int, nms_bufs: Optional["NmsBuffers"] = None, conf_thres: float = 0.25, classes_mask: Optional[torch.Tensor] = None) -> None:
+    """One Detect branch (kind 1 = box, 2 = class) of one level from its second 3x3 conv to rows of ``pred`` through
+    ``dy_detect_branch_fused``.  x: the branch's first conv output (N, 64, H, W); pc3: the 3x3 Conv packed in
+    DY_WLAYOUT_HALO3X3; (w1, b1): ``pack_frag1x1`` of the plain 1x1 conv."""
+    require_device(x, "branch input")
+    if pc3.layout != _lib.DY_WLAYOUT_HALO3X3 or pc3.dtype != x.dtype or pc3.k != 3 or pc3.stride != 1:
+        raise ValueError("detect_branch_fused: the 3x3 conv must be packed in DY_WLAYOUT_HALO3X3 for x's dtype")
+    n, c, h, w = x.shape
+    d = BranchDesc()
+    d.x, d.ld_x = view_params(x)
+    d.w3, d.b3, d.w1, d.b1, d.out = pc3.w.data_ptr(), pc3.b.data_ptr(), w1.data_ptr(), b1.data_ptr(), pred.data_ptr()
+    d.batch, d.h, d.w, d.c_in, d.c_mid, d.nc, d.reg_max, d.kind, d.dtype = n, h, w, c, pc3.cout, nc, reg_max, kind, dy_dtype(x.dtype)
+    d.anchors, d.anchor0, d.stride = pred.shape[2], anchor0, float(stride)
+    if pred.dtype != torch.float32 or pred.shape[0] != n or pred.shape[1] != 4 + nc or not pred.is_contiguous():
+        raise ValueError("detect_branch_fused: pred must be a contiguous fp32 (N, 4 + nc, A) tensor")
+    if kind == 2 and nms_bufs is not None:
+        if (nms_bufs.batch, nms_bufs.anchors) != (n, pred.shape[2]):
+            raise ValueError("detect_branch_fused: nms_bufs were sized for another batch / anchor count")
+        d.nms_workspace, d.nms_workspace_bytes = nms_bufs.workspace.data_ptr(), nms_bufs.workspace.numel()
+        d.conf_thres = conf_thres
+        d.classes_mask = classes_mask.data_ptr() if classes_mask is not None else None
+    _launch(lib().dy_detect_branch_fused, (C.byref(d),), keep=(d, x, pc3, w1, b1, pred, nms_bufs, classes_mask))
 
 
 def pack_frag1x1(weight: torch.Tensor, bias: torch.Tensor, dtype: torch.dtype, device) -> Tuple[torch.Tensor, torch.Tensor]:

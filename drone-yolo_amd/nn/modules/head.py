@@ -139,8 +139,56 @@ class Detect(nn.Module):
             tc = m(tc)
         return tb, tc
 
+    fuse_branch = True  # second 3x3 conv + 1x1 + decode of every branch in one kernel where dy_detect_branch_fused is built
+
+    def _branches_fusable(self, dtype) -> bool:
+        """Every level's branches end Conv(c, 64, 3) -> Conv(64, 64, 3) -> Conv2d(64, 4*reg_max | nc <= 16, 1) in 16-bit storage."""
+        if not self.fuse_branch or self.reg_max != 16:
+            return False
+        for i in range(self.nl):
+            for seq, kind in ((self.cv2[i], 1), (self.cv3[i], 2)):
+                mods = list(seq)
+                if len(mods) != 3 or not (isinstance(mods[0], Conv) and isinstance(mods[1], Conv)) or isinstance(mods[1], DWConv):
+                    return False
+                c1 = mods[1].conv
+                if not (c1.kernel_size == (3, 3) and c1.stride == (1, 1) and c1.groups == 1 and isinstance(mods[1].act, nn.SiLU)):
+                    return False
+                if not H.branch_fused_supported(c1.in_channels, c1.out_channels, mods[2].out_channels, kind, self.nc, self.reg_max, dtype):
+                    return False
+        return True
+
+    def _forward_branch_fused(self, x):
+        """Inference with each branch's second 3x3 conv, its 1x1 conv and its share of the decode (+ NMS candidate filter) in ONE
+        kernel per (level, branch): the trunk outputs never reach HBM (dy_detect_branch_fused, csrc/conv3x3_hhead.hip)."""
+        n = x[0].shape[0]
+        A = sum(t.shape[2] * t.shape[3] for t in x)
+        dtype, dev = x[0].dtype, x[0].device
+        pred = torch.empty((n, 4 + self.nc, A), dtype=torch.float32, device=dev)
+        fused = getattr(self, "fused_nms", None)
+        bufs, conf, mask = None, 0.25, None
+        if fused is not None:
+            make_bufs, conf, mask = fused
+            bufs = make_bufs(n, A)
+            H.nms_reset_counts(bufs)
+        pb, pc = self._packed_tail(dtype, dev)
+        a0 = 0
+        for i in range(self.nl):
+            pf = self._packed_first(i, dtype, dev)
+            if pf is None:
+                tb, tc = self.cv2[i][0](x[i]), self.cv3[i][0](x[i])
+            else:
+                both = H.conv2d(x[i], pf[0])
+                tb, tc = both[:, : pf[1]], both[:, pf[1] :]
+            H.detect_branch_fused(tb, self.cv2[i][1]._packed_for(tb), pb[i][0], pb[i][1], 1, self.nc, self.reg_max, float(self.stride[i]), pred, a0)
+            H.detect_branch_fused(tc, self.cv3[i][1]._packed_for(tc), pc[i][0], pc[i][1], 2, self.nc, self.reg_max, float(self.stride[i]), pred, a0,
+                                  nms_bufs=bufs, conf_thres=conf, classes_mask=mask)
+            a0 += x[i].shape[2] * x[i].shape[3]
+        return pred
+
     def _forward_fused(self, x):
         """Inference with the branch tails, decode and NMS filter in one launch (dy_detect_head_decode)."""
+        if self._branches_fusable(x[0].dtype):
+            return self._forward_branch_fused(x)
         tr = [self._trunks(i, x[i]) for i in range(self.nl)]
         xb, xc = [t[0] for t in tr], [t[1] for t in tr]
         pb, pc = self._packed_tail(xb[0].dtype, xb[0].device)

@@ -137,6 +137,36 @@ int32_t dy_conv_k_pad(int32_t cin, int32_t ksize, int32_t dtype);
 int32_t dy_conv_cout_pad(int32_t cout);
 int32_t dy_conv2d_nhwc(const dy_conv_desc* d, dy_stream_t stream);
 
+/* ---- one Detect branch from its second 3x3 convolution to the decoded output ------------------------------
+ * Replaces in ONE kernel per (level, branch), 16-bit storage: Detect.forward's cv2[i][1] -> cv2[i][2] (kind 1, box) or cv3[i][1] ->
+ * cv3[i][2] (kind 2, class) of the legacy v8 head (nn/modules/head.py:43-57, 64-70), each Conv = SiLU(conv + folded BatchNorm
+ * bias) (conv.py:53-55), and that branch's share of Detect._inference (head.py:100-131): kind 1 = DFL (block.py:58-76) + dist2bbox on the
+ * anchor grid (tal.py:333-357) x stride -> rows 0..3 of pred; kind 2 = sigmoid -> rows 4.. of pred + the NMS candidate filter
+ * (ops.py:250,290-295: best class score > conf_thres, optional class mask) appended to the dy_nms workspace.
+ * x: NHWC (batch, h, w, c_in) pitch ld_x, the output of the branch's FIRST conv.  w3 / b3: the 3x3 c_in -> c_mid conv in
+ * DY_WLAYOUT_HALO3X3, bias fp32[64].  w1 / b1: the plain 1x1 conv in DY_WLAYOUT_FRAG1X1 (kind 1: c_mid -> 4*reg_max, bias fp32[64];
+ * kind 2: c_mid -> nc <= 16, bias fp32[16] zero padded).  out: pred (batch, 4 + nc, anchors) fp32; this level's anchors are
+ * [anchor0, anchor0 + h*w) in row-major (y, x) order.  kind 2 with nms_workspace: candidates are APPENDED — zero the counts once per
+ * pass with dy_nms_reset_counts before the first class branch; then dy_nms(prefiltered = 1).
+ * Built for c_in = c_mid = 64, reg_max 16, DY_BF16 / DY_F16 (dy_detect_branch_fused_supported tells). */
+typedef struct dy_branch_desc {
+  const void* x;
+  const void* w3;
+  const float* b3;
+  const void* w1;
+  const float* b1;
+  float* out;
+  int32_t batch, h, w, ld_x, c_in, c_mid, nc, reg_max, kind, dtype, anchors, anchor0;
+  float stride;
+  void* nms_workspace;
+  int64_t nms_workspace_bytes;
+  float conf_thres;
+  const uint8_t* classes_mask;
+} dy_branch_desc;
+int32_t dy_detect_branch_fused_supported(int32_t c_in, int32_t c_mid, int32_t c_out, int32_t kind, int32_t nc, int32_t reg_max, int32_t dtype);
+int32_t dy_detect_branch_fused(const dy_branch_desc* d, dy_stream_t stream);
+int32_t dy_nms_reset_counts(void* nms_workspace, int32_t batch, dy_stream_t stream);
+
 /* ---- fused C2f block (n = 1, hidden 32) -------------------------------------------------------------
  * Replaces in ONE kernel: C2f.forward (nn/modules/block.py:237-242) = cv1 (Conv 1x1 cin -> 2*hidden) -> chunk(2) ->
  * Bottleneck(hidden, hidden, shortcut, k = (3,3), e = 1.0) (block.py:337-350) -> cat -> cv2 (Conv 1x1 3*hidden -> cout), each

@@ -550,7 +550,7 @@ def test_detect_stacked_first_convs_match_separate(dtype, device):
             m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
     det = det.to(device)
     xs = [nhwc(quantize(torch.randn(2, c, s, s, generator=g), dtype), dtype, device) for c, s in ((64, 40), (128, 20), (256, 10))]
-    assert det._packed_first(0, dtype, device) is None and det._packed_first(1, dtype, device) is not None
+    assert det._packed_first(0, dtype, device) is not None and det._packed_first(1, dtype, device) is not None  # from 64 input channels up
     for i, x in enumerate(xs):
         det.fuse_first = True
         tb, tc = det._trunks(i, x)
@@ -559,6 +559,59 @@ def test_detect_stacked_first_convs_match_separate(dtype, device):
         torch.cuda.synchronize()
         check_close(back(tb), back(sb), dtype, f"stacked box trunk level {i}", extra=3.0)
         check_close(back(tc), back(sc), dtype, f"stacked class trunk level {i}", extra=3.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_detect_branch_fused_matches_tail_path(dtype, device):
+    """dy_detect_branch_fused (second 3x3 conv + 1x1 + decode share + candidate filter of one branch in one kernel) against the
+    layer-by-layer trunks + fused tail (dy_detect_head_decode) on the same 16-bit inputs: same operands and rounding points
+    (the 3x3 output is rounded to the storage type in both), different summation orders -> decoded boxes / scores agree to a few
+    roundings of the trunk activations, and the candidate lists hold the same anchors except where a score sits at conf.
+    Ragged maps (23x37: tiles overhang) and a class mask are part of the case."""
+    from drone_yolo_amd.nn.modules import Detect
+
+    g = torch.Generator().manual_seed(11)
+
+    class LegacyDetect(Detect):
+        legacy = True
+
+    det = LegacyDetect(nc=10, ch=(64, 128)).eval()
+    for prm in det.parameters():
+        prm.data = torch.randn(prm.shape, generator=g) * (0.05 if prm.dim() > 1 else 0.2) + (1.0 if prm.dim() == 1 else 0.0)
+    for m in det.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+    det = det.to(device)
+    det.stride = torch.tensor([4.0, 8.0])
+    xs = [nhwc(quantize(torch.randn(3, c, h, w, generator=g), dtype), dtype, device) for c, h, w in ((64, 23, 37), (128, 12, 19))]
+    A = 23 * 37 + 12 * 19
+    mask = torch.ones(10, dtype=torch.uint8)
+    mask[3] = 0
+    outs = []
+    for fuse_branch in (True, False):
+        det.fuse_branch, det.fuse_tail = fuse_branch, True
+        holder = {}
+
+        def make_bufs(nb, anchors):
+            holder["b"] = H.NmsBuffers(nb, anchors, 300, device)
+            return holder["b"]
+
+        det.fused_nms = (make_bufs, 0.5, mask.to(device))
+        assert det._branches_fusable(dtype)
+        y, _ = det(xs)
+        bufs = H.nms(y, 0.5, 0.7, max_det=300, nc=10, classes_mask=mask.to(device), bufs=holder["b"], prefiltered=True)
+        torch.cuda.synchronize()
+        outs.append((y.cpu(), bufs.count.cpu().clone(), bufs.index.cpu().clone(), bufs.out.cpu().clone()))
+    det.fused_nms = None
+    (y1, c1, i1, o1), (y0, c0, i0, o0) = outs
+    assert tuple(y1.shape) == (3, 14, A) and bool(torch.isfinite(y1).all())
+    tol = 0.06 if dtype == torch.bfloat16 else 0.01
+    assert float((y1[:, :4] - y0[:, :4]).abs().max()) <= tol * float(y0[:, :4].abs().max()), float((y1[:, :4] - y0[:, :4]).abs().max())
+    assert float((y1[:, 4:] - y0[:, 4:]).abs().max()) <= tol
+    for b in range(3):  # kept detections: same anchors except score-at-threshold / near-tie cases
+        s1, s0 = set(i1[b, : int(c1[b])].tolist()), set(i0[b, : int(c0[b])].tolist())
+        assert len(s1 ^ s0) <= max(2, int(0.05 * len(s0))), (b, len(s1), len(s0), len(s1 ^ s0))
 
 
 @pytest.mark.parametrize("case", [(64, 64, 3, 1, 2, 24, 20, True), (160, 80, 1, 1, 2, 17, 19, True), (80, 160, 3, 2, 2, 24, 28, True), (640, 320, 1, 1, 1, 12, 12, False),
