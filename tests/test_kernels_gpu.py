@@ -598,7 +598,7 @@ def test_detect_branch_fused_matches_tail_path(dtype, device):
             return holder["b"]
 
         det.fused_nms = (make_bufs, 0.5, mask.to(device))
-        assert det._branches_fusable(dtype)
+        assert det._branches_fusable(dtype) == fuse_branch
         y, _ = det(xs)
         bufs = H.nms(y, 0.5, 0.7, max_det=300, nc=10, classes_mask=mask.to(device), bufs=holder["b"], prefiltered=True)
         torch.cuda.synchronize()
