@@ -116,6 +116,14 @@ def conv_work(plan):
                         d.batch * A * ((d.c_box + d.c_cls) * es + (4 + d.nc) * 4) + d.n_levels * (co_b * d.c_box + d.nc * d.c_cls) * es,
                         f"{d.c_box}->{co_b} + {d.c_cls}->{d.nc} k1, {d.n_levels} levels, + decode (fused tail)"))
             continue
+        if fn.__name__ == "dy_detect_branch_fused":  # second 3x3 conv + 1x1 + decode share of one Detect branch, one launch
+            d = args[0]._obj
+            es = 2
+            px = d.batch * d.h * d.w
+            co1 = 4 * d.reg_max if d.kind == 1 else d.nc
+            out.append((i, 2.0 * px * (9 * d.c_in * d.c_mid + d.c_mid * co1), px * (d.c_in * es + (4 if d.kind == 1 else d.nc) * 4) + (9 * d.c_in * d.c_mid + d.c_mid * co1) * es,
+                        f"Detect {'box' if d.kind == 1 else 'cls'} branch {d.c_in}->{d.c_mid} k3 + 1x1 -> {co1} + decode {d.h}x{d.w} (fused)"))
+            continue
         if fn.__name__ != "dy_conv2d_nhwc":
             continue
         d = args[0]._obj

@@ -53,6 +53,33 @@ constexpr int kHhTH = 8, kHhTW = 16, kHhHH = 10, kHhHW = 24;
 constexpr int kHhStage = 16 * 1024, kHhStages = 2;
 constexpr int kHhMid = 2 * kHhTH * kHhTW * 64;  // 16 KB: the tile's 3x3 output, [chunk][row][pixel] x 64 B
 
+// Exchange between the four 16-lane quarters of a wave without touching LDS (v_permlane16_swap / v_permlane32_swap, gfx950):
+// quarter_pair(v): every lane gets (its own quarter pair's two values) -> combine with op: rows {0,1} and {2,3}; half_pair: {0,1} with {2,3}.
+__device__ __forceinline__ void quarter_views(float v, float& a, float& b) {  // a = rows (0,0,2,2), b = rows (1,1,3,3) of v
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void half_views(float v, float& a, float& b) {  // a = rows (0,1,0,1), b = rows (2,3,2,3) of v
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float wave_quarters_max(float v) {
+  float a, b;
+  quarter_views(v, a, b);
+  v = fmaxf(a, b);
+  half_views(v, a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float wave_quarters_sum(float v) {
+  float a, b;
+  quarter_views(v, a, b);
+  v = a + b;
+  half_views(v, a, b);
+  return a + b;
+}
+
 template <typename T, int KIND>
 __global__ __launch_bounds__(256, 3) void conv3x3_hhead_kernel(const HheadArgs p) {
   constexpr int EPC = Elem<T>::EPC;  // 8
@@ -128,8 +155,6 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hhead_kernel(const HheadArgs p
   for (int q = 0; q < 3; ++q) lane_base[q] = (lr + q) * 64 + ((lq ^ (((lr + q) >> 1) & 3)) * 16);
 
   f32x4 acc[kHhTH];
-#pragma unroll
-  for (int o = 0; o < kHhTH; ++o) acc[o] = bias3;
 
   auto compute = [&](int stg, int c) {
     const unsigned char* sa = smem + stg * kHhStage;
@@ -153,11 +178,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hhead_kernel(const HheadArgs p
   typedef __attribute__((ext_vector_type(4))) T t4;
   const int mid_w = (wave >> 1) * (kHhTH * kHhTW * 64) + lr * 64 + ((((wave & 1) * 2 + (lq >> 1)) ^ ((lr >> 1) & 3)) * 16) + (lq & 1) * 8;  // + o * 1024
   const int mid_r = lane_base[0];                                                                                                          // + c2 * 8192 + o * 1024
-  auto tail = [&](int tile) {
-    const int tx = tile % p.tilesX;
-    const int r_ = tile / p.tilesX;
-    const int ty = r_ % p.tilesY, n = r_ / p.tilesY;
-    // 1. SiLU, round to the storage type (where the layer-by-layer path rounds), into `mid`
+  // tail, part 1 (end of the tile's last item): SiLU, round to the storage type (where the layer-by-layer path rounds), into `mid`.
+  // The item's closing barrier publishes it.
+  auto tail_mid = [&]() {
 #pragma unroll
     for (int o = 0; o < kHhTH; ++o) {
       t4 ov;
@@ -165,38 +188,36 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hhead_kernel(const HheadArgs p
       for (int e = 0; e < 4; ++e) ov[e] = Elem<T>::from_f32(silu_f32(acc[o][e]));
       *reinterpret_cast<u32x2*>(mid + mid_w + o * (kHhTW * 64)) = __builtin_bit_cast(u32x2, ov);
     }
+  };
+  // tail, part 2, DEFERRED to the start of the next item (after that item's DMA has been issued, before its MFMAs): the global
+  // stores then have a whole item of matrix work behind them before the item's closing s_waitcnt vmcnt(0), instead of being waited
+  // for right after they were issued (first version: the fused kernels cost as much as conv + separate tail kernel)
+  auto tail_out = [&](int tile) {
+    const int tx = tile % p.tilesX;
+    const int r_ = tile / p.tilesX;
+    const int ty = r_ % p.tilesY, n = r_ / p.tilesY;
     u32x4 w1reg[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) w1reg[c] = w1g[c * (KIND == 1 ? 4 : 1) * 64];
     const f32x4 bias1 = *reinterpret_cast<const f32x4*>(b1g);
-    __syncthreads();  // (the accumulators are dead from here to the end of the tail: their registers hold the logits)
     if constexpr (KIND == 1) {
-      // 2. 1x1: side `wave`, bins lq*4 .. +3 of pixel (o, lr)
-      f32x4 lg[kHhTH];
+      // 1x1: side `wave`, bins lq*4 .. +3 of pixel (o, lr); then DFL = softmax expectation over the side's 16 bins
 #pragma unroll
       for (int o = 0; o < kHhTH; ++o) {
-        lg[o] = bias1;
+        f32x4 lg = bias1;
 #pragma unroll
         for (int c2 = 0; c2 < NCH; ++c2)
-          lg[o] = Elem<T>::mma(w1reg[c2], *reinterpret_cast<const u32x4*>(mid + mid_r + c2 * (kHhTH * kHhTW * 64) + o * (kHhTW * 64)), lg[o]);
-      }
-      // 3. DFL: softmax expectation over the side's 16 bins = 4 per lane x the four lane quarters
-#pragma unroll
-      for (int o = 0; o < kHhTH; ++o) {
-        float m = fmaxf(fmaxf(lg[o][0], lg[o][1]), fmaxf(lg[o][2], lg[o][3]));
-        m = fmaxf(m, __shfl_xor(m, 16));
-        m = fmaxf(m, __shfl_xor(m, 32));
+          lg = Elem<T>::mma(w1reg[c2], *reinterpret_cast<const u32x4*>(mid + mid_r + c2 * (kHhTH * kHhTW * 64) + o * (kHhTW * 64)), lg);
+        const float m = wave_quarters_max(fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3])));
         float den = 0.f, num = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float ex = __builtin_amdgcn_exp2f((lg[o][e] - m) * 1.4426950408889634f);
+          const float ex = __builtin_amdgcn_exp2f((lg[e] - m) * 1.4426950408889634f);
           den += ex;
           num += ex * (float)(lq * 4 + e);
         }
-        den += __shfl_xor(den, 16);
-        num += __shfl_xor(num, 16);
-        den += __shfl_xor(den, 32);
-        num += __shfl_xor(num, 32);
+        den = wave_quarters_sum(den);
+        num = wave_quarters_sum(num);
         if (lq == 0) dsm[wave * (kHhTH * kHhTW) + o * kHhTW + lr] = num * __builtin_amdgcn_rcpf(den);
       }
       __syncthreads();
@@ -213,20 +234,15 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hhead_kernel(const HheadArgs p
         op[(size_t)(axis + 2) * p.A] = (hi - lo) * p.stride;
       }
     } else {
-      // 2. 1x1 64 -> nc (one 16-cout fragment): the waves split the rows
-      f32x4 lg[2];
+      // 1x1 64 -> nc (one 16-cout fragment): the waves split the rows; sigmoid, scores out, first arg-max, candidate filter
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int o = wave * 2 + j;
-        lg[j] = bias1;
+        f32x4 lg = bias1;
 #pragma unroll
         for (int c2 = 0; c2 < NCH; ++c2)
-          lg[j] = Elem<T>::mma(w1reg[c2], *reinterpret_cast<const u32x4*>(mid + mid_r + c2 * (kHhTH * kHhTW * 64) + o * (kHhTW * 64)), lg[j]);
-      }
-      // 3. sigmoid, scores out, first arg-max over the classes, candidate filter
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int yy = ty * kHhTH + wave * 2 + j, xx = tx * kHhTW + lr;
+          lg = Elem<T>::mma(w1reg[c2], *reinterpret_cast<const u32x4*>(mid + mid_r + c2 * (kHhTH * kHhTW * 64) + o * (kHhTW * 64)), lg);
+        const int yy = ty * kHhTH + o, xx = tx * kHhTW + lr;
         const bool inside = yy < p.H && xx < p.W;
         const int a = p.a0 + yy * p.W + xx;
         float* op = p.out + (size_t)n * (size_t)(4 + p.nc) * p.A + (size_t)a;
@@ -235,7 +251,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hhead_kernel(const HheadArgs p
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int c = lq * 4 + e;
-          const float pr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(lg[j][e] * -1.4426950408889634f));
+          const float pr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(lg[e] * -1.4426950408889634f));
           if (c < p.nc) {
             if (inside) op[(size_t)(4 + c) * p.A] = pr;
             if (pr > best) best = pr, bj = c;  // ascending c: the first maximum stays
@@ -265,8 +281,6 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hhead_kernel(const HheadArgs p
         }
       }
     }
-#pragma unroll
-    for (int o = 0; o < kHhTH; ++o) acc[o] = bias3;
   };
 
   // ---- item pipeline: two stages, the next item's DMA in flight during this item's MFMAs, one barrier per item ----
@@ -274,20 +288,27 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hhead_kernel(const HheadArgs p
   issue_dma(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  int c_tile = sb;
+  int c_tile = sb, pending = -1;
   for (int it = 0; it < nItems; it += NCH) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       issue_dma((c & 1) ^ 1);  // the other stage was last read one item ago: every wave has passed that item's barrier
+      if (c == 0) {
+        if (pending >= 0) tail_out(pending);  // the previous tile's 1x1 + decode: `mid` was published by the barrier that ended it
+#pragma unroll
+        for (int o = 0; o < kHhTH; ++o) acc[o] = bias3;  // (only now: the accumulator registers are free during tail_out)
+      }
       compute(c & 1, c);
       if (c == NCH - 1) {
-        tail(c_tile);
+        tail_mid();
+        pending = c_tile;
         c_tile += G;
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();  // next item's halo complete and visible; `mid` / `dsm` free again for the next tile's tail
+      __syncthreads();  // next item's halo complete and visible; `mid` written (last chunk) / `dsm` free again
     }
   }
+  if (pending >= 0) tail_out(pending);
 }
 
 template <typename T>
