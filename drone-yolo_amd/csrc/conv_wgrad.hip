@@ -54,6 +54,23 @@ __device__ __forceinline__ void tr_read_frags(const void* base, u32x4 (&out)[4])
   out[3] = u32x4{r6[0], r6[1], r7[0], r7[1]};
 }
 
+// Two 16-channel fragments (channels 0..31 from `base`): the half-tile form of the above.
+template <int PITCH, int ROW2 = 16 * PITCH>
+__device__ __forceinline__ void tr_read_frags2(const void* base, u32x4 (&out)[2]) {
+  u32x2 r0, r1, r2, r3;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %4 offset:%5\n\t"
+      "ds_read_b64_tr_b16 %1, %4 offset:%6\n\t"
+      "ds_read_b64_tr_b16 %2, %4 offset:%7\n\t"
+      "ds_read_b64_tr_b16 %3, %4 offset:%8\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+      : "v"((unsigned)(uintptr_t)base), "n"(0), "n"(ROW2), "n"(32), "n"(32 + ROW2)
+      : "memory");
+  out[0] = u32x4{r0[0], r0[1], r1[0], r1[1]};
+  out[1] = u32x4{r2[0], r2[1], r3[0], r3[1]};
+}
+
 template <typename T, int WCO, int WCI>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   constexpr int E = Elem<T>::EPC;
@@ -214,18 +231,23 @@ struct Wgrad3Args {
   int tilesCo, tilesCi, stepsX, stepsY, nSteps, steps_per_block;
 };
 
-template <typename T, int S>
-__global__ __launch_bounds__(192) void conv_wgrad3x3_kernel(const Wgrad3Args p) {
+// CW = cout fragments (of 16) per wave: 4 -> three waves (one per kernel row) with 3 x 64 x 64 accumulators each = 192 registers of
+// accumulators, ONE workgroup per CU: < 1 wave per SIMD, 95-270 TFLOP/s (r01).  2 -> six waves (kernel row x cout half), 96
+// accumulator registers, two workgroups per CU = three waves per SIMD: the dz fragment reads halve, the x reads stay.
+template <typename T, int S, int CW>
+__global__ __launch_bounds__(192 * (4 / CW)) void conv_wgrad3x3_kernel(const Wgrad3Args p) {
+  constexpr int NT = 192 * (4 / CW);
   constexpr int E = Elem<T>::EPC;                // 8
   constexpr int PITCH = 64 * (int)sizeof(T) + 32;  // 160 B rows: 64 channels + pad (conflict-free transposed reads)
   constexpr int HH = S + 3, HW = 15 * S + 3;     // x halo of a 2 x 16 output step: 4 x 18 (S = 1), 5 x 33 (S = 2)
   constexpr int NPX = HH * HW;
   constexpr int DZ_BYTES = 32 * PITCH, X_BYTES = NPX * PITCH, STAGE = DZ_BYTES + X_BYTES;
   constexpr int NCHK = (32 + NPX) * 8;           // 16-byte chunks per step
-  constexpr int PER = (NCHK + 191) / 192;
+  constexpr int PER = (NCHK + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
-  const int tid = threadIdx.x, lane = tid & 63, r_ = tid >> 6;  // wave = kernel row
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r_ = wv % 3, chf = wv / 3;  // wave = (kernel row, cout part of CW fragments)
   const int lr = lane & 15, lq = lane >> 4;
   int t = blockIdx.y;
   const int tci = t % p.tilesCi, tco = t / p.tilesCi;
@@ -236,11 +258,11 @@ __global__ __launch_bounds__(192) void conv_wgrad3x3_kernel(const Wgrad3Args p) 
   const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ dg = reinterpret_cast<const T*>(p.dz);
 
-  f32x4 acc[3][4][4];
+  f32x4 acc[3][CW][4];
 #pragma unroll
   for (int q = 0; q < 3; ++q)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < CW; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -252,7 +274,7 @@ __global__ __launch_bounds__(192) void conv_wgrad3x3_kernel(const Wgrad3Args p) 
     const int y0 = by * 2, x0 = bx * 16;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      const int id = k * 192 + tid;
+      const int id = k * NT + tid;
       u32x4 v = zero_chunk();
       if (id < 32 * 8) {  // dz: pixel (row id/128, col (id/8)%16), chunk id%8
         const int px = id >> 3, ch = id & 7;
@@ -273,7 +295,7 @@ __global__ __launch_bounds__(192) void conv_wgrad3x3_kernel(const Wgrad3Args p) 
     unsigned char* base = smem + buf * STAGE;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      const int id = k * 192 + tid;
+      const int id = k * NT + tid;
       if (id < NCHK) {
         const int px = id >> 3, ch = id & 7;  // dz rows first, the halo rows follow in the same pitch
         *reinterpret_cast<u32x4*>(base + px * PITCH + ch * 16) = stage[k];
@@ -295,15 +317,16 @@ __global__ __launch_bounds__(192) void conv_wgrad3x3_kernel(const Wgrad3Args p) 
     if (st + 1 < s_end) load_step(st + 1);  // in flight during the MFMAs
     const unsigned char* tdz = smem + buf * STAGE;
     const unsigned char* tx = tdz + DZ_BYTES;
-    u32x4 a[4];
-    tr_read_frags<PITCH, 16 * PITCH>(tdz + dz_lane, a);
+    u32x4 a[CW];
+    if constexpr (CW == 4) tr_read_frags<PITCH, 16 * PITCH>(tdz + dz_lane, a);
+    else tr_read_frags2<PITCH, 16 * PITCH>(tdz + dz_lane + chf * 64, a);  // channels [32*chf, 32*chf + 32) of the dz rows
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       u32x4 b[4];
       // tap (r_, q): halo pixel of output (row, col) is ((row*S + r_) * HW + col*S + q); the second output row is S halo rows below
       tr_read_frags<PITCH, S * HW * PITCH>(tx + x_lane + (r_ * HW + q) * PITCH, b);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < CW; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[q][i][j] = Elem<T>::mma(a[i], b[j], acc[q][i][j]);
     }
@@ -313,13 +336,13 @@ __global__ __launch_bounds__(192) void conv_wgrad3x3_kernel(const Wgrad3Args p) 
   for (int q = 0; q < 3; ++q) {
     const int tap = r_ * 3 + q;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < CW; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int ci = ci0 + j * 16 + lr;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int co = co0 + i * 16 + lq * 4 + e;
+          const int co = co0 + (chf * CW + i) * 16 + lq * 4 + e;
           if (co < p.Cout && ci < p.Cin) atomicAdd(p.dw + ((size_t)co * 9 + tap) * p.Cin + ci, acc[q][i][j][e]);
         }
       }
@@ -334,13 +357,15 @@ static int launch_wgrad3(const WgradArgs& a, int batch, hipStream_t st) {
   p.stepsX = (p.Wo + 15) / 16, p.stepsY = (p.Ho + 1) / 2;
   p.nSteps = batch * p.stepsY * p.stepsX;
   const int ny = p.tilesCo * p.tilesCi;
-  int slabs = (768 + ny - 1) / ny;  // ~3 workgroups of 3 waves per CU overall
+  int slabs = (512 + ny - 1) / ny;  // two six-wave workgroups per CU overall
   const int max_slabs = (p.nSteps + 7) / 8;
   if (slabs > max_slabs) slabs = max_slabs;
   if (slabs < 1) slabs = 1;
   p.steps_per_block = (p.nSteps + slabs - 1) / slabs;
   const unsigned gx = (unsigned)((p.nSteps + p.steps_per_block - 1) / p.steps_per_block);
-  hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, S>), dim3(gx, (unsigned)ny), dim3(192), 0, st, p);
+  static const int cw4 = dy_ablate("DYOLO_WGRAD3_CW4");
+  if (cw4) hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, S, 4>), dim3(gx, (unsigned)ny), dim3(192), 0, st, p);
+  else hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, S, 2>), dim3(gx, (unsigned)ny), dim3(384), 0, st, p);
   return check_launch("conv_wgrad3x3_kernel");
 }
 
