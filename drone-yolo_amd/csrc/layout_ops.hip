@@ -161,6 +161,63 @@ __global__ __launch_bounds__(256) void quantize_fp8_kernel(const T* __restrict__
   }
 }
 
+
+// ---- weight packing on the device (training: the fp32 master weights are re-packed every step) ------------------------------
+// One thread per DESTINATION element of the packed buffer: it works out which logical weight W[co][ci][r][q] the element holds in
+// the requested layout (include/dyolo.h: DY_WLAYOUT_ROWS / HALO3X3 / FRAG1X1; zero in the padding) and fetches it from the master
+// tensor through its strides.  `tf` = transpose + flip: W[co][ci][r][q] = w[ci][co][k-1-r][k-1-q], the weights of the convolution
+// that computes the input gradient.  Replaces the pad / permute / flip / cast chain of torch kernels (4-6 launches per
+// convolution and step) by one launch.
+struct PackArgs {
+  const float* w;
+  long long s_co, s_ci, s_r, s_q;  // element strides of the SOURCE tensor's (cout, cin, r, q) axes
+  int lco, lci_valid, lci, k, tf;  // logical (cout, cin) of the packed convolution: lci_valid channels exist, the layout is lci wide
+  int layout, e, a, b, nf;         // ROWS: a = k_pad, b = cout_pad; HALO3X3 / FRAG1X1: a = chunks per (co-tile), nf = BN / 16
+  long long total;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs p, T* __restrict__ dst) {
+  const int lco = p.lco, lci = p.lci;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+    int co, ci, r, q;
+    if (p.layout == DY_WLAYOUT_ROWS) {
+      co = (int)(i / p.a);
+      const int kk = (int)(i - (long long)co * p.a);
+      const int tap = kk / lci;
+      ci = kk - tap * lci;
+      r = tap / p.k, q = tap - r * p.k;
+      if (tap >= p.k * p.k) co = 1 << 30;  // row padding
+    } else {  // fragment orders: (((nt * nch + c) * taps + tap) * NF + j) * 64 + lq * 16 + lr) * E + e
+      const int taps = p.layout == DY_WLAYOUT_HALO3X3 ? 9 : 1;
+      long long t = i;
+      const int e = (int)(t % p.e);
+      t /= p.e;
+      const int lr = (int)(t % 16);
+      t /= 16;
+      const int lq = (int)(t % 4);
+      t /= 4;
+      const int j = (int)(t % p.nf);
+      t /= p.nf;
+      const int tap = (int)(t % taps);
+      t /= taps;
+      const int c = (int)(t % p.a);
+      const int nt = (int)(t / p.a);
+      co = (nt * p.nf + j) * 16 + lr;
+      ci = c * 4 * p.e + lq * p.e + e;
+      r = tap / 3, q = tap - r * 3;
+      if (taps == 1) r = q = 0;
+    }
+    float v = 0.f;
+    if (co < lco && ci < p.lci_valid) {
+      const int sr = p.tf ? p.k - 1 - r : r, sq = p.tf ? p.k - 1 - q : q;
+      const int sco = p.tf ? ci : co, sci = p.tf ? co : ci;
+      v = p.w[sco * p.s_co + sci * p.s_ci + sr * p.s_r + sq * p.s_q];
+    }
+    dst[i] = Elem<T>::from_f32(v);
+  }
+}
+
 static inline int grid_for(long long items) {
   long long b = (items + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 2048 * 4 ? 2048 * 4 : b));
@@ -305,4 +362,45 @@ extern "C" int32_t dy_quantize_fp8_nhwc(const void* src, void* dst, int64_t rows
   else
     hipLaunchKernelGGL((quantize_fp8_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)src, (fp8_t*)dst, (long long)rows, c / 16, ld_src, ld_dst, inv);
   return check_launch("quantize_fp8_kernel");
+}
+
+extern "C" int32_t dy_pack_conv_weights(const float* w, int64_t s_co, int64_t s_ci, int64_t s_r, int64_t s_q, int32_t cout, int32_t cin, int32_t ksize,
+                                        int32_t transpose_flip, int32_t cin_logical, void* dst, int64_t dst_elems, int32_t dtype, int32_t w_layout, dy_stream_t stream) {
+  const int es = dtype_size_no_fp8(dtype);
+  DY_REQUIRE(w && dst && es && cout > 0 && cin > 0 && ksize >= 1 && dst_elems > 0 && aligned16(dst), DY_ERR_INVALID_ARG, "dy_pack_conv_weights: bad arguments");
+  const int e = 16 / es;
+  const int lco = transpose_flip ? cin : cout;
+  int lci = transpose_flip ? cout : cin;
+  if (cin_logical > 0) {  // the input view carries zero-padded channels (the 3-channel image padded to one chunk)
+    DY_REQUIRE(!transpose_flip && cin_logical >= cin, DY_ERR_INVALID_ARG, "dy_pack_conv_weights: cin_logical");
+    lci = cin_logical;
+  }
+  PackArgs p{};
+  p.w = w, p.s_co = s_co, p.s_ci = s_ci, p.s_r = s_r, p.s_q = s_q, p.k = ksize, p.tf = transpose_flip ? 1 : 0, p.layout = w_layout, p.e = e;
+  p.lco = lco, p.lci_valid = transpose_flip ? cout : cin, p.lci = lci;
+  long long need = 0;
+  if (w_layout == DY_WLAYOUT_ROWS) {
+    p.a = dy_conv_k_pad(lci, ksize, dtype), p.b = dy_conv_cout_pad(lco);
+    need = (long long)p.b * p.a;
+  } else if (w_layout == DY_WLAYOUT_HALO3X3) {
+    DY_REQUIRE(ksize == 3, DY_ERR_INVALID_ARG, "dy_pack_conv_weights: DY_WLAYOUT_HALO3X3 is for 3x3 kernels");
+    const int bn = lco > 32 ? 64 : 32, kc = 4 * e;
+    p.nf = bn / 16, p.a = (lci + kc - 1) / kc;
+    need = (long long)((lco + bn - 1) / bn) * p.a * 9 * p.nf * 64 * e;
+  } else if (w_layout == DY_WLAYOUT_FRAG1X1) {
+    DY_REQUIRE(ksize == 1, DY_ERR_INVALID_ARG, "dy_pack_conv_weights: DY_WLAYOUT_FRAG1X1 is for 1x1 kernels");
+    const int bn = lco > 64 ? 128 : (lco > 16 ? 64 : 16), kc = 4 * e;
+    p.nf = bn / 16, p.a = (lci + kc - 1) / kc;
+    need = (long long)((lco + bn - 1) / bn) * p.a * p.nf * 64 * e;
+  } else {
+    DY_REQUIRE(false, DY_ERR_INVALID_ARG, "dy_pack_conv_weights: unknown w_layout %d", w_layout);
+  }
+  DY_REQUIRE(dst_elems == need, DY_ERR_INVALID_ARG, "dy_pack_conv_weights: dst holds %lld elements, the layout needs %lld", (long long)dst_elems, need);
+  p.total = need;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int grid = grid_for(need);
+  if (dtype == DY_BF16) hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, p, (bf16_t*)dst);
+  else if (dtype == DY_F16) hipLaunchKernelGGL((pack_weights_kernel<f16_t>), dim3(grid), dim3(256), 0, st, p, (f16_t*)dst);
+  else hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(grid), dim3(256), 0, st, p, (float*)dst);
+  return check_launch("pack_weights_kernel");
 }

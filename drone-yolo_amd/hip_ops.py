@@ -203,11 +203,41 @@ class PackedConv:
 
     def __init__(self, weight: torch.Tensor, bias: torch.Tensor, stride: int, pad: int, groups: int, act: bool,
                  dtype: torch.dtype, device, cin_pad: Optional[int] = None, halo: Optional[bool] = None,
-                 for_out_f32: bool = False):
+                 for_out_f32: bool = False, transpose_flip: bool = False):
         """``halo`` = False forces the generic row layout (both special layouts off); ``for_out_f32``: the conv
-        will be called with out_f32=True (Detect heads), which narrows the shapes the streaming kernel is built for."""
+        will be called with out_f32=True (Detect heads), which narrows the shapes the streaming kernel is built for.
+        ``transpose_flip``: pack W'[ci][co][r][q] = weight[co][ci][k-1-r][k-1-q] (the input-gradient convolution) — device packing only.
+        fp32 weights that already live on the device (training: the master weights, every step) are packed by ONE
+        ``dy_pack_conv_weights`` launch instead of the pad / permute / flip / cast chain below."""
         L = lib()
-        if cin_pad is not None and cin_pad > weight.shape[1]:
+        dev_pack = weight.is_cuda and weight.dtype == torch.float32 and dtype != FP8 and groups == 1 and weight.device == torch.device(device)
+        if transpose_flip and not dev_pack:
+            raise ValueError("PackedConv(transpose_flip=True) needs fp32 weights on the target device")
+        self._src = weight if dev_pack else None
+        cin_logical = 0
+        if dev_pack:
+            src = weight.detach()
+            if cin_pad is not None and cin_pad > weight.shape[1]:
+                cin_logical = cin_pad
+            lshape = (src.shape[1], src.shape[0], src.shape[2], src.shape[3]) if transpose_flip else tuple(src.shape)
+            if cin_logical:
+                lshape = (lshape[0], cin_logical, lshape[2], lshape[3])
+            weight = torch.empty(lshape, device="meta")  # shape carrier for the layout decision below; data moves in _device_pack
+
+            def _device_pack(layout: int, n_elems: int) -> torch.Tensor:
+                out = torch.empty(n_elems, dtype=dtype, device=src.device)
+                st = src.stride()
+                _launch(L.dy_pack_conv_weights, (src.data_ptr(), st[0], st[1], st[2], st[3], src.shape[0], src.shape[1], src.shape[2], int(transpose_flip), cin_logical,
+                                                 out.data_ptr(), n_elems, dy_dtype(dtype), layout), keep=(src, out))
+                return out
+
+            def _device_bias(n: int) -> torch.Tensor:
+                if bias.numel() == n and bias.is_cuda and bias.dtype == torch.float32:
+                    return bias.detach()
+                bp = torch.zeros((n,), dtype=torch.float32, device=src.device)
+                bp[: bias.numel()] = bias.detach().to(torch.float32)
+                return bp
+        elif cin_pad is not None and cin_pad > weight.shape[1]:
             # the input view carries zero-padded channels (the 3-channel image padded to one 16-byte chunk)
             if groups != 1:
                 raise ValueError("cin_pad is only meaningful for dense convolutions")
@@ -252,8 +282,11 @@ class PackedConv:
             e = elems_per_chunk(dtype)
             kc, bn = 4 * e, (64 if cout > 32 else 32)
             nt, nch = -(-cout // bn), -(-self.cin // kc)
-            wpad = _pad_to(weight.detach().to(torch.float32), (nt * bn, nch * kc, 3, 3))
             self.k_pad, self.cout_pad = 0, L.dy_conv_cout_pad(cout)
+            if dev_pack:
+                self.w, self.b = _device_pack(self.layout, nt * nch * 9 * (bn // 16) * 64 * e), _device_bias(self.cout_pad)
+                return
+            wpad = _pad_to(weight.detach().to(torch.float32), (nt * bn, nch * kc, 3, 3))
             self.w = _permute_cast(wpad.reshape(nt, bn // 16, 16, nch, 4, e, 3, 3).permute(0, 3, 6, 7, 1, 4, 2, 5), dtype, device)
             self.b = _pad_to(bias.detach().to(torch.float32).to(wdev), (self.cout_pad,)).to(device)
             return
@@ -272,6 +305,10 @@ class PackedConv:
             self.layout = _lib.DY_WLAYOUT_FRAG1X1
             kc, bn = 4 * e, (128 if cout > 64 else (64 if cout > 16 else 16))
             nt = -(-cout // bn)
+            if dev_pack:
+                self.k_pad, self.cout_pad = 0, max(L.dy_conv_cout_pad(cout), nt * bn)
+                self.w, self.b = _device_pack(self.layout, nt * nkg * (bn // 16) * 64 * e), _device_bias(self.cout_pad)
+                return
             wpad = torch.zeros((nt * bn, nkg * kc), dtype=torch.float32, device=wdev)
             wpad[:cout, : self.cin] = weight.detach().to(torch.float32).view(cout, self.cin)
             wp = wpad.view(nt, bn // 16, 16, nkg, 4, e).permute(0, 3, 1, 4, 2, 5).contiguous().view(-1)
@@ -284,6 +321,9 @@ class PackedConv:
         if groups == 1:
             self.k_pad = L.dy_conv_k_pad(self.cin, k, dy_dtype(dtype))
             self.cout_pad = L.dy_conv_cout_pad(cout)
+            if dev_pack:
+                self.w, self.b = _device_pack(self.layout, self.cout_pad * self.k_pad), _device_bias(self.cout_pad)
+                return
             if self.k_pad == k * k * cin_g and self.cout_pad == cout:  # nothing to pad: one permute + cast kernel
                 self.w = _permute_cast(weight.detach().permute(0, 2, 3, 1), dtype, device)
                 self.b = bias.detach().to(torch.float32).to(device)
@@ -862,13 +902,16 @@ def colsum(z: torch.Tensor) -> torch.Tensor:
 def pack_dgrad(weight: torch.Tensor, stride: int, dtype: torch.dtype, device) -> PackedConv:
     """Weights of the convolution that computes dx from dz: w'[ci][co][r][q] = w[co][ci][k-1-r][k-1-q], stride 1,
     pad k-1-pad (= pad for the 'same' convolutions of this model); stride-2 layers run on the generic / LDS-DMA kernels
-    (zero-dilated gather), stride-1 3x3 layers may take the halo kernel."""
+    (zero-dilated gather), stride-1 3x3 layers may take the halo kernel.  Device-resident fp32 weights (training) are
+    transposed, flipped, cast and laid out by one ``dy_pack_conv_weights`` launch."""
     k = weight.shape[2]
+    halo = None if (stride == 1 and k == 3) else False  # the streaming 1x1 kernel has no residual (accumulate) input
+    if weight.is_cuda and weight.dtype == torch.float32 and dtype != FP8 and weight.device == torch.device(device):
+        return PackedConv(weight, zero_bias(weight.shape[1], weight.device), 1, k // 2, 1, False, dtype, device, halo=halo, transpose_flip=True)
     wt = weight.detach().permute(1, 0, 2, 3)  # a view: the packing copy below does the layout change
     if k > 1:
         wt = wt.flip(2, 3)
-    return PackedConv(wt, zero_bias(wt.shape[0], wt.device), 1, k // 2, 1, False, dtype, device,
-                      halo=None if (stride == 1 and k == 3) else False)  # the streaming 1x1 kernel has no residual (accumulate) input
+    return PackedConv(wt, zero_bias(wt.shape[0], wt.device), 1, k // 2, 1, False, dtype, device, halo=halo)
 
 
 def conv_dgrad(dz: torch.Tensor, pc: PackedConv, stride: int, out: Optional[torch.Tensor] = None,

@@ -133,6 +133,15 @@ typedef struct dy_conv_desc {
  * Replaces nothing in the reference (it has no fp8 path); it is the hand-over from the image stem (run in fp16) to the fp8 layers. */
 int32_t dy_quantize_fp8_nhwc(const void* src, void* dst, int64_t rows, int32_t c, int32_t ld_src, int32_t ld_dst, int32_t src_dtype, float act_scale,
                              dy_stream_t stream);
+/* Pack the fp32 master weights of a convolution into a dy_conv_desc weight layout, on the device, in ONE launch (training re-packs
+ * every step; replaces the host-side pad / permute / flip / cast of hip_ops.PackedConv).  w: fp32, read through the element strides
+ * (s_co, s_ci, s_r, s_q) of its (cout, cin, r, q) axes — any memory layout.  transpose_flip = 1 packs the weights of the convolution
+ * that computes the INPUT gradient: W'[ci][co][r][q] = w[co][ci][k-1-r][k-1-q] (logical cout / cin swapped).  cin_logical > cin: the
+ * packed convolution sees cin_logical input channels, the extra ones zero (the 3-channel image padded to one chunk).  dst: `dtype`
+ * (not DY_FP8), exactly the element count of the layout (ROWS: dy_conv_cout_pad x dy_conv_k_pad; fragment layouts as documented
+ * at dy_conv_desc.w_layout), padding written as zeros. */
+int32_t dy_pack_conv_weights(const float* w, int64_t s_co, int64_t s_ci, int64_t s_r, int64_t s_q, int32_t cout, int32_t cin, int32_t ksize,
+                             int32_t transpose_flip, int32_t cin_logical, void* dst, int64_t dst_elems, int32_t dtype, int32_t w_layout, dy_stream_t stream);
 int32_t dy_conv_k_pad(int32_t cin, int32_t ksize, int32_t dtype);
 int32_t dy_conv_cout_pad(int32_t cout);
 int32_t dy_conv2d_nhwc(const dy_conv_desc* d, dy_stream_t stream);

@@ -681,3 +681,31 @@ def test_fp8_quantize_and_pool(device):
         assert torch.equal(y1.cpu().float(), m1) and torch.equal(y2.cpu().float(), m2) and torch.equal(y3.cpu().float(), m3)
     finally:
         H.set_fp8_act_scale(1.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32], ids=["bf16", "f16", "f32"])
+def test_device_weight_packing_equals_host_packing(dtype, device):
+    """dy_pack_conv_weights (one launch: layout + zero padding + cast, and transpose + flip for the input-gradient convolution)
+    writes exactly the bytes the host-side pad / permute / flip / cast chain of PackedConv produces, for every weight layout
+    (ROWS incl. padded rows / columns, HALO3X3, FRAG1X1), for a strided (permuted) source and for a zero-padded input channel."""
+    g = torch.Generator().manual_seed(2)
+    cases = [(64, 64, 3, 1, None), (48, 40, 3, 1, None), (128, 256, 3, 2, None), (96, 192, 1, 1, None), (20, 100, 1, 1, None), (256, 128, 3, 1, None), (32, 3, 3, 2, 8),
+             (16, 16, 3, 1, None)]
+    for cout, cin, k, s_, cin_pad in cases:
+        w = torch.randn(cout, cin, k, k, generator=g)
+        b = torch.randn(cout, generator=g)
+        host = H.PackedConv(w, b, s_, k // 2, 1, True, dtype, device, cin_pad=cin_pad)
+        dev = H.PackedConv(w.to(device), b.to(device), s_, k // 2, 1, True, dtype, device, cin_pad=cin_pad)
+        torch.cuda.synchronize()
+        assert (host.layout, host.k_pad, host.cout_pad, host.cin, host.cout) == (dev.layout, dev.k_pad, dev.cout_pad, dev.cin, dev.cout), (cout, cin, k)
+        assert host.w.numel() == dev.w.numel() and torch.equal(host.w.cpu().reshape(-1).view(torch.uint8), dev.w.cpu().reshape(-1).view(torch.uint8)), (cout, cin, k, host.layout)
+        assert torch.equal(host.b.cpu(), dev.b.cpu())
+        if cin_pad is None and cin >= 16:
+            # a permuted (OHWI-stored) source and the transposed / flipped pack of the input-gradient convolution
+            w_ohwi = w.permute(0, 2, 3, 1).contiguous().to(device).permute(0, 3, 1, 2)
+            dev2 = H.PackedConv(w_ohwi, b.to(device), s_, k // 2, 1, True, dtype, device)
+            hd = H.pack_dgrad(w, s_, dtype, device)
+            dd = H.pack_dgrad(w_ohwi, s_, dtype, device)
+            torch.cuda.synchronize()
+            assert torch.equal(dev2.w.cpu().reshape(-1).view(torch.uint8), host.w.cpu().reshape(-1).view(torch.uint8))
+            assert hd.layout == dd.layout and torch.equal(hd.w.cpu().reshape(-1).view(torch.uint8), dd.w.cpu().reshape(-1).view(torch.uint8)), (cout, cin, k, hd.layout)
