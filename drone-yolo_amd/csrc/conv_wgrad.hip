@@ -234,15 +234,18 @@ struct Wgrad3Args {
 // CW = cout fragments (of 16) per wave: 4 -> three waves (one per kernel row) with 3 x 64 x 64 accumulators each = 192 registers of
 // accumulators, ONE workgroup per CU: < 1 wave per SIMD, 95-270 TFLOP/s (r01).  2 -> six waves (kernel row x cout half), 96
 // accumulator registers, two workgroups per CU = three waves per SIMD: the dz fragment reads halve, the x reads stay.
-template <typename T, int S, int CW>
-__global__ __launch_bounds__(192 * (4 / CW)) void conv_wgrad3x3_kernel(const Wgrad3Args p) {
+// RS = output rows per step (2 or 4): a step of 4 rows does twice the MFMAs per staged halo row pair and per barrier, and the one
+// step of global-load prefetch then covers twice the time (the kernel is latency bound: one step of 32 pixels is ~0.2 us of MFMAs).
+template <typename T, int S, int CW, int RS>
+__global__ __launch_bounds__(192 * (4 / CW), (CW == 2 && S == 1 ? 3 : 1)) void conv_wgrad3x3_kernel(const Wgrad3Args p) {
   constexpr int NT = 192 * (4 / CW);
   constexpr int E = Elem<T>::EPC;                // 8
   constexpr int PITCH = 64 * (int)sizeof(T) + 32;  // 160 B rows: 64 channels + pad (conflict-free transposed reads)
-  constexpr int HH = S + 3, HW = 15 * S + 3;     // x halo of a 2 x 16 output step: 4 x 18 (S = 1), 5 x 33 (S = 2)
+  constexpr int HH = (RS - 1) * S + 3, HW = 15 * S + 3;  // x halo of an RS x 16 output step: 4 x 18 (S = 1, RS = 2), 5 x 33 (S = 2, RS = 2), 6 x 18 (S = 1, RS = 4)
   constexpr int NPX = HH * HW;
-  constexpr int DZ_BYTES = 32 * PITCH, X_BYTES = NPX * PITCH, STAGE = DZ_BYTES + X_BYTES;
-  constexpr int NCHK = (32 + NPX) * 8;           // 16-byte chunks per step
+  constexpr int NDZ = RS * 16;
+  constexpr int DZ_BYTES = NDZ * PITCH, X_BYTES = NPX * PITCH, STAGE = DZ_BYTES + X_BYTES;
+  constexpr int NCHK = (NDZ + NPX) * 8;          // 16-byte chunks per step
   constexpr int PER = (NCHK + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
@@ -271,17 +274,17 @@ __global__ __launch_bounds__(192 * (4 / CW)) void conv_wgrad3x3_kernel(const Wgr
     const int bx = step % p.stepsX;
     int rest = step / p.stepsX;
     const int by = rest % p.stepsY, n = rest / p.stepsY;
-    const int y0 = by * 2, x0 = bx * 16;
+    const int y0 = by * RS, x0 = bx * 16;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       const int id = k * NT + tid;
       u32x4 v = zero_chunk();
-      if (id < 32 * 8) {  // dz: pixel (row id/128, col (id/8)%16), chunk id%8
+      if (id < NDZ * 8) {  // dz: pixel (row id/128, col (id/8)%16), chunk id%8
         const int px = id >> 3, ch = id & 7;
         const int yy = y0 + (px >> 4), xx = x0 + (px & 15), co = co0 + ch * E;
         if (yy < p.Ho && xx < p.Wo && co < p.Cout) v = *reinterpret_cast<const u32x4*>(dg + ((long long)(n * p.Ho + yy) * p.Wo + xx) * p.lddz + co);
       } else if (id < NCHK) {
-        const int idx = id - 32 * 8;
+        const int idx = id - NDZ * 8;
         const int px = idx >> 3, ch = idx & 7;
         const int hy = px / HW, hx = px - hy * HW;
         const int gy = y0 * S - 1 + hy, gx = x0 * S - 1 + hx, ci = ci0 + ch * E;
@@ -317,18 +320,21 @@ __global__ __launch_bounds__(192 * (4 / CW)) void conv_wgrad3x3_kernel(const Wgr
     if (st + 1 < s_end) load_step(st + 1);  // in flight during the MFMAs
     const unsigned char* tdz = smem + buf * STAGE;
     const unsigned char* tx = tdz + DZ_BYTES;
-    u32x4 a[CW];
-    if constexpr (CW == 4) tr_read_frags<PITCH, 16 * PITCH>(tdz + dz_lane, a);
-    else tr_read_frags2<PITCH, 16 * PITCH>(tdz + dz_lane + chf * 64, a);  // channels [32*chf, 32*chf + 32) of the dz rows
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      u32x4 b[4];
-      // tap (r_, q): halo pixel of output (row, col) is ((row*S + r_) * HW + col*S + q); the second output row is S halo rows below
-      tr_read_frags<PITCH, S * HW * PITCH>(tx + x_lane + (r_ * HW + q) * PITCH, b);
+    for (int hh = 0; hh < RS / 2; ++hh) {  // one 32-pixel MFMA k-step per pair of output rows
+      u32x4 a[CW];
+      if constexpr (CW == 4) tr_read_frags<PITCH, 16 * PITCH>(tdz + dz_lane + hh * 32 * PITCH, a);
+      else tr_read_frags2<PITCH, 16 * PITCH>(tdz + dz_lane + hh * 32 * PITCH + chf * 64, a);  // channels [32*chf, 32*chf + 32) of the dz rows
 #pragma unroll
-      for (int i = 0; i < CW; ++i)
+      for (int q = 0; q < 3; ++q) {
+        u32x4 b[4];
+        // tap (r_, q): halo pixel of output (row, col) is ((row*S + r_) * HW + col*S + q); the second output row is S halo rows below
+        tr_read_frags<PITCH, S * HW * PITCH>(tx + x_lane + ((hh * 2 * S + r_) * HW + q) * PITCH, b);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[q][i][j] = Elem<T>::mma(a[i], b[j], acc[q][i][j]);
+        for (int i = 0; i < CW; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[q][i][j] = Elem<T>::mma(a[i], b[j], acc[q][i][j]);
+      }
     }
   }
 
@@ -349,12 +355,12 @@ __global__ __launch_bounds__(192 * (4 / CW)) void conv_wgrad3x3_kernel(const Wgr
   }
 }
 
-template <typename T, int S>
-static int launch_wgrad3(const WgradArgs& a, int batch, hipStream_t st) {
+template <typename T, int S, int RS>
+static int launch_wgrad3_rs(const WgradArgs& a, int batch, hipStream_t st) {
   Wgrad3Args p{};
   p.x = a.x, p.dz = a.dz, p.dw = a.dw, p.H = a.H, p.W = a.W, p.Cin = a.Cin, p.ldx = a.ldx, p.Ho = a.Ho, p.Wo = a.Wo, p.Cout = a.Cout, p.lddz = a.lddz;
   p.tilesCo = (p.Cout + 63) / 64, p.tilesCi = (p.Cin + 63) / 64;
-  p.stepsX = (p.Wo + 15) / 16, p.stepsY = (p.Ho + 1) / 2;
+  p.stepsX = (p.Wo + 15) / 16, p.stepsY = (p.Ho + RS - 1) / RS;
   p.nSteps = batch * p.stepsY * p.stepsX;
   const int ny = p.tilesCo * p.tilesCi;
   int slabs = (512 + ny - 1) / ny;  // two six-wave workgroups per CU overall
@@ -364,9 +370,20 @@ static int launch_wgrad3(const WgradArgs& a, int batch, hipStream_t st) {
   p.steps_per_block = (p.nSteps + slabs - 1) / slabs;
   const unsigned gx = (unsigned)((p.nSteps + p.steps_per_block - 1) / p.steps_per_block);
   static const int cw4 = dy_ablate("DYOLO_WGRAD3_CW4");
-  if (cw4) hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, S, 4>), dim3(gx, (unsigned)ny), dim3(192), 0, st, p);
-  else hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, S, 2>), dim3(gx, (unsigned)ny), dim3(384), 0, st, p);
+  if (cw4) hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, S, 4, RS>), dim3(gx, (unsigned)ny), dim3(192), 0, st, p);
+  else hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, S, 2, RS>), dim3(gx, (unsigned)ny), dim3(384), 0, st, p);
   return check_launch("conv_wgrad3x3_kernel");
+}
+
+template <typename T, int S>
+static int launch_wgrad3(const WgradArgs& a, int batch, hipStream_t st) {
+  // four output rows per step where the map is tall enough to fill them (stride 1: the 6 x 18 halo + 64 dz pixels are 27 KB a stage);
+  // stride 2 keeps two rows (its halo is 5 x 33 already)
+  static const int rs2 = dy_ablate("DYOLO_WGRAD3_RS2");
+  if constexpr (S == 1) {
+    if (!rs2 && a.Ho % 4 == 0) return launch_wgrad3_rs<T, 1, 4>(a, batch, st);
+  }
+  return launch_wgrad3_rs<T, S, 2>(a, batch, st);
 }
 
 template <typename T, int WCO, int WCI>
