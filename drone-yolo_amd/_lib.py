@@ -112,9 +112,9 @@ class C2fDesc(C.Structure):
     """Mirror of ``dy_c2f_desc``."""
 
     _fields_ = [
-        ("x", _vp), ("y", _vp), ("w_cv1", _vp), ("w_m_cv1", _vp), ("w_m_cv2", _vp), ("w_cv2", _vp), ("bias", _vp),
-        ("batch", _i32), ("h", _i32), ("w", _i32), ("cin", _i32), ("hidden", _i32), ("cout", _i32), ("ld_x", _i32), ("ld_y", _i32),
-        ("shortcut", _i32), ("dtype", _i32),
+        ("x", _vp), ("x_lo", _vp), ("y", _vp), ("w_cv1", _vp), ("w_m_cv1", _vp), ("w_m_cv2", _vp), ("w_cv2", _vp), ("bias", _vp),
+        ("batch", _i32), ("h", _i32), ("w", _i32), ("cin", _i32), ("cin_lo", _i32), ("hidden", _i32), ("cout", _i32),
+        ("ld_x", _i32), ("ld_x_lo", _i32), ("ld_y", _i32), ("shortcut", _i32), ("dtype", _i32),
     ]  # fmt: skip
 
 
@@ -149,7 +149,7 @@ SIGNATURES = {
     "dy_conv_k_pad": (_i32, [_i32, _i32, _i32]),
     "dy_conv_cout_pad": (_i32, [_i32]),
     "dy_conv2d_nhwc": (_i32, [C.POINTER(ConvDesc), _vp]),
-    "dy_c2f_fused_supported": (_i32, [_i32, _i32, _i32, _i32, _i32]),
+    "dy_c2f_fused_supported": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "dy_c2f_fused": (_i32, [C.POINTER(C2fDesc), _vp]),
     "dy_stem2_fused_supported": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "dy_stem2_fused": (_i32, [C.POINTER(Stem2Desc), _vp]),

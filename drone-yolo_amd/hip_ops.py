@@ -153,11 +153,12 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def _launch(fn, args: tuple, keep: Sequence[object] = ()) -> None:
+def _launch(fn, args: tuple, keep: Sequence[object] = (), record: bool = True) -> None:
+    """``record=False``: one-time preparation (weight packing) that must not be replayed with a plan recorded around it."""
     rc = fn(*args, _stream())
     if rc:
         check(rc, fn.__name__)
-    if _recording is not None:
+    if _recording is not None and record:
         _recording.ops.append((fn, args, False))
         _recording.keep.extend(keep)
 
@@ -228,7 +229,7 @@ class PackedConv:
                 out = torch.empty(n_elems, dtype=dtype, device=src.device)
                 st = src.stride()
                 _launch(L.dy_pack_conv_weights, (src.data_ptr(), st[0], st[1], st[2], st[3], src.shape[0], src.shape[1], src.shape[2], int(transpose_flip), cin_logical,
-                                                 out.data_ptr(), n_elems, dy_dtype(dtype), layout), keep=(src, out))
+                                                 out.data_ptr(), n_elems, dy_dtype(dtype), layout), record=False)
                 return out
 
             def _device_bias(n: int) -> torch.Tensor:
@@ -1007,22 +1008,32 @@ class PackedC2f:
         self.shortcut, self.dtype = bool(shortcut), dtype
 
 
-def c2f_fused_supported(cin: int, hidden: int, cout: int, n: int, dtype: torch.dtype) -> bool:
-    return dtype != FP8 and bool(lib().dy_c2f_fused_supported(cin, hidden, cout, n, dy_dtype(dtype)))
+def c2f_fused_supported(cin: int, hidden: int, cout: int, n: int, dtype: torch.dtype, cin_lo: int = 0) -> bool:
+    """``cin`` counts every input channel of cv1; ``cin_lo`` of them come through a fused 2x upsample (the folded Concat)."""
+    return dtype != FP8 and bool(lib().dy_c2f_fused_supported(cin, cin_lo, hidden, cout, n, dy_dtype(dtype)))
 
 
-def c2f_fused(x: torch.Tensor, pk: PackedC2f, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Whole C2f block in one ``dy_c2f_fused`` launch; x: NHWC view (N, cin, H, W) of pk.dtype."""
+def c2f_fused(x: torch.Tensor, pk: PackedC2f, out: Optional[torch.Tensor] = None, x_lo: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Whole C2f block in one ``dy_c2f_fused`` launch; x: NHWC view (N, c, H, W) of pk.dtype.  With ``x_lo`` (N, c_lo, H/2, W/2) the
+    block input is cat(upsample2x(x_lo), x) — the Upsample + Concat in front of the neck's C2f — and pk.cin = c_lo + c."""
     require_device(x, "c2f input")
     n, c, h, w = x.shape
-    if c != pk.cin or x.dtype != pk.dtype:
+    c_lo = 0
+    if x_lo is not None:
+        require_device(x_lo, "c2f upsampled input")
+        c_lo = x_lo.shape[1]
+        if x_lo.shape[0] != n or (2 * x_lo.shape[2], 2 * x_lo.shape[3]) != (h, w) or x_lo.dtype != x.dtype:
+            raise ValueError("c2f_fused: x_lo must be the half-resolution map of the same batch and dtype")
+    if c + c_lo != pk.cin or x.dtype != pk.dtype:
         raise ValueError("c2f_fused: input channels / dtype do not match the packed block")
     if out is None:
         out = alloc_nhwc(n, pk.cout, h, w, x.dtype, x.device)
     d = C2fDesc()
     (d.x, d.ld_x), (d.y, d.ld_y) = view_params(x), view_params(out)
+    if x_lo is not None:
+        d.x_lo, d.ld_x_lo = view_params(x_lo)
     d.w_cv1, d.w_m_cv1, d.w_m_cv2, d.w_cv2, d.bias = pk.w1.data_ptr(), pk.wa.data_ptr(), pk.wb.data_ptr(), pk.w2.data_ptr(), pk.bias.data_ptr()
-    d.batch, d.h, d.w, d.cin, d.hidden, d.cout = n, h, w, pk.cin, pk.hidden, pk.cout
+    d.batch, d.h, d.w, d.cin, d.cin_lo, d.hidden, d.cout = n, h, w, pk.cin, c_lo, pk.hidden, pk.cout
     d.shortcut, d.dtype = int(pk.shortcut), dy_dtype(x.dtype)
-    _launch(lib().dy_c2f_fused, (C.byref(d),), keep=(d, x, out, pk))
+    _launch(lib().dy_c2f_fused, (C.byref(d),), keep=(d, x, x_lo, out, pk))
     return out

@@ -57,7 +57,7 @@ class C2f(nn.Module):
         self.cv2 = Conv((2 + n) * self.c, c2, 1)
         self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, g, k=((3, 3), (3, 3)), e=1.0) for _ in range(n))
 
-    fuse_block = True  # one-kernel execution where dy_c2f_fused is built for the shape (the stride-4 backbone block)
+    fuse_block = True  # one-kernel execution where dy_c2f_fused is built for the shape (the stride-4 backbone and neck blocks)
 
     def _packed_block(self, dtype, device):
         convs = (self.cv1, self.m[0].cv1, self.m[0].cv2, self.cv2)
@@ -75,9 +75,13 @@ class C2f(nn.Module):
         ``kw`` (x2= / up2x=) is forwarded to cv1 so that a Concat(+Upsample) in front of this block
         can be folded into cv1's gather.
         """
-        if not kw and self.fuse_block and len(self.m) == 1 and H.c2f_fused_supported(
-                x.shape[1], self.c, self.cv2.conv.out_channels, 1, x.dtype) and not self.training:
-            return H.c2f_fused(x, self._packed_block(x.dtype, x.device), out=out)
+        if self.fuse_block and len(self.m) == 1 and not self.training:
+            cout = self.cv2.conv.out_channels
+            if not kw and H.c2f_fused_supported(x.shape[1], self.c, cout, 1, x.dtype):
+                return H.c2f_fused(x, self._packed_block(x.dtype, x.device), out=out)
+            x2 = kw.get("x2")
+            if kw.get("up2x") and x2 is not None and len(kw) == 2 and H.c2f_fused_supported(x.shape[1] + x2.shape[1], self.c, cout, 1, x.dtype, cin_lo=x.shape[1]):
+                return H.c2f_fused(x2, self._packed_block(x.dtype, x.device), out=out, x_lo=x)  # Upsample + Concat + C2f in one launch
         n, _, hb, wb = x.shape
         h, w = (2 * hb, 2 * wb) if kw.get("up2x") else (hb, wb)
         c = self.c

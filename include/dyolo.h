@@ -179,25 +179,29 @@ int32_t dy_nms_reset_counts(void* nms_workspace, int32_t batch, dy_stream_t stre
 /* ---- fused C2f block (n = 1, hidden 32) -------------------------------------------------------------
  * Replaces in ONE kernel: C2f.forward (nn/modules/block.py:237-242) = cv1 (Conv 1x1 cin -> 2*hidden) -> chunk(2) ->
  * Bottleneck(hidden, hidden, shortcut, k = (3,3), e = 1.0) (block.py:337-350) -> cat -> cv2 (Conv 1x1 3*hidden -> cout), each
- * Conv = SiLU(conv + folded BatchNorm bias) (conv.py:53-55), for the stride-4 C2f of the Drone-YOLO-s backbone
- * (yolov8-p2-repvgg.yaml layer 2).  Intermediates stay in LDS, rounded to `dtype` where the layer-by-layer path rounds.
- * x: NHWC (batch, h, w, cin) pitch ld_x; y: NHWC (batch, h, w, cout) pitch ld_y.  Weights (BatchNorm folded):
+ * Conv = SiLU(conv + folded BatchNorm bias) (conv.py:53-55), for the stride-4 C2f blocks of Drone-YOLO-s: the backbone's
+ * (yolov8-p2-repvgg.yaml layer 2) and, with cin_lo > 0, the neck's (layer 21) together with the nn.Upsample(2, 'nearest') and
+ * Concat (conv.py:323-335) in front of it: the block input is then [upsample2x(x_lo) (cin_lo channels) | x (cin - cin_lo)].
+ * Intermediates stay on chip, rounded to `dtype` where the layer-by-layer path rounds.
+ * x: NHWC (batch, h, w, cin - cin_lo) pitch ld_x; x_lo: NHWC (batch, h/2, w/2, cin_lo) pitch ld_x_lo, or NULL with cin_lo = 0;
+ * y: NHWC (batch, h, w, cout) pitch ld_y.  Weights (BatchNorm folded):
  *   w_cv1   DY_WLAYOUT_FRAG1X1 of (2*hidden, cin);      w_cv2   DY_WLAYOUT_FRAG1X1 of (cout, 3*hidden);
  *   w_m_cv1, w_m_cv2   DY_WLAYOUT_HALO3X3 of (hidden, hidden, 3, 3);
  *   bias    fp32: cv1 [2*hidden] | m.cv1 [hidden] | m.cv2 [hidden] | cv2 [cout].
- * Built for cin 64, hidden 32, cout 64, DY_BF16 / DY_F16 (dy_c2f_fused_supported tells); other shapes: run the four
- * dy_conv2d_nhwc calls. */
+ * Built for 64 direct channels (+ 128 upsampled), hidden 32, cout 64, DY_BF16 / DY_F16 (dy_c2f_fused_supported tells); other
+ * shapes: run the four dy_conv2d_nhwc calls. */
 typedef struct dy_c2f_desc {
   const void* x;
+  const void* x_lo;
   void* y;
   const void* w_cv1;
   const void* w_m_cv1;
   const void* w_m_cv2;
   const void* w_cv2;
   const float* bias;
-  int32_t batch, h, w, cin, hidden, cout, ld_x, ld_y, shortcut, dtype;
+  int32_t batch, h, w, cin, cin_lo, hidden, cout, ld_x, ld_x_lo, ld_y, shortcut, dtype;
 } dy_c2f_desc;
-int32_t dy_c2f_fused_supported(int32_t cin, int32_t hidden, int32_t cout, int32_t n_bottlenecks, int32_t dtype);
+int32_t dy_c2f_fused_supported(int32_t cin, int32_t cin_lo, int32_t hidden, int32_t cout, int32_t n_bottlenecks, int32_t dtype);
 int32_t dy_c2f_fused(const dy_c2f_desc* d, dy_stream_t stream);
 
 /* Fused stem.  Replaces in one pass: the predictor's dtype/layout step for tensor sources

@@ -84,8 +84,9 @@ def test_new_entry_points_validate_without_gpu():
     assert h.dy_sgd_step(null, null, null, 10, 0.1, 0.9, 0.0, 1, 1, null, 10.0, null) == -1
     assert h.dy_adamw_step(null, null, null, null, 10, 0.1, 0.9, 0.999, 1e-8, 0.0, 0, null, 10.0, null) == -1
     # shape support queries are pure host functions
-    assert h.dy_c2f_fused_supported(64, 32, 64, 1, L.DY_BF16) == 1 and h.dy_c2f_fused_supported(64, 32, 64, 2, L.DY_BF16) == 0
-    assert h.dy_c2f_fused_supported(64, 32, 64, 1, L.DY_F32) == 0 and h.dy_c2f_fused_supported(192, 32, 64, 1, L.DY_BF16) == 0
+    assert h.dy_c2f_fused_supported(64, 0, 32, 64, 1, L.DY_BF16) == 1 and h.dy_c2f_fused_supported(64, 0, 32, 64, 2, L.DY_BF16) == 0
+    assert h.dy_c2f_fused_supported(64, 0, 32, 64, 1, L.DY_F32) == 0 and h.dy_c2f_fused_supported(192, 0, 32, 64, 1, L.DY_BF16) == 0
+    assert h.dy_c2f_fused_supported(192, 128, 32, 64, 1, L.DY_F16) == 1 and h.dy_c2f_fused_supported(192, 64, 32, 64, 1, L.DY_F16) == 0
     assert h.dy_detect_head_decode_supported(64, 64, 10, 16, L.DY_BF16) == 1 and h.dy_detect_head_decode_supported(64, 80, 80, 16, L.DY_BF16) == 0
     assert h.dy_stem2_fused(ctypes.byref(L.Stem2Desc()), null) == -1
     assert h.dy_stem2_fused_supported(3, 32, 64, 640, 640, L.DY_BF16) == 1 and h.dy_stem2_fused_supported(3, 32, 64, 642, 640, L.DY_BF16) == 0

@@ -533,6 +533,52 @@ def test_c2f_fused_block_matches_layerwise(shape, shortcut, dtype, device):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("shape,shortcut", [((2, 40, 36), False), ((1, 34, 50), True), ((3, 16, 16), False), ((2, 160, 160), False)])
+def test_c2f_fused_block_with_upsample_concat(shape, shortcut, dtype, device):
+    """The neck's stride-4 block: nn.Upsample(2, 'nearest') + Concat + C2f(192, 64) in one dy_c2f_fused launch against the CPU
+    chain on cat(upsample(x_lo), x) with every intermediate rounded to the storage dtype, and against the layer-by-layer device
+    path (cv1 gathering both sources, two 3x3 launches, cv2)."""
+    from drone_yolo_amd.nn.modules import C2f
+    from drone_yolo_amd.nn.modules.conv import fold_conv_bn
+
+    n, h, w = shape
+    g = torch.Generator().manual_seed(h + w)
+    blk = C2f(192, 64, n=1, shortcut=shortcut).eval()
+    for prm in blk.parameters():
+        prm.data = torch.randn(prm.shape, generator=g) * (0.08 if prm.dim() > 1 else 0.3) + (1.0 if prm.dim() == 1 else 0.0)
+    for m in blk.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+            m.eps = 1e-3
+    q = lambda t: quantize(t, dtype)  # noqa: E731
+    x_lo, x_hi = q(torch.randn((n, 128, h // 2, w // 2), generator=g)), q(torch.randn((n, 64, h, w), generator=g))
+    x = torch.cat((F.interpolate(x_lo, scale_factor=2, mode="nearest"), x_hi), 1)
+
+    def cba(conv, t, k):
+        wt, b = fold_conv_bn(conv.conv.weight, None, conv.bn)
+        return q(F.silu(F.conv2d(t, q(wt), b, 1, k // 2)))
+
+    y = cba(blk.cv1, x, 1)
+    y0, y1 = y[:, :32], y[:, 32:]
+    t = cba(blk.m[0].cv1, y1, 3)
+    wt, b = fold_conv_bn(blk.m[0].cv2.conv.weight, None, blk.m[0].cv2.bn)
+    y2 = F.silu(F.conv2d(t, q(wt), b, 1, 1))
+    y2 = q(y2 + y1) if shortcut else q(y2)
+    ref = cba(blk.cv2, torch.cat((y0, y1, y2), 1), 1)
+    blk = blk.to(device)
+    lo_d, hi_d = nhwc(x_lo, dtype, device, ld=128 + 8, c_off=8), nhwc(x_hi, dtype, device, ld=64 + 16, c_off=8)
+    assert H.c2f_fused_supported(192, 32, 64, 1, dtype, cin_lo=128)
+    blk.fuse_block = True
+    got = blk(lo_d, x2=hi_d, up2x=True)
+    blk.fuse_block = False
+    layerwise = blk(lo_d, x2=hi_d, up2x=True)
+    torch.cuda.synchronize()
+    check_close(back(got), ref, dtype, "fused upsample + concat + C2f vs CPU chain", extra=3.0)
+    check_close(back(got), back(layerwise), dtype, "fused upsample + concat + C2f vs layer-by-layer device path", extra=3.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 def test_detect_stacked_first_convs_match_separate(dtype, device):
     """Detect._trunks: cv2[i][0] / cv3[i][0] stacked into one conv on the deep levels == the two separate branches."""
     from drone_yolo_amd.nn.modules import Detect
