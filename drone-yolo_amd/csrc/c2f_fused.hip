@@ -144,28 +144,36 @@ __global__ __launch_bounds__(512) void c2f_fused_kernel(const C2fArgs p) {
   // issued where it is needed costs its whole latency (with two waves per SIMD there is little to hide it): every batch of loads
   // is issued one stage early, and sched_barrier pins the place.  A batch = the pixel-operand chunks of up to 8 fragments for k
   // chunk c plus cv1's two weight fragments for it (from L2); chunks c and c + 1 are in flight while c computes.
-  auto halo_offsets = [&](int h, int n, int ty0, int tx0, bool valid, unsigned (&olo)[8], unsigned (&ohi)[8], bool (&ok)[8]) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int px = 16 * (h * 8 + i) + lrv;  // pass h covers halo pixels 128 h .. 128 h + 127 (240 in all)
-      const int hy = px / 20, hx = px - hy * 20;
-      const int gy = ty0 - 2 + hy, gx = tx0 - 2 + hx;
-      ok[i] = valid && (h * 8 + i) < 15 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-      pix_off(ok[i], n, gy, gx, &olo[i], &ohi[i]);
+  // Phase A runs in four passes of row-aligned fragments (16 consecutive pixels of one halo row each, slot = 20 hr + hc):
+  //   pass 0 / 1: the strip's own rows 0..3 / 4..7 (halo rows 2 + r, columns 2..17) - BOTH halves of cv1, so y0 and the
+  //               strip's y1 are born in registers in result-lane order and x is read once;
+  //   pass 2:     halo rows 0, 1, 10, 11, columns 2..17 (y1 only);   pass 3: columns 0, 1, 18, 19 of all 12 rows (48 px, y1 only).
+  auto pass_pixel = [&](int h, int i, int* hr, int* hc) {
+    if (h < 2) {
+      *hr = 2 + h * 4 + i, *hc = 2 + lrv;
+    } else if (h == 2) {
+      *hr = i < 2 ? i : 8 + i, *hc = 2 + lrv;
+    } else {
+      const int idx = i * 16 + lrv;  // 48 live
+      *hr = idx >> 2, *hc = (idx & 3) + ((idx & 2) ? 16 : 0);
     }
   };
-  auto issue_y1 = [&](int c, int nf, const unsigned (&olo)[8], const unsigned (&ohi)[8], u32x4 (&av)[8], u32x4 (&bv)[2]) {
+  auto pass_offsets = [&](int h, int n, int ty0, int tx0, bool valid, unsigned (&olo)[4], unsigned (&ohi)[4]) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) bv[j] = __builtin_amdgcn_raw_buffer_load_b128(w1rs, w1off + (unsigned)((c * 4 + 2 + j) * 1024), 0, 0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (i < nf) av[i] = load_x(c, olo[i], ohi[i]);
+    for (int i = 0; i < 4; ++i) {
+      int hr, hc;
+      pass_pixel(h, i, &hr, &hc);
+      const int gy = ty0 - 2 + hr, gx = tx0 - 2 + hc;
+      pix_off(valid && !(h == 3 && i == 3) && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W, n, gy, gx, &olo[i], &ohi[i]);
+    }
   };
-  auto issue_y0 = [&](int c, const unsigned (&olo)[4], const unsigned (&ohi)[4], u32x4 (&av)[4], u32x4 (&bv)[2]) {
+  // one batch: k chunk c of the pass's fragments + cv1's weight fragments for it (4 when the pass also makes y0, else the y1 two)
+  auto issue_pass = [&](int h, int c, const unsigned (&olo)[4], const unsigned (&ohi)[4], u32x4 (&av)[4], u32x4 (&bv)[4]) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) bv[j] = __builtin_amdgcn_raw_buffer_load_b128(w1rs, w1off + (unsigned)((c * 4 + j) * 1024), 0, 0);
+    for (int j = (h < 2 ? 0 : 2); j < 4; ++j) bv[j] = __builtin_amdgcn_raw_buffer_load_b128(w1rs, w1off + (unsigned)((c * 4 + j) * 1024), 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) av[i] = load_x(c, olo[i], ohi[i]);
+    for (int i = 0; i < 4; ++i)
+      if (!(h == 3 && i == 3)) av[i] = load_x(c, olo[i], ohi[i]);
   };
   // cv2's weight fragments of k chunk c in result-lane k order: lane (cout lr, quarter lq) takes k = {4 lq .., 16 + 4 lq ..}
   auto issue_w2 = [&](int c, u32x4 (&wq)[4]) {
@@ -187,16 +195,15 @@ __global__ __launch_bounds__(512) void c2f_fused_kernel(const C2fArgs p) {
   const int G = (int)gridDim.x;
   const int lb = (G & 7) ? (int)blockIdx.x : ((int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3));
   int strip = lb * 8 + wave;
-  u32x4 a[2][8], b[2][2];  // loop carried: chunks 0 and 1 of the NEXT phase-A pass, in flight
+  u32x4 a[2][4], b[2][4];  // loop carried: chunks 0 and 1 of the NEXT phase-A pass, in flight
   {
     int n, ty0, tx0;
     decode(strip, &n, &ty0, &tx0);
     C2F_PIN_WEIGHT_POINTERS();
-    unsigned olo[8], ohi[8];
-    bool ok[8];
-    halo_offsets(0, n, ty0, tx0, strip < p.nStrips, olo, ohi, ok);
-    issue_y1(0, 8, olo, ohi, a[0], b[0]);
-    issue_y1(1, 8, olo, ohi, a[1], b[1]);
+    unsigned olo[4], ohi[4];
+    pass_offsets(0, n, ty0, tx0, strip < p.nStrips, olo, ohi);
+    issue_pass(0, 0, olo, ohi, a[0], b[0]);
+    issue_pass(0, 1, olo, ohi, a[1], b[1]);
   }
   for (; strip < p.nStrips; strip += G * 8) {
     int n, ty0, tx0;
@@ -207,46 +214,53 @@ __global__ __launch_bounds__(512) void c2f_fused_kernel(const C2fArgs p) {
     unsigned long long stamp = __builtin_amdgcn_s_memtime();
 #endif
 
-    // ---- A: cv1 -> y1 on the 20 x 12 halo (240 px = 15 fragments, two passes of 8 + 7) ----
+    // ---- A: cv1 on the 20 x 12 halo -> y1 (LDS), and on the strip itself -> y0, y1 in result-lane order (registers: cv2's k
+    // chunks 0 and 1, and the shortcut) ----
+    u32x2 y0c[8][2], y1c[8][2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int nf = h ? 7 : 8;
-      f32x4 acc[8][2];
-      unsigned olo[8], ohi[8];
-      bool ok[8];
-      halo_offsets(h, n, ty0, tx0, true, olo, ohi, ok);
+    for (int h = 0; h < 4; ++h) {
+      C2F_PIN_LANE();
+      f32x4 acc[4][4];
+      unsigned olo[4], ohi[4];
+      if (KC > 2) pass_offsets(h, n, ty0, tx0, true, olo, ohi);  // chunks 2.. are issued from here
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = *reinterpret_cast<const f32x4*>(sbias + 32 + j * 16 + lq * 4);
+        for (int j = (h < 2 ? 0 : 2); j < 4; ++j) acc[i][j] = *reinterpret_cast<const f32x4*>(sbias + j * 16 + lq * 4);
 #pragma unroll
       for (int c = 0; c < KC; ++c) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-          if (i < nf) {
+        for (int i = 0; i < 4; ++i)
+          if (!(h == 3 && i == 3)) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = Elem<T>::mma(b[c & 1][j], a[c & 1][i], acc[i][j]);
+            for (int j = (h < 2 ? 0 : 2); j < 4; ++j) acc[i][j] = Elem<T>::mma(b[c & 1][j], a[c & 1][i], acc[i][j]);
           }
-        if (c + 2 < KC) issue_y1(c + 2, nf, olo, ohi, a[c & 1], b[c & 1]);
+        if (c + 2 < KC) issue_pass(h, c + 2, olo, ohi, a[c & 1], b[c & 1]);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (h == 0) {  // the second pass's first two chunks fly during the first pass's epilogue
-        unsigned plo[8], phi[8];
-        bool pk[8];
-        halo_offsets(1, n, ty0, tx0, true, plo, phi, pk);
-        issue_y1(0, 7, plo, phi, a[0], b[0]);
-        issue_y1(1, 7, plo, phi, a[1], b[1]);
+      if (h < 3) {  // the next pass's first two chunks fly during this pass's epilogue
+        unsigned plo[4], phi[4];
+        pass_offsets(h + 1, n, ty0, tx0, true, plo, phi);
+        issue_pass(h + 1, 0, plo, phi, a[0], b[0]);
+        issue_pass(h + 1, 1, plo, phi, a[1], b[1]);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (i < nf) {
-          const int px = 16 * (h * 8 + i) + lrv;
+      for (int i = 0; i < 4; ++i)
+        if (!(h == 3 && i == 3)) {
+          int hr, hc;
+          pass_pixel(h, i, &hr, &hc);
+          const bool inside = (unsigned)(ty0 - 2 + hr) < (unsigned)p.H && (unsigned)(tx0 - 2 + hc) < (unsigned)p.W;
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
+          for (int j = 2; j < 4; ++j) {
             u32x2 v = pack4(silu4(acc[i][j]));
-            if (!ok[i]) v = u32x2{0u, 0u};  // the 3x3 that follows pads y1 with zeros, not with SiLU(bias)
-            *reinterpret_cast<u32x2*>(slot_addr(px, j * 2 + (lqv >> 1)) + (lqv & 1) * 8) = v;
+            if (!inside) v = u32x2{0u, 0u};  // the 3x3 that follows pads y1 with zeros, not with SiLU(bias)
+            if (h < 2) y1c[h * 4 + i][j - 2] = v;
+            *reinterpret_cast<u32x2*>(slot_addr(hr * 20 + hc, (j - 2) * 2 + (lqv >> 1)) + (lqv & 1) * 8) = v;
+          }
+          if (h < 2) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) y0c[h * 4 + i][j] = pack4(silu4(acc[i][j]));
           }
         }
     }
@@ -254,17 +268,10 @@ __global__ __launch_bounds__(512) void c2f_fused_kernel(const C2fArgs p) {
     C2F_PIN_LANE();
     C2F_STAMP(0);
 
-    // the strip's own y1 in result-lane order (channels {4q.., 16+4q..} of pixel lr): cv2's k chunk 1 and the shortcut
-    u32x2 y1c[8][2];
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) y1c[r][j] = *reinterpret_cast<const u32x2*>(slot_addr((r + 2) * 20 + lrv + 2, j * 2 + (lqv >> 1)) + (lqv & 1) * 8);
-
     // ---- B: m.cv1 3x3 on the 18 x 10 ring -> t, ring row R stored over y1 row R.  Three passes of 4 fragments: ring rows 0..3,
     // rows 4..7 (columns 0..15 each), then rows 8..9 and the columns 16..17 of all ten rows (20 px, two fragments).  A pass
     // overwrites y1 rows / columns that no later pass reads: row passes leave columns 16..19 alone and only touch rows below the
-    // next pass's first row; the strip's own y1 (rows 2..9) was lifted into registers above ----
+    // next pass's first row; the strip's own y1 (rows 2..9) is in registers since phase A ----
     {
 #pragma unroll
       for (int hb = 0; hb < 3; ++hb) {
@@ -322,8 +329,7 @@ __global__ __launch_bounds__(512) void c2f_fused_kernel(const C2fArgs p) {
 
     // ---- C: m.cv2 3x3 on the strip (+ y1 with a shortcut) -> y2 in result-lane order ----
     u32x2 y2c[8][2];
-    u32x4 da[2][4], db[2][2], wq[2][4];  // phase D / E operands in flight
-    unsigned dlo[4], dhi[4];
+    u32x4 wq[2][4];  // cv2 weight chunks in flight
 #pragma unroll
     for (int hc = 0; hc < 2; ++hc) {  // four rows at a time: registers
       f32x4 acc[4][2];
@@ -351,11 +357,7 @@ __global__ __launch_bounds__(512) void c2f_fused_kernel(const C2fArgs p) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      if (hc == 1) {  // phase D's first batch (rows 0..3, chunks 0 and 1) and cv2's first weight chunk fly during this epilogue
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pix_off((ty0 + i) < p.H && (tx0 + lr) < p.W, n, ty0 + i, tx0 + lr, &dlo[i], &dhi[i]);
-        issue_y0(0, dlo, dhi, da[0], db[0]);
-        issue_y0(1, dlo, dhi, da[1], db[1]);
+      if (hc == 1) {  // cv2's first weight chunk flies during this epilogue
         issue_w2(0, wq[0]);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -377,32 +379,11 @@ __global__ __launch_bounds__(512) void c2f_fused_kernel(const C2fArgs p) {
     C2F_PIN_LANE();
     C2F_STAMP(2);
 
-    // ---- D + E, four rows at a time: cv1 -> y0 on the rows (result-lane order, registers), then cv2 1x1 on [y0 | y1 | y2] ->
-    // global.  A result lane holds channels {4q..4q+3, 16+4q..16+4q+3} of its pixel; cv2's weight lane (cout lr, quarter lq) is
-    // fetched with the same k order (two 8-byte pieces of the FRAG1X1 image), so the three inputs never go back through LDS. ----
+    // ---- E, four rows at a time: cv2 1x1 on [y0 | y1 | y2] -> global.  A result lane holds channels {4q..4q+3, 16+4q..16+4q+3} of
+    // its pixel; cv2's weight lane (cout lr, quarter lq) is fetched with the same k order (two 8-byte pieces of the FRAG1X1
+    // image), so the three inputs never go back through LDS. ----
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      u32x2 y0c[4][2];
-      {
-        f32x4 acc0[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc0[i][j] = *reinterpret_cast<const f32x4*>(sbias + j * 16 + lq * 4);
-#pragma unroll
-        for (int c = 0; c < KC; ++c) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc0[i][j] = Elem<T>::mma(db[c & 1][j], da[c & 1][i], acc0[i][j]);
-          if (c + 2 < KC) issue_y0(c + 2, dlo, dhi, da[c & 1], db[c & 1]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) y0c[i][j] = pack4(silu4(acc0[i][j]));
-      }
       f32x4 acc[4][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -414,8 +395,8 @@ __global__ __launch_bounds__(512) void c2f_fused_kernel(const C2fArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int r = half * 4 + i;
-          const u32x2 s0 = c == 0 ? y0c[i][0] : (c == 1 ? y1c[r][0] : y2c[r][0]);
-          const u32x2 s1 = c == 0 ? y0c[i][1] : (c == 1 ? y1c[r][1] : y2c[r][1]);
+          const u32x2 s0 = c == 0 ? y0c[r][0] : (c == 1 ? y1c[r][0] : y2c[r][0]);
+          const u32x2 s1 = c == 0 ? y0c[r][1] : (c == 1 ? y1c[r][1] : y2c[r][1]);
           const u32x4 av = u32x4{s0[0], s0[1], s1[0], s1[1]};
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = Elem<T>::mma(wq[c & 1][j], av, acc[i][j]);
@@ -424,20 +405,15 @@ __global__ __launch_bounds__(512) void c2f_fused_kernel(const C2fArgs p) {
       }
       // the next batch of loads goes out BEFORE this half's stores (vmcnt retires in order: a load behind a store waits for it)
       if (half == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pix_off((ty0 + 4 + i) < p.H && (tx0 + lr) < p.W, n, ty0 + 4 + i, tx0 + lr, &dlo[i], &dhi[i]);
-        issue_y0(0, dlo, dhi, da[0], db[0]);
-        issue_y0(1, dlo, dhi, da[1], db[1]);
         issue_w2(0, wq[0]);
       } else {
         int nn, nty0, ntx0;
         const int next = strip + G * 8;
         decode(next, &nn, &nty0, &ntx0);
-        unsigned olo[8], ohi[8];
-        bool ok[8];
-        halo_offsets(0, nn, nty0, ntx0, next < p.nStrips, olo, ohi, ok);
-        issue_y1(0, 8, olo, ohi, a[0], b[0]);
-        issue_y1(1, 8, olo, ohi, a[1], b[1]);
+        unsigned olo[4], ohi[4];
+        pass_offsets(0, nn, nty0, ntx0, next < p.nStrips, olo, ohi);
+        issue_pass(0, 0, olo, ohi, a[0], b[0]);
+        issue_pass(0, 1, olo, ohi, a[1], b[1]);
       }
       __builtin_amdgcn_sched_barrier(0);
       // Result lanes hold 8-byte pieces of 16 different pixel rows: stored like that, every lane is its own L1 request (measured:
