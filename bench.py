@@ -100,12 +100,13 @@ def conv_work(plan):
             out.append((i, 2.0 * d.n * (h0 * w0 * 32 * 27 + h1 * w1 * 64 * 288), d.n * 3 * d.h * d.w * 4 + d.n * h1 * w1 * 64 * es + (32 * 27 + 64 * 288) * es,
                         f"3->32 k3 s2 + 32->64 k3 s2 {d.h}x{d.w} (fused stem + layer 1, fp32 NCHW in)"))
             continue
-        if fn.__name__ == "dy_c2f_fused":  # whole C2f block (cv1, Bottleneck 3x3 3x3, cv2) in one launch
+        if fn.__name__ == "dy_c2f_fused":  # whole C2f block (cv1, Bottleneck 3x3 3x3, cv2) in one launch; cin_lo channels arrive through a fused 2x upsample
             d = args[0]._obj
             es, c = 2, d.hidden
             px = d.batch * d.h * d.w
-            out.append((i, 2.0 * px * (d.cin * 2 * c + 2 * 9 * c * c + 3 * c * d.cout), px * (d.cin + d.cout) * es + (d.cin * 2 * c + 18 * c * c + 3 * c * d.cout) * es,
-                        f"C2f {d.cin}->{d.cout} (hidden {c}: 1x1, 3x3, 3x3, 1x1 fused) {d.h}x{d.w}"))
+            in_elems = px * (d.cin - d.cin_lo) + (px // 4) * d.cin_lo
+            out.append((i, 2.0 * px * (d.cin * 2 * c + 2 * 9 * c * c + 3 * c * d.cout), (in_elems + px * d.cout) * es + (d.cin * 2 * c + 18 * c * c + 3 * c * d.cout) * es,
+                        f"C2f {d.cin}->{d.cout} (hidden {c}: 1x1, 3x3, 3x3, 1x1 fused" + (f", {d.cin_lo} ch through Upsample + Concat" if d.cin_lo else "") + f") {d.h}x{d.w}"))
             continue
         if fn.__name__ == "dy_detect_head_decode":  # fused tail: both 1x1 convs of every level + decode in one launch
             d = args[0]._obj
