@@ -6,9 +6,14 @@
 // the prologue:
 //   - a 512-thread workgroup (8 waves) loads the n-tile's weights (fragment order, <= 96 KB) and bias
 //     into LDS once; then every WAVE walks its own list of 16*MF-pixel row tiles:
-//   - A fragments are loaded straight from global memory into registers in MFMA operand shape (lane =
-//     (k-chunk, pixel): 16 bytes of one pixel's channels), the next tile's fragments are in flight
-//     while the current tile is multiplied — register double buffering, no LDS, no barrier;
+//   - A fragments are loaded straight from global memory into registers, the next tile's are in flight
+//     while the current tile is multiplied — register double buffering, no LDS bytes, no barrier.  The
+//     loads run in LOADER order: lane 4 p + q takes chunk q of pixel p, so a quad of lanes reads 64
+//     contiguous bytes and the L1 sees 16 requests per instruction.  In MFMA operand order (lane 16 q + p)
+//     every lane of a quad is another pixel row = 64 requests per instruction, and the L1's request rate,
+//     not HBM, bounded these layers at 4-5 TB/s.  ds_bpermute_b32 turns loader order into operand order
+//     when a tile's registers are handed to the multiply (crossbar only, four per 16-byte chunk); used
+//     up to K = 192, beyond that the crossbar passes cost more than the requests they save;
 //   - the gather understands the folded Concat/Upsample in front of C2f.cv1 (channels [0,split) from x
 //     through a 2x nearest upsample, the rest from x2), like conv_igemm.hip;
 //   - weights are the MFMA A operand, so a lane holds 4 consecutive output channels of one pixel;
@@ -70,10 +75,15 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const Conv1Args p) 
   int mt = group * 8 + wave;
   if (mt >= p.nMT) return;
 
+  // measured per layer (B = 256): K = 128 -10 %, K = 192 -2 %, K = 256 +4 %, K = 384 +11 %: the crossbar passes grow with K, the
+  // saved L1 requests do not pay for them from K = 256 up
+  constexpr bool LOADER = NKG * KCE * (int)sizeof(T) <= 384;
+  const int lp = LOADER ? lane >> 2 : lr, lc = LOADER ? lane & 3 : lq;  // pixel and chunk-in-k-group this lane loads
+  const int to_operand = 4 * (lr * 4 + lq);           // ds_bpermute byte index: operand lane (lr, lq) <- loader lane 4 lr + lq
   auto load_tile = [&](int tile, u32x4 (&a)[MF][NKG]) {
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
-      int m = tile * (MF * 16) + i * 16 + lr;
+      int m = tile * (MF * 16) + i * 16 + lp;
       m = m < p.M ? m : p.M - 1;  // rows past the end load a valid row and are never stored
       size_t off1, off2 = (size_t)m * (size_t)p.ldx2;
       if (p.up2x) {
@@ -85,7 +95,7 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const Conv1Args p) 
       }
 #pragma unroll
       for (int kg = 0; kg < NKG; ++kg) {
-        const int c = kg * KCE + lq * EPC;
+        const int c = kg * KCE + lc * EPC;
         u32x4 v = zero_chunk();
         if (c < p.split) {
           v = *reinterpret_cast<const u32x4*>(xg + off1 + c);
@@ -173,7 +183,10 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const Conv1Args p) 
 #pragma unroll
     for (int i = 0; i < MF; ++i)
 #pragma unroll
-      for (int kg = 0; kg < NKG; ++kg) a_cur[i][kg] = a_nxt[i][kg];
+      for (int kg = 0; kg < NKG; ++kg) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) a_cur[i][kg][w] = LOADER ? (unsigned)__builtin_amdgcn_ds_bpermute(to_operand, (int)a_nxt[i][kg][w]) : a_nxt[i][kg][w];
+      }
     const int nx = mt + stride;
     if (nx < p.nMT) load_tile(nx, a_nxt);
     process(mt, a_cur);

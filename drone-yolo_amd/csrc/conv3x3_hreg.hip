@@ -179,7 +179,10 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hreg_kernel(const HregArgs p) 
     const int r = tile / p.tilesX;
     const int ty = r % p.tilesY, n = r / p.tilesY;
     const int xx = tx * kHrTW + lr;
-    const int co = nt * 64 + wave * 16 + lq * 4;
+    // A result lane holds 8 bytes (4 channels) of pixel lr in tile row o.  Stored like that, each of the 64 lanes is its own
+    // L1 request.  v_permlane16_swap between the rows of a pair (o, o + 1) leaves 16 contiguous bytes in every lane - quarter lq
+    // gets channels 8 (lq >> 1) .. + 7 of row o + (lq & 1) - so a pair of rows leaves in one 16-byte store instead of two 8-byte ones.
+    u32x2 pk[kHrTH];
 #pragma unroll
     for (int o = 0; o < kHrTH; ++o) {
       float v[4] = {acc[o][0], acc[o][1], acc[o][2], acc[o][3]};
@@ -195,11 +198,18 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hreg_kernel(const HregArgs p) 
       t4 ov;
 #pragma unroll
       for (int e = 0; e < 4; ++e) ov[e] = Elem<T>::from_f32(v[e]);
-      const int yy = ty * kHrTH + o;
-      const bool ok = yy < p.H && xx < p.W;
-      const unsigned off = ok ? (unsigned)((((size_t)(n * p.H + yy) * p.W + xx) * (size_t)p.ldy + co) * sizeof(T)) : 0xfffffff0u;
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ov), yrs, HR_DBG(1) ? 0xfffffff0u : off, 0, 0);
+      pk[o] = __builtin_bit_cast(u32x2, ov);
       acc[o] = bias4;
+    }
+    const int co16 = nt * 64 + wave * 16 + (lq >> 1) * 8;
+#pragma unroll
+    for (int o = 0; o < kHrTH; o += 2) {
+      const auto sx = __builtin_amdgcn_permlane16_swap(pk[o][0], pk[o + 1][0], false, false);
+      const auto sy = __builtin_amdgcn_permlane16_swap(pk[o][1], pk[o + 1][1], false, false);
+      const int yy = ty * kHrTH + o + (lq & 1);
+      const bool ok = yy < p.H && xx < p.W;
+      const unsigned off = ok ? (unsigned)((((size_t)(n * p.H + yy) * p.W + xx) * (size_t)p.ldy + co16) * sizeof(T)) : 0xfffffff0u;
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{sx[0], sy[0], sx[1], sy[1]}, yrs, HR_DBG(1) ? 0xfffffff0u : off, 0, 0);
     }
   };
 
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hreg_kernel(const HregArgs p) 
   // Item i lives in stage i % 3.  At the start of item i the DMA of item i + 2 goes into stage (i + 2) % 3, last read in
   // item i - 1 (every wave has passed the barrier that ended it).  At the end of item i the wave waits until ITS pieces of
   // item i + 1 have landed: younger than those are only the 4 DMA instructions of item i + 2 and, when the item ended a
-  // tile, the tile's 8 output stores -> s_waitcnt vmcnt(4) / vmcnt(12); the barrier then publishes everyone's pieces.
+  // tile, the tile's 4 output stores -> s_waitcnt vmcnt(4) / vmcnt(8); the barrier then publishes everyone's pieces.
   setup_tile(l_tile);
   issue_dma(0);
   issue_dma(1 % kHrStages);
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hreg_kernel(const HregArgs p) 
       if (c == NCH - 1) {
         epilogue(c_tile);
         c_tile += Gs;
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       }
