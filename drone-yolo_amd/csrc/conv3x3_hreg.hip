@@ -159,19 +159,19 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hreg_kernel(const HregArgs p) 
   // residual of the tile that ends with this item (Bottleneck shortcut): requested at the START of the item, BEFORE the next
   // DMA is issued — the loads are then older than that DMA and their wait (at the epilogue) leaves it in flight
   typedef __attribute__((ext_vector_type(4))) T t4;
-  u32x2 rv[kHrTH];
+  u32x4 rl[kHrTH / 2];  // 16 bytes per lane and row pair, in the store order of the epilogue (quarter lq: row o + (lq & 1), channels 8 (lq >> 1) ..)
   auto load_residual = [&](int tile) {
     const int tx = tile % p.tilesX;
     const int r = tile / p.tilesX;
     const int ty = r % p.tilesY, n = r / p.tilesY;
     const int xx = tx * kHrTW + lr;
-    const int co = nt * 64 + wave * 16 + lq * 4;
+    const int co16 = nt * 64 + wave * 16 + (lq >> 1) * 8;
 #pragma unroll
-    for (int o = 0; o < kHrTH; ++o) {
-      const int yy = ty * kHrTH + o;
+    for (int o = 0; o < kHrTH; o += 2) {
+      const int yy = ty * kHrTH + o + (lq & 1);
       const bool ok = yy < p.H && xx < p.W;
-      const unsigned off = ok ? (unsigned)((((size_t)(n * p.H + yy) * p.W + xx) * (size_t)p.ldres + co) * sizeof(T)) : 0xfffffff0u;
-      rv[o] = __builtin_amdgcn_raw_buffer_load_b64(rrs, off, 0, 0);  // zero records without a residual: returns 0
+      const unsigned off = ok ? (unsigned)((((size_t)(n * p.H + yy) * p.W + xx) * (size_t)p.ldres + co16) * sizeof(T)) : 0xfffffff0u;
+      rl[o / 2] = __builtin_amdgcn_raw_buffer_load_b128(rrs, off, 0, 0);
     }
   };
   auto epilogue = [&](int tile) {
@@ -190,8 +190,10 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hreg_kernel(const HregArgs p) 
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
       }
-      if constexpr (RES) {
-        const t4 rr = __builtin_bit_cast(t4, rv[o]);
+      if constexpr (RES) {  // the row pair's 16-byte pieces back in result-lane order: the store-side swap run backwards
+        const auto sx = __builtin_amdgcn_permlane16_swap(rl[o / 2][0], rl[o / 2][2], false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(rl[o / 2][1], rl[o / 2][3], false, false);
+        const t4 rr = __builtin_bit_cast(t4, u32x2{sx[o & 1], sy[o & 1]});
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += Elem<T>::to_f32(rr[e]);
       }
@@ -273,13 +275,14 @@ int conv3x3_hreg_try(const dy_conv_desc* d, hipStream_t st) {
   if (!(d->dtype == DY_BF16 || d->dtype == DY_F16) || d->out_f32 || d->stride != 1 || d->ksize != 3 || d->pad != 1 || d->groups > 1 || d->up2x || d->x2) return 1;
   // measured (B = 256, alternating A/B against conv3x3_halo, tools/bench_conv.py): 64->64 @160 650 -> 598 us, @80 150 -> 141, @40 55 -> 42,
   // @20 29 -> 18, 64->128 @80 285 -> 268; cin 32 (one chunk per tile: an epilogue every item) 205-250 -> 227-252: no gain, stays on
-  // the halo kernel; with a Bottleneck residual (8-byte gathers of 32-byte segments) 210 -> 237 @80: stays there too
+  // the halo kernel; with a Bottleneck residual (halo -> this kernel): 8-byte gathers 210 -> 237 @80, 16-byte pieces per row pair 187 -> 203:
+  // stays there too
   if (d->cin != 64 || d->cout % 64 != 0 || d->cout > 256 || d->residual) return 1;
   if (d->ho != d->h || d->wo != d->w_in) return 1;
   const long long xb = (long long)d->batch * d->h * d->w_in * d->ld_x * 2, yb = (long long)d->batch * d->ho * d->wo * d->ld_y * 2;
   const long long rb = d->residual ? (long long)d->batch * d->ho * d->wo * d->ld_res * 2 : 0;
   if (xb >= (1ll << 31) || yb >= (1ll << 32) - 64 || rb >= (1ll << 32) - 64) return 1;  // 32-bit element offsets / buffer descriptors
-  if (d->ld_y % 4 || (d->residual && d->ld_res % 4)) return 1;
+  if (d->ld_y % 8 || (reinterpret_cast<uintptr_t>(d->y) & 15) || (d->residual && (d->ld_res % 8 || (reinterpret_cast<uintptr_t>(d->residual) & 15)))) return 1;  // 16-byte stores / residual loads
   HregArgs a{};
   a.x = d->x, a.w = d->w, a.bias = d->bias, a.res = d->residual, a.y = d->y;
   a.N = d->batch, a.H = d->h, a.W = d->w_in, a.Cin = d->cin, a.ldx = d->ld_x, a.Cout = d->cout, a.ldy = d->ld_y, a.ldres = d->ld_res, a.act = d->act;
