@@ -34,6 +34,13 @@ def bottleneck_train(m, x):
 
 
 def c2f_train(m, x):
+    """One autograd node per block (A.C2fTrain) for the plain form of the Drone-YOLO YAMLs; ``m.fuse_block_train = False`` runs
+    the op-by-op graph (chunk, Bottlenecks, cat as separate nodes)."""
+    plain = all(cv.conv.groups == 1 for mm in m.m for cv in (mm.cv1, mm.cv2)) and m.cv1.conv.groups == 1 and m.cv2.conv.groups == 1
+    if plain and getattr(m, "fuse_block_train", True):
+        convs = [m.cv1] + [cv for mm in m.m for cv in (mm.cv1, mm.cv2)] + [m.cv2]
+        if all(isinstance(cv.act, nn.SiLU) for cv in convs):
+            return A.C2fTrain.apply(x, m, *[t for cv in convs for t in (cv.conv.weight, cv.bn.weight, cv.bn.bias)])
     a, b = A.Chunk2.apply(conv_train(m.cv1, x))
     ys = [a, b]
     for mm in m.m:
