@@ -286,6 +286,7 @@ def train_bench(a):
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss, items = tr.step(batch)
+    t_enq = time.perf_counter() - t0  # the host's share: all launches of the K steps are queued (or a step made the host wait)
     torch.cuda.synchronize()
     P.barrier()
     dt = P.max_over_ranks(time.perf_counter() - t0, dev)
@@ -293,7 +294,7 @@ def train_bench(a):
         total = a.batch * world * a.steps
         print(json.dumps({"metric": "train images/sec @640x640 Drone-YOLO-s", "value": round(total / dt, 2), "unit": "images/sec", "n_gpus": world,
                           "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+                          "vs_baseline": None, "dtype": a.dtype, "data": "synthetic", "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3),
                           "config": {"workload": "Drone-YOLO-s training step 640x640: uint8 batch -> forward (batch-stat BN) -> v8DetectionLoss -> backward -> "
                                                  "SUM all-reduce -> clip -> SGD nesterov -> EMA", "batch_per_gpu": a.batch, "global_batch": a.batch * world,
                                      "labels_per_image": "Poisson(50)", "parallelism": f"data parallel x{world}, one flat fp32 gradient all-reduce",
