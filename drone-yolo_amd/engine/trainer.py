@@ -392,13 +392,56 @@ class DetectionTrainer:
         will_step = ni - self.last_opt_step >= self.accumulate
         if self.buckets is not None:
             self.buckets.arm(will_step)  # the backward that precedes an optimizer step all-reduces its buckets as they fill
-        loss, items = self.model(batch)
-        loss.backward()
+        loss, items = self._forward_backward(batch)
         self.iters += 1
         if will_step:
             self.optimizer_step()
             self.last_opt_step = ni
         return loss.detach() * self.world, items  # the reference reports loss * world_size (trainer.py:382-383)
+
+    graph_steps = True  # single rank: forward + loss + backward recorded once as a hipGraph and replayed (see _forward_backward)
+
+    def _forward_backward(self, batch: Dict[str, torch.Tensor]):
+        """loss, items = model(batch); loss.backward() (trainer.py:379-389).
+
+        A step is ~2,400 kernel launches from Python; the GPU needs ~40 ms for them, the host 40-130 ms depending on what
+        else runs on the box, so the step is host bound.  With one rank the whole forward + loss + backward is therefore
+        captured into a hipGraph (torch.cuda.CUDAGraph: activations live in the graph's private pool) once per (image shape,
+        label capacity) and replayed: the images and the label table are copied into static buffers, the parameter gradients
+        accumulate into the flat gradient buffer exactly as in the eager backward.  Nothing in it depends on a host value that
+        changes between steps; the optimizer step (learning rate, momentum, EMA decay, first-step flag) stays outside.
+        Several ranks run eagerly: the bucketed all-reduce is issued from autograd hooks."""
+        use = (self.graph_steps and self.world == 1 and self.buckets is None and self.iters >= 2 and batch["img"].is_cuda
+               and self.model.training and not os.environ.get("DYOLO_FORCE_DEVICE"))
+        if not use:
+            loss, items = self.model(batch)
+            loss.backward()
+            return loss, items
+        model = self.model
+        if getattr(model, "criterion", None) is None:
+            model.criterion = model.init_criterion()
+        img = batch["img"]
+        b, _, h, w = img.shape
+        gt = model.criterion.targets_to_gt(batch, b, (h, w))
+        cap = max(64, -(-gt.shape[1] // 64) * 64)
+        key = (tuple(img.shape), img.dtype, cap, model.train_dtype)
+        gs = getattr(self, "_graph", None)
+        if gs is None or gs["key"] != key:
+            gs = dict(key=key, img=torch.empty_like(img), gt=torch.zeros((b, cap, 5), dtype=torch.float32, device=img.device))
+            gs["img"].copy_(img)
+            torch.cuda.synchronize(img.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss, items = model.criterion.from_gt(model.forward_train(gs["img"]), gs["gt"])
+                loss.backward()
+            gs.update(g=g, loss=loss, items=items)
+            self._graph = gs
+        gs["img"].copy_(img, non_blocking=True)
+        gs["gt"].zero_()
+        if gt.shape[1]:
+            gs["gt"][:, : gt.shape[1]].copy_(gt.to(img.device, non_blocking=True))
+        gs["g"].replay()
+        return gs["loss"], gs["items"]
 
     def optimizer_step(self) -> None:
         """unscale (no scaler: bf16 / fp32), clip 10, step, zero_grad, EMA — trainer.py:591-599."""

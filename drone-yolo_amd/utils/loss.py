@@ -40,13 +40,22 @@ class v8DetectionLoss:
         out[..., 1:5] = xywh2xyxy(out[..., 1:5] * scale_tensor)
         return out
 
-    def __call__(self, preds, batch):
-        feats = preds[1] if isinstance(preds, tuple) else preds
-        bs = feats[0].shape[0]
-        imgsz = torch.tensor(feats[0].shape[2:], dtype=torch.float32) * float(self.stride[0])  # (h, w)
+    def targets_to_gt(self, batch, batch_size: int, img_hw) -> torch.Tensor:
+        """The batch's labels as the (B, n_max, 5) pixel-box table on the host (``preprocess``); img_hw = (h, w) of the images."""
+        imgsz = torch.tensor([float(img_hw[0]), float(img_hw[1])], dtype=torch.float32)
         targets = torch.cat((batch["batch_idx"].view(-1, 1).float().cpu(), batch["cls"].view(-1, 1).float().cpu(),
                              batch["bboxes"].float().cpu()), 1)
-        gt = self.preprocess(targets, bs, imgsz[[1, 0, 1, 0]])
+        return self.preprocess(targets, batch_size, imgsz[[1, 0, 1, 0]])
+
+    def __call__(self, preds, batch):
+        feats = preds[1] if isinstance(preds, tuple) else preds
+        hw = (feats[0].shape[2] * float(self.stride[0]), feats[0].shape[3] * float(self.stride[0]))
+        return self.from_gt(preds, self.targets_to_gt(batch, feats[0].shape[0], hw))
+
+    def from_gt(self, preds, gt: torch.Tensor):
+        """loss, loss_items from the box table itself (host or device, zero rows = padding): what ``__call__`` does after
+        ``preprocess``.  A trainer that replays the step as a hipGraph keeps ``gt`` in a static device buffer."""
+        feats = preds[1] if isinstance(preds, tuple) else preds
         strides = [float(s) for s in self.stride]
         if any(f.requires_grad for f in feats):
             if self.topk != 10:

@@ -302,6 +302,37 @@ def test_trainer_step_matches_oracle(opt, device):
         off += n
 
 
+def test_graphed_steps_equal_eager_steps(device):
+    """DetectionTrainer replays forward + loss + backward as a hipGraph from its third step on (single rank).  Five steps with
+    changing labels, graphed against eager: same losses, same parameters, same BatchNorm statistics (both sum wgrad / BN
+    partials with fp32 atomics in whatever order the waves arrive: 2e-3 of each tensor's max)."""
+    import copy
+
+    from drone_yolo_amd.engine.trainer import DetectionTrainer
+    from oracle import loss_oracle as LO
+
+    g, m, d, model, sd, img, labels = _train_case("tn64")
+    runs = {}
+    for graphed in (False, True):
+        mdl = copy.deepcopy(model)
+        tr = DetectionTrainer(mdl, dict(optimizer="SGD", lr0=0.01, momentum=0.937, batch=64, dtype="fp32", warmup_epochs=0.0))
+        tr.graph_steps = graphed
+        losses = []
+        for it in range(5):
+            lab = LO.synthetic_labels(img.shape[0], 100 + it, n_mean=m["n_mean"] + 3 * it)  # another label count every step
+            loss, _ = tr.step(dict(img=img.to(device), **lab), epoch=0, nb=1000)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        assert (getattr(tr, "_graph", None) is not None) == graphed
+        runs[graphed] = (losses, {k: v.detach().float().cpu().clone() for k, v in mdl.state_dict().items()})
+    for a, b in zip(runs[False][0], runs[True][0]):
+        assert abs(a - b) <= 1e-3 * abs(a), (runs[False][0], runs[True][0])
+    for k, v in runs[False][1].items():
+        if v.is_floating_point() and "dfl.conv" not in k:
+            err = float((runs[True][1][k] - v).abs().max()) / max(float(v.abs().max()), 1e-6)
+            assert err <= 2e-3, (k, err)
+
+
 def test_optimizer_kernels_match_torch_optim(device):
     """dy_sgd_step / dy_adamw_step / dy_ema_update / dy_sumsq_f32 (clip folded in) against torch.optim + clip_grad_norm_ on
     the same tensors, three steps, element-wise."""
