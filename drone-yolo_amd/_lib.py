@@ -185,6 +185,7 @@ SIGNATURES = {
     "dy_sgd_step": (_i32, [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _i32, _i32, _vp, _f32, _vp]),
     "dy_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _f32, _vp]),
     "dy_ema_update": (_i32, [_vp, _vp, _i64, _f32, _vp]),
+    "dy_grad_sink_flush": (_i32, [_vp, _i32, _vp, _vp, _vp]),
     "dy_bn_workspace_bytes": (_i64, [_i32]),
     "dy_bn_train_fwd": (_i32, [C.POINTER(BnDesc), _vp]),
     "dy_bn_train_bwd": (_i32, [C.POINTER(BnDesc), _vp]),

@@ -399,6 +399,34 @@ extern "C" int32_t dy_adamw_step(float* p, const float* grad, float* m, float* v
   return check_launch("dy_adamw_step");
 }
 
+// grad += sink (sink -> 0), weight blocks transposed from the weight-gradient kernels' (cout, k, k, cin) to torch's (cout, cin, k, k).
+// blockIdx.y = parameter, blockIdx.x strides over its elements in the DESTINATION order (coalesced read-modify-write of grad; the
+// gather from sink has stride cin and stays in L2: the whole sink is 44 MB for scale s).
+__global__ __launch_bounds__(256) void grad_sink_flush_kernel(const long long* __restrict__ entries, float* __restrict__ grad, float* __restrict__ sink) {
+  const long long off = entries[4 * blockIdx.y], cout = entries[4 * blockIdx.y + 1], cin = entries[4 * blockIdx.y + 2], kk = entries[4 * blockIdx.y + 3];
+  const long long n = cout * cin * (kk > 1 ? kk : 1);
+  for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < n; j += (long long)gridDim.x * 256) {
+    long long src = j;
+    if (kk > 1) {
+      const long long co = j / (cin * kk), r = j - co * cin * kk;
+      const long long ci = r / kk, t = r - ci * kk;
+      src = (co * kk + t) * cin + ci;
+    }
+    const float v = sink[off + src];
+    if (v != 0.f) {
+      grad[off + j] += v;
+      sink[off + src] = 0.f;
+    }
+  }
+}
+
+extern "C" int32_t dy_grad_sink_flush(const int64_t* entries, int32_t n_entries, float* grad, float* sink, dy_stream_t stream) {
+  DY_REQUIRE(entries && grad && sink && n_entries > 0, DY_ERR_INVALID_ARG, "dy_grad_sink_flush: bad arguments");
+  hipLaunchKernelGGL(grad_sink_flush_kernel, dim3(32, (unsigned)n_entries), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const long long*>(entries), grad, sink);
+  return check_launch("dy_grad_sink_flush");
+}
+
 extern "C" int32_t dy_ema_update(float* ema, const float* p, int64_t n, float decay, dy_stream_t stream) {
   DY_REQUIRE(ema && p && n > 0, DY_ERR_INVALID_ARG, "dy_ema_update: bad arguments");
   hipLaunchKernelGGL(ema_kernel, dim3(grid1(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ema, p, (long long)n, decay);

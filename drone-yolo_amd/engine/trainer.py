@@ -112,6 +112,29 @@ class FlatState:
             yield slice(off, off + s)
             off += s
 
+    def enable_sink(self) -> None:
+        """A second flat buffer the backward kernels write this batch's parameter gradients into (nn/autograd_ops.py::grad_sink:
+        weight gradients in the wgrad kernels' (cout, k, k, cin) order, BatchNorm gradients as they are), folded into G by ONE
+        ``dy_grad_sink_flush`` launch per batch (``flush_sink``) — instead of autograd's AccumulateGrad per parameter: ~240
+        element-wise launches plus the zero-fills of as many temporaries per step.  Single rank only: the bucketed all-reduce is
+        driven by AccumulateGrad hooks."""
+        self.S = torch.zeros_like(self.G)
+        rows = []
+        for k, (off, c) in self.offsets.items():
+            p = self.params[k]
+            p._dy_sink = self.S[off : off + c]
+            if p.dim() == 4 and p.shape[2] * p.shape[3] > 1:
+                rows.append((off, p.shape[0], p.shape[1], p.shape[2] * p.shape[3]))
+            else:
+                rows.append((off, c, 1, 1))
+        self.sink_entries = torch.tensor(rows, dtype=torch.int64, device=self.G.device)
+
+    def flush_sink(self) -> None:
+        if getattr(self, "S", None) is not None:
+            from .. import hip_ops as H
+
+            H.grad_sink_flush_(self.sink_entries, self.G, self.S)
+
 
 class ModelEMA:
     """Exponential moving average of parameters and floating buffers — torch_utils.py:515-545 (decay 0.9999, tau 2000)."""
@@ -356,6 +379,8 @@ class DetectionTrainer:
         self.iters = 0
         self.last_opt_step = -1
         self.buckets = P.GradBuckets(self.flat, n_buckets=int(os.environ.get("DYOLO_GRAD_BUCKETS", 4))) if self.world > 1 else None
+        if self.world == 1 and self.grad_sink:
+            self.flat.enable_sink()
 
     # ---- schedules (state lives in self.sched) ------------------------------------------------------------------------------
     cur_lrs = property(lambda self: self.sched.cur_lrs)
@@ -400,6 +425,7 @@ class DetectionTrainer:
         return loss.detach() * self.world, items  # the reference reports loss * world_size (trainer.py:382-383)
 
     graph_steps = True  # single rank: forward + loss + backward recorded once as a hipGraph and replayed (see _forward_backward)
+    grad_sink = True  # single rank: parameter gradients through FlatState's sink (one flush per batch) instead of AccumulateGrad
 
     def _forward_backward(self, batch: Dict[str, torch.Tensor]):
         """loss, items = model(batch); loss.backward() (trainer.py:379-389).
@@ -413,9 +439,13 @@ class DetectionTrainer:
         Several ranks run eagerly: the bucketed all-reduce is issued from autograd hooks."""
         use = (self.graph_steps and self.world == 1 and self.buckets is None and self.iters >= 2 and batch["img"].is_cuda
                and self.model.training and not os.environ.get("DYOLO_FORCE_DEVICE"))
+        from ..nn.autograd_ops import sink_armed
+
         if not use:
-            loss, items = self.model(batch)
-            loss.backward()
+            with sink_armed():
+                loss, items = self.model(batch)
+                loss.backward()
+            self.flat.flush_sink()
             return loss, items
         model = self.model
         if getattr(model, "criterion", None) is None:
@@ -431,9 +461,10 @@ class DetectionTrainer:
             gs["img"].copy_(img)
             torch.cuda.synchronize(img.device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g), sink_armed():
                 loss, items = model.criterion.from_gt(model.forward_train(gs["img"]), gs["gt"])
                 loss.backward()
+                self.flat.flush_sink()
             gs.update(g=g, loss=loss, items=items)
             self._graph = gs
         gs["img"].copy_(img, non_blocking=True)

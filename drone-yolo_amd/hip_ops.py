@@ -235,6 +235,8 @@ class PackedConv:
             def _device_bias(n: int) -> torch.Tensor:
                 if bias.numel() == n and bias.is_cuda and bias.dtype == torch.float32:
                     return bias.detach()
+                if bias is _ZERO_BIAS.get((bias.numel(), str(src.device))):  # the shared zeros (training, gradient convolutions): no fill + copy per call
+                    return zero_bias(n, src.device)
                 bp = torch.zeros((n,), dtype=torch.float32, device=src.device)
                 bp[: bias.numel()] = bias.detach().to(torch.float32)
                 return bp
@@ -856,8 +858,9 @@ def silu_bwd(u: torch.Tensor, dy: torch.Tensor, out: Optional[torch.Tensor] = No
 # ---- convolution gradients ----------------------------------------------------------------------------------------
 
 
-def conv_wgrad(x: torch.Tensor, dz: torch.Tensor, ksize: int, stride: int, pad: int) -> torch.Tensor:
-    """d loss / d weight of z = conv2d(x, w, stride, pad): fp32 (cout, cin, k, k), through ``dy_conv2d_wgrad_nhwc``."""
+def conv_wgrad(x: torch.Tensor, dz: torch.Tensor, ksize: int, stride: int, pad: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """d loss / d weight of z = conv2d(x, w, stride, pad): fp32 (cout, cin, k, k), through ``dy_conv2d_wgrad_nhwc``.
+    ``out``: a contiguous fp32 (cout, k, k, cin) tensor the kernel ADDS into (a trainer's gradient sink) instead of a fresh zeroed one."""
     require_device(x, "wgrad input")
     n, cin, h, w = x.shape
     cout, ho, wo = dz.shape[1], dz.shape[2], dz.shape[3]
@@ -867,7 +870,12 @@ def conv_wgrad(x: torch.Tensor, dz: torch.Tensor, ksize: int, stride: int, pad: 
     (d.x, d.ld_x), (dzp, lddz) = view_params(x), view_params(dz)
     d.batch, d.h, d.w_in, d.cin, d.ho, d.wo, d.cout = n, h, w, cin, ho, wo, cout
     d.ksize, d.stride, d.pad, d.groups, d.dtype = ksize, stride, pad, 1, dy_dtype(x.dtype)
-    dw = torch.zeros((cout, ksize, ksize, cin), dtype=torch.float32, device=x.device)
+    if out is not None:
+        if tuple(out.shape) != (cout, ksize, ksize, cin) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("conv_wgrad: out must be a contiguous fp32 (cout, k, k, cin) tensor")
+        dw = out
+    else:
+        dw = torch.zeros((cout, ksize, ksize, cin), dtype=torch.float32, device=x.device)
     _launch(lib().dy_conv2d_wgrad_nhwc, (C.byref(d), dzp, lddz, dw.data_ptr()), keep=(d, x, dz, dw))
     return dw.permute(0, 3, 1, 2)
 
@@ -971,6 +979,12 @@ def adamw_step_(p: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torch.T
 
 def ema_update_(ema: torch.Tensor, p: torch.Tensor, decay: float) -> None:
     _launch(lib().dy_ema_update, (ema.data_ptr(), p.data_ptr(), p.numel(), decay), keep=(ema, p))
+
+
+def grad_sink_flush_(entries: torch.Tensor, grad: torch.Tensor, sink: torch.Tensor) -> None:
+    """grad += sink, sink = 0 for every parameter block of ``entries`` (device int64 (n, 4): offset, cout, cin, kk) in one
+    ``dy_grad_sink_flush`` launch; conv-weight blocks of ``sink`` are in the weight-gradient kernels' (cout, k, k, cin) order."""
+    _launch(lib().dy_grad_sink_flush, (entries.data_ptr(), entries.shape[0], grad.data_ptr(), sink.data_ptr()), keep=(entries, grad, sink))
 
 
 # ---- image sources ------------------------------------------------------------------------------------------------------

@@ -40,11 +40,41 @@ def conv_bn_fwd(x, weight, gamma, beta, bn, stride, pad, act, out=None):
     return z, st, y
 
 
+_SINK_ARMED = [False]  # set by the trainer around ITS forward + backward only: a backward run by anybody else keeps autograd's gradients
+
+
+class sink_armed:
+    def __enter__(self):
+        _SINK_ARMED[0] = True
+
+    def __exit__(self, *exc):
+        _SINK_ARMED[0] = False
+        return False
+
+
+def grad_sink(p):
+    """The flat fp32 slot a trainer set aside for this parameter's gradient of the current batch (``FlatState.enable_sink``), or
+    None.  With a slot the backward kernels write there and return no gradient to autograd, and one ``dy_grad_sink_flush`` per
+    batch adds every slot to ``param.grad`` — instead of one AccumulateGrad add (and one zero-filled temporary) per parameter."""
+    return getattr(p, "_dy_sink", None) if _SINK_ARMED[0] else None
+
+
 def conv_bn_bwd(dy, x, z, weight, gamma, beta, st, stride, pad, act, need_dx=True, dx_out=None, dx_accumulate=None):
     """(dx, dw, dgamma, dbeta) of conv_bn_fwd.  ``dx_accumulate``: a gradient already held for x (another consumer's
-    contribution), added in the dgrad epilogue; ``dx_out`` may be that same view (in place: a lane reads what it then overwrites)."""
-    dz, dgamma, dbeta = H.bn_train_bwd(as_nhwc(dy), z, gamma, beta, st, act)
-    dw = H.conv_wgrad(x, dz, weight.shape[2], stride, pad)[:, : weight.shape[1]]
+    contribution), added in the dgrad epilogue; ``dx_out`` may be that same view (in place: a lane reads what it then overwrites).
+    Parameter gradients that went to the trainer's sink come back as None."""
+    sg, sb, sw = grad_sink(gamma), grad_sink(beta), grad_sink(weight)
+    dz, dgamma, dbeta = H.bn_train_bwd(as_nhwc(dy), z, gamma, beta, st, act, dgamma=sg, dbeta=sb)
+    if sg is not None:
+        dgamma = None
+    if sb is not None:
+        dbeta = None
+    cout, cin, k, _ = weight.shape
+    if sw is not None and x.shape[1] == cin:  # (the image stem's input is padded to one chunk: its gradient is sliced, below)
+        H.conv_wgrad(x, dz, k, stride, pad, out=sw.view(cout, k, k, cin))
+        dw = None
+    else:
+        dw = H.conv_wgrad(x, dz, k, stride, pad)[:, :cin]
     dx = None
     if need_dx:
         dx = H.conv_dgrad(dz, H.pack_dgrad(weight, stride, x.dtype, x.device), stride, out=dx_out, accumulate=dx_accumulate)
@@ -177,10 +207,20 @@ class RepVGGTrain(torch.autograd.Function):
     def backward(ctx, dy):
         x, z3, z1, u, w3, g3, b3, w1, g1, b1 = ctx.saved_tensors
         du = H.silu_bwd(u, as_nhwc(dy))
-        dz3, dg3, db3 = H.bn_train_bwd(du, z3, g3, b3, ctx.s3, False)
-        dz1, dg1, db1 = H.bn_train_bwd(du, z1, g1, b1, ctx.s1, False)
-        dw3 = H.conv_wgrad(x, dz3, 3, ctx.stride, 1)
-        dw1 = H.conv_wgrad(x, dz1, 1, ctx.stride, 0)
+        dz3, dg3, db3 = H.bn_train_bwd(du, z3, g3, b3, ctx.s3, False, dgamma=grad_sink(g3), dbeta=grad_sink(b3))
+        dz1, dg1, db1 = H.bn_train_bwd(du, z1, g1, b1, ctx.s1, False, dgamma=grad_sink(g1), dbeta=grad_sink(b1))
+        dg3, db3 = (None if grad_sink(g3) is not None else dg3), (None if grad_sink(b3) is not None else db3)
+        dg1, db1 = (None if grad_sink(g1) is not None else dg1), (None if grad_sink(b1) is not None else db1)
+        if grad_sink(w3) is not None:
+            H.conv_wgrad(x, dz3, 3, ctx.stride, 1, out=grad_sink(w3).view(w3.shape[0], 3, 3, w3.shape[1]))
+            dw3 = None
+        else:
+            dw3 = H.conv_wgrad(x, dz3, 3, ctx.stride, 1)
+        if grad_sink(w1) is not None:
+            H.conv_wgrad(x, dz1, 1, ctx.stride, 0, out=grad_sink(w1).view(w1.shape[0], 1, 1, w1.shape[1]))
+            dw1 = None
+        else:
+            dw1 = H.conv_wgrad(x, dz1, 1, ctx.stride, 0)
         dx = H.conv_dgrad(dz3, H.pack_dgrad(w3, ctx.stride, x.dtype, x.device), ctx.stride)
         dx = H.conv_dgrad(dz1, H.pack_dgrad(w1, ctx.stride, x.dtype, x.device), ctx.stride, accumulate=dx)
         return dx, dw3, dg3, db3, dw1, dg1, db1, None, None, None

@@ -511,13 +511,21 @@ int32_t dy_add_nhwc(const void* a, const void* b, void* out, int64_t rows, int32
  *   min(1, max_norm / (sqrt(*grad_sumsq) + 1e-6)) inside the step — no host synchronisation.
  * dy_sgd_step:   g = clip*grad + wd*p;  buf = first_step ? g : momentum*buf + g;  p -= lr * (nesterov ? g + momentum*buf : buf).
  * dy_adamw_step: p *= 1 - lr*wd;  m,v = moments of clip*grad;  p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps); step >= 1.
- * dy_ema_update: ema = decay*ema + (1-decay)*p. */
+ * dy_ema_update: ema = decay*ema + (1-decay)*p.
+ * dy_grad_sink_flush: grad += sink (then sink = 0) for every parameter in ONE launch, where `sink` holds what the backward
+ *   kernels produced this batch at the parameter's offset in the flat buffers: weight gradients of dy_conv2d_wgrad_nhwc in
+ *   ITS layout (cout, k, k, cin), BatchNorm / bias gradients as they are.  Replaces what autograd's AccumulateGrad does per
+ *   parameter (engine/trainer.py:381-389 `loss.backward()`: `param.grad += new`, here ~240 element-wise launches and the
+ *   zero-fills of as many temporaries per step).  entries (device, n_entries x 4 int64): {offset, cout, cin, kk}; kk > 1: the
+ *   block [offset, offset + cout*cin*kk) of `grad` is (cout, cin, k, k) = torch's layout, of `sink` (cout, k, k, cin);
+ *   kk <= 1: plain vector of cout*cin elements. */
 int32_t dy_sumsq_f32(const float* g, int64_t n, double* out, dy_stream_t stream);
 int32_t dy_sgd_step(float* p, const float* grad, float* buf, int64_t n, float lr, float momentum, float weight_decay, int32_t nesterov,
                     int32_t first_step, const double* grad_sumsq, float max_norm, dy_stream_t stream);
 int32_t dy_adamw_step(float* p, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                       float weight_decay, int32_t step, const double* grad_sumsq, float max_norm, dy_stream_t stream);
 int32_t dy_ema_update(float* ema, const float* p, int64_t n, float decay, dy_stream_t stream);
+int32_t dy_grad_sink_flush(const int64_t* entries, int32_t n_entries, float* grad, float* sink, dy_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -333,6 +333,27 @@ def test_graphed_steps_equal_eager_steps(device):
             assert err <= 2e-3, (k, err)
 
 
+def test_grad_sink_flush_matches_permuted_add(device):
+    """dy_grad_sink_flush: grad += sink with conv-weight blocks transposed (cout, k, k, cin) -> (cout, cin, k, k), vectors as they
+    are, sink zeroed — against the same thing done per block in torch."""
+    g = torch.Generator().manual_seed(3)
+    blocks = [(64, 32, 9), (48, 1, 1), (16, 8, 1), (10, 1, 1), (128, 64, 9), (7, 3, 49)]
+    rows, off = [], 0
+    for co, ci, kk in blocks:
+        rows.append((off, co, ci, kk) if kk > 1 else (off, co * ci, 1, 1))
+        off += co * ci * kk
+    grad0, sink0 = torch.randn(off, generator=g), torch.randn(off, generator=g)
+    ref = grad0.clone()
+    for (o, co, ci, kk) in [(r[0], b[0], b[1], b[2]) for r, b in zip(rows, blocks)]:
+        n = co * ci * kk
+        blk = sink0[o : o + n]
+        ref[o : o + n] += (blk.view(co, kk, ci).permute(0, 2, 1).reshape(-1) if kk > 1 else blk)
+    grad, sink = grad0.to(device), sink0.to(device)
+    H.grad_sink_flush_(torch.tensor(rows, dtype=torch.int64, device=device), grad, sink)
+    torch.cuda.synchronize()
+    assert torch.allclose(grad.cpu(), ref, rtol=0, atol=1e-6) and float(sink.abs().max()) == 0.0
+
+
 def test_optimizer_kernels_match_torch_optim(device):
     """dy_sgd_step / dy_adamw_step / dy_ema_update / dy_sumsq_f32 (clip folded in) against torch.optim + clip_grad_norm_ on
     the same tensors, three steps, element-wise."""
