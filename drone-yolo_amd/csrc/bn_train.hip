@@ -50,6 +50,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const BnArgs p) {
   float* red = reinterpret_cast<float*>(dyn_smem);  // [2][R][c]
   const int tid = threadIdx.x;
   const int ch = tid % p.nch, rr = tid / p.nch;
+  if (blockIdx.x == 0)  // the totals bn_sum_partials_kernel (the next launch) adds into: zeroed here instead of by a memset node per call
+    for (int i = tid; i < 2 * p.c; i += 256) p.acc[i] = 0.0;
   float s0[E], s1[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) s0[e] = 0.f, s1[e] = 0.f;
@@ -290,7 +292,6 @@ static int bn_prepare(const dy_bn_desc* d, BnArgs* a, const char* who, bool bwd)
 
 template <typename T>
 static int bn_fwd_t(const BnArgs& a, hipStream_t st) {
-  if (hipMemsetAsync(a.acc, 0, (size_t)2 * a.c * 8, st) != hipSuccess) return check_launch("dy_bn_train_fwd memset");
   const unsigned blocks = (unsigned)((a.rows + a.rows_per_block - 1) / a.rows_per_block);
   const size_t smem = (size_t)2 * a.R * a.c * 4;
   hipLaunchKernelGGL((bn_reduce_kernel<T, 0>), dim3(blocks), dim3(256), smem, st, a);
@@ -304,7 +305,6 @@ static int bn_fwd_t(const BnArgs& a, hipStream_t st) {
 
 template <typename T>
 static int bn_bwd_t(const BnArgs& a, hipStream_t st) {
-  if (hipMemsetAsync(a.acc, 0, (size_t)2 * a.c * 8, st) != hipSuccess) return check_launch("dy_bn_train_bwd memset");
   const unsigned blocks = (unsigned)((a.rows + a.rows_per_block - 1) / a.rows_per_block);
   const size_t smem = (size_t)2 * a.R * a.c * 4;
   hipLaunchKernelGGL((bn_reduce_kernel<T, 1>), dim3(blocks), dim3(256), smem, st, a);
