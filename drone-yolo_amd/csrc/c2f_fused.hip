@@ -158,6 +158,9 @@ __global__ __launch_bounds__(512) void c2f_fused_kernel(const C2fArgs p) {
       *hr = idx >> 2, *hc = (idx & 3) + ((idx & 2) ? 16 : 0);
     }
   };
+  // Fragments i and i - 1 (i odd) of passes 0..2 are the halo rows 2k and 2k + 1: through the 2x upsample they read the SAME
+  // half-resolution row, so for the upsampled source's k chunks the odd fragment reuses the even one's registers (half the loads)
+  auto lo_twin = [&](int h, int c, int i) -> bool { return KC_LO > 0 && c < KC_LO && h < 3 && (i & 1); };
   auto pass_offsets = [&](int h, int n, int ty0, int tx0, bool valid, unsigned (&olo)[4], unsigned (&ohi)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(512) void c2f_fused_kernel(const C2fArgs p) {
     for (int j = (h < 2 ? 0 : 2); j < 4; ++j) bv[j] = __builtin_amdgcn_raw_buffer_load_b128(w1rs, w1off + (unsigned)((c * 4 + j) * 1024), 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (!(h == 3 && i == 3)) av[i] = load_x(c, olo[i], ohi[i]);
+      if (!(h == 3 && i == 3) && !lo_twin(h, c, i)) av[i] = load_x(c, olo[i], ohi[i]);
   };
   // cv2's weight fragments of k chunk c in result-lane k order: lane (cout lr, quarter lq) takes k = {4 lq .., 16 + 4 lq ..}
   auto issue_w2 = [&](int c, u32x4 (&wq)[4]) {
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(512) void c2f_fused_kernel(const C2fArgs p) {
         for (int i = 0; i < 4; ++i)
           if (!(h == 3 && i == 3)) {
 #pragma unroll
-            for (int j = (h < 2 ? 0 : 2); j < 4; ++j) acc[i][j] = Elem<T>::mma(b[c & 1][j], a[c & 1][i], acc[i][j]);
+            for (int j = (h < 2 ? 0 : 2); j < 4; ++j) acc[i][j] = Elem<T>::mma(b[c & 1][j], a[c & 1][lo_twin(h, c, i) ? i - 1 : i], acc[i][j]);
           }
         if (c + 2 < KC) issue_pass(h, c + 2, olo, ohi, a[c & 1], b[c & 1]);
         __builtin_amdgcn_sched_barrier(0);
