@@ -223,12 +223,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 // (S+3) x (15*S+3)... halo of x they touch ONCE, wave r owns kernel row r (taps (r,0), (r,1), (r,2): three 64 x 64
 // accumulator tiles), the dz fragments are read once per step and every tap's x fragments are transposed reads at
 // lane base + compile-time offset of the same halo tile: ~180 flop per staged byte.
+#ifdef DYOLO_ABLATE
+__device__ float wgrad3_probe_scratch[8][64 * 128 * 9];  // timing probe: per-XCD atomic targets (DYOLO_WGRAD3_DBG bit 16)
+#endif
+
 struct Wgrad3Args {
   const void* x;
   const void* dz;
   float* dw;
   int H, W, Cin, ldx, Ho, Wo, Cout, lddz;
   int tilesCo, tilesCi, stepsX, stepsY, nSteps, steps_per_block;
+  int dbg;  // timing probes (-DDYOLO_ABLATE builds, DYOLO_WGRAD3_DBG): 1 no global loads, 2 no LDS staging stores, 4 no MFMAs, 8 no transposed reads
 };
 
 // CW = cout fragments (of 16) per wave: 4 -> three waves (one per kernel row) with 3 x 64 x 64 accumulators each = 192 registers of
@@ -236,8 +241,11 @@ struct Wgrad3Args {
 // accumulator registers, two workgroups per CU = three waves per SIMD: the dz fragment reads halve, the x reads stay.
 // RS = output rows per step (2 or 4): a step of 4 rows does twice the MFMAs per staged halo row pair and per barrier, and the one
 // step of global-load prefetch then covers twice the time (the kernel is latency bound: one step of 32 pixels is ~0.2 us of MFMAs).
-template <typename T, int S, int CW, int RS>
-__global__ __launch_bounds__(192 * (4 / CW), (CW == 2 && S == 1 ? 3 : 1)) void conv_wgrad3x3_kernel(const Wgrad3Args p) {
+// PF = steps of global loads in flight in registers (1 or 2).  One step is ~0.4 us of MFMAs per workgroup, a load from HBM ~1-2 us:
+// without any global load the 64 -> 64 @160 launch takes 249 us instead of 513 (probes, ablate build).  PF = 2 costs 16 more
+// registers (two waves per SIMD instead of three), so it runs where the launch has one workgroup per CU anyway (see the slab rule).
+template <typename T, int S, int CW, int RS, int PF>
+__global__ __launch_bounds__(192 * (4 / CW), (CW == 2 && S == 1 ? (PF == 2 ? 2 : 3) : 1)) void conv_wgrad3x3_kernel(const Wgrad3Args p) {
   constexpr int NT = 192 * (4 / CW);
   constexpr int E = Elem<T>::EPC;                // 8
   constexpr int PITCH = 64 * (int)sizeof(T) + 32;  // 160 B rows: 64 channels + pad (conflict-free transposed reads)
@@ -269,8 +277,8 @@ __global__ __launch_bounds__(192 * (4 / CW), (CW == 2 && S == 1 ? 3 : 1)) void c
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  u32x4 stage[PER];
-  auto load_step = [&](int step) {
+  u32x4 stage[PF][PER];
+  auto load_step = [&](int step, u32x4 (&stg)[PER]) {
     const int bx = step % p.stepsX;
     int rest = step / p.stepsX;
     const int by = rest % p.stepsY, n = rest / p.stepsY;
@@ -279,6 +287,12 @@ __global__ __launch_bounds__(192 * (4 / CW), (CW == 2 && S == 1 ? 3 : 1)) void c
     for (int k = 0; k < PER; ++k) {
       const int id = k * NT + tid;
       u32x4 v = zero_chunk();
+#ifdef DYOLO_ABLATE
+      if (p.dbg & 1) {
+        stg[k] = u32x4{(unsigned)id, 0x3c003c00u, (unsigned)step, 0x3c003c00u};
+        continue;
+      }
+#endif
       if (id < NDZ * 8) {  // dz: pixel (row id/128, col (id/8)%16), chunk id%8
         const int px = id >> 3, ch = id & 7;
         const int yy = y0 + (px >> 4), xx = x0 + (px & 15), co = co0 + ch * E;
@@ -291,17 +305,20 @@ __global__ __launch_bounds__(192 * (4 / CW), (CW == 2 && S == 1 ? 3 : 1)) void c
         if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && ci < p.Cin)
           v = *reinterpret_cast<const u32x4*>(xg + ((long long)(n * p.H + gy) * p.W + gx) * p.ldx + ci);
       }
-      stage[k] = v;
+      stg[k] = v;
     }
   };
-  auto store_step = [&](int buf) {
+  auto store_step = [&](int buf, const u32x4 (&stg)[PER]) {
+#ifdef DYOLO_ABLATE
+    if (p.dbg & 2) return;
+#endif
     unsigned char* base = smem + buf * STAGE;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       const int id = k * NT + tid;
       if (id < NCHK) {
         const int px = id >> 3, ch = id & 7;  // dz rows first, the halo rows follow in the same pitch
-        *reinterpret_cast<u32x4*>(base + px * PITCH + ch * 16) = stage[k];
+        *reinterpret_cast<u32x4*>(base + px * PITCH + ch * 16) = stg[k];
       }
     }
   };
@@ -312,29 +329,61 @@ __global__ __launch_bounds__(192 * (4 / CW), (CW == 2 && S == 1 ? 3 : 1)) void c
   const int dz_lane = (lq * 4 + q4) * PITCH + pp * 8;
   const int x_lane = ((lq * 4 + q4) * S) * PITCH + pp * 8;
 
-  if (s_begin < s_end) load_step(s_begin);
-  int buf = 0;
-  for (int st = s_begin; st < s_end; ++st, buf ^= 1) {
-    store_step(buf);  // stage `buf` was last read two steps ago: the barrier of the previous step covers it
+  auto step_body = [&](int st, int buf, u32x4 (&stg)[PER]) {
+    store_step(buf, stg);  // stage `buf` was last read two steps ago: the barrier of the previous step covers it
     __syncthreads();
-    if (st + 1 < s_end) load_step(st + 1);  // in flight during the MFMAs
+    if (st + PF < s_end) load_step(st + PF, stg);  // in flight during the MFMAs of PF steps
     const unsigned char* tdz = smem + buf * STAGE;
     const unsigned char* tx = tdz + DZ_BYTES;
 #pragma unroll
     for (int hh = 0; hh < RS / 2; ++hh) {  // one 32-pixel MFMA k-step per pair of output rows
       u32x4 a[CW];
-      if constexpr (CW == 4) tr_read_frags<PITCH, 16 * PITCH>(tdz + dz_lane + hh * 32 * PITCH, a);
-      else tr_read_frags2<PITCH, 16 * PITCH>(tdz + dz_lane + hh * 32 * PITCH + chf * 64, a);  // channels [32*chf, 32*chf + 32) of the dz rows
+#ifdef DYOLO_ABLATE
+      const bool no_tr = p.dbg & 8, no_mma = p.dbg & 4;
+      if (no_tr) {
+#pragma unroll
+        for (int i = 0; i < CW; ++i) a[i] = u32x4{(unsigned)st, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+      } else
+#endif
+      {
+        if constexpr (CW == 4) tr_read_frags<PITCH, 16 * PITCH>(tdz + dz_lane + hh * 32 * PITCH, a);
+        else tr_read_frags2<PITCH, 16 * PITCH>(tdz + dz_lane + hh * 32 * PITCH + chf * 64, a);  // channels [32*chf, 32*chf + 32) of the dz rows
+      }
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         u32x4 b[4];
         // tap (r_, q): halo pixel of output (row, col) is ((row*S + r_) * HW + col*S + q); the second output row is S halo rows below
-        tr_read_frags<PITCH, S * HW * PITCH>(tx + x_lane + ((hh * 2 * S + r_) * HW + q) * PITCH, b);
+#ifdef DYOLO_ABLATE
+        if (no_tr) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b[j] = u32x4{(unsigned)q, 0x3c003c00u, 0x3c003c00u, (unsigned)st};
+        } else
+#endif
+          tr_read_frags<PITCH, S * HW * PITCH>(tx + x_lane + ((hh * 2 * S + r_) * HW + q) * PITCH, b);
+#ifdef DYOLO_ABLATE
+        if (no_mma) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(b[j]), "v"(a[0]));
+          continue;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < CW; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[q][i][j] = Elem<T>::mma(a[i], b[j], acc[q][i][j]);
       }
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < PF; ++d)
+    if (s_begin + d < s_end) load_step(s_begin + d, stage[d]);
+  if constexpr (PF == 1) {
+    int buf = 0;
+    for (int st = s_begin; st < s_end; ++st, buf ^= 1) step_body(st, buf, stage[0]);
+  } else {
+    for (int st = s_begin; st < s_end; st += 2) {  // two steps per trip: LDS stage and register set by the step's parity
+      step_body(st, 0, stage[0]);
+      if (st + 1 < s_end) step_body(st + 1, 1, stage[1]);
     }
   }
 
@@ -349,6 +398,14 @@ __global__ __launch_bounds__(192 * (4 / CW), (CW == 2 && S == 1 ? 3 : 1)) void c
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int co = co0 + (chf * CW + i) * 16 + lq * 4 + e;
+#ifdef DYOLO_ABLATE
+          if ((p.dbg & 16) && p.Cout * p.Cin <= 64 * 128) {
+            const unsigned xcd = (blockIdx.x + gridDim.x * blockIdx.y) & 7;
+            if (co < p.Cout && ci < p.Cin) atomicAdd(&wgrad3_probe_scratch[xcd][((size_t)co * 9 + tap) * p.Cin + ci], acc[q][i][j][e]);
+            continue;
+          }
+          if (p.dbg & 32) continue;  // no atomics at all
+#endif
           if (co < p.Cout && ci < p.Cin) atomicAdd(p.dw + ((size_t)co * 9 + tap) * p.Cin + ci, acc[q][i][j][e]);
         }
       }
@@ -363,15 +420,28 @@ static int launch_wgrad3_rs(const WgradArgs& a, int batch, hipStream_t st) {
   p.stepsX = (p.Wo + 15) / 16, p.stepsY = (p.Ho + RS - 1) / RS;
   p.nSteps = batch * p.stepsY * p.stepsX;
   const int ny = p.tilesCo * p.tilesCi;
-  int slabs = (512 + ny - 1) / ny;  // two six-wave workgroups per CU overall
+  // Pixel slabs: every slab ends with Cout x Cin x 9 fp32 atomics, so their number is a trade between filling the CUs and atomic
+  // traffic (512 slabs of a 64 x 64 layer = 18.9 M atomics ~ 65 us, a third of the launch at 80 x 80), and a workgroup alone on
+  // its CU may hold two steps of loads in registers (PF = 2).  Measured at B = 64 (tools/bench_wgrad.py; DYOLO_WGRAD3_SLABS / _PF2
+  // in the ablate build): stride 1, 256 workgroups + PF 2 against 512 + PF 1: 64 -> 64 @160 288 / 518 us (420 TFLOP/s), @80 114 /
+  // 180, 128 -> 128 @40 101 / 171, 64 -> 128 @80 184 / 223, 256 -> 256 @20 118 / 144; stride 2 (two rows per step, halo 5 x 33)
+  // the other way round: 64 -> 64 173 / 185, 32 -> 64 @320 408 / 660, 128 -> 256 267 / 307.
+  static const int force_pf2 = dy_ablate("DYOLO_WGRAD3_PF2");  // probe: 1 = one workgroup per CU + two steps of loads in flight for every shape, 2 = for none
+  const int target = force_pf2 == 2 ? 512 : ((S == 1 || force_pf2 == 1) ? 256 : 512);
+  int slabs = (target + ny - 1) / ny;
   const int max_slabs = (p.nSteps + 7) / 8;
   if (slabs > max_slabs) slabs = max_slabs;
   if (slabs < 1) slabs = 1;
   p.steps_per_block = (p.nSteps + slabs - 1) / slabs;
+  p.dbg = dy_ablate("DYOLO_WGRAD3_DBG");
+#ifdef DYOLO_ABLATE
+  if (const int sl = dy_ablate("DYOLO_WGRAD3_SLABS")) p.steps_per_block = (p.nSteps + sl - 1) / sl;  // probe: another pixel-slab count
+#endif
   const unsigned gx = (unsigned)((p.nSteps + p.steps_per_block - 1) / p.steps_per_block);
   static const int cw4 = dy_ablate("DYOLO_WGRAD3_CW4");
-  if (cw4) hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, S, 4, RS>), dim3(gx, (unsigned)ny), dim3(192), 0, st, p);
-  else hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, S, 2, RS>), dim3(gx, (unsigned)ny), dim3(384), 0, st, p);
+  if (cw4) hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, S, 4, RS, 1>), dim3(gx, (unsigned)ny), dim3(192), 0, st, p);
+  else if (target == 256) hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, S, 2, RS, 2>), dim3(gx, (unsigned)ny), dim3(384), 0, st, p);
+  else hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, S, 2, RS, 1>), dim3(gx, (unsigned)ny), dim3(384), 0, st, p);
   return check_launch("conv_wgrad3x3_kernel");
 }
 

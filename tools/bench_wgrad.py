@@ -7,9 +7,14 @@ from drone_yolo_amd import hip_ops as H
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--lib", default="", help="another build of libdyolo.so (make ABLATE=1 OUT=...): reads DYOLO_WGRAD3_* probes")
 ap.add_argument("shapes", nargs="*", default=["32,64,3,2,320", "64,64,3,1,160", "32,32,3,1,160", "64,128,3,2,160", "64,64,3,1,80", "128,128,3,1,40",
                                                "256,256,3,1,20", "128,64,3,1,80", "192,128,1,1,80", "96,64,1,1,160", "768,512,1,1,20"])
 a = ap.parse_args()
+if a.lib:
+    from drone_yolo_amd import _lib
+
+    _lib.LIB_PATH = os.path.abspath(a.lib)
 dev = torch.device("cuda", 0)
 dt = torch.bfloat16
 for sh in a.shapes:
@@ -28,4 +33,4 @@ for sh in a.shapes:
     us = st.elapsed_time(en) / a.iters * 1e3
     fl = 2.0 * a.batch * ho * ho * cout * cin * k * k
     by = (x.numel() + dz.numel()) * 2
-    print(f"{sh:<18s} B={a.batch}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s  {by / us / 1e3:7.0f} GB/s (x + dz once)")
+    print(f"{sh:<18s} B={a.batch} dbg={os.environ.get('DYOLO_WGRAD3_DBG', '0')}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s  {by / us / 1e3:7.0f} GB/s (x + dz once)")
