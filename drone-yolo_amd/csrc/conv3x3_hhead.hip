@@ -234,7 +234,12 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hhead_kernel(const HheadArgs p
         op[(size_t)(axis + 2) * p.A] = (hi - lo) * p.stride;
       }
     } else {
-      // 1x1 64 -> nc (one 16-cout fragment): the waves split the rows; sigmoid, scores out, first arg-max, candidate filter
+      // 1x1 64 -> nc (one 16-cout fragment): the waves split the rows; sigmoid, scores out, first arg-max, candidate filter.
+      // The wave's two rows are filtered together: ONE counter atomic (with return: the wave waits for it) per wave and tile
+      // instead of one per row - on the P2 level every tile has candidates and the atomics of an image all hit one address.
+      float bestv[2];
+      int bjv[2], av[2];
+      bool passv[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int o = wave * 2 + j;
@@ -263,19 +268,24 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hhead_kernel(const HheadArgs p
           const int oj = __shfl_xor(bj, sh);
           if (ob > best || (ob == best && oj < bj)) best = ob, bj = oj;
         }
-        if (p.keys != nullptr) {
-          bool pass = inside && lq == 0 && best > p.conf;
-          if (pass && p.cmask) pass = p.cmask[bj] != 0;
-          const unsigned long long mk = __ballot(pass);
-          if (mk != 0ull) {
-            const int leader = __ffsll((long long)mk) - 1;
-            int base = 0;
-            if (lane == leader) base = atomicAdd(p.counts + n, __popcll(mk));
-            base = __shfl(base, leader);
-            if (pass) {
-              const int pos = base + __popcll(mk & ((1ull << lane) - 1ull));
-              p.keys[(size_t)n * p.P + pos] = ((unsigned long long)(~__float_as_uint(best)) << 32) | (unsigned long long)(unsigned)a;
-              p.cls[(size_t)n * p.A + a] = (unsigned short)bj;
+        bool pass = p.keys != nullptr && inside && lq == 0 && best > p.conf;
+        if (pass && p.cmask) pass = p.cmask[bj] != 0;
+        bestv[j] = best, bjv[j] = bj, av[j] = a, passv[j] = pass;
+      }
+      if (p.keys != nullptr) {
+        const unsigned long long mk0 = __ballot(passv[0]), mk1 = __ballot(passv[1]);
+        const int n0 = __popcll(mk0), total = n0 + __popcll(mk1);
+        if (total != 0) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(p.counts + n, total);
+          base = __shfl(base, 0);
+          const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if (passv[j]) {
+              const int pos = base + (j ? n0 : 0) + __popcll((j ? mk1 : mk0) & below);
+              p.keys[(size_t)n * p.P + pos] = ((unsigned long long)(~__float_as_uint(bestv[j])) << 32) | (unsigned long long)(unsigned)av[j];
+              p.cls[(size_t)n * p.A + av[j]] = (unsigned short)bjv[j];
             }
           }
         }
