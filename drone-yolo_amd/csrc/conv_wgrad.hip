@@ -463,8 +463,11 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
   p.tilesCi = (p.Cin + 64 * WCI - 1) / (64 * WCI);
   const int ny = p.ks * p.ks * p.tilesCo * p.tilesCi;
   constexpr int STEP = 32 * (4 / (WCO * WCI));
-  // pixel slabs: fill ~4 workgroups per CU overall, but keep every slab at least 8 steps long
-  long long slabs = (1024 + ny - 1) / ny;
+  // pixel slabs: ~2 workgroups per CU overall, every slab at least 8 steps long.  Every slab ends with its tile's fp32 atomics, and with 1024 workgroups those cost more
+  // than the extra latency hiding bought (B = 64, tools/bench_wgrad.py, 1024 -> 512 -> 256 workgroups: 192 -> 128 @80 124 / 104 / 136 us,
+  // 384 -> 256 @40 106 / 79 / 106, 64 -> 64 @160 163 / 131 / 134, 768 -> 512 @20 96 / 80 / 100)
+  static const int tgt = dy_ablate("DYOLO_WGRAD_TARGET");  // probe: workgroups overall
+  long long slabs = ((tgt ? tgt : 512) + ny - 1) / ny;
   const long long max_slabs = (p.M + 8LL * STEP - 1) / (8LL * STEP);
   if (slabs > max_slabs) slabs = max_slabs;
   if (slabs < 1) slabs = 1;
