@@ -145,6 +145,7 @@ class BnDesc(C.Structure):
 SIGNATURES = {
     "dy_version": (_i32, []),
     "dy_last_error_string": (C.c_char_p, []),
+    "dy_last_kernel_name": (C.c_char_p, []),
     "dy_dtype_size": (_i32, [_i32]),
     "dy_conv_k_pad": (_i32, [_i32, _i32, _i32]),
     "dy_conv_cout_pad": (_i32, [_i32]),
@@ -182,8 +183,9 @@ SIGNATURES = {
     "dy_maxpool_bwd_nhwc": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dy_add_nhwc": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dy_sumsq_f32": (_i32, [_vp, _i64, _vp, _vp]),
-    "dy_sgd_step": (_i32, [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _i32, _i32, _vp, _f32, _vp]),
-    "dy_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _f32, _vp]),
+    "dy_sgd_step": (_i32, [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _i32, _i32, _vp, _f32, _vp, _vp]),
+    "dy_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _f32, _vp, _vp]),
+    "dy_amp_update": (_i32, [_vp, _vp, _f32, _f32, _i32, _vp]),
     "dy_ema_update": (_i32, [_vp, _vp, _i64, _f32, _vp]),
     "dy_grad_sink_flush": (_i32, [_vp, _i32, _vp, _vp, _vp]),
     "dy_bn_workspace_bytes": (_i64, [_i32]),

@@ -7,6 +7,7 @@
 namespace dy {
 
 static thread_local char g_err[512] = {0};
+static thread_local const char* g_kernel = "";  // name the last launching call passed to check_launch (static storage)
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -18,6 +19,7 @@ void set_error(const char* fmt, ...) {
 // Launch errors surface here; hipGetLastError also clears the sticky flag so that one
 // failed call does not poison the next.
 int check_launch(const char* what) {
+  g_kernel = what;
   const hipError_t e = hipGetLastError();
   if (e == hipSuccess) return DY_OK;
   set_error("%s: %s", what, hipGetErrorString(e));
@@ -29,6 +31,8 @@ int check_launch(const char* what) {
 extern "C" int32_t dy_version(void) { return (DYOLO_VERSION_MAJOR << 16) | DYOLO_VERSION_MINOR; }
 
 extern "C" const char* dy_last_error_string(void) { return dy::g_err; }
+
+extern "C" const char* dy_last_kernel_name(void) { return dy::g_kernel; }
 
 extern "C" int32_t dy_dtype_size(int32_t dtype) {
   switch (dtype) {

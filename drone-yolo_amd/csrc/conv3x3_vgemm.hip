@@ -584,6 +584,7 @@ static int launch_vgemm(const ConvArgs& a, hipStream_t st) {
   static const int var = dy_ablate("DYOLO_VGEMM_VAR");
   const bool narrow = g.S <= 6 * 64;  // maps up to 62 wide: 48 KiB halo stages leave room for a third weight stage
   const dim3 gr((unsigned)grid), bl(512);
+  const char* name = "conv3x3_vgemm_kernel";
   if (!narrow) {
     if (var == 1)
       hipLaunchKernelGGL((conv3x3_vgemm_kernel<T, 7, 3, true>), gr, bl, 0, st, p, g);
@@ -599,10 +600,11 @@ static int launch_vgemm(const ConvArgs& a, hipStream_t st) {
     // sixteen waves of 32 x 64 hide more of the per-step waits than eight of 64 x 64: 3-5 % faster on every shape in an
     // alternating A/B (tools/ab_conv.sh; 128->128 @40x40 160 -> 151 us, 256->256 @20x20 145 -> 138 us)
     hipLaunchKernelGGL((conv3x3_vgemm16_kernel<T, 3, 3>), gr, dim3(1024), 0, st, p, g);
+    name = "conv3x3_vgemm16_kernel";
   } else {
     hipLaunchKernelGGL((conv3x3_vgemm_kernel<T, 6, 3, false>), gr, bl, 0, st, p, g);
   }
-  return check_launch("conv3x3_vgemm_kernel");
+  return check_launch(name);
 }
 
 // Returns 1 when the shape is not one this kernel is built for, else the launch status.

@@ -462,7 +462,7 @@ static int launch_glds_persist(const ConvArgs& a, hipStream_t st) {
   int grid = 256 * per_cu;
   if (grid > p.nblk) grid = p.nblk;
   hipLaunchKernelGGL((conv_gemm_glds_persist_kernel<T, BN>), dim3((unsigned)grid), dim3(256), 0, st, p);
-  return check_launch("conv_gemm_glds_persist_kernel");
+  return check_launch(BN == 128 ? "conv_gemm_glds_persist_kernel<128>" : "conv_gemm_glds_persist_kernel<64>");
 }
 
 template <typename T, int BM, int BN, int STAGES, int WN = 2>
@@ -473,7 +473,8 @@ static int launch_glds(const ConvArgs& a, hipStream_t st) {
   p.nblk = tilesM * p.tilesN;
   auto kern = conv_gemm_glds_kernel<T, BM, BN, STAGES, WN>;
   hipLaunchKernelGGL(kern, dim3((unsigned)p.nblk), dim3(BM * WN), 0, st, p);  // static LDS only (up to 144 KiB)
-  return check_launch("conv_gemm_glds_kernel");
+  return check_launch(BM == 256 && BN == 256 ? "conv_gemm_glds_kernel<256,256>" : BM == 256 ? "conv_gemm_glds_kernel<256,128>"
+                      : BN == 128 ? "conv_gemm_glds_kernel<128,128>" : "conv_gemm_glds_kernel<128,64>");
 }
 
 template <typename T>

@@ -138,17 +138,39 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if ((threadIdx.x & 63) == 0 && s != 0.0) atomicAdd(out, s);
 }
 
+// Loss-scaling state of torch.cuda.amp.GradScaler kept on the device (reference: engine/trainer.py:271, 389, 591-599):
+//   amp[0] scale, amp[1] growth tracker (unskipped steps since the last change), amp[2] found_inf of the last step, amp[3] skipped steps.
+// With `amp` the optimizer kernels fold `scaler.unscale_` into the step (grad / scale; the clip norm is sqrt(sumsq) / scale) and skip
+// the step when the squared-gradient sum is not finite, as `scaler.step` does; dy_amp_update is `scaler.update()`.
+struct StepScale {
+  float inv, clip;
+  bool skip;
+};
+__device__ __forceinline__ StepScale step_scale(const double* sumsq, float max_norm, const float* amp) {
+  StepScale r{1.f, 1.f, false};
+  if (amp) r.inv = 1.f / amp[0];
+  if (sumsq) {
+    const double ss = *sumsq;
+    if (amp && !(ss == ss && ss < 1.7e308)) {
+      r.skip = true;
+      return r;
+    }
+    const float c = max_norm / ((float)sqrt(ss) * r.inv + 1e-6f);
+    r.clip = c < 1.f ? c : 1.f;
+  }
+  return r;
+}
+
 // torch.optim.SGD (momentum, nesterov, weight decay) with the clip coefficient folded in:
 //   g = clip * grad + wd * p;  buf = first ? g : mom * buf + g;  p -= lr * (nesterov ? g + mom * buf : buf)
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ buf, long long n, float lr, float mom,
-                                                  float wd, int nesterov, int first, const double* sumsq, float max_norm) {
-  float clip = 1.f;
-  if (sumsq) {
-    const float c = max_norm / ((float)sqrt(*sumsq) + 1e-6f);
-    clip = c < 1.f ? c : 1.f;
-  }
+                                                  float wd, int nesterov, int first, const double* sumsq, float max_norm, const float* amp) {
+  const StepScale sc = step_scale(sumsq, max_norm, amp);
+  if (sc.skip) return;
+  // (a skipped first step leaves buf at its zeros, so the next step's mom * buf + g equals the "first" form: no extra state)
+  const float k = sc.inv * sc.clip;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    float g = grad[i] * clip + wd * p[i];
+    float g = grad[i] * k + wd * p[i];
     const float b = first ? g : mom * buf[i] + g;
     buf[i] = b;
     g = nesterov ? g + mom * b : b;
@@ -158,14 +180,14 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 
 // torch.optim.AdamW: p *= 1 - lr*wd;  m, v moments;  p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v, long long n,
-                                                    float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s, const double* sumsq, float max_norm) {
-  float clip = 1.f;
-  if (sumsq) {
-    const float c = max_norm / ((float)sqrt(*sumsq) + 1e-6f);
-    clip = c < 1.f ? c : 1.f;
-  }
+                                                    float lr, float b1, float b2, float eps, float wd, int step, const double* sumsq, float max_norm, const float* amp) {
+  const StepScale sc = step_scale(sumsq, max_norm, amp);
+  if (sc.skip) return;
+  const float t = (float)(step - (amp ? (int)amp[3] : 0));  // optimizer.step() calls that really ran (skipped ones leave state['step'] alone)
+  const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
+  const float k = sc.inv * sc.clip;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const float g = grad[i] * clip;
+    const float g = grad[i] * k;
     float pp = p[i] * (1.f - lr * wd);
     const float mm = m[i] * b1 + (1.f - b1) * g;
     const float vv = v[i] * b2 + (1.f - b2) * g * g;
@@ -173,6 +195,27 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     v[i] = vv;
     pp -= (lr / bc1) * mm / (sqrtf(vv) / bc2s + eps);
     p[i] = pp;
+  }
+}
+
+// GradScaler.update(): found_inf -> scale *= backoff, tracker = 0; else tracker += 1 and scale *= growth every `interval` clean steps
+__global__ void amp_update_kernel(float* amp, const double* sumsq, float growth, float backoff, int interval) {
+  if (threadIdx.x || blockIdx.x) return;
+  const double ss = *sumsq;
+  const bool bad = !(ss == ss && ss < 1.7e308);
+  amp[2] = bad ? 1.f : 0.f;
+  if (bad) {
+    amp[0] *= backoff;
+    amp[1] = 0.f;
+    amp[3] += 1.f;
+  } else {
+    const float t = amp[1] + 1.f;
+    if ((int)t >= interval) {
+      amp[0] *= growth;
+      amp[1] = 0.f;
+    } else {
+      amp[1] = t;
+    }
   }
 }
 
@@ -383,20 +426,28 @@ extern "C" int32_t dy_sumsq_f32(const float* g, int64_t n, double* out, dy_strea
 }
 
 extern "C" int32_t dy_sgd_step(float* p, const float* grad, float* buf, int64_t n, float lr, float momentum, float weight_decay, int32_t nesterov, int32_t first_step,
-                               const double* grad_sumsq, float max_norm, dy_stream_t stream) {
+                               const double* grad_sumsq, float max_norm, const float* amp_state, dy_stream_t stream) {
   DY_REQUIRE(p && grad && buf && n > 0, DY_ERR_INVALID_ARG, "dy_sgd_step: bad arguments");
+  DY_REQUIRE(!amp_state || grad_sumsq, DY_ERR_INVALID_ARG, "dy_sgd_step: amp_state needs grad_sumsq (the overflow check reads it)");
   hipLaunchKernelGGL(sgd_kernel, dim3(grid1(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, grad, buf, (long long)n, lr, momentum, weight_decay, nesterov,
-                     first_step, grad_sumsq, max_norm);
+                     first_step, grad_sumsq, max_norm, amp_state);
   return check_launch("dy_sgd_step");
 }
 
 extern "C" int32_t dy_adamw_step(float* p, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
-                                 int32_t step, const double* grad_sumsq, float max_norm, dy_stream_t stream) {
+                                 int32_t step, const double* grad_sumsq, float max_norm, const float* amp_state, dy_stream_t stream) {
   DY_REQUIRE(p && grad && m && v && n > 0 && step >= 1, DY_ERR_INVALID_ARG, "dy_adamw_step: bad arguments");
-  const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid1(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, grad, m, v, (long long)n, lr, beta1, beta2, eps, weight_decay, bc1,
-                     bc2s, grad_sumsq, max_norm);
+  DY_REQUIRE(!amp_state || grad_sumsq, DY_ERR_INVALID_ARG, "dy_adamw_step: amp_state needs grad_sumsq (the overflow check reads it)");
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid1(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, grad, m, v, (long long)n, lr, beta1, beta2, eps, weight_decay,
+                     step, grad_sumsq, max_norm, amp_state);
   return check_launch("dy_adamw_step");
+}
+
+extern "C" int32_t dy_amp_update(float* amp_state, const double* grad_sumsq, float growth_factor, float backoff_factor, int32_t growth_interval, dy_stream_t stream) {
+  DY_REQUIRE(amp_state && grad_sumsq && growth_factor >= 1.f && backoff_factor > 0.f && backoff_factor <= 1.f && growth_interval >= 1, DY_ERR_INVALID_ARG,
+             "dy_amp_update: bad arguments");
+  hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), amp_state, grad_sumsq, growth_factor, backoff_factor, growth_interval);
+  return check_launch("dy_amp_update");
 }
 
 // grad += sink (sink -> 0), weight blocks transposed from the weight-gradient kernels' (cout, k, k, cin) to torch's (cout, cin, k, k).

@@ -109,7 +109,10 @@ class Model(nn.Module):
         if multi and last.exists():
             self._load(str(last))
         elif not multi:
-            self.model.eval()  # the live model carries the trained weights (flat-buffer views); packs are dropped by train() -> eval()
+            # the reference continues with best/last.pt = the EMA weights whatever the GPU count (model.py:812-814); the live model holds
+            # the raw optimizer weights (flat-buffer views), so the EMA state is loaded into it (same values last.pt carries, fp32)
+            self.model.load_state_dict(self.trainer.ema.state_dict(self.model))
+            self.model.eval()  # packs are dropped by train() -> eval()
         self.predictor = None
         return out
 

@@ -53,13 +53,15 @@ def get_cfg(overrides: Optional[dict] = None) -> dict:
     return cfg
 
 
-def param_group_names(model: nn.Module) -> Tuple[List[str], List[str], List[str]]:
-    """(decay weights, norm weights, biases) in module order — build_optimizer's split (trainer.py:795-808)."""
+def param_group_names(model: nn.Module, include_frozen: bool = False) -> Tuple[List[str], List[str], List[str]]:
+    """(decay weights, norm weights, biases) in module order — build_optimizer's split (trainer.py:795-808).  The reference does
+    not filter on requires_grad (its decay group also holds the frozen ``model.N.dfl.conv.weight``): ``include_frozen`` gives that
+    enumeration (the optimizer state-dict's indices); the flat training buffers hold the trainable parameters only."""
     g0, g1, g2 = [], [], []
     bn = tuple(v for k, v in nn.__dict__.items() if "Norm" in k)
     for mname, m in model.named_modules():
         for pname, p in m.named_parameters(recurse=False):
-            if not p.requires_grad:
+            if not p.requires_grad and not include_frozen:
                 continue
             full = f"{mname}.{pname}" if mname else pname
             if "bias" in full:
@@ -116,8 +118,8 @@ class FlatState:
         """A second flat buffer the backward kernels write this batch's parameter gradients into (nn/autograd_ops.py::grad_sink:
         weight gradients in the wgrad kernels' (cout, k, k, cin) order, BatchNorm gradients as they are), folded into G by ONE
         ``dy_grad_sink_flush`` launch per batch (``flush_sink``) — instead of autograd's AccumulateGrad per parameter: ~240
-        element-wise launches plus the zero-fills of as many temporaries per step.  Single rank only: the bucketed all-reduce is
-        driven by AccumulateGrad hooks."""
+        element-wise launches plus the zero-fills of as many temporaries per step.  With several ranks ``parallel.GradBuckets`` flushes
+        the sink bucket by bucket (``use_sink``) and all-reduces each bucket behind its flush."""
         self.S = torch.zeros_like(self.G)
         rows = []
         for k, (off, c) in self.offsets.items():
@@ -290,6 +292,49 @@ class OptimSchedule:
             self.cur_momentum = float(np.interp(ni, xi, [a["warmup_momentum"], a["momentum"]]))
 
 
+_EXT_EVENTS: Dict[str, bool] = {}
+
+
+def external_events_work(device) -> bool:
+    """Does an EXTERNAL event recorded inside a hipGraph order a second stream on this runtime?  Probed once per device with a
+    small graph: a chain of kernels ends in a write of ``x``, the event is recorded behind it, and a side stream that waits for the
+    event copies ``x`` — a wait that did nothing would copy the stale value while the chain still runs.  Three replays, three values."""
+    key = str(device)
+    if key in _EXT_EVENTS:
+        return _EXT_EVENTS[key]
+    ok = False
+    try:
+        ev = torch.cuda.Event(external=True)
+        side = torch.cuda.Stream(device=device)
+        a = torch.randn(2048, 2048, device=device)
+        src = torch.zeros(1, device=device)
+        x = torch.zeros(1, device=device)
+        y = torch.zeros(1, device=device)
+        torch.cuda.synchronize(device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            t = a
+            for _ in range(24):  # a few ms of work in front of the write
+                t = torch.mm(t, a) * 1e-3
+            x.copy_(src + t[0, 0] * 0.0)
+            ev.record()
+            for _ in range(4):
+                t = torch.mm(t, a) * 1e-3
+        ok = True
+        for val in (3.0, 7.0, 11.0):
+            src.fill_(val)
+            g.replay()
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                y.copy_(x)
+            torch.cuda.synchronize(device)
+            ok = ok and float(y) == val
+    except Exception:
+        ok = False
+    _EXT_EVENTS[key] = ok
+    return ok
+
+
 # ---- trainer -------------------------------------------------------------------------------------------------------------
 class DetectionTrainer:
     """``DetectionTrainer(model, overrides)`` for tensor batches (``step``) or ``DetectionTrainer(overrides=...)`` +
@@ -374,13 +419,18 @@ class DetectionTrainer:
         self.buf1 = torch.zeros(n, dtype=torch.float32, device=self.device)  # momentum / first moment
         self.buf2 = torch.zeros(n, dtype=torch.float32, device=self.device) if name == "AdamW" else None
         self.sumsq = torch.zeros(1, dtype=torch.float64, device=self.device)
+        # GradScaler(enabled=amp) of the reference (trainer.py:271) for fp16 storage: {scale, growth tracker, found_inf, skipped} on the
+        # device, so a step never waits for the host.  bf16 / fp32 storage have fp32's exponent range: no scaler (scale stays 1).
+        self.amp_state = torch.tensor([65536.0, 0.0, 0.0, 0.0], dtype=torch.float32, device=self.device) if self.model.train_dtype == torch.float16 else None
         self.ema = ModelEMA(self.flat)
         self.opt_steps = 0
         self.iters = 0
         self.last_opt_step = -1
         self.buckets = P.GradBuckets(self.flat, n_buckets=int(os.environ.get("DYOLO_GRAD_BUCKETS", 4))) if self.world > 1 else None
-        if self.world == 1 and self.grad_sink:
+        if self.grad_sink:
             self.flat.enable_sink()
+            if self.buckets is not None:
+                self.buckets.use_sink()  # several ranks: the sink is flushed bucket by bucket, each flush followed by the bucket's all-reduce
 
     # ---- schedules (state lives in self.sched) ------------------------------------------------------------------------------
     cur_lrs = property(lambda self: self.sched.cur_lrs)
@@ -424,28 +474,41 @@ class DetectionTrainer:
             self.last_opt_step = ni
         return loss.detach() * self.world, items  # the reference reports loss * world_size (trainer.py:382-383)
 
-    graph_steps = True  # single rank: forward + loss + backward recorded once as a hipGraph and replayed (see _forward_backward)
-    grad_sink = True  # single rank: parameter gradients through FlatState's sink (one flush per batch) instead of AccumulateGrad
+    graph_steps = os.environ.get("DYOLO_TRAIN_GRAPH", "1") != "0"  # forward + loss + backward recorded once as a hipGraph and replayed (see _forward_backward)
+    grad_sink = True  # parameter gradients through FlatState's sink (one flush per batch / per bucket) instead of AccumulateGrad
 
     def _forward_backward(self, batch: Dict[str, torch.Tensor]):
         """loss, items = model(batch); loss.backward() (trainer.py:379-389).
 
         A step is ~2,400 kernel launches from Python; the GPU needs ~40 ms for them, the host 40-130 ms depending on what
-        else runs on the box, so the step is host bound.  With one rank the whole forward + loss + backward is therefore
-        captured into a hipGraph (torch.cuda.CUDAGraph: activations live in the graph's private pool) once per (image shape,
-        label capacity) and replayed: the images and the label table are copied into static buffers, the parameter gradients
-        accumulate into the flat gradient buffer exactly as in the eager backward.  Nothing in it depends on a host value that
-        changes between steps; the optimizer step (learning rate, momentum, EMA decay, first-step flag) stays outside.
-        Several ranks run eagerly: the bucketed all-reduce is issued from autograd hooks."""
-        use = (self.graph_steps and self.world == 1 and self.buckets is None and self.iters >= 2 and batch["img"].is_cuda
-               and self.model.training and not os.environ.get("DYOLO_FORCE_DEVICE"))
+        else runs on the box, so the step is host bound.  The whole forward + loss + backward is therefore captured into a
+        hipGraph (torch.cuda.CUDAGraph: activations live in the graph's private pool) once per (image shape, label capacity)
+        and replayed: the images and the label table are copied into static buffers, the parameter gradients accumulate into
+        the flat gradient buffer exactly as in the eager backward.  Nothing in it depends on a host value that changes between
+        steps; the optimizer step (learning rate, momentum, EMA decay, first-step flag) stays outside.
+        Several ranks (reference: DistributedDataParallel, trainer.py:274, whose bucket all-reduces overlap backward): the same ONE
+        graph; inside it every gradient bucket's sink flush is followed by an EXTERNAL event record (a graph node), and after the
+        replay is launched the bucket all-reduces are issued on a second stream, each behind its bucket's event — bucket k's ring
+        runs under the backward kernels of buckets k+1.. — so the host still enqueues ~10 calls per step instead of ~2,400."""
+        use = (self.graph_steps and self.iters >= 2 and batch["img"].is_cuda and self.model.training
+               and (self.world == 1 or self.grad_sink))
         from ..nn.autograd_ops import sink_armed
+
+        bk = self.buckets
+
+        def backward(loss):
+            # scaler.scale(loss).backward() (trainer.py:389): the seed of the backward pass is the device-resident scale
+            with sink_armed(bk.note if bk is not None else None):
+                (loss * self.amp_state[0] if self.amp_state is not None else loss).backward()
+            if bk is not None:
+                bk.end_backward()  # buckets backward did not run down (parameters without a gradient): flushed / issued in order
+            else:
+                self.flat.flush_sink()
 
         if not use:
             with sink_armed():
                 loss, items = self.model(batch)
-                loss.backward()
-            self.flat.flush_sink()
+            backward(loss)
             return loss, items
         model = self.model
         if getattr(model, "criterion", None) is None:
@@ -453,29 +516,60 @@ class DetectionTrainer:
         img = batch["img"]
         b, _, h, w = img.shape
         gt = model.criterion.targets_to_gt(batch, b, (h, w))
-        cap = max(64, -(-gt.shape[1] // 64) * 64)
-        key = (tuple(img.shape), img.dtype, cap, model.train_dtype)
-        gs = getattr(self, "_graph", None)
-        if gs is None or gs["key"] != key:
+        # label capacity of the static table: multiples of 64, never shrinking for a shape (Poisson(50) counts wander across 64 from
+        # batch to batch; re-capturing on every crossing was a silent cliff), one graph per (shape, capacity) kept in a small dict
+        caps = self.__dict__.setdefault("_graph_caps", {})
+        shape_key = (tuple(img.shape), img.dtype, model.train_dtype)
+        cap = max(caps.get(shape_key, 128), -(-gt.shape[1] // 64) * 64)
+        caps[shape_key] = cap
+        key = shape_key + (cap,)
+        graphs = self.__dict__.setdefault("_graphs", {})
+        gs = graphs.get(key)
+        if gs is None:
+            for k in [k for k in graphs if k[:3] == shape_key]:  # a smaller capacity of this shape is never used again
+                del graphs[k]
             gs = dict(key=key, img=torch.empty_like(img), gt=torch.zeros((b, cap, 5), dtype=torch.float32, device=img.device))
             gs["img"].copy_(img)
+            armed = bk.armed if bk is not None else False
+            if bk is not None:
+                if bk.events is None and os.environ.get("DYOLO_DDP_OVERLAP", "1") != "0" and external_events_work(img.device):
+                    bk.make_events()
+                self._graph_events = bk.events is not None
+                bk.arm(armed, capturing=True)
             torch.cuda.synchronize(img.device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g), sink_armed():
-                loss, items = model.criterion.from_gt(model.forward_train(gs["img"]), gs["gt"])
-                loss.backward()
-                self.flat.flush_sink()
+            with torch.cuda.graph(g):
+                with sink_armed():
+                    loss, items = model.criterion.from_gt(model.forward_train(gs["img"]), gs["gt"])
+                backward(loss)
+            if bk is not None:
+                bk.arm(armed)
             gs.update(g=g, loss=loss, items=items)
-            self._graph = gs
+            graphs[key] = gs
+        self._graph = gs
         gs["img"].copy_(img, non_blocking=True)
         gs["gt"].zero_()
         if gt.shape[1]:
             gs["gt"][:, : gt.shape[1]].copy_(gt.to(img.device, non_blocking=True))
         gs["g"].replay()
-        return gs["loss"], gs["items"]
+        if bk is not None:
+            bk.exchange_after_replay()
+        return gs["loss"].clone(), gs["items"].clone()  # the static outputs are overwritten by the next replay (the epoch mean keeps them)
+
+    def step_form(self) -> str:
+        """How a step is issued (for the bench line): eager launches, one hipGraph, or one hipGraph with the bucket exchange behind it."""
+        graphed = getattr(self, "_graph", None) is not None
+        if self.world == 1:
+            return "forward + loss + backward replayed as ONE hipGraph, gradients through the sink (one flush)" if graphed else "eager launches"
+        if graphed:
+            return ("forward + loss + backward replayed as ONE hipGraph; per-bucket sink flush + external event inside the graph, bucket all-reduces "
+                    "issued behind those events (overlap with the remaining backward)" if getattr(self, "_graph_events", False) else
+                    "forward + loss + backward replayed as ONE hipGraph; bucket all-reduces issued after it")
+        return "eager launches, bucket all-reduces from autograd hooks"
 
     def optimizer_step(self) -> None:
-        """unscale (no scaler: bf16 / fp32), clip 10, step, zero_grad, EMA — trainer.py:591-599."""
+        """scaler.unscale_, clip 10, scaler.step, scaler.update, zero_grad, EMA — trainer.py:591-599.  The scaler exists for fp16
+        storage only; unscale and the skip-on-overflow live inside the step kernels (``amp_state``), so nothing here reads the device."""
         from .. import hip_ops as H
 
         G, Pm = self.flat.G, self.flat.P
@@ -489,11 +583,21 @@ class DetectionTrainer:
                 continue
             wd = self.weight_decay if gi == 0 else 0.0
             if self.opt_name == "SGD":
-                H.sgd_step_(Pm[sl], G[sl], self.buf1[sl], self.cur_lrs[gi], self.cur_momentum, wd, True, self.opt_steps == 1, self.sumsq, 10.0)
+                H.sgd_step_(Pm[sl], G[sl], self.buf1[sl], self.cur_lrs[gi], self.cur_momentum, wd, True, self.opt_steps == 1, self.sumsq, 10.0, self.amp_state)
             else:
-                H.adamw_step_(Pm[sl], G[sl], self.buf1[sl], self.buf2[sl], self.cur_lrs[gi], (self.momentum, 0.999), 1e-8, wd, self.opt_steps, self.sumsq, 10.0)
+                H.adamw_step_(Pm[sl], G[sl], self.buf1[sl], self.buf2[sl], self.cur_lrs[gi], (self.momentum, 0.999), 1e-8, wd, self.opt_steps, self.sumsq, 10.0,
+                              self.amp_state)
+        if self.amp_state is not None:
+            H.amp_update_(self.amp_state, self.sumsq)
         G.zero_()
         self.ema.update()
+
+    def scaler_state_dict(self) -> Optional[dict]:
+        """GradScaler.state_dict() of the device state (host read: checkpoint time only)."""
+        if self.amp_state is None:
+            return None
+        sc, tr, _, _ = self.amp_state.cpu().tolist()
+        return {"scale": sc, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "_growth_tracker": int(tr)}
 
     # ---- the loop --------------------------------------------------------------------------------------------------------
     def train(self):
@@ -501,18 +605,30 @@ class DetectionTrainer:
         devs = self._device_list()
         world = len(devs) if len(devs) > 1 else 1
         if world > 1 and "LOCAL_RANK" not in os.environ:
-            from ..utils.dist import ddp_cleanup, generate_ddp_command, rank_env, visible_gpu_count
+            from ..utils.dist import ddp_cleanup, generate_ddp_command, rank_env, visible_device_env, visible_gpu_count
 
             rehearsal = bool(os.environ.get("DYOLO_FORCE_DEVICE"))
             if not rehearsal and visible_gpu_count() < world:
                 raise RuntimeError(f"device={self.args['device']!r} asks for {world} GPUs, this node has {visible_gpu_count()}")
+            # local rank i must run on the i-th REQUESTED GPU (select_device exports CUDA_VISIBLE_DEVICES=device, torch_utils.py:183)
+            env = rank_env(None if rehearsal else visible_device_env(devs))
             overrides = {k: v for k, v in self.args.items()}
+            tmp_data = None
+            if isinstance(overrides.get("data"), dict):  # tensors do not survive repr() into the rank script: hand them over as a file
+                import tempfile
+
+                tmp_data = os.path.join(tempfile.mkdtemp(prefix="dyolo_data_"), "data.pt")
+                torch.save({k: v for k, v in overrides["data"].items()}, tmp_data)
+                overrides["data"] = tmp_data
             cmd, file = generate_ddp_command(world, overrides)
             try:
                 LOGGER.info(f"DDP: debug command {' '.join(cmd)}")
-                subprocess.run(cmd, check=True, env=rank_env())
+                subprocess.run(cmd, check=True, env=env)
             finally:
                 ddp_cleanup(file)
+                if tmp_data and os.path.exists(tmp_data):
+                    os.remove(tmp_data)
+                    os.rmdir(os.path.dirname(tmp_data))
             return None
         return self._do_train(world)
 
@@ -601,10 +717,12 @@ class DetectionTrainer:
     def optimizer_state_dict(self) -> dict:
         """``torch.optim`` state-dict layout of the reference's optimizer (param_groups: biases, decay weights, norm weights —
         trainer.py:810-819), built from the flat moment buffers."""
-        g0, g1, g2 = self.flat.groups
+        g0, g1, g2 = param_group_names(self.model, include_frozen=True)  # the reference's enumeration: frozen parameters keep their index
         order = list(g2) + list(g0) + list(g1)
         state = {}
         for i, k in enumerate(order):
+            if k not in self.flat.offsets:
+                continue  # frozen (dfl.conv.weight): never received a gradient, so torch.optim holds no state entry for it
             off, c = self.flat.offsets[k]
             shape = self.flat.params[k].shape
             if self.opt_name == "SGD":

@@ -966,15 +966,23 @@ def sumsq_into(acc: torch.Tensor, g: torch.Tensor) -> None:
 
 
 def sgd_step_(p: torch.Tensor, grad: torch.Tensor, buf: torch.Tensor, lr: float, momentum: float, weight_decay: float, nesterov: bool,
-              first_step: bool, grad_sumsq: Optional[torch.Tensor] = None, max_norm: float = 10.0) -> None:
+              first_step: bool, grad_sumsq: Optional[torch.Tensor] = None, max_norm: float = 10.0, amp_state: Optional[torch.Tensor] = None) -> None:
     _launch(lib().dy_sgd_step, (p.data_ptr(), grad.data_ptr(), buf.data_ptr(), p.numel(), lr, momentum, weight_decay, int(nesterov), int(first_step),
-                                grad_sumsq.data_ptr() if grad_sumsq is not None else None, max_norm), keep=(p, grad, buf, grad_sumsq))
+                                grad_sumsq.data_ptr() if grad_sumsq is not None else None, max_norm, amp_state.data_ptr() if amp_state is not None else None),
+            keep=(p, grad, buf, grad_sumsq, amp_state))
 
 
 def adamw_step_(p: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, betas, eps: float, weight_decay: float, step: int,
-                grad_sumsq: Optional[torch.Tensor] = None, max_norm: float = 10.0) -> None:
+                grad_sumsq: Optional[torch.Tensor] = None, max_norm: float = 10.0, amp_state: Optional[torch.Tensor] = None) -> None:
     _launch(lib().dy_adamw_step, (p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, betas[0], betas[1], eps, weight_decay, step,
-                                  grad_sumsq.data_ptr() if grad_sumsq is not None else None, max_norm), keep=(p, grad, m, v, grad_sumsq))
+                                  grad_sumsq.data_ptr() if grad_sumsq is not None else None, max_norm, amp_state.data_ptr() if amp_state is not None else None),
+            keep=(p, grad, m, v, grad_sumsq, amp_state))
+
+
+def amp_update_(amp_state: torch.Tensor, grad_sumsq: torch.Tensor, growth: float = 2.0, backoff: float = 0.5, interval: int = 2000) -> None:
+    """``GradScaler.update()`` on the device state {scale, growth tracker, found_inf, skipped} (fp32[4]); no host synchronisation."""
+    assert amp_state.dtype == torch.float32 and amp_state.numel() >= 4 and grad_sumsq.dtype == torch.float64
+    _launch(lib().dy_amp_update, (amp_state.data_ptr(), grad_sumsq.data_ptr(), growth, backoff, interval), keep=(amp_state, grad_sumsq))
 
 
 def ema_update_(ema: torch.Tensor, p: torch.Tensor, decay: float) -> None:

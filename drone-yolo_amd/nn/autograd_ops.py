@@ -41,22 +41,50 @@ def conv_bn_fwd(x, weight, gamma, beta, bn, stride, pad, act, out=None):
 
 
 _SINK_ARMED = [False]  # set by the trainer around ITS forward + backward only: a backward run by anybody else keeps autograd's gradients
+_SINK_NOTE = [None]  # callback(param): this parameter's sink slot was just handed out, i.e. the kernels that write it are launched next
 
 
 class sink_armed:
+    """``note``: called with every parameter whose sink slot a backward function takes (parallel.GradBuckets counts its buckets down
+    with it: when the NEXT slot is taken, the previous parameter's gradient kernels are already in the stream)."""
+
+    def __init__(self, note=None):
+        self.note = note
+
     def __enter__(self):
         _SINK_ARMED[0] = True
+        _SINK_NOTE[0] = self.note
 
     def __exit__(self, *exc):
         _SINK_ARMED[0] = False
+        _SINK_NOTE[0] = None
         return False
 
 
 def grad_sink(p):
     """The flat fp32 slot a trainer set aside for this parameter's gradient of the current batch (``FlatState.enable_sink``), or
     None.  With a slot the backward kernels write there and return no gradient to autograd, and one ``dy_grad_sink_flush`` per
-    batch adds every slot to ``param.grad`` — instead of one AccumulateGrad add (and one zero-filled temporary) per parameter."""
-    return getattr(p, "_dy_sink", None) if _SINK_ARMED[0] else None
+    batch (per gradient bucket with several ranks) adds every slot to ``param.grad`` — instead of one AccumulateGrad add (and one
+    zero-filled temporary) per parameter."""
+    if not _SINK_ARMED[0]:
+        return None
+    s = getattr(p, "_dy_sink", None)
+    if s is not None and _SINK_NOTE[0] is not None:
+        _SINK_NOTE[0](p)
+    return s
+
+
+def _commits_sink(fn):
+    """Decorator for a Function's ``backward``: when it returns, every kernel that writes the sink slots it took is in the stream —
+    tell the listener (``note(None)``), which may then flush / exchange a gradient bucket whose last parameter this was."""
+
+    def backward(ctx, *grads):
+        out = fn(ctx, *grads)
+        if _SINK_ARMED[0] and _SINK_NOTE[0] is not None:
+            _SINK_NOTE[0](None)
+        return out
+
+    return staticmethod(backward)
 
 
 def conv_bn_bwd(dy, x, z, weight, gamma, beta, st, stride, pad, act, need_dx=True, dx_out=None, dx_accumulate=None):
@@ -91,7 +119,7 @@ class ConvBnAct(torch.autograd.Function):
         ctx.st, ctx.stride, ctx.pad, ctx.act, ctx.need_dx = st, stride, pad, act, need_dx
         return y
 
-    @staticmethod
+    @_commits_sink
     def backward(ctx, dy):
         x, z, weight, gamma, beta = ctx.saved_tensors
         dx, dw, dgamma, dbeta = conv_bn_bwd(dy, x, z, weight, gamma, beta, ctx.st, ctx.stride, ctx.pad, ctx.act, need_dx=ctx.need_dx)
@@ -135,7 +163,7 @@ class C2fTrain(torch.autograd.Function):
         ctx.states, ctx.geo, ctx.c, ctx.nb, ctx.add = states, geo, c, nb, [bool(mm.add) for mm in block.m]
         return y
 
-    @staticmethod
+    @_commits_sink
     def backward(ctx, dy):
         c, nb, geo, S = ctx.c, ctx.nb, ctx.geo, ctx.states
         t_all = ctx.saved_tensors
@@ -203,7 +231,7 @@ class RepVGGTrain(torch.autograd.Function):
         ctx.s3, ctx.s1, ctx.stride = s3, s1, stride
         return y
 
-    @staticmethod
+    @_commits_sink
     def backward(ctx, dy):
         x, z3, z1, u, w3, g3, b3, w1, g1, b1 = ctx.saved_tensors
         du = H.silu_bwd(u, as_nhwc(dy))

@@ -127,12 +127,14 @@ class GradBuckets:
                 cur = []
         if cur:
             self.buckets.append({"names": cur})
+        self.bucket_of = {}
         for bi, b in enumerate(self.buckets):
             rng = {}
             for k in b["names"]:
                 o, c = flat.offsets[k]
                 lo, hi = rng.get(group_of[k], (o, o + c))
                 rng[group_of[k]] = (min(lo, o), max(hi, o + c))
+                self.bucket_of[id(flat.params[k])] = bi
             b["ranges"] = [rng[g] for g in sorted(rng)]
             b["numel"] = sum(hi - lo for lo, hi in b["ranges"])
             assert b["numel"] == sum(flat.offsets[k][1] for k in b["names"]), "a bucket must be contiguous within each group"
@@ -143,33 +145,116 @@ class GradBuckets:
         self.next = 0
         self.works: list = []
         self.issued_during_backward = 0
+        # sink mode (FlatState.enable_sink): gradients land in the sink, a bucket is flushed into G when its last one is in the stream
+        self.sink_entries: Optional[List[torch.Tensor]] = None
+        self.capturing = False  # inside a hipGraph capture: a ready bucket is flushed and marked by an event, exchanged after the replay
+        self.events: Optional[list] = None
+        self.comm_stream = None
+        self._noted: dict = {}
+        self._seen: set = set()
 
-    def arm(self, on: bool) -> None:
+    # ---- sink mode ---------------------------------------------------------------------------------------------------------
+    def use_sink(self) -> None:
+        """Per-bucket slices of ``flat.sink_entries`` (call after ``FlatState.enable_sink``): a bucket's parameters are flushed by one
+        ``dy_grad_sink_flush`` as soon as the backward function that produced its last gradient has returned."""
+        rows = {k: i for i, k in enumerate(self.flat.offsets)}
+        self.sink_entries = [self.flat.sink_entries[torch.tensor([rows[k] for k in b["names"]], device=self.flat.sink_entries.device)].contiguous()
+                             for b in self.buckets]
+
+    def note(self, p) -> None:
+        """Listener of nn/autograd_ops.sink_armed: ``p`` = a parameter whose sink slot a backward function just took; ``None`` = that
+        function has returned (its kernels are in the stream): every parameter noted since the last ``None`` is complete."""
+        if p is not None:
+            if id(p) not in self._seen:
+                self._seen.add(id(p))
+                self._noted[id(p)] = self.bucket_of.get(id(p))
+            return
+        done, self._noted = self._noted, {}
+        for bi in done.values():
+            if bi is not None:
+                self._ready(bi)
+
+    def arm(self, on: bool, capturing: bool = False) -> None:
         """Call before a backward: ``on`` when that backward is followed by the optimizer step (the last micro-batch of an
-        accumulation window) — earlier micro-batches only accumulate locally."""
+        accumulation window) — earlier micro-batches only accumulate locally.  ``capturing``: the backward is being captured into a
+        hipGraph — ready buckets are flushed and marked (``events``), ``exchange_after_replay`` issues the all-reduces."""
         self.armed = bool(on) and self.world > 1
+        self.capturing = capturing
         self.pending = [len(b["names"]) for b in self.buckets]
         self.next, self.works, self.issued_during_backward = 0, [], 0
+        self._noted, self._seen = {}, set()
+
+    def _all_reduce(self, g: torch.Tensor) -> None:
+        if g.is_cuda and dist.get_backend() != "nccl":
+            # rehearsal of N ranks on fewer GPUs (DYOLO_DIST_BACKEND=gloo): the exchange goes through host memory
+            h = g.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            g.copy_(h)
+        else:
+            self.works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
 
     def _issue(self, bi: int) -> None:
         for lo, hi in self.buckets[bi]["ranges"]:
-            g = self.flat.G[lo:hi]
-            if g.is_cuda and dist.get_backend() != "nccl":
-                # rehearsal of N ranks on fewer GPUs (DYOLO_DIST_BACKEND=gloo): the exchange goes through host memory
-                h = g.cpu()
-                dist.all_reduce(h, op=dist.ReduceOp.SUM)
-                g.copy_(h)
-            else:
-                self.works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
+            self._all_reduce(self.flat.G[lo:hi])
+
+    def _bucket_ready(self, bi: int) -> None:
+        """All gradients of bucket ``bi`` are in the stream."""
+        if self.sink_entries is not None:
+            from . import hip_ops as H
+
+            H.grad_sink_flush_(self.sink_entries[bi], self.flat.G, self.flat.S)
+        if self.capturing:
+            if self.events is not None:
+                self.events[bi].record()  # external event: an event-record node of the graph, waited on by the comm stream per replay
+        elif self.armed:
+            self._issue(bi)
+            self.issued_during_backward += 1
 
     def _ready(self, bi: int) -> None:
-        if not self.armed:
+        if not (self.armed or self.capturing or self.sink_entries is not None):
+            return
+        if not self.pending:
             return
         self.pending[bi] -= 1
         while self.next < len(self.buckets) and self.pending[self.next] <= 0:  # in order, identically on every rank
-            self._issue(self.next)
+            self._bucket_ready(self.next)
             self.next += 1
-            self.issued_during_backward += 1
+
+    def end_backward(self) -> None:
+        """After ``loss.backward()``: buckets whose parameters received no gradient this step (or whose count did not run down) are
+        flushed / issued now, in order."""
+        self.note(None)
+        while self.next < len(self.buckets):
+            self._bucket_ready(self.next)
+            self.next += 1
+
+    def make_events(self) -> bool:
+        """One EXTERNAL event per bucket (torch.cuda.Event(external=True): recorded inside a capture it becomes an event-record node
+        instead of a captured cross-stream dependency) and the stream the exchange is issued on.  False when this HIP runtime does
+        not take such events (then the exchange simply follows the whole graph)."""
+        try:
+            self.events = [torch.cuda.Event(external=True) for _ in self.buckets]
+            self.comm_stream = torch.cuda.Stream(device=self.flat.G.device)
+            return True
+        except Exception:
+            self.events, self.comm_stream = None, None
+            return False
+
+    def exchange_after_replay(self) -> None:
+        """The step's graph (forward + loss + backward, per-bucket flush + event) has been launched on the current stream: issue
+        every bucket's all-reduce behind ITS event on the comm stream, so the ring of bucket k runs under the backward kernels of the
+        buckets after it.  Without events the all-reduces follow the whole graph on the current stream."""
+        self.next = len(self.buckets)  # the graph flushed every bucket; nothing is left for end_backward / finish to issue
+        if not self.armed:
+            return
+        self.works = []
+        for bi in range(len(self.buckets)):
+            if self.events is None:
+                self._issue(bi)
+                continue
+            self.comm_stream.wait_event(self.events[bi])
+            with torch.cuda.stream(self.comm_stream):
+                self._issue(bi)
 
     def finish(self) -> None:
         if self.world <= 1:
@@ -177,11 +262,11 @@ class GradBuckets:
         if not self.armed:  # a step without an armed backward (should not happen): one plain all-reduce
             dist.all_reduce(self.flat.G, op=dist.ReduceOp.SUM)
             return
-        while self.next < len(self.buckets):  # parameters that received no gradient this step
-            self._issue(self.next)
-            self.next += 1
+        self.end_backward()  # (a no-op after the trainer's own end_backward / exchange_after_replay)
         for w in self.works:
             w.wait()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.works, self.armed = [], False
 
 

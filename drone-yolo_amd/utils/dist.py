@@ -31,8 +31,32 @@ def rank_env(extra: Optional[dict] = None) -> dict:
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     env.setdefault("OMP_NUM_THREADS", "4")
-    env.update(extra or {})
+    for k, v in (extra or {}).items():
+        if v is None:
+            env.pop(k, None)
+        else:
+            env[k] = v
     return env
+
+
+def visible_device_env(devs: Sequence[int]) -> dict:
+    """Environment that makes local rank i run on the i-th REQUESTED GPU (reference: select_device sets CUDA_VISIBLE_DEVICES to the
+    ``device`` string, utils/torch_utils.py:183, so ``device="2,3"`` trains on GPUs 2 and 3, not 0 and 1).  Ids are positions in what
+    this process can see (an outer HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES list is honoured and mapped through); they are checked
+    against the device count without initialising HIP.  Only HIP_VISIBLE_DEVICES is exported (CUDA_VISIBLE_DEVICES is cleared) so the
+    two lists cannot compound."""
+    devs = [int(d) for d in devs]
+    have = visible_gpu_count()
+    bad = [d for d in devs if d < 0 or d >= have]
+    if bad or len(set(devs)) != len(devs):
+        raise RuntimeError(f"device ids {devs}: {'duplicates' if not bad else f'{bad} not among the {have} visible GPU(s)'}")
+    outer = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+    if outer:
+        outer_ids = [x.strip() for x in outer.split(",") if x.strip() != ""]
+        ids = [outer_ids[d] for d in devs]
+    else:
+        ids = [str(d) for d in devs]
+    return {"HIP_VISIBLE_DEVICES": ",".join(ids), "CUDA_VISIBLE_DEVICES": None}
 
 
 def torchrun_command(world_size: int, script: str, argv: Sequence[str] = (), port: Optional[int] = None) -> List[str]:

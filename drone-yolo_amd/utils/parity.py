@@ -105,17 +105,27 @@ def golden_case(npz_name: str, tag: str):
 
 
 def detection_parity(nms_bufs, exp_rows, exp_idx) -> dict:
-    """Gate numbers of one pass (``nms_bufs``: hip_ops.NmsBuffers of the device pass) against the reference rows."""
+    """Gate numbers of one pass (``nms_bufs``: hip_ops.NmsBuffers of the device pass) against the reference rows.  Two-sided:
+    ``missed`` = reference detections this pass does not keep with the same (anchor index, class); ``extra`` = detections this pass
+    keeps that the reference does not (same key) — so a pass that kept everything would not read as a perfect match."""
     counts = nms_bufs.count.cpu().tolist()
     out_rows, out_idx = nms_bufs.out.cpu().numpy(), nms_bufs.index.cpu().numpy()
-    stats, sets_equal, n_ref, n_hit = [], True, 0, 0
+    stats, sets_equal, n_ref, n_hit, n_got, missed_img, extra_img = [], True, 0, 0, 0, [], []
     for i, c in enumerate(counts):
         st = match_stats(out_rows[i, :c], out_idx[i, :c], exp_rows[i], exp_idx[i])
         stats.append(st)
-        n_ref += len(exp_idx[i])
-        n_hit += round(st[0] * len(exp_idx[i]))
+        ref_keys = {(int(a), int(r[5])) for a, r in zip(exp_idx[i], exp_rows[i])}
+        got_keys = {(int(a), int(r[5])) for a, r in zip(out_idx[i, :c], out_rows[i, :c])}
+        n_ref += len(ref_keys)
+        n_got += len(got_keys)
+        n_hit += len(ref_keys & got_keys)
+        missed_img.append(len(ref_keys - got_keys))
+        extra_img.append(len(got_keys - ref_keys))
         sets_equal &= sorted(out_idx[i, :c].tolist()) == sorted(int(a) for a in exp_idx[i])
-    return {"images": len(counts), "ref_detections": n_ref, "match_rate": round(n_hit / max(n_ref, 1), 5),
+    missed, extra = sum(missed_img), sum(extra_img)
+    return {"images": len(counts), "ref_detections": n_ref, "kept_detections": n_got, "match_rate": round(n_hit / max(n_ref, 1), 5),
+            "missed": missed, "extra": extra, "missed_frac": round(missed / max(n_ref, 1), 5), "extra_frac": round(extra / max(n_ref, 1), 5),
+            "missed_max_image": max(missed_img, default=0), "extra_max_image": max(extra_img, default=0),
             "match_rate_min_image": round(min(s[0] for s in stats), 5), "iou_min": round(min(s[1] for s in stats), 6),
             "iou_mean": round(float(np.mean([s[2] for s in stats])), 6), "counts_equal": counts == [len(r) for r in exp_idx],
             "kept_sets_identical": bool(sets_equal)}

@@ -59,6 +59,10 @@ typedef enum dy_wlayout { DY_WLAYOUT_ROWS = 0, DY_WLAYOUT_HALO3X3 = 1, DY_WLAYOU
 int32_t dy_version(void);
 /* Message of the last error raised on this thread ("" if none). Host string. */
 const char* dy_last_error_string(void);
+/* Introspection for measurement (bench.py's roofline.dominant_kernel): name of the device kernel the last launching call on this
+ * thread dispatched to ("conv3x3_vgemm16_kernel", "conv_gemm_glds_kernel<256,256>", ...), so that live per-launch timings can be
+ * grouped by the same symbols a rocprofv3 kernel trace reports.  Host string with static storage; "" before the first launch. */
+const char* dy_last_kernel_name(void);
 /* Size in bytes of one element of `dtype` (2, 2, 4, 1) or 0 if unknown. */
 int32_t dy_dtype_size(int32_t dtype);
 
@@ -511,6 +515,13 @@ int32_t dy_add_nhwc(const void* a, const void* b, void* out, int64_t rows, int32
  *   min(1, max_norm / (sqrt(*grad_sumsq) + 1e-6)) inside the step — no host synchronisation.
  * dy_sgd_step:   g = clip*grad + wd*p;  buf = first_step ? g : momentum*buf + g;  p -= lr * (nesterov ? g + momentum*buf : buf).
  * dy_adamw_step: p *= 1 - lr*wd;  m,v = moments of clip*grad;  p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps); step >= 1.
+ * amp_state (optional DEVICE float[4], needs grad_sumsq): the state of torch.cuda.amp.GradScaler (engine/trainer.py:271 `GradScaler`, :389
+ *   `scaler.scale(loss).backward()`, :593-596 `unscale_` / `step` / `update`) for fp16 storage — {scale, growth tracker, found_inf of
+ *   the last step, skipped steps}.  With it the step kernels divide the gradient by the scale (`unscale_`; the clip norm becomes
+ *   sqrt(*grad_sumsq) / scale) and leave p / buf / m / v untouched when *grad_sumsq is not finite (`scaler.step` skips);
+ *   AdamW's bias correction counts only the steps that ran.  The caller multiplies the loss gradient by amp_state[0] on the device.
+ * dy_amp_update: `scaler.update()` — found_inf: scale *= backoff, tracker = 0, skipped += 1; else tracker += 1 and, every
+ *   growth_interval clean steps, scale *= growth (torch defaults: 65536 initial, 2, 0.5, 2000).  Call after the step kernels.
  * dy_ema_update: ema = decay*ema + (1-decay)*p.
  * dy_grad_sink_flush: grad += sink (then sink = 0) for every parameter in ONE launch, where `sink` holds what the backward
  *   kernels produced this batch at the parameter's offset in the flat buffers: weight gradients of dy_conv2d_wgrad_nhwc in
@@ -521,9 +532,10 @@ int32_t dy_add_nhwc(const void* a, const void* b, void* out, int64_t rows, int32
  *   kk <= 1: plain vector of cout*cin elements. */
 int32_t dy_sumsq_f32(const float* g, int64_t n, double* out, dy_stream_t stream);
 int32_t dy_sgd_step(float* p, const float* grad, float* buf, int64_t n, float lr, float momentum, float weight_decay, int32_t nesterov,
-                    int32_t first_step, const double* grad_sumsq, float max_norm, dy_stream_t stream);
+                    int32_t first_step, const double* grad_sumsq, float max_norm, const float* amp_state, dy_stream_t stream);
 int32_t dy_adamw_step(float* p, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                      float weight_decay, int32_t step, const double* grad_sumsq, float max_norm, dy_stream_t stream);
+                      float weight_decay, int32_t step, const double* grad_sumsq, float max_norm, const float* amp_state, dy_stream_t stream);
+int32_t dy_amp_update(float* amp_state, const double* grad_sumsq, float growth_factor, float backoff_factor, int32_t growth_interval, dy_stream_t stream);
 int32_t dy_ema_update(float* ema, const float* p, int64_t n, float decay, dy_stream_t stream);
 int32_t dy_grad_sink_flush(const int64_t* entries, int32_t n_entries, float* grad, float* sink, dy_stream_t stream);
 

@@ -267,3 +267,51 @@ def test_tensor_loader_is_a_distributed_sampler():
                 m_src, m_dst = d["batch_idx"] == i, b["batch_idx"] == j
                 assert torch.equal(b["bboxes"][m_dst], d["bboxes"][m_src]) and torch.equal(b["cls"][m_dst], d["cls"][m_src])
         assert sorted(set(seen)) == list(range(11)) and len(seen) == 12
+
+
+def test_requested_device_ids_reach_the_ranks(monkeypatch):
+    """``device="2,3"`` must train on GPUs 2 and 3 (select_device exports CUDA_VISIBLE_DEVICES=device, reference
+    utils/torch_utils.py:183), not on 0..N-1: the launcher's rank environment carries HIP_VISIBLE_DEVICES = the requested list,
+    mapped through an outer visibility list, validated against the device count without initialising HIP."""
+    from drone_yolo_amd.utils import dist as DI
+
+    monkeypatch.setattr(DI, "visible_gpu_count", lambda: 8)
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
+    env = DI.rank_env(DI.visible_device_env([2, 3]))
+    assert env["HIP_VISIBLE_DEVICES"] == "2,3" and "CUDA_VISIBLE_DEVICES" not in env
+    assert env["MASTER_ADDR"] == "127.0.0.1" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert DI.rank_env(DI.visible_device_env([4, 5, 6, 7]))["HIP_VISIBLE_DEVICES"] == "4,5,6,7"
+    with pytest.raises(RuntimeError, match="not among"):
+        DI.visible_device_env([2, 9])
+    with pytest.raises(RuntimeError, match="duplicates"):
+        DI.visible_device_env([1, 1])
+    # an outer list (this process sees 4 GPUs that are physical 4..7): positions map through it and the stale CUDA_ list is dropped
+    monkeypatch.setattr(DI, "visible_gpu_count", lambda: 4)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4,5,6,7")
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "0,1")
+    env = DI.rank_env(DI.visible_device_env([1, 3]))
+    assert env["HIP_VISIBLE_DEVICES"] == "5,7" and "CUDA_VISIBLE_DEVICES" not in env
+
+
+def test_optimizer_groups_enumerate_frozen_parameters_like_the_reference():
+    """build_optimizer (reference trainer.py:795-819) does not filter on requires_grad, so its decay group holds the
+    frozen ``model.N.dfl.conv.weight`` and every later index counts it; the state-dict enumeration must do the same (the flat
+    training buffers still hold trainable parameters only)."""
+    from drone_yolo_amd.engine.trainer import param_group_names
+
+    m = D.DetectionModel("yolov8n-p2-repvgg.yaml", nc=10, verbose=False)
+    for k, v in m.named_parameters():
+        v.requires_grad_(".dfl" not in k)
+    g0, g1, g2 = param_group_names(m)
+    f0, f1, f2 = param_group_names(m, include_frozen=True)
+    assert "model.28.dfl.conv.weight" not in g0 and "model.28.dfl.conv.weight" in f0
+    assert len(f0) == len(g0) + 1 and f1 == g1 and f2 == g2
+    # the reference's own enumeration, restated: every module's direct parameters, bias / norm weight / other
+    ref0, ref1, ref2 = [], [], []
+    bn = tuple(v for k, v in torch.nn.__dict__.items() if "Norm" in k)
+    for mn, mod in m.named_modules():
+        for pn, p in mod.named_parameters(recurse=False):
+            full = f"{mn}.{pn}" if mn else pn
+            (ref2 if "bias" in full else ref1 if isinstance(mod, bn) else ref0).append(full)
+    assert (f0, f1, f2) == (ref0, ref1, ref2) and len(ref0) + len(ref1) + len(ref2) == len(list(m.parameters()))

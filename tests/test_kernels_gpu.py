@@ -492,7 +492,7 @@ def test_letterbox_kernel_bit_exact(shape, imgsz, auto, device):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("shape,shortcut", [((2, 64, 40, 36), True), ((3, 64, 16, 16), False), ((1, 64, 33, 50), True), ((2, 64, 160, 160), True)])
-def test_c2f_fused_block_matches_layerwise(shape, shortcut, dtype, device):
+def test_c2f_fused_block_matches_cpu_chain_and_layerwise(shape, shortcut, dtype, device):
     """dy_c2f_fused against the CPU chain conv -> round -> conv ... with every intermediate rounded to the storage dtype
     (what both the layer-by-layer device path and the fused kernel do), and against the layer-by-layer device path."""
     from drone_yolo_amd.nn.modules import C2f
@@ -534,7 +534,7 @@ def test_c2f_fused_block_matches_layerwise(shape, shortcut, dtype, device):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("shape,shortcut", [((2, 40, 36), False), ((1, 34, 50), True), ((3, 16, 16), False), ((2, 160, 160), False)])
-def test_c2f_fused_block_with_upsample_concat(shape, shortcut, dtype, device):
+def test_c2f_fused_block_with_upsample_concat_matches_cpu_chain(shape, shortcut, dtype, device):
     """The neck's stride-4 block: nn.Upsample(2, 'nearest') + Concat + C2f(192, 64) in one dy_c2f_fused launch against the CPU
     chain on cat(upsample(x_lo), x) with every intermediate rounded to the storage dtype, and against the layer-by-layer device
     path (cv1 gathering both sources, two 3x3 launches, cv2)."""
@@ -658,6 +658,76 @@ def test_detect_branch_fused_matches_tail_path(dtype, device):
     for b in range(3):  # kept detections: same anchors except score-at-threshold / near-tie cases
         s1, s0 = set(i1[b, : int(c1[b])].tolist()), set(i0[b, : int(c0[b])].tolist())
         assert len(s1 ^ s0) <= max(2, int(0.05 * len(s0))), (b, len(s1), len(s0), len(s1 ^ s0))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("shapes", [((64, 23, 37), (128, 12, 19)), ((64, 8, 16), (64, 5, 3)), ((64, 40, 40), (256, 9, 11))], ids=["ragged", "tiny", "square+deep"])
+def test_detect_branch_fused_matches_cpu_chain(shapes, dtype, device):
+    """Localising test: dy_detect_branch_fused — second 3x3 conv + SiLU, 1x1 to 4*reg_max box bins / nc class
+    logits, DFL softmax-expectation + dist2bbox / sigmoid — against an fp32 CPU chain on the SAME quantised operands:
+    F.conv2d -> SiLU -> round to the storage type (the trunk activations' rounding points, head.py:64-72) -> 1x1 in fp32 ->
+    the oracle's Detect decode (head.py:100-131, tal.py:333-363).  No other HIP path is involved in the expectation, so a
+    defect points at this kernel (or at the trunk's first conv, which the CPU chain restates too)."""
+    from drone_yolo_amd.nn.modules import Detect
+    from drone_yolo_amd.nn.modules.conv import fold_conv_bn
+
+    g = torch.Generator().manual_seed(17 + shapes[0][1])
+
+    class LegacyDetect(Detect):
+        legacy = True
+
+    nc = 10
+    det = LegacyDetect(nc=nc, ch=tuple(s[0] for s in shapes)).eval()
+    for prm in det.parameters():
+        prm.data = torch.randn(prm.shape, generator=g) * (0.05 if prm.dim() > 1 else 0.2) + (1.0 if prm.dim() == 1 else 0.0)
+    for m in det.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+    strides = [4.0, 8.0]
+    q = lambda t: quantize(t, dtype)  # noqa: E731
+    xs_cpu = [q(torch.randn(3, c, h, w, generator=g)) for c, h, w in shapes]
+
+    def cba(conv, t):
+        wt, b = fold_conv_bn(conv.conv.weight.detach(), None, conv.bn)
+        return q(F.silu(F.conv2d(t, q(wt), b, 1, 1)))
+
+    feats = []
+    with torch.no_grad():
+        for i, x in enumerate(xs_cpu):
+            tb = cba(det.cv2[i][1], cba(det.cv2[i][0], x))
+            tc = cba(det.cv3[i][1], cba(det.cv3[i][0], x))
+            lb = F.conv2d(tb.double(), q(det.cv2[i][2].weight.detach()).double(), det.cv2[i][2].bias.detach().double()).float()
+            lc = F.conv2d(tc.double(), q(det.cv3[i][2].weight.detach()).double(), det.cv3[i][2].bias.detach().double()).float()
+            feats.append(torch.cat((lb, lc), 1))
+    ref = O.detect_decode(feats, strides, nc)
+    det = det.to(device)
+    det.stride = torch.tensor(strides)
+    xs = [nhwc(t, dtype, device) for t in xs_cpu]
+    det.fuse_branch, det.fuse_tail = True, True
+    holder = {}
+
+    def make_bufs(nb, anchors):
+        holder["b"] = H.NmsBuffers(nb, anchors, 300, device)
+        return holder["b"]
+
+    det.fused_nms = (make_bufs, 0.5, None)
+    assert det._branches_fusable(dtype)
+    y, _ = det(xs)
+    torch.cuda.synchronize()
+    det.fused_nms = None
+    y = y.cpu()
+    assert tuple(y.shape) == tuple(ref.shape) and bool(torch.isfinite(y).all())
+    # same operands, same rounding points; only fp32 summation order (and rare 1-ulp flips of a trunk activation) differ
+    box_tol = (0.03 if dtype == torch.bfloat16 else 0.004) * float(ref[:, :4].abs().max())
+    cls_tol = 0.03 if dtype == torch.bfloat16 else 0.004
+    assert float((y[:, :4] - ref[:, :4]).abs().max()) <= box_tol, (float((y[:, :4] - ref[:, :4]).abs().max()), box_tol)
+    assert float((y[:, 4:] - ref[:, 4:]).abs().max()) <= cls_tol, float((y[:, 4:] - ref[:, 4:]).abs().max())
+    # the candidate filter inside the class branch: every anchor whose reference score clears conf by a margin is listed
+    bufs = H.nms(y.to(device), 0.5, 0.7, max_det=300, nc=nc, bufs=holder["b"], prefiltered=True)
+    plain = H.nms(y.to(device), 0.5, 0.7, max_det=300, nc=nc)
+    torch.cuda.synchronize()
+    assert torch.equal(bufs.count, plain.count) and torch.equal(bufs.index, plain.index)
 
 
 @pytest.mark.parametrize("case", [(64, 64, 3, 1, 2, 24, 20, True), (160, 80, 1, 1, 2, 17, 19, True), (80, 160, 3, 2, 2, 24, 28, True), (640, 320, 1, 1, 1, 12, 12, False),

@@ -157,11 +157,15 @@ def test_end_to_end_against_reference_vectors(tag, dtype, device):
         # reduced-precision storage: a score within rounding of conf or of a neighbour may flip.  Floors = the measured level
         # (profiles/r01_parity_report.jsonl, r02) minus a margin: bf16 may lose 3 % of the reference detections (at least one:
         # the small cases keep 2..17 boxes), fp16 1 %; matched boxes IoU >= 0.998 (bf16) / 0.9995 (fp16)
+        # two-sided: detections the reference does not keep ("extra") are bounded like the ones it keeps and we lose ("missed")
         tol, iou_floor = (0.03, 0.998) if dtype == torch.bfloat16 else (0.01, 0.9995)
         for i, st in enumerate(stats):
             n_ref = max(len(exp_idx[i]), 1)
             allowed = max(1, int(tol * n_ref))
             assert st[0] >= 1.0 - allowed / n_ref - 1e-9, f"{tag} [{dtype}] image {i}: only {st[0]:.4f} of {n_ref} reference detections reproduced"
+            ref_keys = {(int(a), int(r[5])) for a, r in zip(exp_idx[i], exp_rows[i])}
+            got_keys = {(int(a), int(k)) for a, k in zip(cf.nms.index[i, :counts[i]].cpu().tolist(), cf.nms.out[i, :counts[i], 5].cpu().tolist())}
+            assert len(got_keys - ref_keys) <= allowed, f"{tag} [{dtype}] image {i}: {len(got_keys - ref_keys)} detections the reference does not keep (of {n_ref})"
         assert iou_min >= iou_floor, f"{tag} [{dtype}]: min IoU {iou_min:.5f} < {iou_floor}"
 
 
@@ -203,11 +207,13 @@ def test_bench_configuration_against_reference_rows(tag, dtype, device):
         # fp16 = the headline dtype: IoU bar met, at most 1 % of the reference detections (at least one) lost to score near-ties;
         # bf16 (not a headline dtype): 4 %, and the worst single box at IoU >= 0.993 - measured 0.9949 .. 0.9957 over the r02 kernel
         # revisions (one box of ~1100 sets the minimum; the mean stays at 0.9991), minus a margin
-        tol, iou_floor = (0.01, 0.999) if dtype == torch.float16 else (0.04, 0.993)
+        # r03: the gate is two-sided — `missed` (reference detections lost) and `extra` (kept here, absent in the reference) are
+        # bounded separately: fp16 0.3 % each (measured r02: 0 / 1 of 1,103 on s640bench, 1 / ? of 1,122 on s640b4), bf16 4 % each
+        tol, iou_floor = (0.003, 0.999) if dtype == torch.float16 else (0.04, 0.993)
         if tag == "s640b4lo" and dtype == torch.bfloat16:
             tol = 0.20  # every one of this case's 45 detections scores within 0.08 logit of conf: bf16 scores (+-2e-3) flip 7 of them (r02)
-        misses = par["ref_detections"] - round(par["match_rate"] * par["ref_detections"])
-        assert misses <= max(1, int(tol * par["ref_detections"])) and par["iou_min"] >= iou_floor, par
+        allowed = max(1, int(tol * par["ref_detections"]))
+        assert par["missed"] <= allowed and par["extra"] <= allowed and par["iou_min"] >= iou_floor, par
 
 
 def test_plan_follows_the_live_weights(device):
@@ -278,7 +284,7 @@ def test_config4_tiled_scale_l_against_reference_rows(device):
             assert par["counts_equal"] and par["match_rate"] >= 0.999 and par["iou_min"] >= 0.999, par
             assert got.shape == exp_merged.shape and merged_common >= 0.995, merged_common
         else:  # fp16 storage: at most 1 % of the detections lost to near-tie flips
-            assert par["match_rate"] >= 0.99 and par["iou_min"] >= 0.998, par
+            assert par["missed_frac"] <= 0.01 and par["extra_frac"] <= 0.01 and par["iou_min"] >= 0.998, par
             assert merged_common >= 0.97, merged_common
         del tp, cf, res
         torch.cuda.empty_cache()
@@ -300,7 +306,7 @@ def test_config5_shape_scale_x_1536_against_reference_rows(device):
         if dtype == torch.float32:
             assert par["counts_equal"] and par["match_rate"] >= 0.999 and par["iou_min"] >= 0.999, par
         else:
-            assert par["match_rate"] >= 0.99 and par["iou_min"] >= 0.998, par
+            assert par["missed_frac"] <= 0.01 and par["extra_frac"] <= 0.01 and par["iou_min"] >= 0.998, par
         del pred, cf
         torch.cuda.empty_cache()
 
