@@ -527,7 +527,7 @@ def main():
         shares, csv_file = profile_shares(a.batch)
         for k, e in by.items():
             e["avg_us"] = round(e["us"] / e["launches_per_pass"], 1)
-            e["achieved_TFLOPs"] = round(e["gflop"] / e["us"] * 1e-3, 1) if e["us"] else None
+            e["achieved_TFLOPs"] = round(e["gflop"] / e["us"] * 1e3, 1) if e["us"] else None  # GFLOP / us = 1e15 FLOP/s
             e["share_live"] = round(e["us"] / (tconv * 1e6), 4)
             base = k.split("<")[0]
             if base in shares:

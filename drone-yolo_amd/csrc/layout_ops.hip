@@ -99,45 +99,50 @@ __device__ __forceinline__ u32x4 chunk_max(u32x4 a, u32x4 b) {
   return Chunk<T>::pack(fa);
 }
 
+// One workgroup = one image x G consecutive 16-byte channel chunks (G*16 contiguous bytes per pixel: whole 128-byte lines at G = 8;
+// the round-2 kernel took ONE chunk per workgroup, so every line of x was fetched by eight workgroups: 0.42 GB read for a 52 MB
+// input by the counters).  Two LDS images [pixel][G chunks]: row maxima into tmp, column maxima back into cur (nobody reads cur in
+// that phase) and out to y_pass.
 template <typename T>
-__global__ __launch_bounds__(256) void sppf_maxpool3_kernel(const T* __restrict__ x, T* __restrict__ y1,
+__global__ __launch_bounds__(512) void sppf_maxpool3_kernel(const T* __restrict__ x, T* __restrict__ y1,
                                                             T* __restrict__ y2, T* __restrict__ y3, int h, int w,
-                                                            int cchunks, int ld, int r) {
+                                                            int cgroups, int G, int ld, int r) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
   constexpr int EPC = Elem<T>::EPC;
-  const int hw = h * w;
+  const int hw = h * w, tot = hw * G;
   u32x4* cur = reinterpret_cast<u32x4*>(dyn_smem);
-  u32x4* tmp = cur + hw;
-  u32x4* nxt = tmp + hw;
-  const int img = blockIdx.x / cchunks;
-  const int cc = blockIdx.x - img * cchunks;
-  const size_t base = (size_t)img * hw * ld + (size_t)cc * EPC;
-  for (int p = threadIdx.x; p < hw; p += 256) cur[p] = *reinterpret_cast<const u32x4*>(x + base + (size_t)p * ld);
+  u32x4* tmp = cur + tot;
+  const int img = blockIdx.x / cgroups;
+  const int cg = blockIdx.x - img * cgroups;
+  const size_t base = (size_t)img * hw * ld + (size_t)cg * G * EPC;
+  for (int i = threadIdx.x; i < tot; i += 512) {
+    const int p = i / G, g = i - p * G;
+    cur[i] = *reinterpret_cast<const u32x4*>(x + base + (size_t)p * ld + g * EPC);
+  }
   __syncthreads();
   T* outs[3] = {y1, y2, y3};
 #pragma unroll 1
   for (int pass = 0; pass < 3; ++pass) {
-    for (int p = threadIdx.x; p < hw; p += 256) {
+    for (int i = threadIdx.x; i < tot; i += 512) {
+      const int p = i / G, g = i - p * G;
       const int yy = p / w, xx = p - yy * w;
       const int x0 = xx - r < 0 ? 0 : xx - r, x1 = xx + r >= w ? w - 1 : xx + r;
-      u32x4 m = cur[yy * w + x0];
-      for (int q = x0 + 1; q <= x1; ++q) m = chunk_max<T>(m, cur[yy * w + q]);
-      tmp[p] = m;
+      u32x4 m = cur[(yy * w + x0) * G + g];
+      for (int q = x0 + 1; q <= x1; ++q) m = chunk_max<T>(m, cur[(yy * w + q) * G + g]);
+      tmp[i] = m;
     }
     __syncthreads();
     T* o = outs[pass];
-    for (int p = threadIdx.x; p < hw; p += 256) {
+    for (int i = threadIdx.x; i < tot; i += 512) {
+      const int p = i / G, g = i - p * G;
       const int yy = p / w, xx = p - yy * w;
       const int y0 = yy - r < 0 ? 0 : yy - r, y1e = yy + r >= h ? h - 1 : yy + r;
-      u32x4 m = tmp[y0 * w + xx];
-      for (int q = y0 + 1; q <= y1e; ++q) m = chunk_max<T>(m, tmp[q * w + xx]);
-      nxt[p] = m;
-      *reinterpret_cast<u32x4*>(o + base + (size_t)p * ld) = m;
+      u32x4 m = tmp[(y0 * w + xx) * G + g];
+      for (int q = y0 + 1; q <= y1e; ++q) m = chunk_max<T>(m, tmp[(q * w + xx) * G + g]);
+      cur[i] = m;
+      *reinterpret_cast<u32x4*>(o + base + (size_t)p * ld + g * EPC) = m;
     }
     __syncthreads();
-    u32x4* t = cur;
-    cur = nxt;
-    nxt = t;
   }
 }
 
@@ -321,18 +326,26 @@ extern "C" int32_t dy_sppf_maxpool3(const void* x, void* y1, void* y2, void* y3,
   DY_REQUIRE(k >= 1 && (k & 1), DY_ERR_INVALID_ARG, "dy_sppf_maxpool3: k must be odd");
   DY_REQUIRE(aligned16(x) && aligned16(y1) && aligned16(y2) && aligned16(y3), DY_ERR_INVALID_ARG,
              "dy_sppf_maxpool3: views must be 16-byte aligned");
-  DY_REQUIRE((long long)h * w <= 3072, DY_ERR_UNSUPPORTED, "dy_sppf_maxpool3: h*w=%d exceeds the LDS-resident limit 3072", h * w);
+  DY_REQUIRE((long long)h * w <= 4608, DY_ERR_UNSUPPORTED, "dy_sppf_maxpool3: h*w=%d exceeds the LDS-resident limit 4608", h * w);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const size_t smem = (size_t)h * w * 16 * 3;
   const int cchunks = c / epc;
-  const dim3 grid((unsigned)(n * cchunks));
+  // chunks per workgroup: the largest divisor of the chunk count (at most 8 = a whole 128-byte line per pixel) whose two LDS images fit
+  int G = 1;
+  for (int g = 8; g >= 1; --g)
+    if (cchunks % g == 0 && (size_t)h * w * 32 * g <= 147456) {
+      G = g;
+      break;
+    }
+  const size_t smem = (size_t)h * w * 32 * G;
+  const int cgroups = cchunks / G;
+  const dim3 grid((unsigned)(n * cgroups));
 #define DY_SPPF_LAUNCH(T)                                                                                          \
   do {                                                                                                              \
     if (smem > 48 * 1024)                                                                                           \
       (void)hipFuncSetAttribute((const void*)sppf_maxpool3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                 (int)smem);                                                                         \
-    hipLaunchKernelGGL((sppf_maxpool3_kernel<T>), grid, dim3(256), smem, st, (const T*)x, (T*)y1, (T*)y2, (T*)y3, h, \
-                       w, cchunks, ld, k / 2);                                                                      \
+    hipLaunchKernelGGL((sppf_maxpool3_kernel<T>), grid, dim3(512), smem, st, (const T*)x, (T*)y1, (T*)y2, (T*)y3, h, \
+                       w, cgroups, G, ld, k / 2);                                                                   \
   } while (0)
   if (dtype == DY_BF16)
     DY_SPPF_LAUNCH(bf16_t);

@@ -509,7 +509,9 @@ class DetectionTrainer:
             with sink_armed():
                 loss, items = self.model(batch)
             backward(loss)
-            return loss, items
+            # detached: a caller that keeps the loss must not keep the autograd graph alive — its AccumulateGrad nodes would stay bound to
+            # this stream, and the next capture (another stream) then breaks inside hipStreamEndCapture (seen as a segfault on ROCm 7.0)
+            return loss.detach(), items.detach()
         model = self.model
         if getattr(model, "criterion", None) is None:
             model.criterion = model.init_criterion()

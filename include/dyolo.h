@@ -296,7 +296,7 @@ int32_t dy_copy_nhwc(const void* src, void* dst, int32_t n, int32_t h, int32_t w
 /* Replaces: SPPF's three chained MaxPool2d(k,1,k//2) (nn/modules/block.py:185-191).
  * x: (n,h,w,c) pitch ld.  y1,y2,y3: pooled once/twice/thrice, same pitch ld (the
  * channel slices of the SPPF concat buffer).  k odd, (k/2)*3 halo; h*w*16B*3 must
- * fit LDS (h*w <= 3072). */
+ * fit LDS (h*w <= 4608; a workgroup takes up to eight 16-byte channel chunks of one image: whole lines). */
 int32_t dy_sppf_maxpool3(const void* x, void* y1, void* y2, void* y3, int32_t n, int32_t h, int32_t w,
                          int32_t c, int32_t ld, int32_t k, int32_t dtype, dy_stream_t stream);
 

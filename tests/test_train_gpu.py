@@ -470,8 +470,10 @@ def test_yolo_train_api_end_to_end(device, tmp_path):
     # reloads (model.py:812-814) — not the raw optimizer weights, so single- and multi-GPU runs of one script predict alike
     ema_sd = {k: v.float() for k, v in ck["ema"].state_dict().items()}
     live = yolo.model.state_dict()
-    worst = max(float((live[k].cpu().float() - v).abs().max()) / max(float(v.abs().max()), 1e-6) for k, v in ema_sd.items() if v.is_floating_point() and "dfl" not in k)
-    assert worst <= 2e-3, worst  # fp16 rounding of the checkpoint
+    for k, v in ema_sd.items():  # fp16 rounding of the checkpoint: 2^-11 relative, 6e-8 absolute in fp16's subnormal range (biases that left 0 by ~1e-6)
+        if v.is_floating_point() and "dfl" not in k:
+            err = float((live[k].cpu().float() - v).abs().max())
+            assert err <= 1e-3 * float(v.abs().max()) + 1e-7, (k, err, float(v.abs().max()))
     o, c = yolo.trainer.flat.offsets["model.0.conv.weight"]
     ema_w = yolo.trainer.ema.P[o : o + c].view_as(w0).cpu()
     assert torch.equal(live["model.0.conv.weight"].cpu(), ema_w)  # the EMA copy itself (fp32), not the raw optimizer weights
