@@ -26,6 +26,17 @@ int check_launch(const char* what) {
   return DY_ERR_LAUNCH;
 }
 
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned* p, long long words) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < words; i += (long long)gridDim.x * 256) p[i] = 0u;
+}
+
+void zero_async(void* p, size_t bytes, hipStream_t stream) {
+  const long long words = (long long)(bytes / 4);
+  if (words <= 0) return;
+  const long long blocks = (words + 255) / 256;
+  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, stream, reinterpret_cast<unsigned*>(p), words);
+}
+
 }  // namespace dy
 
 extern "C" int32_t dy_version(void) { return (DYOLO_VERSION_MAJOR << 16) | DYOLO_VERSION_MINOR; }

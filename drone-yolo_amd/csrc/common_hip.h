@@ -195,6 +195,10 @@ static inline int dtype_size_no_fp8(int dtype) { return dtype == DY_FP8 ? 0 : dy
 // ---- host-side error plumbing ----------------------------------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+// Zero `bytes` (a multiple of 4) at `p` on `stream` with a KERNEL.  Never hipMemsetAsync in this library: captured into a hipGraph the
+// memset becomes a memset NODE, and on ROCm 7.0 such a node was seen to lose its order against the kernels around it — replays of a
+// captured training step returned a doubled BCE sum (the accumulators were cleared at the wrong time).  Defined in api.cpp.
+void zero_async(void* p, size_t bytes, hipStream_t stream);
 
 #define DY_REQUIRE(cond, code, ...)   \
   do {                                \

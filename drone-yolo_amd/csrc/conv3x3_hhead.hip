@@ -373,6 +373,6 @@ extern "C" int32_t dy_detect_branch_fused(const dy_branch_desc* d, dy_stream_t s
 
 extern "C" int32_t dy_nms_reset_counts(void* nms_workspace, int32_t batch, dy_stream_t stream) {
   DY_REQUIRE(nms_workspace && batch > 0, DY_ERR_INVALID_ARG, "dy_nms_reset_counts: bad arguments");
-  if (hipMemsetAsync(nms_workspace, 0, (size_t)batch * 4, reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return check_launch("dy_nms_reset_counts");
-  return DY_OK;
+  zero_async(nms_workspace, (size_t)batch * 4, reinterpret_cast<hipStream_t>(stream));
+  return check_launch("dy_nms_reset_counts");
 }

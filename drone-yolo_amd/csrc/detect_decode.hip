@@ -162,7 +162,7 @@ extern "C" int32_t dy_detect_decode(const dy_decode_desc* d, dy_stream_t stream)
     a.P = w.P;
     a.conf = d->conf_thres;
     a.cmask = d->classes_mask;
-    if (hipMemsetAsync(w.counts, 0, (size_t)d->batch * 4, st) != hipSuccess) return check_launch("dy_detect_decode memset");
+    zero_async(w.counts, (size_t)d->batch * 4, st);
   }
   const size_t smem = (size_t)kDecTile * ldmax * 4;
   DY_REQUIRE(smem <= 160 * 1024, DY_ERR_UNSUPPORTED, "dy_detect_decode: head pitch %d too large for the LDS tile", ldmax);

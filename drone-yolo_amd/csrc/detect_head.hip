@@ -286,7 +286,7 @@ extern "C" int32_t dy_detect_head_decode(const dy_head_decode_desc* d, dy_stream
     a.counts = w.counts, a.keys = w.keys, a.cls = w.cls, a.P = w.P;
     a.conf = d->conf_thres;
     a.cmask = d->classes_mask;
-    if (hipMemsetAsync(w.counts, 0, (size_t)d->batch * 4, st) != hipSuccess) return check_launch("dy_detect_head_decode memset");
+    zero_async(w.counts, (size_t)d->batch * 4, st);
   }
   const int nkb = (d->c_box + kc - 1) / kc, nkc = (d->c_cls + kc - 1) / kc;
   const size_t smem = (size_t)(nkb * 4 + nkc * a.nfc) * 1024 + (size_t)(4 * d->reg_max + a.mtc * 16) * 4 + (size_t)kHeadTile * pitch * 4;

@@ -483,7 +483,7 @@ extern "C" int32_t dy_detection_loss(const dy_loss_desc* d, dy_stream_t stream) 
   a.acc = reinterpret_cast<double*>(ws);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // zero the per-box maxima and the accumulators (contiguous tail of the workspace)
-  if (hipMemsetAsync(a.gmax_al, 0, 2 * lalign(bg * 4) + lalign(6 * 8), st) != hipSuccess) return check_launch("dy_detection_loss memset");
+  zero_async(a.gmax_al, 2 * lalign(bg * 4) + lalign(6 * 8), st);  // a kernel, never a memset node (common_hip.h)
   const long long tot = (long long)d->batch * A;
   const unsigned blocks = (unsigned)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
   hipLaunchKernelGGL(loss_decode_kernel, dim3(blocks), dim3(256), 0, st, a);

@@ -289,7 +289,7 @@ extern "C" int32_t dy_nms(const dy_nms_desc* d, dy_stream_t stream) {
   a.SL = a.P < 16384 ? a.P : 16384;
 
   if (!d->prefiltered) {
-    if (hipMemsetAsync(a.counts, 0, (size_t)d->batch * 4, st) != hipSuccess) return check_launch("dy_nms memset");
+    zero_async(a.counts, (size_t)d->batch * 4, st);
     const long long total = (long long)d->batch * d->anchors;
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;

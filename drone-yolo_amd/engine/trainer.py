@@ -306,20 +306,19 @@ def external_events_work(device) -> bool:
     try:
         ev = torch.cuda.Event(external=True)
         side = torch.cuda.Stream(device=device)
-        a = torch.randn(2048, 2048, device=device)
+        a = torch.rand(32 * 1024 * 1024, device=device)  # 128 MB: every pass below is ~60 us of plain element-wise work (no library calls inside a capture)
         src = torch.zeros(1, device=device)
         x = torch.zeros(1, device=device)
         y = torch.zeros(1, device=device)
         torch.cuda.synchronize(device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            t = a
-            for _ in range(24):  # a few ms of work in front of the write
-                t = torch.mm(t, a) * 1e-3
-            x.copy_(src + t[0, 0] * 0.0)
+            for _ in range(40):  # a few ms of work in front of the write
+                a.mul_(0.999).add_(1e-3)
+            x.copy_(src + a[0] * 0.0)
             ev.record()
-            for _ in range(4):
-                t = torch.mm(t, a) * 1e-3
+            for _ in range(8):
+                a.mul_(0.999).add_(1e-3)
         ok = True
         for val in (3.0, 7.0, 11.0):
             src.fill_(val)
