@@ -91,14 +91,16 @@ def conv_bn_bwd(dy, x, z, weight, gamma, beta, st, stride, pad, act, need_dx=Tru
     """(dx, dw, dgamma, dbeta) of conv_bn_fwd.  ``dx_accumulate``: a gradient already held for x (another consumer's
     contribution), added in the dgrad epilogue; ``dx_out`` may be that same view (in place: a lane reads what it then overwrites).
     Parameter gradients that went to the trainer's sink come back as None."""
-    sg, sb, sw = grad_sink(gamma), grad_sink(beta), grad_sink(weight)
+    cout, cin, k, _ = weight.shape
+    # (the image stem's input is padded to one chunk: its weight gradient is sliced below and goes through autograd — its sink slot must
+    #  not be taken, or a listener would count the parameter done before AccumulateGrad has added it)
+    sg, sb, sw = grad_sink(gamma), grad_sink(beta), (grad_sink(weight) if x.shape[1] == cin else None)
     dz, dgamma, dbeta = H.bn_train_bwd(as_nhwc(dy), z, gamma, beta, st, act, dgamma=sg, dbeta=sb)
     if sg is not None:
         dgamma = None
     if sb is not None:
         dbeta = None
-    cout, cin, k, _ = weight.shape
-    if sw is not None and x.shape[1] == cin:  # (the image stem's input is padded to one chunk: its gradient is sliced, below)
+    if sw is not None:
         H.conv_wgrad(x, dz, k, stride, pad, out=sw.view(cout, k, k, cin))
         dw = None
     else:

@@ -139,7 +139,7 @@ class GradBuckets:
             b["numel"] = sum(hi - lo for lo, hi in b["ranges"])
             assert b["numel"] == sum(flat.offsets[k][1] for k in b["names"]), "a bucket must be contiguous within each group"
             for k in b["names"]:
-                flat.params[k].register_post_accumulate_grad_hook(lambda p, bi=bi: self._ready(bi))
+                flat.params[k].register_post_accumulate_grad_hook(lambda p: self._param_done(p))
         self.armed = False
         self.pending: List[int] = []
         self.next = 0
@@ -152,6 +152,7 @@ class GradBuckets:
         self.comm_stream = None
         self._noted: dict = {}
         self._seen: set = set()
+        self._done: set = set()
 
     # ---- sink mode ---------------------------------------------------------------------------------------------------------
     def use_sink(self) -> None:
@@ -170,9 +171,19 @@ class GradBuckets:
                 self._noted[id(p)] = self.bucket_of.get(id(p))
             return
         done, self._noted = self._noted, {}
-        for bi in done.values():
-            if bi is not None:
-                self._ready(bi)
+        for pid in done:
+            self._param_done(pid)
+
+    def _param_done(self, p) -> None:
+        """The gradient of parameter ``p`` (the object, or its id) is complete and in the stream: count its bucket down — once per
+        backward, whichever way the gradient came (sink slot or AccumulateGrad)."""
+        pid = p if isinstance(p, int) else id(p)
+        if pid in self._done or not self.pending:
+            return
+        self._done.add(pid)
+        bi = self.bucket_of.get(pid)
+        if bi is not None:
+            self._ready(bi)
 
     def arm(self, on: bool, capturing: bool = False) -> None:
         """Call before a backward: ``on`` when that backward is followed by the optimizer step (the last micro-batch of an
@@ -182,7 +193,7 @@ class GradBuckets:
         self.capturing = capturing
         self.pending = [len(b["names"]) for b in self.buckets]
         self.next, self.works, self.issued_during_backward = 0, [], 0
-        self._noted, self._seen = {}, set()
+        self._noted, self._seen, self._done = {}, set(), set()
 
     def _all_reduce(self, g: torch.Tensor) -> None:
         if g.is_cuda and dist.get_backend() != "nccl":
