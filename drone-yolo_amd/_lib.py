@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdyolo.so")
 
 DY_BF16, DY_F16, DY_F32, DY_FP8 = 0, 1, 2, 3
-DY_ACT_NONE, DY_ACT_SILU = 0, 1
+DY_ACT_NONE, DY_ACT_SILU, DY_ACT_SILU_L2E = 0, 1, 2
 DY_MAX_LEVELS = 8
 DY_WLAYOUT_ROWS, DY_WLAYOUT_HALO3X3, DY_WLAYOUT_FRAG1X1 = 0, 1, 2
 
@@ -44,7 +44,7 @@ class BranchDesc(C.Structure):
         ("batch", _i32), ("h", _i32), ("w", _i32), ("ld_x", _i32), ("c_in", _i32), ("c_mid", _i32), ("nc", _i32), ("reg_max", _i32),
         ("kind", _i32), ("dtype", _i32), ("anchors", _i32), ("anchor0", _i32),
         ("stride", _f32),
-        ("nms_workspace", _vp), ("nms_workspace_bytes", _i64), ("conf_thres", _f32), ("classes_mask", _vp),
+        ("nms_workspace", _vp), ("nms_workspace_bytes", _i64), ("conf_thres", _f32), ("classes_mask", _vp), ("act_l2e", _i32),
     ]  # fmt: skip
 
 
@@ -114,7 +114,7 @@ class C2fDesc(C.Structure):
     _fields_ = [
         ("x", _vp), ("x_lo", _vp), ("y", _vp), ("w_cv1", _vp), ("w_m_cv1", _vp), ("w_m_cv2", _vp), ("w_cv2", _vp), ("bias", _vp),
         ("batch", _i32), ("h", _i32), ("w", _i32), ("cin", _i32), ("cin_lo", _i32), ("hidden", _i32), ("cout", _i32),
-        ("ld_x", _i32), ("ld_x_lo", _i32), ("ld_y", _i32), ("shortcut", _i32), ("dtype", _i32),
+        ("ld_x", _i32), ("ld_x_lo", _i32), ("ld_y", _i32), ("shortcut", _i32), ("dtype", _i32), ("act_l2e", _i32),
     ]  # fmt: skip
 
 

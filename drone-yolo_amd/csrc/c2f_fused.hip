@@ -47,6 +47,7 @@ struct C2fArgs {
   const void* w2;   // FRAG1X1 order, cout 64, cin 96
   const float* bias;  // b1[64] | bm1[32] | bm2[32] | b2[64]
   int N, H, W, ldx, ldxlo, ldy, tilesX, tilesY, nStrips, shortcut;
+  int l2e;  // SiLU in the log2(e)-scaled activation domain (DY_ACT_SILU_L2E)
   unsigned x_bytes, xlo_bytes, y_bytes;
   int dbg;  // timing probes, -DDYOLO_ABLATE builds only (DYOLO_C2F_DBG): 1 no global x loads, 2 no SiLU, 4 no stores
 };
@@ -95,10 +96,9 @@ __global__ __launch_bounds__(512) void c2f_fused_kernel(const C2fArgs p) {
 #ifdef DYOLO_ABLATE
     if (p.dbg & 2) return a;
 #endif
-    f32x4 v;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = silu_f32(a[e]);
-    return v;
+    float v[4] = {a[0], a[1], a[2], a[3]};
+    apply_act(v, p.l2e ? DY_ACT_SILU_L2E : DY_ACT_SILU);
+    return f32x4{v[0], v[1], v[2], v[3]};
   };
   auto wave_sync = [&]() {  // LDS written by some lanes of this wave, read by others: order it (no other wave touches the region)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -496,6 +496,7 @@ extern "C" int32_t dy_c2f_fused(const dy_c2f_desc* d, dy_stream_t stream) {
   C2fArgs a{};
   a.x = d->x, a.xlo = d->x_lo, a.y = d->y, a.w1 = d->w_cv1, a.wm1 = d->w_m_cv1, a.wm2 = d->w_m_cv2, a.w2 = d->w_cv2, a.bias = d->bias;
   a.N = d->batch, a.H = d->h, a.W = d->w, a.ldx = d->ld_x, a.ldxlo = d->ld_x_lo, a.ldy = d->ld_y, a.shortcut = d->shortcut;
+  a.l2e = d->act_l2e ? 1 : 0;
   a.tilesX = (d->w + 15) / 16, a.tilesY = (d->h + 7) / 8;
   a.nStrips = d->batch * a.tilesY * a.tilesX;
   a.x_bytes = (unsigned)xb, a.xlo_bytes = (unsigned)lb, a.y_bytes = (unsigned)yb;

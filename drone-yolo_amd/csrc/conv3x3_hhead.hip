@@ -39,6 +39,7 @@ struct HheadArgs {
   const float* b1;     // 64 / 16
   float* out;          // pred (N, 4 + nc, A) fp32
   int N, H, W, ldx, A, a0, nc;
+  int l2e;  // the trunk conv's SiLU in the log2(e)-scaled domain (DY_ACT_SILU_L2E)
   float stride;
   int tilesX, tilesY, nSpatial;
   int* counts;
@@ -184,8 +185,10 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hhead_kernel(const HheadArgs p
 #pragma unroll
     for (int o = 0; o < kHhTH; ++o) {
       t4 ov;
+      float v[4] = {acc[o][0], acc[o][1], acc[o][2], acc[o][3]};
+      apply_act(v, p.l2e ? DY_ACT_SILU_L2E : DY_ACT_SILU);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ov[e] = Elem<T>::from_f32(silu_f32(acc[o][e]));
+      for (int e = 0; e < 4; ++e) ov[e] = Elem<T>::from_f32(v[e]);
       *reinterpret_cast<u32x2*>(mid + mid_w + o * (kHhTW * 64)) = __builtin_bit_cast(u32x2, ov);
     }
   };
@@ -358,6 +361,7 @@ extern "C" int32_t dy_detect_branch_fused(const dy_branch_desc* d, dy_stream_t s
   HheadArgs a{};
   a.x = d->x, a.w3 = d->w3, a.b3 = d->b3, a.w1 = d->w1, a.b1 = d->b1, a.out = d->out;
   a.N = d->batch, a.H = d->h, a.W = d->w, a.ldx = d->ld_x, a.A = d->anchors, a.a0 = d->anchor0, a.nc = d->nc, a.stride = d->stride;
+  a.l2e = d->act_l2e ? 1 : 0;
   a.tilesX = (d->w + kHhTW - 1) / kHhTW, a.tilesY = (d->h + kHhTH - 1) / kHhTH;
   a.nSpatial = d->batch * a.tilesX * a.tilesY;
   if (d->kind == 2 && d->nms_workspace) {

@@ -276,10 +276,7 @@ __global__ __launch_bounds__(512) void conv3x3_vgemm_kernel(const ConvArgs p, co
           for (int ii = 0; ii < 2; ++ii) {
             const int i = half * 2 + ii;
             float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-            if (p.act == DY_ACT_SILU) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
-            }
+            apply_act(v, p.act);
             if (rg != nullptr) {
               if (rpx[i] >= 0) {
                 typedef __attribute__((ext_vector_type(4))) T t4;
@@ -515,10 +512,7 @@ __global__ __launch_bounds__(1024) void conv3x3_vgemm16_kernel(const ConvArgs p,
         for (int jj = 0; jj < EG; ++jj) {
           const int j = gq * EG + jj;
           float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-          if (p.act == DY_ACT_SILU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
-          }
+          apply_act(v, p.act);
           if (rpx >= 0) {
             typedef __attribute__((ext_vector_type(4))) T t4;
             const t4 rv = *reinterpret_cast<const t4*>(rg + (size_t)rpx * (size_t)p.ldres + (size_t)(n0 + j * 16 + lq * 4));

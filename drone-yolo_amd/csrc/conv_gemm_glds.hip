@@ -199,10 +199,7 @@ __global__ __launch_bounds__(BM * WN) void conv_gemm_glds_kernel(const ConvArgs 
         for (int ii = 0; ii < 4 / NH; ++ii) {
           const int i = half * (4 / NH) + ii;
           float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-          if (p.act == DY_ACT_SILU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
-          }
+          apply_act(v, p.act);
           if (rg != nullptr) {
             const int m = m0 + i * 16 + lr;
             if (m < p.M) {
@@ -403,10 +400,7 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_persist_kernel(const ConvA
           for (int ii = 0; ii < 2; ++ii) {
             const int i = half * 2 + ii;
             float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-            if (p.act == DY_ACT_SILU) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
-            }
+            apply_act(v, p.act);
             if (rg != nullptr) {
               const int m = m0 + i * 16 + lr;
               if (m < p.M) {

@@ -230,10 +230,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       v[e + 2] = t[2] + bb[2];
       v[e + 3] = t[3] + bb[3];
     }
-    if (p.act == DY_ACT_SILU) {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) v[e] = silu_f32(v[e]);
-    }
+    apply_act(v, p.act);
     const int nvalid = (p.Cout - gcol) < VEC ? (p.Cout - gcol) : VEC;
     if constexpr (!OUTF32) if (rg != nullptr) {
       const T* rp = rg + (size_t)m * (size_t)p.ldres + (size_t)gcol;
@@ -301,6 +298,7 @@ __global__ __launch_bounds__(256) void conv_grouped_kernel(const ConvArgs p, int
       }
     }
     if (p.act == DY_ACT_SILU) acc = silu_f32(acc);
+    else if (p.act == DY_ACT_SILU_L2E) acc = silu_l2e_f32(acc);
     if (rg) acc += Elem<T>::to_f32(rg[(size_t)m * (size_t)p.ldres + co]);
     yg[(size_t)m * (size_t)p.ldy + co] = Elem<T>::from_f32(acc);
   }

@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import DY_ACT_NONE, DY_ACT_SILU, BnDesc, BranchDesc, C2fDesc, ConvDesc, DecodeDesc, HeadDecodeDesc, LossDesc, NmsDesc, Stem2Desc, check, lib
+from ._lib import DY_ACT_NONE, DY_ACT_SILU, DY_ACT_SILU_L2E, BnDesc, BranchDesc, C2fDesc, ConvDesc, DecodeDesc, HeadDecodeDesc, LossDesc, NmsDesc, Stem2Desc, check, lib
 
 FP8 = torch.float8_e4m3fn  # OCP e4m3fn: gfx950's fp8 (MI300's fnuz is another encoding)
 _DTYPES = {torch.bfloat16: _lib.DY_BF16, torch.float16: _lib.DY_F16, torch.float32: _lib.DY_F32, FP8: _lib.DY_FP8}
@@ -194,6 +194,51 @@ def zero_bias(n: int, device) -> torch.Tensor:
     return z
 
 
+# ---- the log2(e)-scaled activation domain (DY_ACT_SILU_L2E, include/dyolo.h) ---------------------------------------------
+LOG2E = 1.4426950408889634
+_SCALED = [False]
+
+
+class scaled_activations:
+    """While active, weights are packed for a pass whose stored activations are log2(e) times the reference's: every bias times
+    log2(e), the weights of a layer that reads raw data (the image) likewise, SiLU as DY_ACT_SILU_L2E (one VALU instruction less per
+    output element), the plain 1x1 convolutions that end the Detect branches divided by log2(e) so that the logits come out in true
+    units.  Max pool, nearest upsample, Concat and the Bottleneck sum commute with the positive scale.  The model executor
+    (nn/tasks.py::_predict_once) turns it on for 16-bit / fp8 storage; modules called on their own stay in the reference's units."""
+
+    def __init__(self, on: bool = True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = _SCALED[0]
+        _SCALED[0] = self.on
+        return self
+
+    def __exit__(self, *exc):
+        _SCALED[0] = self.prev
+        return False
+
+
+def scaled_domain() -> bool:
+    return _SCALED[0]
+
+
+def domain_fold(w: torch.Tensor, b: torch.Tensor, silu: bool, raw_input: bool = False, raw_output: bool = False):
+    """(weight, bias, activation code) of one convolution for the activation domain in force (see ``scaled_activations``)."""
+    if not _SCALED[0]:
+        return w, b, (DY_ACT_SILU if silu else DY_ACT_NONE)
+    w, b = w.detach().float(), b.detach().float()
+    if raw_output:
+        if silu or raw_input:
+            raise ValueError("domain_fold: a layer that leaves the scaled domain is a plain convolution on scaled input")
+        return w / LOG2E, b, DY_ACT_NONE
+    return (w * LOG2E if raw_input else w), b * LOG2E, (DY_ACT_SILU_L2E if silu else DY_ACT_NONE)
+
+
+def _act_code(act) -> int:
+    return int(act) if isinstance(act, int) and not isinstance(act, bool) else (DY_ACT_SILU if act else DY_ACT_NONE)
+
+
 class PackedConv:
     """Folded + packed weights of one convolution in the layout ``dy_conv2d_nhwc`` expects.
 
@@ -249,7 +294,7 @@ class PackedConv:
         wdev = weight.device  # pack where the weights live (CPU for inference setup, the GPU in training: no host round trip)
         assert k == k2, "square kernels only"
         self.cout, self.cin, self.k, self.stride, self.pad, self.groups = cout, cin_g * groups, k, stride, pad, groups
-        self.act = DY_ACT_SILU if act else DY_ACT_NONE
+        self.act = _act_code(act)  # bool (SiLU or none) or a dy_act code
         self.dtype = dtype
         self.layout = _lib.DY_WLAYOUT_ROWS
         self.wscale, self.act_scale = None, 1.0
@@ -422,7 +467,7 @@ class PackedStem:
         if not (k == k2 == 3 and cin * 9 <= 32 and cout <= 80):
             raise ValueError("PackedStem: needs a 3x3 kernel, cin <= 3 and cout <= 80")
         self.cout, self.cin, self.dtype = cout, cin, dtype
-        self.act = DY_ACT_SILU if act else DY_ACT_NONE
+        self.act = _act_code(act)
         cp = -(-cout // 16) * 16
         wp = torch.zeros((cp, 32), dtype=torch.float32)
         wp[:cout, : cin * 9] = weight.detach().to(torch.float32).cpu().reshape(cout, cin * 9)
@@ -460,7 +505,7 @@ class PackedStem2:
             raise ValueError("PackedStem2: built for Conv(3, 32, 3, 2) followed by a 3x3 stride-2 32 -> 64 layer")
         self.stem = PackedStem(w0, b0, act0, dtype, device)
         self.dtype = dtype
-        self.act1 = DY_ACT_SILU if act1 else DY_ACT_NONE
+        self.act1 = _act_code(act1)
         self.w1 = w1.detach().to(torch.float32).cpu().permute(0, 2, 3, 1).reshape(64, 288).to(dtype).contiguous().to(device)
         self.b1 = b1.detach().to(torch.float32).cpu().contiguous().to(device)
 
@@ -621,6 +666,9 @@ def detect_branch_fused(x: torch.Tensor, pc3: "PackedConv", w1: torch.Tensor, b1
     d.w3, d.b3, d.w1, d.b1, d.out = pc3.w.data_ptr(), pc3.b.data_ptr(), w1.data_ptr(), b1.data_ptr(), pred.data_ptr()
     d.batch, d.h, d.w, d.c_in, d.c_mid, d.nc, d.reg_max, d.kind, d.dtype = n, h, w, c, pc3.cout, nc, reg_max, kind, dy_dtype(x.dtype)
     d.anchors, d.anchor0, d.stride = pred.shape[2], anchor0, float(stride)
+    if pc3.act not in (DY_ACT_SILU, DY_ACT_SILU_L2E):
+        raise ValueError("detect_branch_fused: the 3x3 conv must end in SiLU")
+    d.act_l2e = int(pc3.act == DY_ACT_SILU_L2E)  # (the caller packed w1 divided by log2 e then: the logits stay in true units)
     if pred.dtype != torch.float32 or pred.shape[0] != n or pred.shape[1] != 4 + nc or not pred.is_contiguous():
         raise ValueError("detect_branch_fused: pred must be a contiguous fp32 (N, 4 + nc, A) tensor")
     if kind == 2 and nms_bufs is not None:
@@ -1016,8 +1064,10 @@ def letterbox(frames: torch.Tensor, new_w: int, new_h: int, top: int, left: int,
 class PackedC2f:
     """Folded + packed weights of a whole C2f (n = 1) for ``dy_c2f_fused``: (w, b) pairs of cv1, m[0].cv1, m[0].cv2, cv2."""
 
-    def __init__(self, cv1, mcv1, mcv2, cv2, shortcut: bool, dtype: torch.dtype, device):
+    def __init__(self, cv1, mcv1, mcv2, cv2, shortcut: bool, dtype: torch.dtype, device, act_l2e: bool = False):
+        """``act_l2e``: the four (w, b) pairs were folded for the log2(e)-scaled activation domain (biases times log2 e)."""
         (w1, b1), (wa, ba), (wb, bb), (w2, b2) = cv1, mcv1, mcv2, cv2
+        self.act_l2e = bool(act_l2e)
         self.cin, self.hidden, self.cout = w1.shape[1], wa.shape[0], w2.shape[0]
         self.w1, _ = pack_frag1x1(w1, b1, dtype, device)
         self.w2, _ = pack_frag1x1(w2, b2, dtype, device)
@@ -1056,6 +1106,6 @@ def c2f_fused(x: torch.Tensor, pk: PackedC2f, out: Optional[torch.Tensor] = None
         d.x_lo, d.ld_x_lo = view_params(x_lo)
     d.w_cv1, d.w_m_cv1, d.w_m_cv2, d.w_cv2, d.bias = pk.w1.data_ptr(), pk.wa.data_ptr(), pk.wb.data_ptr(), pk.w2.data_ptr(), pk.bias.data_ptr()
     d.batch, d.h, d.w, d.cin, d.cin_lo, d.hidden, d.cout = n, h, w, pk.cin, c_lo, pk.hidden, pk.cout
-    d.shortcut, d.dtype = int(pk.shortcut), dy_dtype(x.dtype)
+    d.shortcut, d.dtype, d.act_l2e = int(pk.shortcut), dy_dtype(x.dtype), int(pk.act_l2e)
     _launch(lib().dy_c2f_fused, (C.byref(d),), keep=(d, x, x_lo, out, pk))
     return out

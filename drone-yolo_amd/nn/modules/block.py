@@ -61,11 +61,12 @@ class C2f(nn.Module):
 
     def _packed_block(self, dtype, device):
         convs = (self.cv1, self.m[0].cv1, self.m[0].cv2, self.cv2)
-        key = (dtype, str(device), tuple((c.conv.weight.data_ptr(), c.conv.weight._version, c.bn.weight._version, c.bn.running_var._version) for c in convs))
+        key = (dtype, str(device), H.scaled_domain(),
+               tuple((c.conv.weight.data_ptr(), c.conv.weight._version, c.bn.weight._version, c.bn.running_var._version) for c in convs))
         cache = self.__dict__.get("_block_cache")
         if cache is None or cache[0] != key:
-            folded = [fold_conv_bn(c.conv.weight, c.conv.bias, c.bn) for c in convs]
-            cache = (key, H.PackedC2f(*folded, shortcut=self.m[0].add, dtype=dtype, device=device))
+            folded = [H.domain_fold(*fold_conv_bn(c.conv.weight, c.conv.bias, c.bn), True)[:2] for c in convs]
+            cache = (key, H.PackedC2f(*folded, shortcut=self.m[0].add, dtype=dtype, device=device, act_l2e=H.scaled_domain()))
             self.__dict__["_block_cache"] = cache
         return cache[1]
 
@@ -205,7 +206,8 @@ class RepVGGBlock(_PackedMixin, nn.Module):
             w, b = self.rbr_reparam.weight, self.rbr_reparam.bias
         else:
             w, b = self.get_equivalent_kernel_bias()
-        return H.PackedConv(w, b, self.stride, self.padding, self.groups, True, dtype, device, cin_pad=cin_pad)
+        w, b, act = H.domain_fold(w, b, True, raw_input=getattr(self, "_raw_input", False))
+        return H.PackedConv(w, b, self.stride, self.padding, self.groups, act, dtype, device, cin_pad=cin_pad)
 
     def forward(self, inputs, out=None):
         _require_eval(self)

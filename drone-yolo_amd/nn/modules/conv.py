@@ -54,7 +54,8 @@ class _PackedMixin:
 
     def _packed_for(self, x: torch.Tensor) -> H.PackedConv:
         cache = self._pack_cache()
-        key = (x.dtype, x.device, x.shape[1], H.fp8_act_scale() if x.dtype == H.FP8 else None)  # an fp8 pack bakes the activation scale in
+        # an fp8 pack bakes the activation scale in; every pack the activation domain it was folded for (H.scaled_activations)
+        key = (x.dtype, x.device, x.shape[1], H.fp8_act_scale() if x.dtype == H.FP8 else None, H.scaled_domain())
         pc = cache.get(key)
         if pc is None:
             pc = cache[key] = self._pack(x.dtype, x.device)
@@ -110,8 +111,11 @@ class Conv(_PackedMixin, nn.Module):
         w, b = fold_conv_bn(self.conv.weight, self.conv.bias, self.bn) if hasattr(self, "bn") else (
             self.conv.weight, self.conv.bias)
         c = self.conv
-        return H.PackedConv(w, b, c.stride[0], c.padding[0], c.groups, isinstance(self.act, nn.SiLU), dtype, device,
-                            cin_pad=cin_pad)
+        if b is None:
+            b = torch.zeros(w.shape[0], device=w.device)
+        # _raw_input: set by the model executor on the layer that reads the image (its input is not in the scaled domain)
+        w, b, act = H.domain_fold(w, b, isinstance(self.act, nn.SiLU), raw_input=getattr(self, "_raw_input", False))
+        return H.PackedConv(w, b, c.stride[0], c.padding[0], c.groups, act, dtype, device, cin_pad=cin_pad)
 
     def forward(self, x, out=None, residual=None, **kw):
         _require_eval(self)
@@ -129,11 +133,12 @@ class Conv(_PackedMixin, nn.Module):
         """fp32 NCHW image -> this layer's NHWC output in ``dtype`` (layout cast + conv + BN + SiLU in one kernel)."""
         _require_eval(self)
         cache = self._pack_cache()
-        key = ("stem", dtype, im.device)
+        key = ("stem", dtype, im.device, H.scaled_domain())
         ps = cache.get(key)
         if ps is None:
             w, b = fold_conv_bn(self.conv.weight, self.conv.bias, self.bn)
-            ps = cache[key] = H.PackedStem(w, b, isinstance(self.act, nn.SiLU), dtype, im.device)
+            w, b, act = H.domain_fold(w, b, isinstance(self.act, nn.SiLU), raw_input=True)  # the image is never in the scaled domain
+            ps = cache[key] = H.PackedStem(w, b, act, dtype, im.device)
         return H.stem_conv(im, ps, out=out, mark_input=mark_input)
 
 
@@ -148,8 +153,9 @@ class PlainConv2d(_PackedMixin, nn.Conv2d):
     """nn.Conv2d with bias and no activation (the last layer of each Detect branch, head.py:43-57)."""
 
     def _pack(self, dtype, device, cin_pad=None) -> H.PackedConv:
-        return H.PackedConv(self.weight, self.bias, self.stride[0], self.padding[0], self.groups, False, dtype, device,
-                            cin_pad=cin_pad, for_out_f32=True)
+        # the last layer of a Detect branch leaves the scaled activation domain: its logits are in true units (weights / log2 e)
+        w, b, act = H.domain_fold(self.weight, self.bias, False, raw_output=True)
+        return H.PackedConv(w, b, self.stride[0], self.padding[0], self.groups, act, dtype, device, cin_pad=cin_pad, for_out_f32=True)
 
     def forward(self, x, out=None, out_f32=False):
         return H.conv2d(x, self._packed_for(x), out=out, out_f32=out_f32)

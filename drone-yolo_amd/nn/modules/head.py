@@ -85,11 +85,12 @@ class Detect(nn.Module):
 
     def _packed_tail(self, dtype, device):
         tails = [s[-1] for s in self.cv2] + [s[-1] for s in self.cv3]
-        key = (dtype, str(device), tuple((m.weight.data_ptr(), m.weight._version, m.bias._version) for m in tails))
+        key = (dtype, str(device), H.scaled_domain(), tuple((m.weight.data_ptr(), m.weight._version, m.bias._version) for m in tails))
         cache = getattr(self, "_tail_cache", None)
         if cache is None or cache[0] != key:
-            pb = [H.pack_frag1x1(s[-1].weight, s[-1].bias, dtype, device) for s in self.cv2]
-            pc = [H.pack_frag1x1(s[-1].weight, s[-1].bias, dtype, device) for s in self.cv3]
+            # (in the scaled activation domain the tails divide by log2 e: the logits the decode reads are in true units)
+            pb = [H.pack_frag1x1(*H.domain_fold(s[-1].weight, s[-1].bias, False, raw_output=True)[:2], dtype, device) for s in self.cv2]
+            pc = [H.pack_frag1x1(*H.domain_fold(s[-1].weight, s[-1].bias, False, raw_output=True)[:2], dtype, device) for s in self.cv3]
             cache = (key, pb, pc)
             self._tail_cache = cache
         return cache[1], cache[2]
@@ -113,7 +114,7 @@ class Detect(nn.Module):
                 and ca.out_channels % 8 == 0 and isinstance(a.act, nn.SiLU) and isinstance(b.act, nn.SiLU)):
             return None
         srcs = [ca.weight, a.bn.weight, a.bn.bias, a.bn.running_mean, a.bn.running_var, cb.weight, b.bn.weight, b.bn.bias, b.bn.running_mean, b.bn.running_var]
-        key = (dtype, str(device), H.fp8_act_scale() if dtype == H.FP8 else None, tuple((t.data_ptr(), t._version) for t in srcs))
+        key = (dtype, str(device), H.fp8_act_scale() if dtype == H.FP8 else None, H.scaled_domain(), tuple((t.data_ptr(), t._version) for t in srcs))
         cache = self.__dict__.setdefault("_first_cache", {})
         hit = cache.get(i)
         if hit is None or hit[0] != key:
@@ -121,7 +122,8 @@ class Detect(nn.Module):
 
             wa, ba = fold_conv_bn(ca.weight, ca.bias, a.bn)
             wb, bb = fold_conv_bn(cb.weight, cb.bias, b.bn)
-            hit = (key, H.PackedConv(torch.cat((wa, wb), 0), torch.cat((ba, bb), 0), 1, 1, 1, True, dtype, device), ca.out_channels)
+            ws, bs, act = H.domain_fold(torch.cat((wa, wb), 0), torch.cat((ba, bb), 0), True)
+            hit = (key, H.PackedConv(ws, bs, 1, 1, 1, act, dtype, device), ca.out_channels)
             cache[i] = hit
         return hit[1], hit[2]
 

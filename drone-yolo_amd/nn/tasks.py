@@ -19,6 +19,7 @@ from __future__ import annotations
 import ast
 import contextlib
 import math
+import os
 import re
 from copy import deepcopy
 from pathlib import Path
@@ -33,6 +34,8 @@ from ..utils import LOGGER
 from ..utils.ops import make_divisible
 from ..utils.torch_utils import initialize_weights
 from .modules import SPPF, Bottleneck, C2f, Concat, Conv, Detect, DWConv, RepVGGBlock, Upsample
+from .modules.block import DFL
+from .modules.conv import PlainConv2d
 
 CFG_DIR = Path(__file__).resolve().parents[1] / "cfg"
 
@@ -184,7 +187,26 @@ class BaseModel(nn.Module):
                     self._place[s] = (m.i, off)
                 off += c
 
+    def _scaled_domain_for(self, dtype) -> bool:
+        """Whether a pass in ``dtype`` runs in the log2(e)-scaled activation domain (hip_ops.scaled_activations): 16-bit and fp8 storage
+        (fp32 keeps the reference's units: it is the bar-exact precision, not a throughput one), layer 0 a Conv / RepVGGBlock (it reads
+        the raw image and is packed with its weights scaled), and nothing but modules known to commute with a positive scale."""
+        ok = self.__dict__.get("_l2e_ok")
+        if ok is None:
+            ok = os.environ.get("DYOLO_L2E", "1") != "0" and isinstance(self.model[0], (Conv, RepVGGBlock)) and not isinstance(self.model[0], DWConv)
+            known = (Conv, RepVGGBlock, C2f, SPPF, Bottleneck, Concat, Upsample, Detect, nn.Sequential, nn.ModuleList, PlainConv2d, nn.Conv2d, nn.BatchNorm2d,
+                     nn.SiLU, nn.Identity, nn.MaxPool2d, DFL)
+            ok = ok and all(isinstance(m, known) for m in self.model.modules())
+            if ok:
+                self.model[0]._raw_input = True
+            self.__dict__["_l2e_ok"] = ok
+        return ok and dtype in (torch.bfloat16, torch.float16, H.FP8)
+
     def _predict_once(self, x, image_dtype=None):
+        with H.scaled_activations(self._scaled_domain_for(image_dtype if image_dtype is not None else x.dtype)):
+            return self._predict_layers(x, image_dtype)
+
+    def _predict_layers(self, x, image_dtype=None):
         """Run every layer.  ``x`` is an NHWC-view tensor (see hip_ops) or, with ``image_dtype`` set, the raw
         contiguous fp32 NCHW image: the first layer then runs the fused stem kernel (layout cast + conv) when
         its shape allows, otherwise the image is converted first."""
@@ -260,14 +282,16 @@ class BaseModel(nn.Module):
         if not H.stem2_fused_supported(c, 32, c1, h, w, dtype):
             return None
         srcs = [m0.conv.weight, m0.bn.weight, m0.bn.bias, m0.bn.running_mean, m0.bn.running_var] + list(m1.parameters()) + list(m1.buffers())
-        key = (dtype, str(image.device), tuple((t.data_ptr(), t._version) for t in srcs))
+        key = (dtype, str(image.device), H.scaled_domain(), tuple((t.data_ptr(), t._version) for t in srcs))
         cache = self.__dict__.get("_stem2_cache")
         if cache is None or cache[0] != key:
             from .modules.conv import fold_conv_bn
 
             w0, b0 = fold_conv_bn(m0.conv.weight, m0.conv.bias, m0.bn)
             w1, b1 = (m1.rbr_reparam.weight, m1.rbr_reparam.bias) if hasattr(m1, "rbr_reparam") else m1.get_equivalent_kernel_bias()
-            cache = (key, H.PackedStem2(w0, b0, True, w1, b1, True, dtype, image.device))
+            w0, b0, a0 = H.domain_fold(w0, b0, True, raw_input=True)  # the image is raw; layer 1 reads layer 0's (scaled) output
+            w1, b1, a1 = H.domain_fold(w1, b1, True)
+            cache = (key, H.PackedStem2(w0, b0, a0, w1, b1, a1, dtype, image.device))
             self.__dict__["_stem2_cache"] = cache
         return cache[1]
 

@@ -49,7 +49,13 @@ typedef enum dy_status {
  * element q stands for the real value q * scale (dy_conv_desc.act_scale for activations, w_scale[co] / act_scale for the weights of
  * output channel co).  Entry points that are not built for it return DY_ERR_INVALID_ARG ("bad dtype"). */
 typedef enum dy_dtype { DY_BF16 = 0, DY_F16 = 1, DY_F32 = 2, DY_FP8 = 3 } dy_dtype;
-typedef enum dy_act { DY_ACT_NONE = 0, DY_ACT_SILU = 1 } dy_act;
+/* DY_ACT_SILU_L2E: SiLU in the log2(e)-SCALED activation domain.  The caller packs every bias multiplied by log2(e) (and the weights of a
+ * layer that reads unscaled data, e.g. the image, likewise), so the accumulator holds t = log2(e) * z; the epilogue computes
+ * t / (1 + 2^-t) = log2(e) * silu(z): every stored activation of the pass is log2(e) times the reference's (max pool, nearest upsample,
+ * Concat and the Bottleneck sum commute with the positive scale) and the layers that leave the domain (the last 1x1 of each Detect
+ * branch) carry weights divided by log2(e).  One VALU instruction less per output element than DY_ACT_SILU (sigmoid(z) = 1 / (1 + 2^-t)
+ * needs no multiply in front of v_exp_f32).  The host mirror uses it for 16-bit / fp8 inference (drone-yolo_amd/hip_ops.py::scaled_activations). */
+typedef enum dy_act { DY_ACT_NONE = 0, DY_ACT_SILU = 1, DY_ACT_SILU_L2E = 2 } dy_act;
 /* Packed weight layouts of dy_conv2d_nhwc (see dy_conv_desc.w_layout). */
 typedef enum dy_wlayout { DY_WLAYOUT_ROWS = 0, DY_WLAYOUT_HALO3X3 = 1, DY_WLAYOUT_FRAG1X1 = 2 } dy_wlayout;
 
@@ -175,6 +181,7 @@ typedef struct dy_branch_desc {
   int64_t nms_workspace_bytes;
   float conf_thres;
   const uint8_t* classes_mask;
+  int32_t act_l2e; /* 1: the trunk conv's SiLU is DY_ACT_SILU_L2E (b3 scaled by log2 e, w1 divided by it: the logits stay in true units) */
 } dy_branch_desc;
 int32_t dy_detect_branch_fused_supported(int32_t c_in, int32_t c_mid, int32_t c_out, int32_t kind, int32_t nc, int32_t reg_max, int32_t dtype);
 int32_t dy_detect_branch_fused(const dy_branch_desc* d, dy_stream_t stream);
@@ -204,6 +211,7 @@ typedef struct dy_c2f_desc {
   const void* w_cv2;
   const float* bias;
   int32_t batch, h, w, cin, cin_lo, hidden, cout, ld_x, ld_x_lo, ld_y, shortcut, dtype;
+  int32_t act_l2e; /* 1: all four SiLUs are DY_ACT_SILU_L2E (input, output and biases in the log2(e)-scaled domain) */
 } dy_c2f_desc;
 int32_t dy_c2f_fused_supported(int32_t cin, int32_t cin_lo, int32_t hidden, int32_t cout, int32_t n_bottlenecks, int32_t dtype);
 int32_t dy_c2f_fused(const dy_c2f_desc* d, dy_stream_t stream);

@@ -105,6 +105,49 @@ GLDS_CASES = [
 ]
 
 
+L2E_CASES = [(64, 64, 3, 1, 2, 40, 36, "hreg / halo 3x3"), (32, 64, 3, 2, 2, 40, 40, "halo s2"), (128, 128, 3, 1, 2, 20, 20, "vgemm"), (256, 256, 1, 1, 2, 40, 40, "glds 1x1"),
+             (192, 128, 1, 1, 2, 40, 40, "stream 1x1"), (16, 24, 3, 1, 1, 12, 12, "generic"), (128, 256, 3, 2, 2, 20, 20, "glds s2")]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("case", L2E_CASES, ids=[c[-1] for c in L2E_CASES])
+def test_conv_silu_in_the_log2e_scaled_domain(case, dtype, device):
+    """DY_ACT_SILU_L2E (include/dyolo.h): the accumulator is t = log2(e) * z and the epilogue returns t / (1 + 2^-t) = log2(e) * silu(z).
+    Against the CPU: conv on the same rounded operands, t * sigmoid(t / log2 e) — every conv kernel's epilogue (the shapes pick them)."""
+    cin, cout, k, s, b, h, w, tag = case
+    g = torch.Generator().manual_seed(hash(tag) % 1013)
+    x = quantize(torch.randn(b, cin, h, w, generator=g), dtype)
+    wt = quantize(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5, dtype)
+    bias = torch.randn(cout, generator=g) * 0.2
+    t = F.conv2d(x.double(), wt.double(), bias.double(), s, k // 2).float()
+    ref = t * torch.sigmoid(t / H.LOG2E)
+    pc = H.PackedConv(wt, bias, s, k // 2, 1, H.DY_ACT_SILU_L2E, dtype, device)
+    got = H.conv2d(nhwc(x, dtype, device), pc)
+    torch.cuda.synchronize()
+    check_close(back(got), ref, dtype, f"silu_l2e {tag}", extra=2.0)
+
+
+def test_scaled_activation_domain_folds(device):
+    """hip_ops.domain_fold: biases (and the weights of the layer that reads raw data) times log2 e, SiLU -> DY_ACT_SILU_L2E, the Detect
+    tails divided by log2 e; a two-layer chain Conv(raw image) -> Conv -> plain 1x1 in the scaled domain returns the true-unit result."""
+    g = torch.Generator().manual_seed(4)
+    dtype = torch.float16
+    x = quantize(torch.rand(2, 8, 24, 20, generator=g), dtype)
+    w0, b0 = torch.randn(32, 8, 3, 3, generator=g) * 0.2, torch.randn(32, generator=g) * 0.1
+    w1, b1 = torch.randn(32, 32, 3, 3, generator=g) * 0.08, torch.randn(32, generator=g) * 0.1
+    w2, b2 = torch.randn(16, 32, 1, 1, generator=g) * 0.2, torch.randn(16, generator=g) * 0.1
+    ref = F.conv2d(F.silu(F.conv2d(F.silu(F.conv2d(x, w0, b0, 1, 1)), w1, b1, 1, 1)), w2, b2)
+    assert H.domain_fold(w0, b0, True)[2] == H.DY_ACT_SILU  # off by default: modules on their own stay in the reference's units
+    with H.scaled_activations(True):
+        f0, f1, f2 = H.domain_fold(w0, b0, True, raw_input=True), H.domain_fold(w1, b1, True), H.domain_fold(w2, b2, False, raw_output=True)
+        assert f0[2] == f1[2] == H.DY_ACT_SILU_L2E and f2[2] == H.DY_ACT_NONE
+        assert torch.allclose(f0[0], w0 * H.LOG2E) and torch.allclose(f1[0], w1) and torch.allclose(f1[1], b1 * H.LOG2E) and torch.allclose(f2[0], w2 / H.LOG2E)
+        pcs = [H.PackedConv(f[0], f[1], 1, k // 2, 1, f[2], dtype, device) for f, k in ((f0, 3), (f1, 3), (f2, 1))]
+    y = H.conv2d(H.conv2d(H.conv2d(nhwc(x, dtype, device), pcs[0]), pcs[1]), pcs[2])
+    torch.cuda.synchronize()
+    check_close(back(y), ref, dtype, "scaled-domain chain", extra=6.0)
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("case", GLDS_CASES, ids=[c[-1] for c in GLDS_CASES])
 def test_conv_glds_big_tile_matches_cpu(case, dtype, device):
