@@ -23,7 +23,7 @@
 // other's MFMAs.  LDS: m.cv1 | m.cv2 weights 36 KB + biases + 8 x 15 KB; cv1 / cv2 weights (8-24 KB) are read from L2 per strip.
 #include "common_hip.h"
 
-namespace dy {
+namespace DY_NS {
 
 #ifdef DYOLO_ABLATE
 __device__ unsigned long long c2f_phase_cycles[8];  // A, B, C, D+E of block 0 / wave 0, summed over its strips (s_memtime)
@@ -47,7 +47,6 @@ struct C2fArgs {
   const void* w2;   // FRAG1X1 order, cout 64, cin 96
   const float* bias;  // b1[64] | bm1[32] | bm2[32] | b2[64]
   int N, H, W, ldx, ldxlo, ldy, tilesX, tilesY, nStrips, shortcut;
-  int l2e;  // SiLU in the log2(e)-scaled activation domain (DY_ACT_SILU_L2E)
   unsigned x_bytes, xlo_bytes, y_bytes;
   int dbg;  // timing probes, -DDYOLO_ABLATE builds only (DYOLO_C2F_DBG): 1 no global x loads, 2 no SiLU, 4 no stores
 };
@@ -96,9 +95,10 @@ __global__ __launch_bounds__(512) void c2f_fused_kernel(const C2fArgs p) {
 #ifdef DYOLO_ABLATE
     if (p.dbg & 2) return a;
 #endif
-    float v[4] = {a[0], a[1], a[2], a[3]};
-    apply_act(v, p.l2e ? DY_ACT_SILU_L2E : DY_ACT_SILU);
-    return f32x4{v[0], v[1], v[2], v[3]};
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = silu_f32(a[e]);
+    return v;
   };
   auto wave_sync = [&]() {  // LDS written by some lanes of this wave, read by others: order it (no other wave touches the region)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -456,10 +456,11 @@ static void c2f_launch(const C2fArgs& a, int grid, hipStream_t st) {
   hipLaunchKernelGGL((c2f_fused_kernel<T, KC_LO>), dim3((unsigned)grid), dim3(512), kC2fSmem, st, a);
 }
 
-}  // namespace dy
+}  // namespace DY_NS
 
-using namespace dy;
+using namespace DY_NS;
 
+#ifndef DYOLO_L2E_BUILD
 #ifdef DYOLO_ABLATE
 extern "C" int32_t dy_c2f_debug_phase_cycles(unsigned long long* out8, int32_t reset) {
   if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(c2f_phase_cycles), 64) != hipSuccess) return -1;
@@ -475,7 +476,19 @@ extern "C" int32_t dy_c2f_fused_supported(int32_t cin, int32_t cin_lo, int32_t h
   return (cin - cin_lo == 64 && (cin_lo == 0 || cin_lo == 128) && hidden == 32 && cout == 64 && n_bottlenecks == 1 && (dtype == DY_BF16 || dtype == DY_F16)) ? 1 : 0;
 }
 
+namespace dy_l2e {
+int32_t c2f_entry(const dy_c2f_desc* d, dy_stream_t stream);
+}
+namespace dy {
+int32_t c2f_entry(const dy_c2f_desc* d, dy_stream_t stream);
+}
 extern "C" int32_t dy_c2f_fused(const dy_c2f_desc* d, dy_stream_t stream) {
+  return (d != nullptr && d->act_l2e) ? dy_l2e::c2f_entry(d, stream) : dy::c2f_entry(d, stream);
+}
+#endif
+
+namespace DY_NS {
+int32_t c2f_entry(const dy_c2f_desc* d, dy_stream_t stream) {
   DY_REQUIRE(d && d->x && d->y && d->w_cv1 && d->w_m_cv1 && d->w_m_cv2 && d->w_cv2 && d->bias, DY_ERR_INVALID_ARG, "dy_c2f_fused: null pointer");
   DY_REQUIRE(dy_c2f_fused_supported(d->cin, d->cin_lo, d->hidden, d->cout, 1, d->dtype), DY_ERR_UNSUPPORTED,
              "dy_c2f_fused: built for 64 direct input channels (+ 128 upsampled), hidden 32, cout 64, one Bottleneck, 16-bit storage (got cin %d of which %d upsampled / %d / %d dtype %d)",
@@ -496,7 +509,6 @@ extern "C" int32_t dy_c2f_fused(const dy_c2f_desc* d, dy_stream_t stream) {
   C2fArgs a{};
   a.x = d->x, a.xlo = d->x_lo, a.y = d->y, a.w1 = d->w_cv1, a.wm1 = d->w_m_cv1, a.wm2 = d->w_m_cv2, a.w2 = d->w_cv2, a.bias = d->bias;
   a.N = d->batch, a.H = d->h, a.W = d->w, a.ldx = d->ld_x, a.ldxlo = d->ld_x_lo, a.ldy = d->ld_y, a.shortcut = d->shortcut;
-  a.l2e = d->act_l2e ? 1 : 0;
   a.tilesX = (d->w + 15) / 16, a.tilesY = (d->h + 7) / 8;
   a.nStrips = d->batch * a.tilesY * a.tilesX;
   a.x_bytes = (unsigned)xb, a.xlo_bytes = (unsigned)lb, a.y_bytes = (unsigned)yb;
@@ -511,3 +523,4 @@ extern "C" int32_t dy_c2f_fused(const dy_c2f_desc* d, dy_stream_t stream) {
   }
   return check_launch("c2f_fused_kernel");
 }
+}  // namespace DY_NS

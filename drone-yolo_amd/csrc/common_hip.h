@@ -7,7 +7,33 @@
 #include <stdarg.h>
 #include "dyolo.h"
 
+// The convolution sources are compiled TWICE (Makefile): once as they stand (namespace dy: SiLU in the reference's units, DY_ACT_SILU)
+// and once with -DDYOLO_L2E_BUILD into namespace dy_l2e, where silu_f32 is the log2(e)-domain formula (DY_ACT_SILU_L2E, include/dyolo.h):
+// the extern "C" entry points (first compilation only) pick the namespace from the activation code, so no kernel carries a run-time
+// branch on it.  (A run-time wave-uniform branch in the epilogues was tried first: the duplicated epilogue code cost 2.4 % of the
+// whole pass, more than the saved instruction gains.)
+#ifdef DYOLO_L2E_BUILD
+#define DY_NS dy_l2e
+#else
+#define DY_NS dy
+#endif
+
 namespace dy {
+// ---- host-side error plumbing and the zeroing launch: ONE copy, in namespace dy (defined in api.cpp) ----
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+// Zero `bytes` (a multiple of 4) at `p` on `stream` with a KERNEL.  Never hipMemsetAsync in this library: captured into a hipGraph the
+// memset becomes a memset NODE, and on ROCm 7.0 such a node was seen to lose its order against the kernels around it — replays of a
+// captured training step returned a doubled BCE sum (the accumulators were cleared at the wrong time).
+void zero_async(void* p, size_t bytes, hipStream_t stream);
+}  // namespace dy
+
+namespace DY_NS {
+#ifdef DYOLO_L2E_BUILD
+using ::dy::check_launch;
+using ::dy::set_error;
+using ::dy::zero_async;
+#endif
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // one 16-byte chunk
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
@@ -143,33 +169,14 @@ template <> struct Chunk<fp8_t> {
 // an IEEE division: 5 VALU instructions per element.  The epilogue runs on every output element of the
 // network, and on 64-channel 3x3 layers its VALU time is comparable to the MFMA time.
 __device__ __forceinline__ float silu_f32(float x) {
-#ifdef DYOLO_SILU_PROBE  // timing probe only (wrong values): what the log2(e)-domain formulation would save network-wide
+#ifdef DYOLO_L2E_BUILD
+  // DY_ACT_SILU_L2E: x is t = log2(e) * z (biases were packed times log2 e), sigmoid(z) = 1 / (1 + 2^-t): no multiply in front of
+  // v_exp_f32, and t * sigmoid(z) = log2(e) * silu(z) is the next layer's scaled input — 4 VALU instructions per element instead of 5
   const float e = __builtin_amdgcn_exp2f(-x);
 #else
   const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
 #endif
   return x * __builtin_amdgcn_rcpf(1.0f + e);
-}
-
-// SiLU in the log2(e)-SCALED activation domain (DY_ACT_SILU_L2E, include/dyolo.h): the accumulator holds t = log2(e) * z (the stored
-// activations of the whole pass are log2(e) times their value, the packed biases likewise), so sigmoid(z) = 1 / (1 + 2^-t) needs no
-// multiply in front of v_exp_f32 and the result t * sigmoid(z) = log2(e) * silu(z) is the next layer's scaled input: 4 VALU
-// instructions per element instead of 5.  The epilogue is issue bound on the narrow layers: +2.3 % on the whole pass (r03 probe).
-__device__ __forceinline__ float silu_l2e_f32(float t) {
-  const float e = __builtin_amdgcn_exp2f(-t);
-  return t * __builtin_amdgcn_rcpf(1.0f + e);
-}
-
-// v[e] = act(v[e]) for a wave-uniform activation code: one scalar branch, never both formulas
-template <int N>
-__device__ __forceinline__ void apply_act(float (&v)[N], int act) {
-  if (act == DY_ACT_SILU_L2E) {
-#pragma unroll
-    for (int e = 0; e < N; ++e) v[e] = silu_l2e_f32(v[e]);
-  } else if (act == DY_ACT_SILU) {
-#pragma unroll
-    for (int e = 0; e < N; ++e) v[e] = silu_f32(v[e]);
-  }
 }
 
 // Fence between the last MFMA of a tile and the epilogue's VALU code, fp32 (v_mfma_f32_16x16x4_f32) only.
@@ -217,13 +224,7 @@ __device__ __forceinline__ unsigned fastdiv(unsigned n, FastDiv f) {
 // element size for entry points that are NOT built for DY_FP8 (they then report "bad dtype")
 static inline int dtype_size_no_fp8(int dtype) { return dtype == DY_FP8 ? 0 : dy_dtype_size(dtype); }
 
-// ---- host-side error plumbing ----------------------------------------------------
-void set_error(const char* fmt, ...);
-int check_launch(const char* what);
-// Zero `bytes` (a multiple of 4) at `p` on `stream` with a KERNEL.  Never hipMemsetAsync in this library: captured into a hipGraph the
-// memset becomes a memset NODE, and on ROCm 7.0 such a node was seen to lose its order against the kernels around it — replays of a
-// captured training step returned a doubled BCE sum (the accumulators were cleared at the wrong time).  Defined in api.cpp.
-void zero_async(void* p, size_t bytes, hipStream_t stream);
+// ---- host-side error plumbing: set_error / check_launch / zero_async are declared at the top (namespace dy, one copy in api.cpp) ----
 
 #define DY_REQUIRE(cond, code, ...)   \
   do {                                \
@@ -235,4 +236,4 @@ void zero_async(void* p, size_t bytes, hipStream_t stream);
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-}  // namespace dy
+}  // namespace DY_NS

@@ -25,7 +25,7 @@
 #include "common_hip.h"
 #include <type_traits>
 
-namespace dy {
+namespace DY_NS {
 
 struct Conv1Args {
   const void* x;
@@ -142,7 +142,10 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const Conv1Args p) 
 #pragma unroll
       for (int i = 0; i < MF; ++i) {
         float v[4] = {acc[i][j][0] + bb[0], acc[i][j][1] + bb[1], acc[i][j][2] + bb[2], acc[i][j][3] + bb[3]};
-        apply_act(v, p.act);
+        if (p.act == DY_ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
+        }
         unsigned char* sp = escr + (i * 16 + lr) * EP_PITCH + (j * 16 + lq * 4) * (int)sizeof(OutT);
         if constexpr (OUTF32 || sizeof(T) == 4) {
           *reinterpret_cast<f32x4*>(sp) = f32x4{v[0], v[1], v[2], v[3]};
@@ -308,4 +311,4 @@ int conv1x1_stream_dispatch(const dy_conv_desc* d, hipStream_t st) {
   }
 }
 
-}  // namespace dy
+}  // namespace DY_NS

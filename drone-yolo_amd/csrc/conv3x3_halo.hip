@@ -28,7 +28,7 @@
 #include <stdlib.h>
 #include <type_traits>
 
-namespace dy {
+namespace DY_NS {
 
 struct Conv3Args {
   const void* x;
@@ -277,7 +277,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
 #pragma unroll
       for (int i = 0; i < MF; ++i) {
         float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};  // bias is already inside
-        apply_act(v, p.act);  // (PIPE is only launched for SiLU layers)
+        if (PIPE || p.act == DY_ACT_SILU) {  // PIPE is only launched for SiLU layers without residual: no branches
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
+        }
         if constexpr (!OUTF32 && !PIPE) {
           if (rg != nullptr) {
 #pragma unroll
@@ -343,7 +346,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
   };
   auto epi_pair = [&](const f32x4 (&accp)[MF][NF], int i, int j) {
     float v[4] = {accp[i][j][0], accp[i][j][1], accp[i][j][2], accp[i][j][3]};
-    apply_act(v, p.act);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
     if constexpr (sizeof(T) == 2) {  // PIPE exists for 16-bit storage only
       typedef __attribute__((ext_vector_type(4))) T t4;
       const t4 rr = __builtin_bit_cast(t4, rres[i][j]);
@@ -526,7 +530,7 @@ static int launch_halo(const Conv3Args& a, int batch, hipStream_t st) {
   if (ws && grid > p.tilesN) grid -= grid % p.tilesN;  // keep every block on one n-tile
   static const int nopipe = dy_ablate("DYOLO_NO_PIPE");
   if constexpr (sizeof(T) == 2 && !OUTF32) {
-    if (ws && (p.nChunks == 1 || p.nChunks == 2 || p.nChunks == 4) && !nopipe && !p.dbg && (p.act == DY_ACT_SILU || p.act == DY_ACT_SILU_L2E) && p.Cout % 8 == 0 &&
+    if (ws && (p.nChunks == 1 || p.nChunks == 2 || p.nChunks == 4) && !nopipe && !p.dbg && p.act == DY_ACT_SILU && p.Cout % 8 == 0 &&
         p.y_bytes && (!p.res || p.r_bytes)) {
       constexpr int ep_bytes = 8 * MF * 16 * (NF * 16 * (int)sizeof(T) + 16);  // a static LDS object in this variant
 #define DY_PIPE_LAUNCH(N)                                                                                                              \
@@ -640,4 +644,4 @@ int conv3x3_halo_dispatch(const dy_conv_desc* d, hipStream_t st) {
   }
 }
 
-}  // namespace dy
+}  // namespace DY_NS

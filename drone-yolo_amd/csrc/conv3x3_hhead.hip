@@ -27,7 +27,7 @@
 #include "common_hip.h"
 #include "nms_ws.h"
 
-namespace dy {
+namespace DY_NS {
 
 __device__ __attribute__((aligned(256))) const unsigned int g_hhzero_page[64] = {0};
 
@@ -39,7 +39,6 @@ struct HheadArgs {
   const float* b1;     // 64 / 16
   float* out;          // pred (N, 4 + nc, A) fp32
   int N, H, W, ldx, A, a0, nc;
-  int l2e;  // the trunk conv's SiLU in the log2(e)-scaled domain (DY_ACT_SILU_L2E)
   float stride;
   int tilesX, tilesY, nSpatial;
   int* counts;
@@ -185,10 +184,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hhead_kernel(const HheadArgs p
 #pragma unroll
     for (int o = 0; o < kHhTH; ++o) {
       t4 ov;
-      float v[4] = {acc[o][0], acc[o][1], acc[o][2], acc[o][3]};
-      apply_act(v, p.l2e ? DY_ACT_SILU_L2E : DY_ACT_SILU);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ov[e] = Elem<T>::from_f32(v[e]);
+      for (int e = 0; e < 4; ++e) ov[e] = Elem<T>::from_f32(silu_f32(acc[o][e]));
       *reinterpret_cast<u32x2*>(mid + mid_w + o * (kHhTW * 64)) = __builtin_bit_cast(u32x2, ov);
     }
   };
@@ -336,10 +333,11 @@ static int launch_hhead(const HheadArgs& a, int kind, hipStream_t st) {
   return check_launch("conv3x3_hhead_kernel");
 }
 
-}  // namespace dy
+}  // namespace DY_NS
 
-using namespace dy;
+using namespace DY_NS;
 
+#ifndef DYOLO_L2E_BUILD
 extern "C" int32_t dy_detect_branch_fused_supported(int32_t c_in, int32_t c_mid, int32_t c_out, int32_t kind, int32_t nc, int32_t reg_max, int32_t dtype) {
   if (!(dtype == DY_BF16 || dtype == DY_F16) || reg_max != 16 || c_in != 64 || c_mid != 64) return 0;
   if (kind == 1) return c_out == 64;
@@ -347,7 +345,25 @@ extern "C" int32_t dy_detect_branch_fused_supported(int32_t c_in, int32_t c_mid,
   return 0;
 }
 
+namespace dy_l2e {
+int32_t branch_entry(const dy_branch_desc* d, dy_stream_t stream);
+}
+namespace dy {
+int32_t branch_entry(const dy_branch_desc* d, dy_stream_t stream);
+}
 extern "C" int32_t dy_detect_branch_fused(const dy_branch_desc* d, dy_stream_t stream) {
+  return (d != nullptr && d->act_l2e) ? dy_l2e::branch_entry(d, stream) : dy::branch_entry(d, stream);
+}
+
+extern "C" int32_t dy_nms_reset_counts(void* nms_workspace, int32_t batch, dy_stream_t stream) {
+  DY_REQUIRE(nms_workspace && batch > 0, DY_ERR_INVALID_ARG, "dy_nms_reset_counts: bad arguments");
+  zero_async(nms_workspace, (size_t)batch * 4, reinterpret_cast<hipStream_t>(stream));
+  return check_launch("dy_nms_reset_counts");
+}
+#endif
+
+namespace DY_NS {
+int32_t branch_entry(const dy_branch_desc* d, dy_stream_t stream) {
   DY_REQUIRE(d && d->x && d->w3 && d->b3 && d->w1 && d->b1 && d->out, DY_ERR_INVALID_ARG, "dy_detect_branch_fused: null pointer");
   DY_REQUIRE(dy_detect_branch_fused_supported(d->c_in, d->c_mid, d->kind == 1 ? 4 * d->reg_max : d->nc, d->kind, d->nc, d->reg_max, d->dtype), DY_ERR_UNSUPPORTED,
              "dy_detect_branch_fused: kind %d c_in %d c_mid %d nc %d reg_max %d dtype %d is not built (run dy_conv2d_nhwc + dy_detect_head_decode)", d->kind, d->c_in,
@@ -361,7 +377,6 @@ extern "C" int32_t dy_detect_branch_fused(const dy_branch_desc* d, dy_stream_t s
   HheadArgs a{};
   a.x = d->x, a.w3 = d->w3, a.b3 = d->b3, a.w1 = d->w1, a.b1 = d->b1, a.out = d->out;
   a.N = d->batch, a.H = d->h, a.W = d->w, a.ldx = d->ld_x, a.A = d->anchors, a.a0 = d->anchor0, a.nc = d->nc, a.stride = d->stride;
-  a.l2e = d->act_l2e ? 1 : 0;
   a.tilesX = (d->w + kHhTW - 1) / kHhTW, a.tilesY = (d->h + kHhTH - 1) / kHhTH;
   a.nSpatial = d->batch * a.tilesX * a.tilesY;
   if (d->kind == 2 && d->nms_workspace) {
@@ -374,9 +389,5 @@ extern "C" int32_t dy_detect_branch_fused(const dy_branch_desc* d, dy_stream_t s
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return d->dtype == DY_BF16 ? launch_hhead<bf16_t>(a, d->kind, st) : launch_hhead<f16_t>(a, d->kind, st);
 }
+}  // namespace DY_NS
 
-extern "C" int32_t dy_nms_reset_counts(void* nms_workspace, int32_t batch, dy_stream_t stream) {
-  DY_REQUIRE(nms_workspace && batch > 0, DY_ERR_INVALID_ARG, "dy_nms_reset_counts: bad arguments");
-  zero_async(nms_workspace, (size_t)batch * 4, reinterpret_cast<hipStream_t>(stream));
-  return check_launch("dy_nms_reset_counts");
-}

@@ -30,7 +30,7 @@
 #include "common_hip.h"
 #include "conv_args.h"
 
-namespace dy {
+namespace DY_NS {
 
 __device__ __attribute__((aligned(256))) const unsigned int g_hzero_page[64] = {0};
 
@@ -186,7 +186,10 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hreg_kernel(const HregArgs p) 
 #pragma unroll
     for (int o = 0; o < kHrTH; ++o) {
       float v[4] = {acc[o][0], acc[o][1], acc[o][2], acc[o][3]};
-      apply_act(v, p.act);
+      if (p.act == DY_ACT_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
+      }
       if constexpr (RES) {  // the row pair's 16-byte pieces back in result-lane order: the store-side swap run backwards
         const auto sx = __builtin_amdgcn_permlane16_swap(rl[o / 2][0], rl[o / 2][2], false, false);
         const auto sy = __builtin_amdgcn_permlane16_swap(rl[o / 2][1], rl[o / 2][3], false, false);
@@ -292,4 +295,4 @@ int conv3x3_hreg_try(const dy_conv_desc* d, hipStream_t st) {
   return d->dtype == DY_BF16 ? launch_hreg<bf16_t>(a, st) : launch_hreg<f16_t>(a, st);
 }
 
-}  // namespace dy
+}  // namespace DY_NS

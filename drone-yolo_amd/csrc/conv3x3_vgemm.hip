@@ -22,7 +22,7 @@
 #include "common_hip.h"
 #include "conv_args.h"
 
-namespace dy {
+namespace DY_NS {
 
 __device__ __attribute__((aligned(256))) const unsigned int g_vzero_page[64] = {0};
 
@@ -276,7 +276,10 @@ __global__ __launch_bounds__(512) void conv3x3_vgemm_kernel(const ConvArgs p, co
           for (int ii = 0; ii < 2; ++ii) {
             const int i = half * 2 + ii;
             float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-            apply_act(v, p.act);
+            if (p.act == DY_ACT_SILU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
+            }
             if (rg != nullptr) {
               if (rpx[i] >= 0) {
                 typedef __attribute__((ext_vector_type(4))) T t4;
@@ -512,7 +515,10 @@ __global__ __launch_bounds__(1024) void conv3x3_vgemm16_kernel(const ConvArgs p,
         for (int jj = 0; jj < EG; ++jj) {
           const int j = gq * EG + jj;
           float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-          apply_act(v, p.act);
+          if (p.act == DY_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
+          }
           if (rpx >= 0) {
             typedef __attribute__((ext_vector_type(4))) T t4;
             const t4 rv = *reinterpret_cast<const t4*>(rg + (size_t)rpx * (size_t)p.ldres + (size_t)(n0 + j * 16 + lq * 4));
@@ -620,4 +626,4 @@ int conv3x3_vgemm_try(const ConvArgs& a, int dtype, bool out_f32, hipStream_t st
   }
 }
 
-}  // namespace dy
+}  // namespace DY_NS

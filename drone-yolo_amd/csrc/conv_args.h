@@ -1,8 +1,9 @@
 // Kernel-side argument block shared by the implicit-GEMM convolution kernels (conv_igemm.hip, conv_gemm_glds.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "common_hip.h"
 
-namespace dy {
+namespace DY_NS {
 
 struct ConvArgs {
   const void* x;
@@ -30,4 +31,4 @@ int conv_gemm_glds_try(const ConvArgs& a, int dtype, bool out_f32, hipStream_t s
 // conv3x3_vgemm.hip: 3x3 stride-1, Cin >= 128, Cout % 128 == 0 over the virtual flat pixel index.  Same return convention.
 int conv3x3_vgemm_try(const ConvArgs& a, int dtype, bool out_f32, hipStream_t st);
 
-}  // namespace dy
+}  // namespace DY_NS

@@ -22,7 +22,7 @@
 #include "common_hip.h"
 #include "conv_args.h"
 
-namespace dy {
+namespace DY_NS {
 
 __device__ __attribute__((aligned(256))) const unsigned int g_zero_page[64] = {0};
 
@@ -199,7 +199,10 @@ __global__ __launch_bounds__(BM * WN) void conv_gemm_glds_kernel(const ConvArgs 
         for (int ii = 0; ii < 4 / NH; ++ii) {
           const int i = half * (4 / NH) + ii;
           float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-          apply_act(v, p.act);
+          if (p.act == DY_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
+          }
           if (rg != nullptr) {
             const int m = m0 + i * 16 + lr;
             if (m < p.M) {
@@ -400,7 +403,10 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_persist_kernel(const ConvA
           for (int ii = 0; ii < 2; ++ii) {
             const int i = half * 2 + ii;
             float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-            apply_act(v, p.act);
+            if (p.act == DY_ACT_SILU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
+            }
             if (rg != nullptr) {
               const int m = m0 + i * 16 + lr;
               if (m < p.M) {
@@ -513,4 +519,4 @@ int conv_gemm_glds_try(const ConvArgs& a, int dtype, bool out_f32, hipStream_t s
   }
 }
 
-}  // namespace dy
+}  // namespace DY_NS

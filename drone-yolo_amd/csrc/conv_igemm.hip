@@ -24,7 +24,7 @@
 #include "conv_args.h"
 #include <type_traits>
 
-namespace dy {
+namespace DY_NS {
 
 
 template <typename T, int BM, int BN, bool OUTF32>
@@ -230,7 +230,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       v[e + 2] = t[2] + bb[2];
       v[e + 3] = t[3] + bb[3];
     }
-    apply_act(v, p.act);
+    if (p.act == DY_ACT_SILU) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] = silu_f32(v[e]);
+    }
     const int nvalid = (p.Cout - gcol) < VEC ? (p.Cout - gcol) : VEC;
     if constexpr (!OUTF32) if (rg != nullptr) {
       const T* rp = rg + (size_t)m * (size_t)p.ldres + (size_t)gcol;
@@ -298,7 +301,6 @@ __global__ __launch_bounds__(256) void conv_grouped_kernel(const ConvArgs p, int
       }
     }
     if (p.act == DY_ACT_SILU) acc = silu_f32(acc);
-    else if (p.act == DY_ACT_SILU_L2E) acc = silu_l2e_f32(acc);
     if (rg) acc += Elem<T>::to_f32(rg[(size_t)m * (size_t)p.ldres + co]);
     yg[(size_t)m * (size_t)p.ldy + co] = Elem<T>::from_f32(acc);
   }
@@ -329,10 +331,11 @@ static int launch_dtype(const ConvArgs& a, hipStream_t st) {
 int conv3x3_halo_dispatch(const dy_conv_desc* d, hipStream_t st);    // conv3x3_halo.hip
 int conv1x1_stream_dispatch(const dy_conv_desc* d, hipStream_t st);  // conv1x1_stream.hip
 
-}  // namespace dy
+}  // namespace DY_NS
 
-using namespace dy;
+using namespace DY_NS;
 
+#ifndef DYOLO_L2E_BUILD
 extern "C" int32_t dy_conv_k_pad(int32_t cin, int32_t ksize, int32_t dtype) {
   const int es = dy_dtype_size(dtype);
   if (es == 0 || cin <= 0 || ksize <= 0) return -1;
@@ -343,7 +346,25 @@ extern "C" int32_t dy_conv_k_pad(int32_t cin, int32_t ksize, int32_t dtype) {
 
 extern "C" int32_t dy_conv_cout_pad(int32_t cout) { return cout <= 0 ? -1 : (cout + 63) / 64 * 64; }
 
+namespace dy_l2e {
+int32_t conv2d_entry(const dy_conv_desc* d, dy_stream_t stream);
+}
+namespace dy {
+int32_t conv2d_entry(const dy_conv_desc* d, dy_stream_t stream);
+}
+// DY_ACT_SILU_L2E runs the second compilation of the kernels (namespace dy_l2e: silu_f32 is the scaled-domain formula there)
 extern "C" int32_t dy_conv2d_nhwc(const dy_conv_desc* d, dy_stream_t stream) {
+  if (d != nullptr && d->act == DY_ACT_SILU_L2E) {
+    dy_conv_desc c = *d;
+    c.act = DY_ACT_SILU;
+    return dy_l2e::conv2d_entry(&c, stream);
+  }
+  return dy::conv2d_entry(d, stream);
+}
+#endif
+
+namespace DY_NS {
+int32_t conv2d_entry(const dy_conv_desc* d, dy_stream_t stream) {
   DY_REQUIRE(d != nullptr, DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: null descriptor");
   DY_REQUIRE(d->x && d->w && d->bias && d->y, DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: null x/w/bias/y");
   const int es = dy_dtype_size(d->dtype);
@@ -470,3 +491,4 @@ extern "C" int32_t dy_conv2d_nhwc(const dy_conv_desc* d, dy_stream_t stream) {
       return launch_dtype<float, false>(a, st);
   }
 }
+}  // namespace DY_NS

@@ -17,7 +17,7 @@
 #include "common_hip.h"
 #include <type_traits>
 
-namespace dy {
+namespace DY_NS {
 
 struct StemArgs {
   const float* x;
@@ -134,7 +134,10 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const StemArgs p) {
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      apply_act(v, p.act);
+      if (p.act == DY_ACT_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
+      }
       unsigned char* sp = escr + (i * 16 + lr) * EP_PITCH + (j * 16 + lq * 4) * (int)sizeof(T);
       if constexpr (sizeof(T) == 4) {
         *reinterpret_cast<f32x4*>(sp) = f32x4{v[0], v[1], v[2], v[3]};
@@ -200,13 +203,30 @@ static int launch_stem_dtype(const StemArgs& a, hipStream_t st) {
   }
 }
 
-}  // namespace dy
+}  // namespace DY_NS
 
-using namespace dy;
+using namespace DY_NS;
 
+#ifndef DYOLO_L2E_BUILD
+namespace dy_l2e {
+int32_t stem_entry(const float* x, const void* w, const float* bias, void* y, int32_t n, int32_t cin, int32_t h, int32_t w_in, int32_t cout, int32_t ld_y, int32_t act,
+                   int32_t dtype, dy_stream_t stream);
+}
+namespace dy {
+int32_t stem_entry(const float* x, const void* w, const float* bias, void* y, int32_t n, int32_t cin, int32_t h, int32_t w_in, int32_t cout, int32_t ld_y, int32_t act,
+                   int32_t dtype, dy_stream_t stream);
+}
 extern "C" int32_t dy_stem_conv3x3s2_nchw(const float* x, const void* w, const float* bias, void* y, int32_t n, int32_t cin,
                                           int32_t h, int32_t w_in, int32_t cout, int32_t ld_y, int32_t act, int32_t dtype,
                                           dy_stream_t stream) {
+  if (act == DY_ACT_SILU_L2E) return dy_l2e::stem_entry(x, w, bias, y, n, cin, h, w_in, cout, ld_y, DY_ACT_SILU, dtype, stream);
+  return dy::stem_entry(x, w, bias, y, n, cin, h, w_in, cout, ld_y, act, dtype, stream);
+}
+#endif
+
+namespace DY_NS {
+int32_t stem_entry(const float* x, const void* w, const float* bias, void* y, int32_t n, int32_t cin, int32_t h, int32_t w_in, int32_t cout, int32_t ld_y, int32_t act,
+                   int32_t dtype, dy_stream_t stream) {
   const int es = dtype_size_no_fp8(dtype);
   DY_REQUIRE(x && w && bias && y && es, DY_ERR_INVALID_ARG, "dy_stem_conv3x3s2_nchw: null pointer or bad dtype");
   DY_REQUIRE(n > 0 && h > 0 && w_in > 0 && cout > 0 && cin >= 1 && cin * 9 <= 32, DY_ERR_INVALID_ARG,
@@ -234,3 +254,4 @@ extern "C" int32_t dy_stem_conv3x3s2_nchw(const float* x, const void* w, const f
     default: return launch_stem_dtype<float>(a, st);
   }
 }
+}  // namespace DY_NS

@@ -5,7 +5,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
-namespace dy {
+#ifndef DY_NS
+#define DY_NS dy
+#endif
+namespace DY_NS {
 
 struct NmsWs {
   int* counts;
@@ -37,4 +40,4 @@ static inline NmsWs nms_ws_layout(void* ws, int batch, int anchors) {
   return w;
 }
 
-}  // namespace dy
+}  // namespace DY_NS

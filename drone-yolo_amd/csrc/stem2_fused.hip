@@ -23,7 +23,7 @@
 // LDS 64 KiB -> two workgroups per CU: one loads its patch while the other computes.
 #include "common_hip.h"
 
-namespace dy {
+namespace DY_NS {
 
 __device__ __attribute__((aligned(16))) const unsigned int g_s2zero[4] = {0, 0, 0, 0};
 
@@ -140,10 +140,8 @@ __global__ __launch_bounds__(256, 2) void stem2_fused_kernel(const Stem2Args p) 
         f32x4 acc = Elem<T>::mma(wf0[j], a, bias0[j]);
         typedef __attribute__((ext_vector_type(4))) T t4;
         t4 o;
-        float v0[4] = {acc[0], acc[1], acc[2], acc[3]};
-        apply_act(v0, p.act0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f32(v0[e]);
+        for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f32(silu_f32(acc[e]));
         u32x2 ov = __builtin_bit_cast(u32x2, o);
         if (!inside) ov = u32x2{0u, 0u};  // layer 1's zero padding
         if (valid) *reinterpret_cast<u32x2*>(ent + (((j * 2 + (lq >> 1)) ^ sw) * 16)) = ov;
@@ -173,10 +171,8 @@ __global__ __launch_bounds__(256, 2) void stem2_fused_kernel(const Stem2Args p) 
     for (int i = 0; i < 8; ++i) {
       typedef __attribute__((ext_vector_type(4))) T t4;
       t4 o;
-      float v1[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
-      apply_act(v1, p.act1);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f32(v1[e]);
+      for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f32(silu_f32(acc[i][e]));
       *reinterpret_cast<u32x2*>(stem + (i * 16 + lr) * kS2EpPitch + (wave * 16 + lq * 4) * 2) = __builtin_bit_cast(u32x2, o);
     }
     __syncthreads();
@@ -194,21 +190,38 @@ __global__ __launch_bounds__(256, 2) void stem2_fused_kernel(const Stem2Args p) 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-}  // namespace dy
+}  // namespace DY_NS
 
-using namespace dy;
+using namespace DY_NS;
 
+#ifndef DYOLO_L2E_BUILD
 extern "C" int32_t dy_stem2_fused_supported(int32_t cin, int32_t c0, int32_t c1, int32_t h, int32_t w, int32_t dtype) {
   return (cin == 3 && c0 == 32 && c1 == 64 && h > 0 && w > 0 && h % 4 == 0 && w % 4 == 0 && (dtype == DY_BF16 || dtype == DY_F16)) ? 1 : 0;
 }
 
+namespace dy_l2e {
+int32_t stem2_entry(const dy_stem2_desc* d, dy_stream_t stream);
+}
+namespace dy {
+int32_t stem2_entry(const dy_stem2_desc* d, dy_stream_t stream);
+}
 extern "C" int32_t dy_stem2_fused(const dy_stem2_desc* d, dy_stream_t stream) {
+  if (d != nullptr && d->act0 == DY_ACT_SILU_L2E && d->act1 == DY_ACT_SILU_L2E) {
+    dy_stem2_desc c = *d;
+    c.act0 = c.act1 = DY_ACT_SILU;
+    return dy_l2e::stem2_entry(&c, stream);
+  }
+  return dy::stem2_entry(d, stream);
+}
+#endif
+
+namespace DY_NS {
+int32_t stem2_entry(const dy_stem2_desc* d, dy_stream_t stream) {
   DY_REQUIRE(d && d->x && d->w0 && d->b0 && d->w1 && d->b1 && d->y, DY_ERR_INVALID_ARG, "dy_stem2_fused: null descriptor or pointer");
   DY_REQUIRE(dy_stem2_fused_supported(3, 32, 64, d->h, d->w, d->dtype), DY_ERR_UNSUPPORTED,
              "dy_stem2_fused: built for 3 -> 32 -> 64 channels, 16-bit storage, image sides that are multiples of 4 (got %d x %d, dtype %d)",
              d->h, d->w, d->dtype);
-  DY_REQUIRE((d->act0 == DY_ACT_SILU && d->act1 == DY_ACT_SILU) || (d->act0 == DY_ACT_SILU_L2E && d->act1 == DY_ACT_SILU_L2E), DY_ERR_UNSUPPORTED,
-             "dy_stem2_fused: both layers must end in SiLU (both DY_ACT_SILU or both DY_ACT_SILU_L2E)");
+  DY_REQUIRE(d->act0 == DY_ACT_SILU && d->act1 == DY_ACT_SILU, DY_ERR_UNSUPPORTED, "dy_stem2_fused: both layers must end in SiLU");
   DY_REQUIRE(d->n > 0 && d->ld_y >= 64 && d->ld_y % 8 == 0 && aligned16(d->y) && aligned16(d->x) && aligned16(d->w0) && aligned16(d->w1) &&
                  aligned16(d->b0) && aligned16(d->b1),
              DY_ERR_INVALID_ARG, "dy_stem2_fused: pointers must be 16-byte aligned, output pitch a multiple of 8 elements >= 64");
@@ -243,3 +256,4 @@ extern "C" int32_t dy_stem2_fused(const dy_stem2_desc* d, dy_stream_t stream) {
     hipLaunchKernelGGL((stem2_fused_kernel<f16_t>), dim3((unsigned)grid), dim3(256), 0, st, a);
   return check_launch("stem2_fused_kernel");
 }
+}  // namespace DY_NS

@@ -157,15 +157,21 @@ def test_end_to_end_against_reference_vectors(tag, dtype, device):
         # reduced-precision storage: a score within rounding of conf or of a neighbour may flip.  Floors = the measured level
         # (profiles/r01_parity_report.jsonl, r02) minus a margin: bf16 may lose 3 % of the reference detections (at least one:
         # the small cases keep 2..17 boxes), fp16 1 %; matched boxes IoU >= 0.998 (bf16) / 0.9995 (fp16)
-        # two-sided: detections the reference does not keep ("extra") are bounded like the ones it keeps and we lose ("missed")
+        # two-sided: detections the reference does not keep ("extra") are bounded like the ones it keeps and we lose ("missed").
+        # A detection whose score sits within the storage type's score error of `conf` is decided by rounding (the v8n320 case keeps 14 boxes,
+        # ALL scored 0.2500 .. 0.2557): such flips are not counted; everything else is, up to `allowed` (NMS near-ties).
         tol, iou_floor = (0.03, 0.998) if dtype == torch.bfloat16 else (0.01, 0.9995)
-        for i, st in enumerate(stats):
+        margin = 2e-3 if dtype == torch.bfloat16 else 5e-4
+        for i in range(len(counts)):
             n_ref = max(len(exp_idx[i]), 1)
             allowed = max(1, int(tol * n_ref))
-            assert st[0] >= 1.0 - allowed / n_ref - 1e-9, f"{tag} [{dtype}] image {i}: only {st[0]:.4f} of {n_ref} reference detections reproduced"
-            ref_keys = {(int(a), int(r[5])) for a, r in zip(exp_idx[i], exp_rows[i])}
-            got_keys = {(int(a), int(k)) for a, k in zip(cf.nms.index[i, :counts[i]].cpu().tolist(), cf.nms.out[i, :counts[i], 5].cpu().tolist())}
-            assert len(got_keys - ref_keys) <= allowed, f"{tag} [{dtype}] image {i}: {len(got_keys - ref_keys)} detections the reference does not keep (of {n_ref})"
+            got_rows = cf.nms.out[i, :counts[i]].cpu().numpy()
+            ref_keys = {(int(a), int(r[5])): float(r[4]) for a, r in zip(exp_idx[i], exp_rows[i])}
+            got_keys = {(int(a), int(r[5])): float(r[4]) for a, r in zip(cf.nms.index[i, :counts[i]].cpu().tolist(), got_rows)}
+            missed = [k for k, sc in ref_keys.items() if k not in got_keys and sc > 0.25 + margin]
+            extra = [k for k, sc in got_keys.items() if k not in ref_keys and sc > 0.25 + margin]
+            assert len(missed) <= allowed, f"{tag} [{dtype}] image {i}: {len(missed)} of {n_ref} reference detections (scored beyond conf + {margin}) lost"
+            assert len(extra) <= allowed, f"{tag} [{dtype}] image {i}: {len(extra)} detections (scored beyond conf + {margin}) the reference does not keep (of {n_ref})"
         assert iou_min >= iou_floor, f"{tag} [{dtype}]: min IoU {iou_min:.5f} < {iou_floor}"
 
 
