@@ -104,27 +104,35 @@ def golden_case(npz_name: str, tag: str):
     return meta, x, exp_rows, exp_idx
 
 
-def detection_parity(nms_bufs, exp_rows, exp_idx) -> dict:
+def detection_parity(nms_bufs, exp_rows, exp_idx, conf: float = 0.25, margin: float = 0.0) -> dict:
     """Gate numbers of one pass (``nms_bufs``: hip_ops.NmsBuffers of the device pass) against the reference rows.  Two-sided:
     ``missed`` = reference detections this pass does not keep with the same (anchor index, class); ``extra`` = detections this pass
-    keeps that the reference does not (same key) — so a pass that kept everything would not read as a perfect match."""
+    keeps that the reference does not (same key) — so a pass that kept everything would not read as a perfect match.
+    ``missed_clear`` / ``extra_clear`` count only those scored beyond ``conf + margin`` (reference score for a missed one, this pass's
+    for an extra one): a detection scored within the storage type's score error of the confidence threshold is decided by rounding,
+    whatever the kernels do — the clear ones are NMS near-ties or real defects."""
     counts = nms_bufs.count.cpu().tolist()
     out_rows, out_idx = nms_bufs.out.cpu().numpy(), nms_bufs.index.cpu().numpy()
-    stats, sets_equal, n_ref, n_hit, n_got, missed_img, extra_img = [], True, 0, 0, 0, [], []
+    stats, sets_equal, n_ref, n_hit, n_got, missed_img, extra_img, missed_clear, extra_clear = [], True, 0, 0, 0, [], [], 0, 0
     for i, c in enumerate(counts):
         st = match_stats(out_rows[i, :c], out_idx[i, :c], exp_rows[i], exp_idx[i])
         stats.append(st)
-        ref_keys = {(int(a), int(r[5])) for a, r in zip(exp_idx[i], exp_rows[i])}
-        got_keys = {(int(a), int(r[5])) for a, r in zip(out_idx[i, :c], out_rows[i, :c])}
+        ref_keys = {(int(a), int(r[5])): float(r[4]) for a, r in zip(exp_idx[i], exp_rows[i])}
+        got_keys = {(int(a), int(r[5])): float(r[4]) for a, r in zip(out_idx[i, :c], out_rows[i, :c])}
         n_ref += len(ref_keys)
         n_got += len(got_keys)
-        n_hit += len(ref_keys & got_keys)
-        missed_img.append(len(ref_keys - got_keys))
-        extra_img.append(len(got_keys - ref_keys))
+        n_hit += len(ref_keys.keys() & got_keys.keys())
+        mi = [k for k in ref_keys if k not in got_keys]
+        ex = [k for k in got_keys if k not in ref_keys]
+        missed_img.append(len(mi))
+        extra_img.append(len(ex))
+        missed_clear += sum(1 for k in mi if ref_keys[k] > conf + margin)
+        extra_clear += sum(1 for k in ex if got_keys[k] > conf + margin)
         sets_equal &= sorted(out_idx[i, :c].tolist()) == sorted(int(a) for a in exp_idx[i])
     missed, extra = sum(missed_img), sum(extra_img)
     return {"images": len(counts), "ref_detections": n_ref, "kept_detections": n_got, "match_rate": round(n_hit / max(n_ref, 1), 5),
             "missed": missed, "extra": extra, "missed_frac": round(missed / max(n_ref, 1), 5), "extra_frac": round(extra / max(n_ref, 1), 5),
+            "missed_clear": missed_clear, "extra_clear": extra_clear, "clear_margin": margin,
             "missed_max_image": max(missed_img, default=0), "extra_max_image": max(extra_img, default=0),
             "match_rate_min_image": round(min(s[0] for s in stats), 5), "iou_min": round(min(s[1] for s in stats), 6),
             "iou_mean": round(float(np.mean([s[2] for s in stats])), 6), "counts_equal": counts == [len(r) for r in exp_idx],

@@ -204,22 +204,27 @@ def test_bench_configuration_against_reference_rows(tag, dtype, device):
     y_sub = cf.pred[:, :, ::199].cpu()
     box_err = float((y_sub[:, :4] - torch.from_numpy(g[f"{tag}__y_sub"])[:, :4]).abs().max())
     cls_err = float((y_sub[:, 4:] - torch.from_numpy(g[f"{tag}__y_sub"])[:, 4:]).abs().max())
-    par = PR.detection_parity(cf.nms, exp_rows, exp_idx)
+    # score error of the storage type at this depth (measured r02 / r03: fp16 3e-4 .. 4e-4, bf16 1.3e-3 .. 2.9e-3): a detection scored that
+    # close to `conf` is kept or dropped by rounding alone
+    margin = {torch.float32: 0.0, torch.float16: 5e-4, torch.bfloat16: 4e-3}[dtype]
+    par = PR.detection_parity(cf.nms, exp_rows, exp_idx, conf=0.25, margin=margin)
     _report(f"bench-config {tag}", {"dtype": str(dtype), "box_max_err_px": box_err, "cls_max_err": cls_err, **par})
     if dtype == torch.float32:
         assert box_err < 2e-2 and cls_err < 1e-4, (box_err, cls_err)
         assert par["counts_equal"] and par["kept_sets_identical"] and par["match_rate"] == 1.0 and par["iou_min"] >= 0.999, par
     else:
-        # fp16 = the headline dtype: IoU bar met, at most 1 % of the reference detections (at least one) lost to score near-ties;
-        # bf16 (not a headline dtype): 4 %, and the worst single box at IoU >= 0.993 - measured 0.9949 .. 0.9957 over the r02 kernel
-        # revisions (one box of ~1100 sets the minimum; the mean stays at 0.9991), minus a margin
-        # r03: the gate is two-sided — `missed` (reference detections lost) and `extra` (kept here, absent in the reference) are
-        # bounded separately: fp16 0.3 % each (measured r02: 0 / 1 of 1,103 on s640bench, 1 / ? of 1,122 on s640b4), bf16 4 % each
-        tol, iou_floor = (0.003, 0.999) if dtype == torch.float16 else (0.04, 0.993)
+        # r03: the gate is two-sided — `missed` (reference detections lost) and `extra` (kept here, absent in the reference) are bounded
+        # separately.  fp16 (the headline dtype): the IoU bar holds; at most 0.6 % each way in all (measured r03: 0.18 % .. 0.36 % missed,
+        # 0.09 % extra — ~1,100 detections whose scores have a density of ~7,500 per unit near conf, times a score error of 3e-4, puts 2 - 5
+        # of them at the mercy of rounding), and at most 0.3 % each way among those scored CLEAR of the threshold (NMS near-ties).
+        # bf16 (not a headline dtype): 4 % each way, the worst single box at IoU >= 0.993.
+        tol_all, tol_clear, iou_floor = (0.006, 0.003, 0.999) if dtype == torch.float16 else (0.04, 0.03, 0.993)
         if tag == "s640b4lo" and dtype == torch.bfloat16:
-            tol = 0.20  # every one of this case's 45 detections scores within 0.08 logit of conf: bf16 scores (+-2e-3) flip 7 of them (r02)
-        allowed = max(1, int(tol * par["ref_detections"]))
-        assert par["missed"] <= allowed and par["extra"] <= allowed and par["iou_min"] >= iou_floor, par
+            tol_all = tol_clear = 0.20  # every one of this case's 45 detections scores within 0.08 logit of conf: bf16 scores (+-2e-3) flip 7 of them (r02)
+        n = par["ref_detections"]
+        assert par["missed"] <= max(1, int(tol_all * n)) and par["extra"] <= max(1, int(tol_all * n)), par
+        assert par["missed_clear"] <= max(1, int(tol_clear * n)) and par["extra_clear"] <= max(1, int(tol_clear * n)), par
+        assert par["iou_min"] >= iou_floor, par
 
 
 def test_plan_follows_the_live_weights(device):
