@@ -32,7 +32,6 @@
 
 namespace DY_NS {
 
-__device__ __attribute__((aligned(256))) const unsigned int g_hzero_page[64] = {0};
 
 struct HregArgs {
   const void* x;
@@ -42,7 +41,7 @@ struct HregArgs {
   void* y;
   int N, H, W, Cin, ldx, Cout, ldy, ldres, act;
   int tilesX, tilesY, tilesN, nSpatial;  // spatial tiles (n, ty, tx) and 64-cout groups
-  unsigned y_bytes, r_bytes;
+  unsigned x_bytes, y_bytes, r_bytes;
   int dbg;  // -DDYOLO_ABLATE builds only (DYOLO_DBG): 1 no output stores, 2 no MFMAs, 4 no DMA after the prologue, 8 no fragment reads
 };
 
@@ -62,8 +61,6 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hreg_kernel(const HregArgs p) 
   __shared__ __attribute__((aligned(1024))) unsigned char smem[kHrStages * kHrStage];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane >> 4, lr = lane & 15;
-  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
-  const T* zp = reinterpret_cast<const T*>(g_hzero_page) + (lane & 3) * EPC;
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res ? p.res : p.y), 0, p.res ? p.r_bytes : 0u, 0x00020000);
 
@@ -89,40 +86,65 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hreg_kernel(const HregArgs p) 
   const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + nt * 64 + wave * 16 + lq * 4);
 
   // ---- loader: slot s = (k * 4 + wave) * 64 + lane of the 10 x 24 x 4 image; pixel = s >> 2, LDS part = s & 3 ----
+  // r03: addressing without per-tile vector arithmetic.  The source is a BUFFER (descriptor shifted back by one image row + one pixel,
+  // so that every offset below is non-negative): a lane's byte offset inside a tile's halo, rel[k] = ((hy W + hx) ldx + part') * 2, is a
+  // constant of the launch; the tile contributes a SCALAR offset (the DMA instruction's soffset).  Interior tiles use rel[k] as it is;
+  // border tiles replace the out-of-image slots by an out-of-range offset — the range check then feeds zeros (the zero padding) — so the
+  // 64-bit address sums, the integer multiplies per slot (quarter-rate instructions) and the zero-page selects of the first version are gone.
   constexpr int NDMA = 4;  // every wave issues exactly 4 wave-instructions per item (w, w + 4, w + 8, w + 12): the waits below are counted
-  int a_off[NDMA];         // element offset of this lane's source chunk (channel part included), -1 = zero page
+  constexpr unsigned kOob = 0xfffffff0u;  // >= num_records of every descriptor here (the host checks the sizes)
+  const unsigned pre = (unsigned)((p.W + 1) * p.ldx) * 2u;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) - pre, 0, p.x_bytes + pre, 0x00020000);
+  unsigned rel[NDMA];  // launch constants
+  int hyx[NDMA];       // hy | hx << 8 of the slot's halo pixel
+#pragma unroll
+  for (int k = 0; k < NDMA; ++k) {
+    const int s = (k * 4 + wave) * 64 + lane;
+    const int pix = s >> 2, part = s & 3;
+    const int hy = pix / kHrHW, hx = pix - hy * kHrHW;
+    const bool dead = hx >= kHrTW + 2 || hy >= kHrHH;  // the row padding (hx >= 18) and the stage's padding (hy == 10): zeros for ever
+    rel[k] = dead ? kOob : (unsigned)((hy * p.W + hx) * p.ldx + (part ^ ((hx >> 1) & 3)) * EPC) * 2u;
+    hyx[k] = hy | (hx << 8);
+  }
+  unsigned voff[NDMA];  // this lane's offsets for the loader's current tile
+  unsigned l_base = 0;  // scalar: byte offset of pixel (ty * 8, tx * 16) of image n, in the shifted descriptor's terms the tile's halo origin
   int l_tile = sb, l_chunk = 0, l_item = 0;
   auto setup_tile = [&](int tile) {
     const int tx = tile % p.tilesX;
     const int r = tile / p.tilesX;
     const int ty = r % p.tilesY, n = r / p.tilesY;
+    const int y0 = ty * kHrTH, x0 = tx * kHrTW;
+    l_base = (unsigned)(((n * p.H + y0) * p.W + x0) * p.ldx) * 2u;
+    const bool interior = y0 > 0 && y0 + kHrTH + 1 <= p.H && x0 > 0 && x0 + kHrTW + 1 <= p.W;  // wave-uniform
+    if (interior) {
 #pragma unroll
-    for (int k = 0; k < NDMA; ++k) {
-      const int s = (k * 4 + wave) * 64 + lane;
-      const int pix = s >> 2, part = s & 3;
-      const int hy = pix / kHrHW, hx = pix - hy * kHrHW;
-      const int gy = ty * kHrTH - 1 + hy, gx = tx * kHrTW - 1 + hx;
-      const bool ok = hx < kHrTW + 2 && hy < kHrHH && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;  // (hy == 10: the stage's padding)
-      a_off[k] = ok ? ((n * p.H + gy) * p.W + gx) * p.ldx + (part ^ ((hx >> 1) & 3)) * EPC : -1;
+      for (int k = 0; k < NDMA; ++k) voff[k] = rel[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < NDMA; ++k) {
+        const int gy = y0 - 1 + (hyx[k] & 255), gx = x0 - 1 + (hyx[k] >> 8);
+        voff[k] = ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) ? rel[k] : kOob;
+      }
     }
   };
-  auto issue_dma = [&](int stage) {  // DMA of item (l_tile, l_chunk) into `stage`, then advance the loader; past the last item: zero page
+  auto issue_dma = [&](int stage) {  // DMA of item (l_tile, l_chunk) into `stage`, then advance the loader; past the last item: zeros
     unsigned char* sa = smem + stage * kHrStage;
-    const int cofs = l_chunk * 4 * EPC;
     const bool live = l_item < nItems && !(HR_DBG(4) && l_item >= 2);
-#pragma unroll
-    for (int k = 0; k < NDMA; ++k) {
-      const T* src = (!live || a_off[k] < 0) ? zp : xg + (size_t)(unsigned)(a_off[k] + cofs);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sa + (k * 4 + wave) * 1024), 16, 0, 0);
-    }
     if (live) {
+      const unsigned soff = l_base + (unsigned)l_chunk * (4u * EPC * (unsigned)sizeof(T));
+#pragma unroll
+      for (int k = 0; k < NDMA; ++k)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(sa + (k * 4 + wave) * 1024), 16, voff[k], soff, 0, 0);
       ++l_item;
       if (++l_chunk == NCH) {
         l_chunk = 0;
         l_tile += Gs;
         if (l_item < nItems) setup_tile(l_tile);
       }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NDMA; ++k)  // keeps the per-item instruction count (the counted waits) — every lane out of range: zeros
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(sa + (k * 4 + wave) * 1024), 16, kOob, 0, 0, 0);
     }
   };
 
@@ -174,11 +196,20 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hreg_kernel(const HregArgs p) 
       rl[o / 2] = __builtin_amdgcn_raw_buffer_load_b128(rrs, off, 0, 0);
     }
   };
+  // store offsets: lane constant (row o + (lq & 1) of the pair, column lr, 8 channels from co16) + a scalar tile offset (soffset)
+  unsigned lane_out[kHrTH / 2];
+  {
+    const int co16 = nt * 64 + wave * 16 + (lq >> 1) * 8;
+#pragma unroll
+    for (int o = 0; o < kHrTH; o += 2) lane_out[o / 2] = (unsigned)(((o + (lq & 1)) * p.W + lr) * p.ldy + co16) * (unsigned)sizeof(T);
+  }
   auto epilogue = [&](int tile) {
     const int tx = tile % p.tilesX;
     const int r = tile / p.tilesX;
     const int ty = r % p.tilesY, n = r / p.tilesY;
-    const int xx = tx * kHrTW + lr;
+    const int y0 = ty * kHrTH, x0 = tx * kHrTW;
+    const unsigned out_base = (unsigned)(((n * p.H + y0) * p.W + x0) * p.ldy) * (unsigned)sizeof(T);  // scalar
+    const bool whole = y0 + kHrTH <= p.H && x0 + kHrTW <= p.W;                                         // wave-uniform: no ragged edge
     // A result lane holds 8 bytes (4 channels) of pixel lr in tile row o.  Stored like that, each of the 64 lanes is its own
     // L1 request.  v_permlane16_swap between the rows of a pair (o, o + 1) leaves 16 contiguous bytes in every lane - quarter lq
     // gets channels 8 (lq >> 1) .. + 7 of row o + (lq & 1) - so a pair of rows leaves in one 16-byte store instead of two 8-byte ones.
@@ -203,15 +234,13 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hreg_kernel(const HregArgs p) 
       pk[o] = __builtin_bit_cast(u32x2, ov);
       acc[o] = bias4;
     }
-    const int co16 = nt * 64 + wave * 16 + (lq >> 1) * 8;
 #pragma unroll
     for (int o = 0; o < kHrTH; o += 2) {
       const auto sx = __builtin_amdgcn_permlane16_swap(pk[o][0], pk[o + 1][0], false, false);
       const auto sy = __builtin_amdgcn_permlane16_swap(pk[o][1], pk[o + 1][1], false, false);
-      const int yy = ty * kHrTH + o + (lq & 1);
-      const bool ok = yy < p.H && xx < p.W;
-      const unsigned off = ok ? (unsigned)((((size_t)(n * p.H + yy) * p.W + xx) * (size_t)p.ldy + co16) * sizeof(T)) : 0xfffffff0u;
-      __builtin_amdgcn_raw_buffer_store_b128(u32x4{sx[0], sy[0], sx[1], sy[1]}, yrs, HR_DBG(1) ? 0xfffffff0u : off, 0, 0);
+      unsigned off = lane_out[o / 2];
+      if (!whole) off = (y0 + o + (lq & 1) < p.H && x0 + lr < p.W) ? off : kOob;
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{sx[0], sy[0], sx[1], sy[1]}, yrs, HR_DBG(1) ? kOob : off, (int)out_base, 0);
     }
   };
 
@@ -290,7 +319,7 @@ int conv3x3_hreg_try(const dy_conv_desc* d, hipStream_t st) {
   a.tilesY = (d->ho + kHrTH - 1) / kHrTH;
   a.tilesN = d->cout / 64;
   a.nSpatial = d->batch * a.tilesY * a.tilesX;
-  a.y_bytes = (unsigned)yb, a.r_bytes = (unsigned)rb;
+  a.x_bytes = (unsigned)xb, a.y_bytes = (unsigned)yb, a.r_bytes = (unsigned)rb;
   a.dbg = dy_ablate("DYOLO_DBG");
   return d->dtype == DY_BF16 ? launch_hreg<bf16_t>(a, st) : launch_hreg<f16_t>(a, st);
 }
