@@ -29,7 +29,6 @@
 
 namespace DY_NS {
 
-__device__ __attribute__((aligned(256))) const unsigned int g_hhzero_page[64] = {0};
 
 struct HheadArgs {
   const void* x;       // trunk input, NHWC (N, H, W, 64), pitch ldx
@@ -39,6 +38,7 @@ struct HheadArgs {
   const float* b1;     // 64 / 16
   float* out;          // pred (N, 4 + nc, A) fp32
   int N, H, W, ldx, A, a0, nc;
+  unsigned x_bytes;
   float stride;
   int tilesX, tilesY, nSpatial;
   int* counts;
@@ -89,8 +89,6 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hhead_kernel(const HheadArgs p
   float* const dsm = reinterpret_cast<float*>(mid + kHhMid);  // [side 4][pixel 128]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane >> 4, lr = lane & 15;
-  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
-  const T* zp = reinterpret_cast<const T*>(g_hhzero_page) + (lane & 3) * EPC;
 
   const int G = (int)gridDim.x;
   const int sb = ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);  // XCD-contiguous tile order (guide T1)
@@ -112,41 +110,61 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hhead_kernel(const HheadArgs p
   const u32x4* const w1g = reinterpret_cast<const u32x4*>(p.w1) + (KIND == 1 ? wave * 64 : 0) + lane;
   const float* const b1g = p.b1 + (KIND == 1 ? wave * 16 : 0) + lq * 4;
 
-  // ---- halo loader (conv3x3_hreg.hip) ----
+  // ---- halo loader (conv3x3_hreg.hip): buffer-addressed LDS-DMA, lane-constant offsets + a scalar tile offset, zeros by range check ----
   constexpr int NDMA = 4;
-  int a_off[NDMA];
+  constexpr unsigned kOob = 0xfffffff0u;
+  const unsigned pre = (unsigned)((p.W + 1) * p.ldx) * 2u;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) - pre, 0, p.x_bytes + pre, 0x00020000);
+  unsigned rel[NDMA];
+  int hyx[NDMA];
+#pragma unroll
+  for (int k = 0; k < NDMA; ++k) {
+    const int s = (k * 4 + wave) * 64 + lane;
+    const int pix = s >> 2, part = s & 3;
+    const int hy = pix / kHhHW, hx = pix - hy * kHhHW;
+    const bool dead = hx >= kHhTW + 2 || hy >= kHhHH;
+    rel[k] = dead ? kOob : (unsigned)((hy * p.W + hx) * p.ldx + (part ^ ((hx >> 1) & 3)) * EPC) * 2u;
+    hyx[k] = hy | (hx << 8);
+  }
+  unsigned voff[NDMA];
+  unsigned l_base = 0;
   int l_tile = sb, l_chunk = 0, l_item = 0;
   auto setup_tile = [&](int tile) {
     const int tx = tile % p.tilesX;
     const int r = tile / p.tilesX;
     const int ty = r % p.tilesY, n = r / p.tilesY;
+    const int y0 = ty * kHhTH, x0 = tx * kHhTW;
+    l_base = (unsigned)(((n * p.H + y0) * p.W + x0) * p.ldx) * 2u;
+    const bool interior = y0 > 0 && y0 + kHhTH + 1 <= p.H && x0 > 0 && x0 + kHhTW + 1 <= p.W;  // wave-uniform
+    if (interior) {
 #pragma unroll
-    for (int k = 0; k < NDMA; ++k) {
-      const int s = (k * 4 + wave) * 64 + lane;
-      const int pix = s >> 2, part = s & 3;
-      const int hy = pix / kHhHW, hx = pix - hy * kHhHW;
-      const int gy = ty * kHhTH - 1 + hy, gx = tx * kHhTW - 1 + hx;
-      const bool ok = hx < kHhTW + 2 && hy < kHhHH && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-      a_off[k] = ok ? ((n * p.H + gy) * p.W + gx) * p.ldx + (part ^ ((hx >> 1) & 3)) * EPC : -1;
+      for (int k = 0; k < NDMA; ++k) voff[k] = rel[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < NDMA; ++k) {
+        const int gy = y0 - 1 + (hyx[k] & 255), gx = x0 - 1 + (hyx[k] >> 8);
+        voff[k] = ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) ? rel[k] : kOob;
+      }
     }
   };
   auto issue_dma = [&](int stage) {
     unsigned char* sa = smem + stage * kHhStage;
-    const int cofs = l_chunk * 4 * EPC;
     const bool live = l_item < nItems;
-#pragma unroll
-    for (int k = 0; k < NDMA; ++k) {
-      const T* src = (!live || a_off[k] < 0) ? zp : xg + (size_t)(unsigned)(a_off[k] + cofs);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sa + (k * 4 + wave) * 1024), 16, 0, 0);
-    }
     if (live) {
+      const unsigned soff = l_base + (unsigned)l_chunk * (4u * EPC * (unsigned)sizeof(T));
+#pragma unroll
+      for (int k = 0; k < NDMA; ++k)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(sa + (k * 4 + wave) * 1024), 16, voff[k], soff, 0, 0);
       ++l_item;
       if (++l_chunk == NCH) {
         l_chunk = 0;
         l_tile += G;
         if (l_item < nItems) setup_tile(l_tile);
       }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NDMA; ++k)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(sa + (k * 4 + wave) * 1024), 16, kOob, 0, 0, 0);
     }
   };
 
@@ -377,6 +395,7 @@ int32_t branch_entry(const dy_branch_desc* d, dy_stream_t stream) {
   HheadArgs a{};
   a.x = d->x, a.w3 = d->w3, a.b3 = d->b3, a.w1 = d->w1, a.b1 = d->b1, a.out = d->out;
   a.N = d->batch, a.H = d->h, a.W = d->w, a.ldx = d->ld_x, a.A = d->anchors, a.a0 = d->anchor0, a.nc = d->nc, a.stride = d->stride;
+  a.x_bytes = (unsigned)((long long)d->batch * d->h * d->w * d->ld_x * 2);
   a.tilesX = (d->w + kHhTW - 1) / kHhTW, a.tilesY = (d->h + kHhTH - 1) / kHhTH;
   a.nSpatial = d->batch * a.tilesX * a.tilesY;
   if (d->kind == 2 && d->nms_workspace) {
