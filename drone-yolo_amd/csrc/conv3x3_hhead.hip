@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hhead_kernel(const HheadArgs p
       const unsigned soff = l_base + (unsigned)l_chunk * (4u * EPC * (unsigned)sizeof(T));
 #pragma unroll
       for (int k = 0; k < NDMA; ++k)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(sa + (k * 4 + wave) * 1024), 16, voff[k], soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(sa + (k * 4 + wave) * 1024), 16, (int)voff[k], (int)soff, 0, 0);
       ++l_item;
       if (++l_chunk == NCH) {
         l_chunk = 0;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hhead_kernel(const HheadArgs p
     } else {
 #pragma unroll
       for (int k = 0; k < NDMA; ++k)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(sa + (k * 4 + wave) * 1024), 16, kOob, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(sa + (k * 4 + wave) * 1024), 16, (int)kOob, 0, 0, 0);
     }
   };
 

@@ -20,6 +20,10 @@ struct ConvArgs {
   int act, up2x;
   int tilesN, nblk;
   int vec_store;
+  // conv_gemm_glds.hip, r03: buffer-addressed staging (lane-constant offsets + scalar step offsets) when every view is below 4 GiB and
+  // the gather is linear in the tap (fast_addr); xb / x2b / wb = bytes addressable from x / x2 / w
+  unsigned xb, x2b, wb;
+  int fast_addr;
   const float* wscale;  // DY_FP8: per-output-channel dequantisation multiplier (act_scale * weight scale), else nullptr
   float act_scale;      // DY_FP8: real value of one activation quantum (x, residual, y); 1 otherwise
 };

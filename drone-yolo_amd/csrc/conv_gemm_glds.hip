@@ -86,30 +86,79 @@ __global__ __launch_bounds__(BM * WN) void conv_gemm_glds_kernel(const ConvArgs 
     b_ptr[j] = wg + (size_t)(tileN * BN + row) * (size_t)p.Kpad + (size_t)(((lane & 7) ^ ((row >> 1) & 7)) * EPC);
   }
 
+  // r03: staging addresses without per-step vector arithmetic (fast_addr).  The first version rebuilt every piece's 64-bit source pointer
+  // per K-step — (n HB + hb) WB + wb times ldx in 64 bits, selects against the zero page: ~95 vector instructions (8 of them 64-bit
+  // multiply-adds) per 32 MFMAs and wave, which made these kernels issue bound.  Now a piece's byte offset for tap (0, 0) is a lane
+  // constant (av1 / av2 for the two Concat sources, bv for the weights), the tap and channel step a SCALAR offset of the buffer
+  // instruction, zero padding an out-of-range offset (the range check feeds zeros): per step two compares and a select per piece.
+  constexpr unsigned kOob = 0xfffffff0u;
+  const unsigned ES = (unsigned)sizeof(T);
+  const unsigned pre1 = (unsigned)((p.pad * p.WB + p.pad) * p.ldx) * ES, pre2 = (unsigned)((p.pad * p.W + p.pad) * p.ldx2) * ES;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) - pre1, 0, p.xb + pre1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t x2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x2)) - pre2, 0, p.x2b + pre2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.wb, 0x00020000);
+  unsigned av1[PA], av2[PA], bv[PB];
+  if (p.fast_addr) {
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int hi0 = a_hi0[i] < 0 && a_hi0[i] < -p.pad ? 0 : a_hi0[i];  // (rows beyond M carry hi0 = -2^28: never valid, any offset will do)
+      const int hb = p.up2x ? (hi0 >> 1) : hi0, wb_ = p.up2x ? (a_wi0[i] >> 1) : a_wi0[i];
+      av1[i] = (unsigned)(((a_n[i] * p.HB + hb) * p.WB + wb_) * p.ldx + a_sw[i]) * ES + pre1;
+      av2[i] = (unsigned)(((a_n[i] * p.H + hi0) * p.W + a_wi0[i]) * p.ldx2 + a_sw[i]) * ES + pre2;
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      const int row = (wave * PB + j) * 8 + prow;
+      bv[j] = (unsigned)((tileN * BN + row) * p.Kpad + (((lane & 7) ^ ((row >> 1) & 7)) * EPC)) * ES;
+    }
+  }
+
   int kc = 0, kr = 0, kq = 0;  // (tap, channel) of the NEXT step to issue (wave-uniform)
   auto issue = [&](int step, int stage) {
     unsigned char* sa = smem + stage * STAGE;
     unsigned char* sb = sa + A_BYTES;
     const bool from_x = kc < p.split;
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const int hi = a_hi0[i] + kr, wi = a_wi0[i] + kq;
-      const bool ok = ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W) && !(p.up2x == 2 && ((hi | wi) & 1));
-      const T* ptr;  // computed for every lane (never dereferenced when !ok): keeps the gather branch-free
+    if (p.fast_addr) {
       if (from_x) {
-        const int hb = p.up2x ? (hi >> 1) : hi, wb = p.up2x ? (wi >> 1) : wi;
-        ptr = xg + (long long)((a_n[i] * p.HB + hb) * p.WB + wb) * (long long)p.ldx + (long long)(kc + a_sw[i]);
-      } else {
-        ptr = x2g + (long long)((a_n[i] * p.H + hi) * p.W + wi) * (long long)p.ldx2 + (long long)(kc - p.split + a_sw[i]);
-      }
-      const T* src = ok ? ptr : zp;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sa + (wave * PA + i) * 1024), 16, 0, 0);
-    }
+        const unsigned soff = (unsigned)((kr * p.WB + kq) * p.ldx + kc) * ES;
 #pragma unroll
-    for (int j = 0; j < PB; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[j] + (size_t)step * BKE),
-                                       (__attribute__((address_space(3))) void*)(sb + (wave * PB + j) * 1024), 16, 0, 0);
+        for (int i = 0; i < PA; ++i) {
+          const bool ok = ((unsigned)(a_hi0[i] + kr) < (unsigned)p.H) && ((unsigned)(a_wi0[i] + kq) < (unsigned)p.W);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(sa + (wave * PA + i) * 1024), 16, (int)(ok ? av1[i] : kOob), (int)soff, 0, 0);
+        }
+      } else {
+        const unsigned soff = (unsigned)((kr * p.W + kq) * p.ldx2 + (kc - p.split)) * ES;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+          const bool ok = ((unsigned)(a_hi0[i] + kr) < (unsigned)p.H) && ((unsigned)(a_wi0[i] + kq) < (unsigned)p.W);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(x2rs, (__attribute__((address_space(3))) void*)(sa + (wave * PA + i) * 1024), 16, (int)(ok ? av2[i] : kOob), (int)soff, 0, 0);
+        }
+      }
+      const unsigned soffw = (unsigned)(step * BKE) * ES;
+#pragma unroll
+      for (int j = 0; j < PB; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(sb + (wave * PB + j) * 1024), 16, (int)bv[j], (int)soffw, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int hi = a_hi0[i] + kr, wi = a_wi0[i] + kq;
+        const bool ok = ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W) && !(p.up2x == 2 && ((hi | wi) & 1));
+        const T* ptr;  // computed for every lane (never dereferenced when !ok): keeps the gather branch-free
+        if (from_x) {
+          const int hb = p.up2x ? (hi >> 1) : hi, wb = p.up2x ? (wi >> 1) : wi;
+          ptr = xg + (long long)((a_n[i] * p.HB + hb) * p.WB + wb) * (long long)p.ldx + (long long)(kc + a_sw[i]);
+        } else {
+          ptr = x2g + (long long)((a_n[i] * p.H + hi) * p.W + wi) * (long long)p.ldx2 + (long long)(kc - p.split + a_sw[i]);
+        }
+        const T* src = ok ? ptr : zp;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(sa + (wave * PA + i) * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < PB; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[j] + (size_t)step * BKE),
+                                         (__attribute__((address_space(3))) void*)(sb + (wave * PB + j) * 1024), 16, 0, 0);
+    }
     kc += BKE;
     if (kc >= p.Cin) {
       kc = 0;
@@ -502,8 +551,17 @@ static int launch_glds_dtype(const ConvArgs& a, hipStream_t st) {
   return persist ? launch_glds_persist<T, 64>(a, st) : launch_glds<T, 128, 64, 2>(a, st);
 }
 
-int conv_gemm_glds_try(const ConvArgs& a, int dtype, bool out_f32, hipStream_t st) {
+int conv_gemm_glds_try(const ConvArgs& a0, int dtype, bool out_f32, hipStream_t st) {
   static const int off = dy_ablate("DYOLO_NO_GLDS");
+  ConvArgs a = a0;
+  {  // buffer-addressed staging: every view below 4 GiB (32-bit byte offsets) and a gather that is linear in the tap
+    const long long es_ = dtype == DY_F32 ? 4 : 2, n = a.HoWo > 0 ? a.M / a.HoWo : 0;
+    const long long xb = n * a.HB * a.WB * a.ldx * es_, x2b = n * a.H * a.W * a.ldx2 * es_, wb = (long long)((a.Cout + 63) / 64 * 64) * a.Kpad * es_;
+    const long long lim = (1ll << 32) - (1ll << 24);
+    static const int slow = dy_ablate("DYOLO_GLDS_SLOW_ADDR");
+    a.fast_addr = (!slow && xb < lim && x2b < lim && wb < lim && (a.up2x == 0 || (a.up2x == 1 && a.ks == 1))) ? 1 : 0;
+    a.xb = (unsigned)(xb < lim ? xb : 0), a.x2b = (unsigned)(x2b < lim ? x2b : 0), a.wb = (unsigned)(wb < lim ? wb : 0);
+  }
   if (dtype == DY_FP8) return 1;  // not built for fp8: the generic kernel runs
   const int es = dtype_size_no_fp8(dtype);
   const int bke = 8 * (16 / es);
