@@ -24,6 +24,12 @@ struct ConvArgs {
   // the gather is linear in the tap (fast_addr); xb / x2b / wb = bytes addressable from x / x2 / w
   unsigned xb, x2b, wb;
   int fast_addr;
+  // conv_gemm_glds.hip, r03: up2x == 2 (input gradient of a stride-2 3x3: a zero-dilated source) tiles the OUTPUT by parity class
+  // (ho & 1, wo & 1): M' = 4 classes x Mq = N HB WB pixels each, a tile holds ONE class, so only the taps that meet non-zero source
+  // pixels are walked (1, 2, 2 or 4 of the 9) instead of multiplying zeros three times out of four.  dil_cls: 1 when on;
+  // dWB / dHW: exact divisions by WB and HB * WB for the row decode
+  int dil_cls, Mq, tilesPerClass;
+  FastDiv dWB, dHW;
   const float* wscale;  // DY_FP8: per-output-channel dequantisation multiplier (act_scale * weight scale), else nullptr
   float act_scale;      // DY_FP8: real value of one activation quantum (x, residual, y); 1 otherwise
 };

@@ -63,21 +63,37 @@ __global__ __launch_bounds__(BM * WN) void conv_gemm_glds_kernel(const ConvArgs 
 
   // ---- per-lane gather bookkeeping: the rows this lane fetches never change over the K loop ----
   const int prow = lane >> 3;  // row inside a piece
+  // dilated-class mode (p.dil_cls, see conv_args.h): tileM = class * tilesPerClass + local tile; a row is pixel (n, yo, xo) of the
+  // half-resolution source grid and stands for output pixel (2 yo + py, 2 xo + px)
+  const int cls = p.dil_cls ? tileM / p.tilesPerClass : 0;
+  const int cpy = cls >> 1, cpx = cls & 1;
+  const int ltile = p.dil_cls ? tileM - cls * p.tilesPerClass : tileM;
   int a_n[PA], a_hi0[PA], a_wi0[PA], a_sw[PA];
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     const int row = (wave * PA + i) * 8 + prow;
-    const int m = tileM * BM + row;
-    const bool ok = m < p.M;
-    const int mm = ok ? m : 0;
-    const int n = mm / p.HoWo;
-    const int rem = mm - n * p.HoWo;
-    const int ho = rem / p.Wo;
-    const int wo = rem - ho * p.Wo;
-    a_n[i] = n;
-    a_hi0[i] = ok ? ho * p.stride - p.pad : -(1 << 28);
-    a_wi0[i] = wo * p.stride - p.pad;
+    const int m = ltile * BM + row;
     a_sw[i] = (((lane & 7) ^ ((row >> 1) & 7))) * EPC;
+    if (p.dil_cls) {
+      const bool ok = m < p.Mq;
+      const unsigned mm = ok ? (unsigned)m : 0u;
+      const unsigned n = fastdiv(mm, p.dHW);
+      const unsigned rem = mm - n * (unsigned)(p.HB * p.WB);
+      const unsigned yo = fastdiv(rem, p.dWB);
+      a_n[i] = (int)n;
+      a_hi0[i] = ok ? (int)yo : -(1 << 28);
+      a_wi0[i] = (int)(rem - yo * (unsigned)p.WB);
+    } else {
+      const bool ok = m < p.M;
+      const int mm = ok ? m : 0;
+      const int n = mm / p.HoWo;
+      const int rem = mm - n * p.HoWo;
+      const int ho = rem / p.Wo;
+      const int wo = rem - ho * p.Wo;
+      a_n[i] = n;
+      a_hi0[i] = ok ? ho * p.stride - p.pad : -(1 << 28);
+      a_wi0[i] = wo * p.stride - p.pad;
+    }
   }
   const T* b_ptr[PB];
 #pragma unroll
@@ -93,7 +109,7 @@ __global__ __launch_bounds__(BM * WN) void conv_gemm_glds_kernel(const ConvArgs 
   // instruction, zero padding an out-of-range offset (the range check feeds zeros): per step two compares and a select per piece.
   constexpr unsigned kOob = 0xfffffff0u;
   const unsigned ES = (unsigned)sizeof(T);
-  const unsigned pre1 = (unsigned)((p.pad * p.WB + p.pad) * p.ldx) * ES, pre2 = (unsigned)((p.pad * p.W + p.pad) * p.ldx2) * ES;
+  const unsigned pre1 = p.dil_cls ? 0u : (unsigned)((p.pad * p.WB + p.pad) * p.ldx) * ES, pre2 = (unsigned)((p.pad * p.W + p.pad) * p.ldx2) * ES;
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) - pre1, 0, p.xb + pre1, 0x00020000);
   const __amdgpu_buffer_rsrc_t x2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x2)) - pre2, 0, p.x2b + pre2, 0x00020000);
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.wb, 0x00020000);
@@ -102,7 +118,7 @@ __global__ __launch_bounds__(BM * WN) void conv_gemm_glds_kernel(const ConvArgs 
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       const int hi0 = a_hi0[i] < 0 && a_hi0[i] < -p.pad ? 0 : a_hi0[i];  // (rows beyond M carry hi0 = -2^28: never valid, any offset will do)
-      const int hb = p.up2x ? (hi0 >> 1) : hi0, wb_ = p.up2x ? (a_wi0[i] >> 1) : a_wi0[i];
+      const int hb = (p.up2x == 1) ? (hi0 >> 1) : hi0, wb_ = (p.up2x == 1) ? (a_wi0[i] >> 1) : a_wi0[i];  // (dil_cls: hi0 / wi0 already are source coordinates)
       av1[i] = (unsigned)(((a_n[i] * p.HB + hb) * p.WB + wb_) * p.ldx + a_sw[i]) * ES + pre1;
       av2[i] = (unsigned)(((a_n[i] * p.H + hi0) * p.W + a_wi0[i]) * p.ldx2 + a_sw[i]) * ES + pre2;
     }
@@ -113,11 +129,36 @@ __global__ __launch_bounds__(BM * WN) void conv_gemm_glds_kernel(const ConvArgs 
     }
   }
 
-  int kc = 0, kr = 0, kq = 0;  // (tap, channel) of the NEXT step to issue (wave-uniform)
+  int kc = 0, kr = p.dil_cls ? (cpy ? 0 : 1) : 0, kq = p.dil_cls ? (cpx ? 0 : 1) : 0;  // (tap, channel) of the NEXT step to issue (wave-uniform)
   auto issue = [&](int step, int stage) {
     unsigned char* sa = smem + stage * STAGE;
     unsigned char* sb = sa + A_BYTES;
     const bool from_x = kc < p.split;
+    if (p.dil_cls) {
+      // tap (kr, kq) of this class reads source pixel (yo + dr, xo + dq), dr = (py - 1 + kr) / 2 in {0, 1}; the weights of the step sit at
+      // K position (kr * 3 + kq) * Cin + kc whatever the step count is
+      const int dr = (cpy - 1 + kr) >> 1, dq = (cpx - 1 + kq) >> 1;
+      const unsigned soff = (unsigned)((dr * p.WB + dq) * p.ldx + kc) * ES;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const bool ok = ((unsigned)(a_hi0[i] + dr) < (unsigned)p.HB) && ((unsigned)(a_wi0[i] + dq) < (unsigned)p.WB);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(sa + (wave * PA + i) * 1024), 16, (int)(ok ? av1[i] : kOob), (int)soff, 0, 0);
+      }
+      const unsigned soffw = (unsigned)((kr * 3 + kq) * p.Cin + kc) * ES;
+#pragma unroll
+      for (int j = 0; j < PB; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(sb + (wave * PB + j) * 1024), 16, (int)bv[j], (int)soffw, 0, 0);
+      kc += BKE;
+      if (kc >= p.Cin) {  // next valid tap of the class: kq (and kr) step by 2 from 1 - parity... i.e. {1} for an even row / column, {0, 2} for an odd one
+        kc = 0;
+        kq += 2;
+        if (kq > 2) {
+          kq = cpx ? 0 : 1;
+          kr += 2;
+        }
+      }
+      return;
+    }
     if (p.fast_addr) {
       if (from_x) {
         const unsigned soff = (unsigned)((kr * p.WB + kq) * p.ldx + kc) * ES;
@@ -198,7 +239,7 @@ __global__ __launch_bounds__(BM * WN) void conv_gemm_glds_kernel(const ConvArgs 
   };
 
   // ---- main loop: one barrier per K-step, the next step's DMA runs under this step's MFMAs ----
-  const int nsteps = p.Kpad / BKE;
+  const int nsteps = p.dil_cls ? (1 + cpy) * (1 + cpx) * (p.Cin / BKE) : p.Kpad / BKE;
   if constexpr (STAGES == 2) {
     issue(0, 0);
     for (int s = 0; s < nsteps; ++s) {
@@ -235,8 +276,18 @@ __global__ __launch_bounds__(BM * WN) void conv_gemm_glds_kernel(const ConvArgs 
   unsigned char* escr = smem + wave * (PXP * EP_PITCH);
   T* __restrict__ yg = reinterpret_cast<T*>(p.y);
   const T* __restrict__ rg = reinterpret_cast<const T*>(p.res);
-  const int m0 = tileM * BM + wm * 64;
+  const int m0 = ltile * BM + wm * 64;
   const int n0 = tileN * BN + wn * (BN / WN);
+  // output pixel index of tile row m (dilated-class mode: row = (n, yo, xo) of the class -> pixel (2 yo + py, 2 xo + px)); -1 = beyond the end
+  auto out_px = [&](int m) -> int {
+    if (!p.dil_cls) return m < p.M ? m : -1;
+    if (m >= p.Mq) return -1;
+    const unsigned n = fastdiv((unsigned)m, p.dHW);
+    const unsigned rem = (unsigned)m - n * (unsigned)(p.HB * p.WB);
+    const unsigned yo = fastdiv(rem, p.dWB);
+    const unsigned xo = rem - yo * (unsigned)p.WB;
+    return (int)((n * (unsigned)p.H + 2u * yo + (unsigned)cpy) * (unsigned)p.W + 2u * xo + (unsigned)cpx);
+  };
 #pragma unroll
   for (int g = 0; g < NFR / EG; ++g) {
 #pragma unroll
@@ -253,8 +304,8 @@ __global__ __launch_bounds__(BM * WN) void conv_gemm_glds_kernel(const ConvArgs 
             for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
           }
           if (rg != nullptr) {
-            const int m = m0 + i * 16 + lr;
-            if (m < p.M) {
+            const int m = out_px(m0 + i * 16 + lr);
+            if (m >= 0) {
               typedef __attribute__((ext_vector_type(4))) T t4;
               const t4 rv = *reinterpret_cast<const t4*>(rg + (size_t)m * (size_t)p.ldres + (size_t)(n0 + j * 16 + lq * 4));
 #pragma unroll
@@ -280,8 +331,8 @@ __global__ __launch_bounds__(BM * WN) void conv_gemm_glds_kernel(const ConvArgs 
       for (int k = 0; k < (PXP * CPP + 63) / 64; ++k) {  // PXP pixels x CPP chunks of 16 bytes
         const int idx = k * 64 + lane;
         const int px = idx / CPP, cc = idx % CPP;
-        const int m = m0 + half * PXP + px;
-        if (px < PXP && m < p.M) {
+        const int m = px < PXP ? out_px(m0 + half * PXP + px) : -1;
+        if (m >= 0) {
           const u32x4 val = *reinterpret_cast<const u32x4*>(escr + px * EP_PITCH + cc * 16);
           *reinterpret_cast<u32x4*>(yg + (size_t)m * (size_t)p.ldy + (size_t)(n0 + g * EG * 16 + cc * EPC)) = val;
         }
@@ -517,7 +568,11 @@ static int launch_glds_persist(const ConvArgs& a, hipStream_t st) {
 template <typename T, int BM, int BN, int STAGES, int WN = 2>
 static int launch_glds(const ConvArgs& a, hipStream_t st) {
   ConvArgs p = a;
-  const int tilesM = (p.M + BM - 1) / BM;
+  int tilesM = (p.M + BM - 1) / BM;
+  if (p.dil_cls) {  // one tile = one parity class of the output (conv_args.h)
+    p.tilesPerClass = (p.Mq + BM - 1) / BM;
+    tilesM = 4 * p.tilesPerClass;
+  }
   p.tilesN = p.Cout / BN;
   p.nblk = tilesM * p.tilesN;
   auto kern = conv_gemm_glds_kernel<T, BM, BN, STAGES, WN>;
@@ -531,7 +586,7 @@ static int launch_glds_dtype(const ConvArgs& a, hipStream_t st) {
   static const int big = dy_ablate("DYOLO_GLDS_BIG");  // 1: 256x128 three-stage, 2: never persistent, 3: always persistent
   // short K (<= 9 steps, the 64-channel stride-2 layers on 160x160 maps: thousands of tiles) measured faster one tile per
   // workgroup; everything else gains 3-14 % from the persistent walk with the next tile's first K-step prefetched
-  const bool persist = big != 2 && (big == 3 || a.Kpad > 9 * 8 * (16 / (int)sizeof(T)));
+  const bool persist = big != 2 && !a.dil_cls && (big == 3 || a.Kpad > 9 * 8 * (16 / (int)sizeof(T)));  // (the parity-class tiling lives in the plain kernel)
   // 256 x 256 tiles (one workgroup per CU; sixteen waves of 64 x 64 = four per SIMD measured 5-14 % faster than eight of 64 x 128:
   // the kernels are wait-bound, not LDS-bound) halve the gathered-operand bytes per flop: 4-19 % faster on
   // the wide 1x1 layers and the 256-cout stride-2 layers at throughput batch sizes (512->256 @40x40: 241 -> 204 us); slower on
@@ -559,8 +614,16 @@ int conv_gemm_glds_try(const ConvArgs& a0, int dtype, bool out_f32, hipStream_t 
     const long long xb = n * a.HB * a.WB * a.ldx * es_, x2b = n * a.H * a.W * a.ldx2 * es_, wb = (long long)((a.Cout + 63) / 64 * 64) * a.Kpad * es_;
     const long long lim = (1ll << 32) - (1ll << 24);
     static const int slow = dy_ablate("DYOLO_GLDS_SLOW_ADDR");
-    a.fast_addr = (!slow && xb < lim && x2b < lim && wb < lim && (a.up2x == 0 || (a.up2x == 1 && a.ks == 1))) ? 1 : 0;
+    const bool small = !slow && xb < lim && x2b < lim && wb < lim;
+    static const int nodil = dy_ablate("DYOLO_GLDS_NO_DIL");
+    a.dil_cls = (small && !nodil && a.up2x == 2 && a.ks == 3 && a.pad == 1 && a.stride == 1 && a.H == 2 * a.HB && a.W == 2 * a.WB && a.split >= a.Cin) ? 1 : 0;
+    a.fast_addr = (small && (a.up2x == 0 || (a.up2x == 1 && a.ks == 1) || a.dil_cls)) ? 1 : 0;
     a.xb = (unsigned)(xb < lim ? xb : 0), a.x2b = (unsigned)(x2b < lim ? x2b : 0), a.wb = (unsigned)(wb < lim ? wb : 0);
+    if (a.dil_cls) {
+      a.Mq = (int)(n * a.HB * a.WB);
+      a.dWB = make_fastdiv((unsigned)a.WB);
+      a.dHW = make_fastdiv((unsigned)(a.HB * a.WB));
+    }
   }
   if (dtype == DY_FP8) return 1;  // not built for fp8: the generic kernel runs
   const int es = dtype_size_no_fp8(dtype);
