@@ -599,9 +599,11 @@ int conv3x3_halo_dispatch(const dy_conv_desc* d, hipStream_t st) {
   DY_REQUIRE(!d->residual || (aligned16(d->residual) && d->ld_res % 4 == 0), DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: residual view misaligned");
   DY_REQUIRE((long long)d->batch * d->h * d->w_in * d->ld_x * es < (1ll << 32) - 64, DY_ERR_UNSUPPORTED, "dy_conv2d_nhwc: input view exceeds 4 GiB (buffer descriptor range)");
   {
-    const int rv = conv3x3_hreg_try(d, st);  // cin 32 / 64, cout % 64 == 0, 16-bit, stride 1
+    const int rv = conv3x3_hreg_try(d, st);  // cin 32 / 64, cout % 64 == 0, 16-bit; stride 2 with cin 64 (r03)
     if (rv <= 0) return rv;
   }
+  DY_REQUIRE(!(d->stride == 2 && d->cin == 64 && d->cout > 32), DY_ERR_UNSUPPORTED,
+             "dy_conv2d_nhwc: a stride-2 64-channel layer in DY_WLAYOUT_HALO3X3 runs on conv3x3_hreg_s2 only (16-bit storage, no residual, views below 2 GiB)");
   Conv3Args a{};
   a.x = d->x;
   a.w = d->w;

@@ -277,6 +277,200 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hreg_kernel(const HregArgs p) 
   }
 }
 
+// ---- stride 2 (r03): the same decomposition for the 64-channel DOWNSAMPLING layers (64->128 @160 of the backbone, 64->64 @160 of
+// the neck), which ran on the flat-M LDS-DMA GEMM with a per-tap gather (399 / 597 TFLOP/s: every input pixel crossed the L2->LDS path
+// 2.25 times and a 128 x 64 tile with K = 576 is nine short steps between a prologue and an epilogue).  Output tile 4 x 16; the halo is
+// 9 rows x 33 columns, kept as TWO column-parity planes per row (A: columns 0, 2, .., 32 of the halo, B: columns 1, 3, .., 31), so
+// that the three taps of an output column are unit-stride fragment reads again — A[j], B[j], A[j + 1] — with the conflict-free
+// swizzle of the stride-1 image (row pitch 40 slots = 2,560 B, plane B at slot 24: both multiples of 256 B).  The LDS-DMA fills the
+// planes through its per-lane SOURCE address (buffer offsets, zeros by range check); per chunk a wave walks the 9 halo rows: even
+// rows feed the kernel rows r = 0 and r = 2 of two output rows (6 MFMAs per 3 reads), odd rows r = 1 (3 per 3): 36 MFMAs per 27
+// reads.  Ring of three 24 KB stages, two workgroups per CU.
+constexpr int kH2TH = 4, kH2TW = 16, kH2HH = 9, kH2Pitch = 40, kH2PlaneB = 24;
+constexpr int kH2Stage = 24 * 1024;  // 9 x 40 slots x 64 B = 23,040 B, padded to 24 wave-instructions (6 per wave)
+
+template <typename T, int NCH>
+__global__ __launch_bounds__(256, 2) void conv3x3_hreg_s2_kernel(const HregArgs p) {
+  constexpr int EPC = Elem<T>::EPC;  // 8
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[kHrStages * kH2Stage];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane >> 4, lr = lane & 15;
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+  const int Ho = (p.H - 1) / 2 + 1, Wo = (p.W - 1) / 2 + 1;
+
+  const int G = (int)gridDim.x;
+  const int logical = ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);
+  const int nt = logical % p.tilesN;
+  const int sb = logical / p.tilesN, Gs = G / p.tilesN;
+  const int myTiles = sb < p.nSpatial ? (p.nSpatial - sb + Gs - 1) / Gs : 0;
+  if (myTiles <= 0) return;
+  const int nItems = myTiles * NCH;
+
+  u32x4 wreg[NCH][9];
+  {
+    const u32x4* wg = reinterpret_cast<const u32x4*>(p.w) + (size_t)nt * NCH * 9 * 4 * 64;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wreg[c][t] = wg[((c * 9 + t) * 4 + wave) * 64 + lane];
+  }
+  const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + nt * 64 + wave * 16 + lq * 4);
+
+  // ---- loader: slot = (k * 4 + wave) * 16 + (lane >> 2) of the 9 x 40 image, part = lane & 3 ----
+  constexpr int NDMA = 6;
+  constexpr unsigned kOob = 0xfffffff0u;
+  const unsigned pre = (unsigned)((p.W + 1) * p.ldx) * 2u;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) - pre, 0, p.x_bytes + pre, 0x00020000);
+  unsigned rel[NDMA];
+  int hyx[NDMA];  // hy | hx << 8 (halo coordinates of the slot's pixel)
+#pragma unroll
+  for (int k = 0; k < NDMA; ++k) {
+    const int s = (k * 4 + wave) * 64 + lane;
+    const int slot = s >> 2, part = s & 3;
+    const int hy = slot / kH2Pitch, c = slot - hy * kH2Pitch;
+    const bool planeB = c >= kH2PlaneB;
+    const int ci = planeB ? c - kH2PlaneB : c;          // column index inside the plane (the swizzle key)
+    const int hx = planeB ? 2 * ci + 1 : 2 * ci;         // halo column
+    const bool dead = hy >= kH2HH || hx > 2 * kH2TW;     // stage padding, plane padding
+    rel[k] = dead ? kOob : (unsigned)((hy * p.W + hx) * p.ldx + (part ^ ((ci >> 1) & 3)) * EPC) * 2u;
+    hyx[k] = hy | (hx << 8);
+  }
+  unsigned voff[NDMA];
+  unsigned l_base = 0;
+  int l_tile = sb, l_chunk = 0, l_item = 0;
+  auto setup_tile = [&](int tile) {
+    const int tx = tile % p.tilesX;
+    const int r = tile / p.tilesX;
+    const int ty = r % p.tilesY, n = r / p.tilesY;
+    const int y0 = 2 * ty * kH2TH, x0 = 2 * tx * kH2TW;  // input coordinates of the tile's first output pixel's centre tap
+    l_base = (unsigned)(((n * p.H + y0) * p.W + x0) * p.ldx) * 2u;
+    const bool interior = y0 > 0 && y0 - 1 + kH2HH <= p.H && x0 > 0 && x0 + 2 * kH2TW <= p.W;  // wave-uniform
+    if (interior) {
+#pragma unroll
+      for (int k = 0; k < NDMA; ++k) voff[k] = rel[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < NDMA; ++k) {
+        const int gy = y0 - 1 + (hyx[k] & 255), gx = x0 - 1 + (hyx[k] >> 8);
+        voff[k] = ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) ? rel[k] : kOob;
+      }
+    }
+  };
+  auto issue_dma = [&](int stage) {
+    unsigned char* sa = smem + stage * kH2Stage;
+    const bool live = l_item < nItems;
+    if (live) {
+      const unsigned soff = l_base + (unsigned)l_chunk * (4u * EPC * (unsigned)sizeof(T));
+#pragma unroll
+      for (int k = 0; k < NDMA; ++k)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(sa + (k * 4 + wave) * 1024), 16, (int)voff[k], (int)soff, 0, 0);
+      ++l_item;
+      if (++l_chunk == NCH) {
+        l_chunk = 0;
+        l_tile += Gs;
+        if (l_item < nItems) setup_tile(l_tile);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NDMA; ++k)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(sa + (k * 4 + wave) * 1024), 16, (int)kOob, 0, 0, 0);
+    }
+  };
+
+  // fragment reads of halo row iy: q = 0 -> plane A column lr, q = 1 -> plane B column lr, q = 2 -> plane A column lr + 1
+  int lane_base[3];
+  lane_base[0] = lr * 64 + ((lq ^ ((lr >> 1) & 3)) * 16);
+  lane_base[1] = (kH2PlaneB + lr) * 64 + ((lq ^ ((lr >> 1) & 3)) * 16);
+  lane_base[2] = (lr + 1) * 64 + ((lq ^ (((lr + 1) >> 1) & 3)) * 16);
+
+  f32x4 acc[kH2TH];
+#pragma unroll
+  for (int o = 0; o < kH2TH; ++o) acc[o] = bias4;
+
+  auto compute = [&](int stg, int c) {
+    const unsigned char* sa = smem + stg * kH2Stage;
+#pragma unroll
+    for (int iy = 0; iy < kH2HH; ++iy) {
+      u32x4 a[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const u32x4*>(sa + lane_base[q] + iy * (kH2Pitch * 64));
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        if ((iy - r) % 2 == 0) {
+          const int o = (iy - r) / 2;
+          if (iy - r >= 0 && o < kH2TH) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc[o] = Elem<T>::mma(wreg[c][r * 3 + q], a[q], acc[o]);  // D[cout][pixel]
+          }
+        }
+      }
+    }
+  };
+
+  typedef __attribute__((ext_vector_type(4))) T t4;
+  unsigned lane_out[kH2TH / 2];
+  {
+    const int co16 = nt * 64 + wave * 16 + (lq >> 1) * 8;
+#pragma unroll
+    for (int o = 0; o < kH2TH; o += 2) lane_out[o / 2] = (unsigned)(((o + (lq & 1)) * Wo + lr) * p.ldy + co16) * (unsigned)sizeof(T);
+  }
+  auto epilogue = [&](int tile) {
+    const int tx = tile % p.tilesX;
+    const int r = tile / p.tilesX;
+    const int ty = r % p.tilesY, n = r / p.tilesY;
+    const int y0 = ty * kH2TH, x0 = tx * kH2TW;  // output coordinates
+    const unsigned out_base = (unsigned)(((n * Ho + y0) * Wo + x0) * p.ldy) * (unsigned)sizeof(T);
+    const bool whole = y0 + kH2TH <= Ho && x0 + kH2TW <= Wo;
+    u32x2 pk[kH2TH];
+#pragma unroll
+    for (int o = 0; o < kH2TH; ++o) {
+      float v[4] = {acc[o][0], acc[o][1], acc[o][2], acc[o][3]};
+      if (p.act == DY_ACT_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
+      }
+      t4 ov;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ov[e] = Elem<T>::from_f32(v[e]);
+      pk[o] = __builtin_bit_cast(u32x2, ov);
+      acc[o] = bias4;
+    }
+#pragma unroll
+    for (int o = 0; o < kH2TH; o += 2) {
+      const auto sx = __builtin_amdgcn_permlane16_swap(pk[o][0], pk[o + 1][0], false, false);
+      const auto sy = __builtin_amdgcn_permlane16_swap(pk[o][1], pk[o + 1][1], false, false);
+      unsigned off = lane_out[o / 2];
+      if (!whole) off = (y0 + o + (lq & 1) < Ho && x0 + lr < Wo) ? off : kOob;
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{sx[0], sy[0], sx[1], sy[1]}, yrs, off, (int)out_base, 0);
+    }
+  };
+
+  // item pipeline as in the stride-1 kernel: 6 DMA instructions per item and wave, 2 output stores per tile
+  setup_tile(l_tile);
+  issue_dma(0);
+  issue_dma(1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int c_tile = sb;
+  int stage = 0;
+  for (int it = 0; it < nItems; it += NCH) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      issue_dma(stage + 2 >= kHrStages ? stage + 2 - kHrStages : stage + 2);
+      compute(stage, c);
+      if (c == NCH - 1) {
+        epilogue(c_tile);
+        c_tile += Gs;
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      stage = stage + 1 == kHrStages ? 0 : stage + 1;
+    }
+  }
+}
+
 template <typename T>
 static int launch_hreg(const HregArgs& a, hipStream_t st) {
   HregArgs p = a;
@@ -297,11 +491,38 @@ static int launch_hreg(const HregArgs& a, hipStream_t st) {
   return check_launch("conv3x3_hreg_kernel");
 }
 
+template <typename T>
+static int launch_hreg_s2(const HregArgs& a, hipStream_t st) {
+  HregArgs p = a;
+  int grid = 256 * 2;  // two 256-thread workgroups per CU (72 KB of LDS each)
+  const long long nwork = (long long)p.nSpatial * p.tilesN;
+  if (nwork < grid) grid = (int)nwork;
+  const int q = 8 * p.tilesN;
+  grid = (grid + q - 1) / q * q;
+  hipLaunchKernelGGL((conv3x3_hreg_s2_kernel<T, 2>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  return check_launch("conv3x3_hreg_s2_kernel");
+}
+
 // Returns 1 when the shape is not one this kernel is built for (the caller then runs conv3x3_halo), else the launch status.
 int conv3x3_hreg_try(const dy_conv_desc* d, hipStream_t st) {
   static const int off = dy_ablate("DYOLO_NO_HREG");
   if (off) return 1;
-  if (!(d->dtype == DY_BF16 || d->dtype == DY_F16) || d->out_f32 || d->stride != 1 || d->ksize != 3 || d->pad != 1 || d->groups > 1 || d->up2x || d->x2) return 1;
+  if (!(d->dtype == DY_BF16 || d->dtype == DY_F16) || d->out_f32 || d->ksize != 3 || d->pad != 1 || d->groups > 1 || d->up2x || d->x2) return 1;
+  if (d->stride == 2) {  // the 64-channel downsampling layers (conv3x3_hreg_s2_kernel)
+    if (d->cin != 64 || d->cout % 64 != 0 || d->cout > 256 || d->residual) return 1;
+    const long long xb2 = (long long)d->batch * d->h * d->w_in * d->ld_x * 2, yb2 = (long long)d->batch * d->ho * d->wo * d->ld_y * 2;
+    if (xb2 >= (1ll << 31) || yb2 >= (1ll << 32) - 64 || d->ld_y % 8 || (reinterpret_cast<uintptr_t>(d->y) & 15)) return 1;
+    HregArgs a{};
+    a.x = d->x, a.w = d->w, a.bias = d->bias, a.res = nullptr, a.y = d->y;
+    a.N = d->batch, a.H = d->h, a.W = d->w_in, a.Cin = d->cin, a.ldx = d->ld_x, a.Cout = d->cout, a.ldy = d->ld_y, a.ldres = 0, a.act = d->act;
+    a.tilesX = (d->wo + kH2TW - 1) / kH2TW;
+    a.tilesY = (d->ho + kH2TH - 1) / kH2TH;
+    a.tilesN = d->cout / 64;
+    a.nSpatial = d->batch * a.tilesY * a.tilesX;
+    a.x_bytes = (unsigned)xb2, a.y_bytes = (unsigned)yb2, a.r_bytes = 0;
+    return d->dtype == DY_BF16 ? launch_hreg_s2<bf16_t>(a, st) : launch_hreg_s2<f16_t>(a, st);
+  }
+  if (d->stride != 1) return 1;
   // measured (B = 256, alternating A/B against conv3x3_halo, tools/bench_conv.py): 64->64 @160 650 -> 598 us, @80 150 -> 141, @40 55 -> 42,
   // @20 29 -> 18, 64->128 @80 285 -> 268; cin 32 (one chunk per tile: an epilogue every item) 205-250 -> 227-252: no gain, stays on
   // the halo kernel; with a Bottleneck residual (halo -> this kernel): 8-byte gathers 210 -> 237 @80, 16-byte pieces per row pair 187 -> 203:

@@ -318,6 +318,8 @@ class PackedConv:
             return
         # stride-2 halo tiles are 17x33 pixels (2 x 45 KB of LDS): only a weight set of <= 36 KB fits beside them
         s2_fits = self.cin <= 4 * elems_per_chunk(dtype) and cout > 32 or self.cin <= 8 * elems_per_chunk(dtype) and cout <= 32
+        # r03: the 64-channel downsampling layers run on the register-weight stride-2 kernel (conv3x3_hreg_s2), same fragment layout
+        s2_fits = s2_fits or (dtype in (torch.bfloat16, torch.float16) and self.cin == 64 and cout % 64 == 0 and cout <= 256 and halo is not False)
         # deep 3x3 layers (small maps, weight sets far beyond LDS) run faster as a flat-M implicit GEMM on the LDS-DMA
         # big-tile kernel behind DY_WLAYOUT_ROWS (conv_gemm_glds.hip): measured at batch 128, 256->256 @20x20 90 vs 162 us
         kstep = 8 * elems_per_chunk(dtype)

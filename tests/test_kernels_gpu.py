@@ -66,6 +66,10 @@ CONV_CASES = [
     (256, 256, 1, 1, 2, 40, 40, True, "1x1 stream 256->256 (2 n-tiles)"),
     (128, 128, 1, 1, 1, 13, 11, True, "1x1 stream odd M tail"),
     (64, 8, 1, 1, 1, 20, 20, False, "1x1 stream cout=8 (NF=1)"),
+    (64, 64, 3, 2, 2, 40, 36, True, "hreg s2 64->64"),
+    (64, 128, 3, 2, 3, 33, 31, True, "hreg s2 64->128 odd dims"),
+    (64, 64, 3, 2, 1, 8, 8, False, "hreg s2 tiny no act"),
+    (64, 64, 3, 2, 2, 160, 160, True, "hreg s2 many tiles"),
 ]
 
 
