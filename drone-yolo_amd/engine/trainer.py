@@ -135,6 +135,7 @@ class FlatState:
         if getattr(self, "S", None) is not None:
             from .. import hip_ops as H
 
+            H.join_side_stream()  # the weight-gradient kernels run on a second stream (hip_ops.conv_wgrad_into)
             H.grad_sink_flush_(self.sink_entries, self.G, self.S)
 
 

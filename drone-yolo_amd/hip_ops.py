@@ -14,6 +14,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 
 from . import _lib
@@ -906,6 +908,49 @@ def silu_bwd(u: torch.Tensor, dy: torch.Tensor, out: Optional[torch.Tensor] = No
 
 
 # ---- convolution gradients ----------------------------------------------------------------------------------------
+
+
+# ---- weight gradients beside the input gradients (r03) -------------------------------------------------------------------
+# In the backward of a layer the weight gradient (x, dz -> dw) feeds nothing but the parameter's gradient, while the input gradient
+# (dz, w -> dx) is what the rest of the backward waits for.  The wgrad kernels are bound by their closing fp32 atomics and by latency
+# (150 - 420 TFLOP/s), the dgrad / BatchNorm kernels by MFMA and HBM: issued on a SECOND stream (forked after dz exists, joined before
+# the gradients are read) the two can overlap; inside the captured step graph a fork / join becomes parallel branches.
+# MEASURED (r03, B = 64, graphed step): 37.5 ms with everything on one stream, 38.4 - 40.5 ms with the weight gradients on the side
+# stream — the hipGraph's branches do not run beside each other to any advantage (the wgrad atomics and the BatchNorm passes contend
+# for the same memory pipeline) — so it is OFF unless DYOLO_WGRAD_SIDE=1 asks for it.
+_WGRAD_SIDE = {"on": os.environ.get("DYOLO_WGRAD_SIDE", "0") == "1", "streams": {}, "used": False}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    st = _WGRAD_SIDE["streams"].get(str(device))
+    if st is None:
+        st = _WGRAD_SIDE["streams"][str(device)] = torch.cuda.Stream(device=device)
+    return st
+
+
+def join_side_stream(device=None) -> None:
+    """Make the current stream wait for every weight-gradient kernel issued on the side stream (call before the gradients / the sink are
+    read: the sink flush, a bucket's flush, the optimizer)."""
+    if not _WGRAD_SIDE["used"]:
+        return
+    for st in _WGRAD_SIDE["streams"].values():
+        torch.cuda.current_stream(st.device).wait_stream(st)
+    _WGRAD_SIDE["used"] = False
+
+
+def conv_wgrad_into(x: torch.Tensor, dz: torch.Tensor, ksize: int, stride: int, pad: int, out: torch.Tensor) -> None:
+    """``conv_wgrad(..., out=out)`` on the side stream (see above) when that is enabled; ``out`` must be a buffer nobody reads before
+    ``join_side_stream`` (a trainer's gradient sink)."""
+    if not _WGRAD_SIDE["on"]:
+        conv_wgrad(x, dz, ksize, stride, pad, out=out)
+        return
+    side = _side_stream(x.device)
+    side.wait_stream(torch.cuda.current_stream(x.device))  # x and dz exist
+    with torch.cuda.stream(side):
+        conv_wgrad(x, dz, ksize, stride, pad, out=out)
+    x.record_stream(side)  # the allocator must not hand their memory out again before the side stream is past this point
+    dz.record_stream(side)
+    _WGRAD_SIDE["used"] = True
 
 
 def conv_wgrad(x: torch.Tensor, dz: torch.Tensor, ksize: int, stride: int, pad: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -101,7 +101,7 @@ def conv_bn_bwd(dy, x, z, weight, gamma, beta, st, stride, pad, act, need_dx=Tru
     if sb is not None:
         dbeta = None
     if sw is not None:
-        H.conv_wgrad(x, dz, k, stride, pad, out=sw.view(cout, k, k, cin))
+        H.conv_wgrad_into(x, dz, k, stride, pad, sw.view(cout, k, k, cin))  # on the side stream: overlaps the input gradient below
         dw = None
     else:
         dw = H.conv_wgrad(x, dz, k, stride, pad)[:, :cin]
@@ -242,12 +242,12 @@ class RepVGGTrain(torch.autograd.Function):
         dg3, db3 = (None if grad_sink(g3) is not None else dg3), (None if grad_sink(b3) is not None else db3)
         dg1, db1 = (None if grad_sink(g1) is not None else dg1), (None if grad_sink(b1) is not None else db1)
         if grad_sink(w3) is not None:
-            H.conv_wgrad(x, dz3, 3, ctx.stride, 1, out=grad_sink(w3).view(w3.shape[0], 3, 3, w3.shape[1]))
+            H.conv_wgrad_into(x, dz3, 3, ctx.stride, 1, grad_sink(w3).view(w3.shape[0], 3, 3, w3.shape[1]))
             dw3 = None
         else:
             dw3 = H.conv_wgrad(x, dz3, 3, ctx.stride, 1)
         if grad_sink(w1) is not None:
-            H.conv_wgrad(x, dz1, 1, ctx.stride, 0, out=grad_sink(w1).view(w1.shape[0], 1, 1, w1.shape[1]))
+            H.conv_wgrad_into(x, dz1, 1, ctx.stride, 0, grad_sink(w1).view(w1.shape[0], 1, 1, w1.shape[1]))
             dw1 = None
         else:
             dw1 = H.conv_wgrad(x, dz1, 1, ctx.stride, 0)

@@ -213,6 +213,7 @@ class GradBuckets:
         if self.sink_entries is not None:
             from . import hip_ops as H
 
+            H.join_side_stream()  # the bucket's weight-gradient kernels run on a second stream (hip_ops.conv_wgrad_into)
             H.grad_sink_flush_(self.sink_entries[bi], self.flat.G, self.flat.S)
         if self.capturing:
             if self.events is not None:
