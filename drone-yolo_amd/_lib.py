@@ -168,6 +168,8 @@ SIGNATURES = {
     "dy_scale_boxes": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "dy_detection_loss_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "dy_conv2d_wgrad_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _i32, _vp, _vp]),
+    "dy_conv2d_wgrad_nhwc_ws": (_i32, [C.POINTER(ConvDesc), _vp, _i32, _vp, _vp, C.c_int64, _vp]),
+    "dy_conv2d_wgrad_workspace_bytes": (C.c_int64, [C.POINTER(ConvDesc), _i32]),
     "dy_quantize_fp8_nhwc": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp]),
     "dy_pack_conv_weights": (_i32, [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _i32, _vp]),
     "dy_detect_branch_fused_supported": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),

@@ -26,6 +26,9 @@ struct WgradArgs {
   float* dw;  // [cout][ks*ks][cin]
   int H, W, Cin, ldx, Ho, Wo, Cout, lddz, ks, stride, pad;
   long long M;
+  long long x_bytes, dz_bytes;  // extents of the views: ((pixels - 1) * pitch + channels rounded up to a chunk) * element size
+  void* ws;                     // optional workspace of the 3x3 kernel (partial sums per pixel slab) and its size
+  size_t ws_bytes;
   int HoWo, tilesCo, tilesCi, rows_per_block;
   FastDiv div_howo, div_wo;  // pixel index -> (image, row, column) without integer division (M < 2^31)
 };
@@ -69,6 +72,52 @@ __device__ __forceinline__ void tr_read_frags2(const void* base, u32x4 (&out)[2]
       : "memory");
   out[0] = u32x4{r0[0], r0[1], r1[0], r1[1]};
   out[1] = u32x4{r2[0], r2[1], r3[0], r3[1]};
+}
+
+// Pipelined form of the above for the 3x3 kernel: the reads of a group are ISSUED without a wait, the wait is a separate statement
+// the destination registers are tied to ("+v": nothing that uses them can be scheduled above it), with the count of younger reads
+// that may stay in flight (LDS returns in order; the counter has 4 bits).
+template <int OFF, int ROW2>
+__device__ __forceinline__ void tr_issue8(unsigned base, u32x2 (&r)[8]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8 offset:%9\n\t"
+      "ds_read_b64_tr_b16 %1, %8 offset:%10\n\t"
+      "ds_read_b64_tr_b16 %2, %8 offset:%11\n\t"
+      "ds_read_b64_tr_b16 %3, %8 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %4, %8 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %5, %8 offset:%14\n\t"
+      "ds_read_b64_tr_b16 %6, %8 offset:%15\n\t"
+      "ds_read_b64_tr_b16 %7, %8 offset:%16"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+      : "v"(base), "n"(OFF), "n"(OFF + ROW2), "n"(OFF + 32), "n"(OFF + 32 + ROW2), "n"(OFF + 64), "n"(OFF + 64 + ROW2), "n"(OFF + 96), "n"(OFF + 96 + ROW2)
+      : "memory");
+}
+template <int OFF, int ROW2>
+__device__ __forceinline__ void tr_issue4(unsigned base, u32x2 (&r)[4]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %4 offset:%5\n\t"
+      "ds_read_b64_tr_b16 %1, %4 offset:%6\n\t"
+      "ds_read_b64_tr_b16 %2, %4 offset:%7\n\t"
+      "ds_read_b64_tr_b16 %3, %4 offset:%8"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+      : "v"(base), "n"(OFF), "n"(OFF + ROW2), "n"(OFF + 32), "n"(OFF + 32 + ROW2)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void tr_wait(u32x2 (&r)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void tr_wait(u32x2 (&r)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N));
+}
+// reads a group of the 3x3 kernel's schedule issues (group g = (k-step g / 3, tap column g % 3): the tap's four x fragments, and the
+// k-step's dz fragments with its first tap), and how many reads of the younger groups are in flight after issuing DEPTH groups ahead
+constexpr int wg3_reads(int g, int cw) { return 8 + (g % 3 == 0 ? 2 * cw : 0); }
+constexpr int wg3_pending(int g, int depth, int ng, int cw) {
+  int n = 0;
+  for (int j = g + 1; j <= g + depth && j < ng; ++j) n += wg3_reads(j, cw);
+  return n > 15 ? 15 : n;
 }
 
 template <typename T, int WCO, int WCI>
@@ -223,9 +272,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 // (S+3) x (15*S+3)... halo of x they touch ONCE, wave r owns kernel row r (taps (r,0), (r,1), (r,2): three 64 x 64
 // accumulator tiles), the dz fragments are read once per step and every tap's x fragments are transposed reads at
 // lane base + compile-time offset of the same halo tile: ~180 flop per staged byte.
-#ifdef DYOLO_ABLATE
-__device__ float wgrad3_probe_scratch[8][64 * 128 * 9];  // timing probe: per-XCD atomic targets (DYOLO_WGRAD3_DBG bit 16)
-#endif
 
 struct Wgrad3Args {
   const void* x;
@@ -233,7 +279,9 @@ struct Wgrad3Args {
   float* dw;
   int H, W, Cin, ldx, Ho, Wo, Cout, lddz;
   int tilesCo, tilesCi, stepsX, stepsY, nSteps, steps_per_block;
-  int dbg;  // timing probes (-DDYOLO_ABLATE builds, DYOLO_WGRAD3_DBG): 1 no global loads, 2 no LDS staging stores, 4 no MFMAs, 8 no transposed reads
+  unsigned x_bytes, dz_bytes;  // extents of the x / dz views (buffer descriptors)
+  float* part;       // workspace (see wgrad3_reduce_kernel): slab s stores its partial sums at part + s * Cout * 9 * Cin instead of atomics on dw; may be null
+  int dbg;  // timing probes (-DDYOLO_ABLATE builds, DYOLO_WGRAD3_DBG): 1 no global loads, 32 no atomics
 };
 
 // CW = cout fragments (of 16) per wave: 4 -> three waves (one per kernel row) with 3 x 64 x 64 accumulators each = 192 registers of
@@ -245,16 +293,19 @@ struct Wgrad3Args {
 // without any global load the 64 -> 64 @160 launch takes 249 us instead of 513 (probes, ablate build).  PF = 2 costs 16 more
 // registers (two waves per SIMD instead of three), so it runs where the launch has one workgroup per CU anyway (see the slab rule).
 template <typename T, int S, int CW, int RS, int PF>
-__global__ __launch_bounds__(192 * (4 / CW), (CW == 2 && S == 1 ? (PF == 2 ? 2 : 3) : 1)) void conv_wgrad3x3_kernel(const Wgrad3Args p) {
+__global__ __launch_bounds__(192 * (4 / CW), (CW == 2 && PF == 1 ? 2 : 1)) void conv_wgrad3x3_kernel(const Wgrad3Args p) {
   constexpr int NT = 192 * (4 / CW);
   constexpr int E = Elem<T>::EPC;                // 8
   constexpr int PITCH = 64 * (int)sizeof(T) + 32;  // 160 B rows: 64 channels + pad (conflict-free transposed reads)
   constexpr int HH = (RS - 1) * S + 3, HW = 15 * S + 3;  // x halo of an RS x 16 output step: 4 x 18 (S = 1, RS = 2), 5 x 33 (S = 2, RS = 2), 6 x 18 (S = 1, RS = 4)
   constexpr int NPX = HH * HW;
   constexpr int NDZ = RS * 16;
-  constexpr int DZ_BYTES = NDZ * PITCH, X_BYTES = NPX * PITCH, STAGE = DZ_BYTES + X_BYTES;
   constexpr int NCHK = (NDZ + NPX) * 8;          // 16-byte chunks per step
   constexpr int PER = (NCHK + NT - 1) / NT;
+  // PF = 2 (a workgroup alone on its CU): the stage is padded to PER * NT chunks so that every thread stores every chunk -- with no
+  // exec-masked store in the loop the compiler's vmcnt counts are exact and the other register set's loads stay in flight
+  constexpr bool FULL = PF == 2;
+  constexpr int DZ_BYTES = NDZ * PITCH, X_BYTES = NPX * PITCH, STAGE = FULL ? PER * NT / 8 * PITCH : DZ_BYTES + X_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -266,9 +317,6 @@ __global__ __launch_bounds__(192 * (4 / CW), (CW == 2 && S == 1 ? (PF == 2 ? 2 :
   const int s_begin = blockIdx.x * p.steps_per_block;
   int s_end = s_begin + p.steps_per_block;
   if (s_end > p.nSteps) s_end = p.nSteps;
-  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
-  const T* __restrict__ dg = reinterpret_cast<const T*>(p.dz);
-
   f32x4 acc[3][CW][4];
 #pragma unroll
   for (int q = 0; q < 3; ++q)
@@ -277,46 +325,70 @@ __global__ __launch_bounds__(192 * (4 / CW), (CW == 2 && S == 1 ? (PF == 2 ? 2 :
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Loader: branch-free buffer loads.  (The first form of this loader chose between the dz and the x branch per lane and read
+  // p.lddz / p.ldx, p.Ho / p.H through a per-lane SELECTED ADDRESS into the kernel-argument segment: a global_load_dword followed by
+  // s_waitcnt vmcnt(0) in front of every 16-byte load, i.e. the loads of a step were serialised and nothing stayed in flight.)
+  // A chunk's role (dz or x) is uniform per (k, wave) -- NDZ * 8 is a multiple of 64 -- so the descriptor and the step's base offset
+  // are scalars; the lane's byte offset inside the step is a launch constant; rows / columns outside the image and dead channel
+  // chunks take an offset beyond num_records and read zeros.  The x descriptor starts (W + 1) pixels early so no offset is negative.
+  constexpr unsigned kOob = 0xfffffff0u;
+  const unsigned pre = (unsigned)((p.W + 1) * p.ldx) * 2u;
+  const __amdgpu_buffer_rsrc_t xrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) - pre, 0, p.x_bytes + pre, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dzrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dz), 0, p.dz_bytes, 0x00020000);
+  const int wvu = __builtin_amdgcn_readfirstlane(wv);
+  unsigned rel[PER];  // launch constants
+  int ryx[PER];       // row | column << 8 inside the step (dz: output pixel, x: halo pixel)
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int id = k * NT + tid;
+    if (id < NDZ * 8) {
+      const int px = id >> 3, ch = id & 7, row = px >> 4, col = px & 15, co = co0 + ch * E;
+      rel[k] = co < p.Cout ? (unsigned)((row * p.Wo + col) * p.lddz + co) * 2u : kOob;
+      ryx[k] = row | (col << 8);
+    } else {
+      const int idx = id - NDZ * 8, px = idx >> 3, ch = idx & 7, hy = px / HW, hx = px - hy * HW, ci = ci0 + ch * E;
+      rel[k] = (id < NCHK && ci < p.Cin) ? (unsigned)((hy * p.W + hx) * p.ldx + ci) * 2u : kOob;
+      ryx[k] = hy | (hx << 8);
+    }
+  }
+
   u32x4 stage[PF][PER];
   auto load_step = [&](int step, u32x4 (&stg)[PER]) {
     const int bx = step % p.stepsX;
     int rest = step / p.stepsX;
     const int by = rest % p.stepsY, n = rest / p.stepsY;
     const int y0 = by * RS, x0 = bx * 16;
+    // steps past the slab's end (the PF = 2 loop issues its loads unconditionally, see below) read zeros: every offset out of range
+    // (a mask the compiler cannot see through: a visible condition is threaded into two copies of the loads behind a scalar branch)
+    unsigned dead = step < s_end ? 0u : 0xffffffffu;
+    asm volatile("" : "+v"(dead));
+    dead = __builtin_amdgcn_readfirstlane(dead);  // (asm results count as divergent)
+    const unsigned dz_base = (unsigned)(((n * p.Ho + y0) * p.Wo + x0) * p.lddz) * 2u & ~dead;
+    const unsigned x_base = (unsigned)(((n * p.H + y0 * S) * p.W + x0 * S) * p.ldx) * 2u & ~dead;  // halo origin in the shifted descriptor's terms
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      const int id = k * NT + tid;
-      u32x4 v = zero_chunk();
 #ifdef DYOLO_ABLATE
       if (p.dbg & 1) {
-        stg[k] = u32x4{(unsigned)id, 0x3c003c00u, (unsigned)step, 0x3c003c00u};
+        stg[k] = u32x4{(unsigned)(k * NT + tid), 0x3c003c00u, (unsigned)step, 0x3c003c00u};
         continue;
       }
 #endif
-      if (id < NDZ * 8) {  // dz: pixel (row id/128, col (id/8)%16), chunk id%8
-        const int px = id >> 3, ch = id & 7;
-        const int yy = y0 + (px >> 4), xx = x0 + (px & 15), co = co0 + ch * E;
-        if (yy < p.Ho && xx < p.Wo && co < p.Cout) v = *reinterpret_cast<const u32x4*>(dg + ((long long)(n * p.Ho + yy) * p.Wo + xx) * p.lddz + co);
-      } else if (id < NCHK) {
-        const int idx = id - NDZ * 8;
-        const int px = idx >> 3, ch = idx & 7;
-        const int hy = px / HW, hx = px - hy * HW;
-        const int gy = y0 * S - 1 + hy, gx = x0 * S - 1 + hx, ci = ci0 + ch * E;
-        if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && ci < p.Cin)
-          v = *reinterpret_cast<const u32x4*>(xg + ((long long)(n * p.H + gy) * p.W + gx) * p.ldx + ci);
-      }
-      stg[k] = v;
+      // role of this (k, wave): known at compile time except for the one k that straddles the dz / x boundary; everything that
+      // depends on it is a scalar select (no branch: the compiler then counts the loads in flight exactly)
+      const bool role_dz = (k + 1) * NT <= NDZ * 8 ? true : (k * NT >= NDZ * 8 ? false : (k * NT + wvu * 64 < NDZ * 8));
+      const int oy = role_dz ? y0 : y0 * S - 1, ox = role_dz ? x0 : x0 * S - 1;
+      const unsigned lim_y = role_dz ? (unsigned)p.Ho : (unsigned)p.H, lim_x = role_dz ? (unsigned)p.Wo : (unsigned)p.W;
+      const unsigned off = (((unsigned)(oy + (ryx[k] & 255)) < lim_y && (unsigned)(ox + (ryx[k] >> 8)) < lim_x) ? rel[k] : kOob) | dead;
+      stg[k] = __builtin_amdgcn_raw_buffer_load_b128(role_dz ? dzrs : xrs, (int)off, (int)(role_dz ? dz_base : x_base), 0);
     }
   };
   auto store_step = [&](int buf, const u32x4 (&stg)[PER]) {
-#ifdef DYOLO_ABLATE
-    if (p.dbg & 2) return;
-#endif
     unsigned char* base = smem + buf * STAGE;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       const int id = k * NT + tid;
-      if (id < NCHK) {
+      if (FULL || id < NCHK) {
         const int px = id >> 3, ch = id & 7;  // dz rows first, the halo rows follow in the same pitch
         *reinterpret_cast<u32x4*>(base + px * PITCH + ch * 16) = stg[k];
       }
@@ -332,61 +404,75 @@ __global__ __launch_bounds__(192 * (4 / CW), (CW == 2 && S == 1 ? (PF == 2 ? 2 :
   auto step_body = [&](int st, int buf, u32x4 (&stg)[PER]) {
     store_step(buf, stg);  // stage `buf` was last read two steps ago: the barrier of the previous step covers it
     __syncthreads();
-    if (st + PF < s_end) load_step(st + PF, stg);  // in flight during the MFMAs of PF steps
-    const unsigned char* tdz = smem + buf * STAGE;
-    const unsigned char* tx = tdz + DZ_BYTES;
-#pragma unroll
-    for (int hh = 0; hh < RS / 2; ++hh) {  // one 32-pixel MFMA k-step per pair of output rows
-      u32x4 a[CW];
-#ifdef DYOLO_ABLATE
-      const bool no_tr = p.dbg & 8, no_mma = p.dbg & 4;
-      if (no_tr) {
-#pragma unroll
-        for (int i = 0; i < CW; ++i) a[i] = u32x4{(unsigned)st, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
-      } else
+    // in flight during the MFMAs of PF steps.  PF = 2: issued on every trip, also past the end (zeros, no memory access) -- the number
+    // of loads in flight is then the same on every path and the s_waitcnt in front of the staging stores lets the other set fly
+    if (PF == 2 || st + PF < s_end) load_step(st + PF, stg);
+    // MFMA section: NG = 3 * RS / 2 groups (k-step of 32 pixels = a pair of output rows, tap column); the transposed reads run
+    // DEPTH groups ahead of the MFMAs that use them
+#ifndef DYOLO_WG3_DEPTH
+#define DYOLO_WG3_DEPTH 2
 #endif
-      {
-        if constexpr (CW == 4) tr_read_frags<PITCH, 16 * PITCH>(tdz + dz_lane + hh * 32 * PITCH, a);
-        else tr_read_frags2<PITCH, 16 * PITCH>(tdz + dz_lane + hh * 32 * PITCH + chf * 64, a);  // channels [32*chf, 32*chf + 32) of the dz rows
+    constexpr int NHH = RS / 2, NG = 3 * NHH, DEPTH = DYOLO_WG3_DEPTH;
+    const unsigned bdz = (unsigned)(uintptr_t)(smem + buf * STAGE) + (unsigned)dz_lane + (CW == 2 ? (unsigned)chf * 64u : 0u);
+    const unsigned bx = (unsigned)(uintptr_t)(smem + buf * STAGE) + (unsigned)(DZ_BYTES + x_lane + r_ * HW * PITCH);
+    u32x2 ra[NHH][2 * CW];
+    u32x2 rb[NG][8];
+    u32x4 a[NHH][CW];
+    auto issue = [&](auto G) {
+      constexpr int g = decltype(G)::value, hh = g / 3, q = g % 3;
+      if constexpr (q == 0) {
+        if constexpr (CW == 4) tr_issue8<hh * 32 * PITCH, 16 * PITCH>(bdz, ra[hh]);
+        else tr_issue4<hh * 32 * PITCH, 16 * PITCH>(bdz, ra[hh]);  // channels [32 * chf, 32 * chf + 32) of the dz rows
       }
+      // tap (r_, q): halo pixel of output (row, col) is ((row*S + r_) * HW + col*S + q); the second output row is S halo rows below
+      tr_issue8<(hh * 2 * S * HW + q) * PITCH, S * HW * PITCH>(bx, rb[g]);
+    };
+    auto run = [&](auto G) {
+      constexpr int g = decltype(G)::value, hh = g / 3, q = g % 3;
+      if constexpr (g + DEPTH < NG) issue(std::integral_constant<int, g + DEPTH>{});
+      constexpr int N = wg3_pending(g, DEPTH, NG, CW);
+      if constexpr (q == 0) {
+        tr_wait<N>(ra[hh]);
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        u32x4 b[4];
-        // tap (r_, q): halo pixel of output (row, col) is ((row*S + r_) * HW + col*S + q); the second output row is S halo rows below
-#ifdef DYOLO_ABLATE
-        if (no_tr) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) b[j] = u32x4{(unsigned)q, 0x3c003c00u, 0x3c003c00u, (unsigned)st};
-        } else
-#endif
-          tr_read_frags<PITCH, S * HW * PITCH>(tx + x_lane + ((hh * 2 * S + r_) * HW + q) * PITCH, b);
-#ifdef DYOLO_ABLATE
-        if (no_mma) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(b[j]), "v"(a[0]));
-          continue;
-        }
-#endif
-#pragma unroll
-        for (int i = 0; i < CW; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[q][i][j] = Elem<T>::mma(a[i], b[j], acc[q][i][j]);
+        for (int i = 0; i < CW; ++i) a[hh][i] = u32x4{ra[hh][2 * i][0], ra[hh][2 * i][1], ra[hh][2 * i + 1][0], ra[hh][2 * i + 1][1]};
       }
+      tr_wait<N>(rb[g]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32x4 b = u32x4{rb[g][2 * j][0], rb[g][2 * j][1], rb[g][2 * j + 1][0], rb[g][2 * j + 1][1]};
+#pragma unroll
+        for (int i = 0; i < CW; ++i) acc[q][i][j] = Elem<T>::mma(a[hh][i], b, acc[q][i][j]);
+      }
+    };
+    issue(std::integral_constant<int, 0>{});
+    if constexpr (DEPTH == 2) issue(std::integral_constant<int, 1>{});
+    run(std::integral_constant<int, 0>{});
+    run(std::integral_constant<int, 1>{});
+    run(std::integral_constant<int, 2>{});
+    if constexpr (NG == 6) {
+      run(std::integral_constant<int, 3>{});
+      run(std::integral_constant<int, 4>{});
+      run(std::integral_constant<int, 5>{});
     }
   };
 #pragma unroll
   for (int d = 0; d < PF; ++d)
-    if (s_begin + d < s_end) load_step(s_begin + d, stage[d]);
+    if (PF == 2 || s_begin + d < s_end) load_step(s_begin + d, stage[d]);
   if constexpr (PF == 1) {
     int buf = 0;
     for (int st = s_begin; st < s_end; ++st, buf ^= 1) step_body(st, buf, stage[0]);
   } else {
     for (int st = s_begin; st < s_end; st += 2) {  // two steps per trip: LDS stage and register set by the step's parity
       step_body(st, 0, stage[0]);
-      if (st + 1 < s_end) step_body(st + 1, 1, stage[1]);
+      step_body(st + 1, 1, stage[1]);  // an odd slab's last trip runs one step of zeros
     }
   }
 
+  // Epilogue.  Every slab ends with Cout x Cin x 9 partial sums.  fp32 atomics on dw take 30-50 us of a launch (9.4 M lane-atomics
+  // with 256 workgroups, whatever the layer: ~1 per clock and L2 channel), more than the MFMAs of the small maps -- so with a
+  // workspace the slab STORES its sums in its own copy and wgrad3_reduce_kernel adds the copies up (16 at a time, 1/16 of the atomics).
+  float* __restrict__ dst = p.part ? p.part + (size_t)blockIdx.x * ((size_t)p.Cout * 9 * p.Cin) : p.dw;
+  const bool plain = p.part != nullptr;
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     const int tap = r_ * 3 + q;
@@ -399,61 +485,108 @@ __global__ __launch_bounds__(192 * (4 / CW), (CW == 2 && S == 1 ? (PF == 2 ? 2 :
         for (int e = 0; e < 4; ++e) {
           const int co = co0 + (chf * CW + i) * 16 + lq * 4 + e;
 #ifdef DYOLO_ABLATE
-          if ((p.dbg & 16) && p.Cout * p.Cin <= 64 * 128) {
-            const unsigned xcd = (blockIdx.x + gridDim.x * blockIdx.y) & 7;
-            if (co < p.Cout && ci < p.Cin) atomicAdd(&wgrad3_probe_scratch[xcd][((size_t)co * 9 + tap) * p.Cin + ci], acc[q][i][j][e]);
-            continue;
-          }
           if (p.dbg & 32) continue;  // no atomics at all
 #endif
-          if (co < p.Cout && ci < p.Cin) atomicAdd(p.dw + ((size_t)co * 9 + tap) * p.Cin + ci, acc[q][i][j][e]);
+          if (co < p.Cout && ci < p.Cin) {
+            float* at = dst + ((size_t)co * 9 + tap) * p.Cin + ci;
+            if (plain) *at = acc[q][i][j][e];
+            else atomicAdd(at, acc[q][i][j][e]);
+          }
         }
       }
   }
 }
 
+// dw[e] += sum over the slabs' copies: thread = (4 consecutive elements, group of 16 slabs); one fp32 atomic per element and group.
+__global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int n, int slabs) {
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= n) return;
+  const int s0 = blockIdx.y * 16, s1 = min(slabs, s0 + 16);
+  const float* src = part + (size_t)s0 * n + e;
+  if (e + 4 <= n && (n & 3) == 0) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int sl = s0; sl < s1; ++sl, src += n) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+      t += v;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) atomicAdd(dw + e + k, t[k]);
+  } else {
+    for (int k = 0; k < 4 && e + k < n; ++k) {
+      float t = 0.f;
+      for (int sl = s0; sl < s1; ++sl) t += part[(size_t)sl * n + e + k];
+      atomicAdd(dw + e + k, t);
+    }
+  }
+}
+
+// Launch geometry of the 3x3 kernel: output rows per step, steps, pixel slabs (= gridDim.x = copies in the workspace).
+struct Wgrad3Plan {
+  int rs, stepsX, stepsY, nSteps, ny, steps_per_block, gx;
+};
+static Wgrad3Plan wgrad3_plan(const WgradArgs& a, int batch, int stride) {
+  Wgrad3Plan g{};
+  // four output rows per step where the map is tall enough to fill them (stride 1: the 6 x 18 halo + 64 dz pixels are 27 KB a stage);
+  // stride 2 keeps two rows (its halo is 5 x 33 already)
+  static const int rs2 = dy_ablate("DYOLO_WGRAD3_RS2");
+  g.rs = (stride == 1 && !rs2 && a.Ho % 4 == 0) ? 4 : 2;
+  g.stepsX = (a.Wo + 15) / 16, g.stepsY = (a.Ho + g.rs - 1) / g.rs;
+  g.nSteps = batch * g.stepsY * g.stepsX;
+  g.ny = ((a.Cout + 63) / 64) * ((a.Cin + 63) / 64);
+  // Pixel slabs: ONE six-wave workgroup per CU (256 overall) with two steps of loads in flight (PF = 2), every slab at least 8 steps.
+  // (r02 ran stride-2 layers with 512 workgroups and one step in flight: that was the loader's serialised loads, see the kernel;
+  // B = 64, 512 + PF 1 -> 256 + PF 2: 64 -> 128 s2 @160 222 -> 182 us, 128 -> 256 s2 235 -> 190, 64 -> 64 s2 176 -> 131.)
+  static const int force_pf2 = dy_ablate("DYOLO_WGRAD3_PF2");  // probe: 2 = 512 workgroups with one step of loads in flight
+  const int target = force_pf2 == 2 ? 512 : 256;
+  int slabs = (target + g.ny - 1) / g.ny;
+  const int max_slabs = (g.nSteps + 7) / 8;
+  if (slabs > max_slabs) slabs = max_slabs;
+  if (slabs < 1) slabs = 1;
+  g.steps_per_block = (g.nSteps + slabs - 1) / slabs;
+#ifdef DYOLO_ABLATE
+  if (const int sl = dy_ablate("DYOLO_WGRAD3_SLABS")) g.steps_per_block = (g.nSteps + sl - 1) / sl;  // probe: another pixel-slab count
+#endif
+  g.gx = (g.nSteps + g.steps_per_block - 1) / g.steps_per_block;
+  return g;
+}
+static size_t wgrad3_workspace_bytes(const WgradArgs& a, int batch, int stride) {
+  const Wgrad3Plan g = wgrad3_plan(a, batch, stride);
+  return g.gx > 1 ? (size_t)g.gx * a.Cout * 9 * a.Cin * sizeof(float) : 0;
+}
+
 template <typename T, int S, int RS>
-static int launch_wgrad3_rs(const WgradArgs& a, int batch, hipStream_t st) {
+static int launch_wgrad3_rs(const WgradArgs& a, const Wgrad3Plan& g, hipStream_t st) {
   Wgrad3Args p{};
   p.x = a.x, p.dz = a.dz, p.dw = a.dw, p.H = a.H, p.W = a.W, p.Cin = a.Cin, p.ldx = a.ldx, p.Ho = a.Ho, p.Wo = a.Wo, p.Cout = a.Cout, p.lddz = a.lddz;
   p.tilesCo = (p.Cout + 63) / 64, p.tilesCi = (p.Cin + 63) / 64;
-  p.stepsX = (p.Wo + 15) / 16, p.stepsY = (p.Ho + RS - 1) / RS;
-  p.nSteps = batch * p.stepsY * p.stepsX;
-  const int ny = p.tilesCo * p.tilesCi;
-  // Pixel slabs: every slab ends with Cout x Cin x 9 fp32 atomics, so their number is a trade between filling the CUs and atomic
-  // traffic (512 slabs of a 64 x 64 layer = 18.9 M atomics ~ 65 us, a third of the launch at 80 x 80), and a workgroup alone on
-  // its CU may hold two steps of loads in registers (PF = 2).  Measured at B = 64 (tools/bench_wgrad.py; DYOLO_WGRAD3_SLABS / _PF2
-  // in the ablate build): stride 1, 256 workgroups + PF 2 against 512 + PF 1: 64 -> 64 @160 288 / 518 us (420 TFLOP/s), @80 114 /
-  // 180, 128 -> 128 @40 101 / 171, 64 -> 128 @80 184 / 223, 256 -> 256 @20 118 / 144; stride 2 (two rows per step, halo 5 x 33)
-  // the other way round: 64 -> 64 173 / 185, 32 -> 64 @320 408 / 660, 128 -> 256 267 / 307.
-  static const int force_pf2 = dy_ablate("DYOLO_WGRAD3_PF2");  // probe: 1 = one workgroup per CU + two steps of loads in flight for every shape, 2 = for none
-  const int target = force_pf2 == 2 ? 512 : ((S == 1 || force_pf2 == 1) ? 256 : 512);
-  int slabs = (target + ny - 1) / ny;
-  const int max_slabs = (p.nSteps + 7) / 8;
-  if (slabs > max_slabs) slabs = max_slabs;
-  if (slabs < 1) slabs = 1;
-  p.steps_per_block = (p.nSteps + slabs - 1) / slabs;
+  p.stepsX = g.stepsX, p.stepsY = g.stepsY, p.nSteps = g.nSteps, p.steps_per_block = g.steps_per_block;
+  p.x_bytes = (unsigned)a.x_bytes, p.dz_bytes = (unsigned)a.dz_bytes;
+  const size_t n = (size_t)a.Cout * 9 * a.Cin;
+  static const int no_part = dy_ablate("DYOLO_WGRAD3_ATOMICS");  // probe: atomics on dw even with a workspace
+  p.part = (!no_part && g.gx > 1 && a.ws && a.ws_bytes >= (size_t)g.gx * n * sizeof(float)) ? reinterpret_cast<float*>(a.ws) : nullptr;
   p.dbg = dy_ablate("DYOLO_WGRAD3_DBG");
-#ifdef DYOLO_ABLATE
-  if (const int sl = dy_ablate("DYOLO_WGRAD3_SLABS")) p.steps_per_block = (p.nSteps + sl - 1) / sl;  // probe: another pixel-slab count
-#endif
-  const unsigned gx = (unsigned)((p.nSteps + p.steps_per_block - 1) / p.steps_per_block);
+  const dim3 grid((unsigned)g.gx, (unsigned)g.ny);
   static const int cw4 = dy_ablate("DYOLO_WGRAD3_CW4");
-  if (cw4) hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, S, 4, RS, 1>), dim3(gx, (unsigned)ny), dim3(192), 0, st, p);
-  else if (target == 256) hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, S, 2, RS, 2>), dim3(gx, (unsigned)ny), dim3(384), 0, st, p);
-  else hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, S, 2, RS, 1>), dim3(gx, (unsigned)ny), dim3(384), 0, st, p);
-  return check_launch("conv_wgrad3x3_kernel");
+  static const int force_pf2 = dy_ablate("DYOLO_WGRAD3_PF2");
+  if (cw4) hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, S, 4, RS, 1>), grid, dim3(192), 0, st, p);
+  else if (force_pf2 != 2) hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, S, 2, RS, 2>), grid, dim3(384), 0, st, p);
+  else hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, S, 2, RS, 1>), grid, dim3(384), 0, st, p);
+  if (const int rc = check_launch("conv_wgrad3x3_kernel")) return rc;
+  if (p.part) {
+    hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3((unsigned)((n / 4 + 256) / 256), (unsigned)((g.gx + 15) / 16)), dim3(256), 0, st, p.part, a.dw, (int)n, g.gx);
+    return check_launch("wgrad3_reduce_kernel");
+  }
+  return 0;
 }
 
 template <typename T, int S>
 static int launch_wgrad3(const WgradArgs& a, int batch, hipStream_t st) {
-  // four output rows per step where the map is tall enough to fill them (stride 1: the 6 x 18 halo + 64 dz pixels are 27 KB a stage);
-  // stride 2 keeps two rows (its halo is 5 x 33 already)
-  static const int rs2 = dy_ablate("DYOLO_WGRAD3_RS2");
+  const Wgrad3Plan g = wgrad3_plan(a, batch, S);
   if constexpr (S == 1) {
-    if (!rs2 && a.Ho % 4 == 0) return launch_wgrad3_rs<T, 1, 4>(a, batch, st);
+    if (g.rs == 4) return launch_wgrad3_rs<T, 1, 4>(a, g, st);
   }
-  return launch_wgrad3_rs<T, S, 2>(a, batch, st);
+  return launch_wgrad3_rs<T, S, 2>(a, g, st);
 }
 
 template <typename T, int WCO, int WCI>
@@ -526,8 +659,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* z, float* out, lon
 
 using namespace dy;
 
-extern "C" int32_t dy_conv2d_wgrad_nhwc(const dy_conv_desc* d, const void* dz, int32_t ld_dz, float* dw, dy_stream_t stream) {
-  DY_REQUIRE(d && d->x && dz && dw, DY_ERR_INVALID_ARG, "dy_conv2d_wgrad_nhwc: null pointer");
+// validation + geometry shared by the entry points; `uses3` = the 3x3 kernel takes this call
+static int wgrad_setup(const dy_conv_desc* d, const void* dz, int32_t ld_dz, float* dw, bool need_ptrs, WgradArgs& a, bool& uses3) {
+  DY_REQUIRE(d && (!need_ptrs || (d->x && dz && dw)), DY_ERR_INVALID_ARG, "dy_conv2d_wgrad_nhwc: null pointer");
   const int es = dtype_size_no_fp8(d->dtype);
   DY_REQUIRE(es != 0 && d->batch > 0 && d->h > 0 && d->w_in > 0 && d->cin > 0 && d->cout > 0 && d->ksize >= 1 && d->stride >= 1 && d->pad >= 0,
              DY_ERR_INVALID_ARG, "dy_conv2d_wgrad_nhwc: bad dims");
@@ -535,23 +669,43 @@ extern "C" int32_t dy_conv2d_wgrad_nhwc(const dy_conv_desc* d, const void* dz, i
   const int epc = 16 / es;
   // channels are read in whole 16-byte chunks: the pitches must cover cin / cout ROUNDED UP to a chunk (what lies in the
   // padding only reaches gradient rows / columns that are never written)
-  DY_REQUIRE(aligned16(d->x) && aligned16(dz) && (d->ld_x * es) % 16 == 0 && (ld_dz * es) % 16 == 0 && d->ld_x >= (d->cin + epc - 1) / epc * epc &&
-                 ld_dz >= (d->cout + epc - 1) / epc * epc,
+  DY_REQUIRE((!need_ptrs || (aligned16(d->x) && aligned16(dz))) && (d->ld_x * es) % 16 == 0 && (ld_dz * es) % 16 == 0 &&
+                 d->ld_x >= (d->cin + epc - 1) / epc * epc && ld_dz >= (d->cout + epc - 1) / epc * epc,
              DY_ERR_INVALID_ARG, "dy_conv2d_wgrad_nhwc: x / dz views must be 16-byte aligned with pitches covering the channels rounded up to %d", epc);
   const int ho = (d->h + 2 * d->pad - d->ksize) / d->stride + 1, wo = (d->w_in + 2 * d->pad - d->ksize) / d->stride + 1;
   DY_REQUIRE(ho == d->ho && wo == d->wo, DY_ERR_INVALID_ARG, "dy_conv2d_wgrad_nhwc: ho/wo (%d,%d) != expected (%d,%d)", d->ho, d->wo, ho, wo);
-  WgradArgs a{};
   a.x = d->x, a.dz = dz, a.dw = dw;
   a.H = d->h, a.W = d->w_in, a.Cin = d->cin, a.ldx = d->ld_x, a.Ho = ho, a.Wo = wo, a.Cout = d->cout, a.lddz = ld_dz;
   a.ks = d->ksize, a.stride = d->stride, a.pad = d->pad;
   a.M = (long long)d->batch * ho * wo;
+  a.x_bytes = (((long long)d->batch * d->h * d->w_in - 1) * d->ld_x + (d->cin + epc - 1) / epc * epc) * es;
+  a.dz_bytes = ((a.M - 1) * ld_dz + (d->cout + epc - 1) / epc * epc) * es;
   DY_REQUIRE(a.M < (1ll << 31), DY_ERR_UNSUPPORTED, "dy_conv2d_wgrad_nhwc: pixel count exceeds int32");
   a.HoWo = ho * wo;
   a.div_howo = make_fastdiv((unsigned)a.HoWo);
   a.div_wo = make_fastdiv((unsigned)wo);
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   static const int no3 = dy_ablate("DYOLO_NO_WGRAD3");
-  if (!no3 && d->ksize == 3 && d->pad == 1 && (d->stride == 1 || d->stride == 2) && es == 2) {  // all nine taps from one staged halo
+  // all nine taps from one staged halo (32-bit byte offsets in its buffer loads: views of 2 GiB and more take the per-tap kernel)
+  uses3 = !no3 && d->ksize == 3 && d->pad == 1 && (d->stride == 1 || d->stride == 2) && es == 2 && a.x_bytes < (1ll << 31) && a.dz_bytes < (1ll << 31);
+  return 0;
+}
+
+extern "C" int64_t dy_conv2d_wgrad_workspace_bytes(const dy_conv_desc* d, int32_t ld_dz) {
+  WgradArgs a{};
+  bool uses3 = false;
+  if (const int rc = wgrad_setup(d, nullptr, ld_dz, nullptr, false, a, uses3)) return rc;
+  return uses3 ? (int64_t)wgrad3_workspace_bytes(a, d->batch, d->stride) : 0;
+}
+
+extern "C" int32_t dy_conv2d_wgrad_nhwc_ws(const dy_conv_desc* d, const void* dz, int32_t ld_dz, float* dw, void* workspace, int64_t workspace_bytes,
+                                           dy_stream_t stream) {
+  WgradArgs a{};
+  bool uses3 = false;
+  if (const int rc = wgrad_setup(d, dz, ld_dz, dw, true, a, uses3)) return rc;
+  DY_REQUIRE(!workspace || (aligned16(workspace) && workspace_bytes >= 0), DY_ERR_INVALID_ARG, "dy_conv2d_wgrad_nhwc_ws: workspace must be 16-byte aligned");
+  a.ws = workspace, a.ws_bytes = workspace ? (size_t)workspace_bytes : 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (uses3) {
     if (d->dtype == DY_BF16) return d->stride == 1 ? launch_wgrad3<bf16_t, 1>(a, d->batch, st) : launch_wgrad3<bf16_t, 2>(a, d->batch, st);
     return d->stride == 1 ? launch_wgrad3<f16_t, 1>(a, d->batch, st) : launch_wgrad3<f16_t, 2>(a, d->batch, st);
   }
@@ -560,6 +714,10 @@ extern "C" int32_t dy_conv2d_wgrad_nhwc(const dy_conv_desc* d, const void* dz, i
     case DY_F16: return launch_wgrad_dtype<f16_t>(a, st);
     default: return launch_wgrad_dtype<float>(a, st);
   }
+}
+
+extern "C" int32_t dy_conv2d_wgrad_nhwc(const dy_conv_desc* d, const void* dz, int32_t ld_dz, float* dw, dy_stream_t stream) {
+  return dy_conv2d_wgrad_nhwc_ws(d, dz, ld_dz, dw, nullptr, 0, stream);
 }
 
 extern "C" int32_t dy_colsum(const void* z, float* out, int64_t rows, int32_t c, int32_t ld, int32_t dtype, dy_stream_t stream) {

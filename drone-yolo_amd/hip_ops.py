@@ -971,8 +971,26 @@ def conv_wgrad(x: torch.Tensor, dz: torch.Tensor, ksize: int, stride: int, pad: 
         dw = out
     else:
         dw = torch.zeros((cout, ksize, ksize, cin), dtype=torch.float32, device=x.device)
-    _launch(lib().dy_conv2d_wgrad_nhwc, (C.byref(d), dzp, lddz, dw.data_ptr()), keep=(d, x, dz, dw))
+    need = lib().dy_conv2d_wgrad_workspace_bytes(C.byref(d), lddz)
+    if need < 0:
+        check(int(need), "dy_conv2d_wgrad_workspace_bytes")
+    ws = _wgrad_workspace(x.device, need) if need else None
+    _launch(lib().dy_conv2d_wgrad_nhwc_ws, (C.byref(d), dzp, lddz, dw.data_ptr(), ws.data_ptr() if need else None, ws.numel() if need else 0),
+            keep=(d, x, dz, dw, ws))
     return dw.permute(0, 3, 1, 2)
+
+
+_WGRAD_WS: dict = {}
+
+
+def _wgrad_workspace(device, need: int) -> torch.Tensor:
+    """Scratch of ``dy_conv2d_wgrad_nhwc_ws`` (the 3x3 kernel's per-slab partial sums, <= ~40 MB at any shape): one buffer per
+    (device, stream) -- calls that share it are ordered on that stream -- grown on demand and never shrunk."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    ws = _WGRAD_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _WGRAD_WS[key] = torch.empty(max(need, 48 << 20), dtype=torch.uint8, device=device)
+    return ws
 
 
 def conv_grouped_bwd(x: torch.Tensor, dz: torch.Tensor, weight: torch.Tensor, stride: int, pad: int, groups: int, need_dx: bool = True):

@@ -449,6 +449,13 @@ int32_t dy_detection_loss(const dy_loss_desc* d, dy_stream_t stream);
  * dy_colsum: out[c] += sum over rows of z[row][c] (bias gradient of the plain Detect convolutions); out zeroed by the caller;
  *   z 16-byte aligned, pitch a multiple of 16 bytes covering c rounded up to one chunk. */
 int32_t dy_conv2d_wgrad_nhwc(const dy_conv_desc* d, const void* dz, int32_t ld_dz, float* dw, dy_stream_t stream);
+/* The same with a caller-owned workspace (device memory, 16-byte aligned, at least dy_conv2d_wgrad_workspace_bytes(d, ld_dz) bytes;
+ * NULL / too small: the call behaves as dy_conv2d_wgrad_nhwc).  The 3x3 kernel (16-bit storage) then STORES each pixel slab's partial
+ * sums in the workspace and a second launch adds them to dw (1/16 of the atomics: 30-50 us less per layer at batch 64).  Calls that
+ * share a workspace must be ordered on one stream.  dy_conv2d_wgrad_workspace_bytes: 0 when the call would not use one; < 0 = dy_status. */
+int32_t dy_conv2d_wgrad_nhwc_ws(const dy_conv_desc* d, const void* dz, int32_t ld_dz, float* dw, void* workspace, int64_t workspace_bytes,
+                                dy_stream_t stream);
+int64_t dy_conv2d_wgrad_workspace_bytes(const dy_conv_desc* d, int32_t ld_dz);
 int32_t dy_colsum(const void* z, float* out, int64_t rows, int32_t c, int32_t ld, int32_t dtype, dy_stream_t stream);
 /* Grouped convolution (DWConv of yolov8-p2-repvgg-sf.yaml:32,38,44; nn/modules/conv.py:102-107, g = gcd(c1, c2)): both gradients
  * of z = conv2d(x, w, stride, pad, groups) given dz — replaces autograd of F.conv2d for that layer.  d describes the FORWARD

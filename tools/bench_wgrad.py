@@ -22,15 +22,22 @@ for sh in a.shapes:
     ho = (hh + 2 * (k // 2) - k) // s + 1
     x = torch.randn(a.batch, hh, hh, cin, device=dev).to(dt).permute(0, 3, 1, 2)
     dz = torch.randn(a.batch, ho, ho, cout, device=dev).to(dt).permute(0, 3, 1, 2)
-    H.conv_wgrad(x, dz, k, s, k // 2)
+    buf = torch.zeros(cout, k, k, cin, device=dev)  # the trainer's form: the kernel adds into a gradient sink
+    H.conv_wgrad(x, dz, k, s, k // 2, out=buf)
+    torch.cuda.synchronize()
+    # the iterations are replayed from a hipGraph: a call costs ~80-100 us of Python + allocator time, more than most of these launches
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        for _ in range(a.iters):
+            H.conv_wgrad(x, dz, k, s, k // 2, out=buf)
+    gr.replay()
     torch.cuda.synchronize()
     st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     st.record()
-    for _ in range(a.iters):
-        H.conv_wgrad(x, dz, k, s, k // 2)
+    gr.replay()
     en.record()
     torch.cuda.synchronize()
     us = st.elapsed_time(en) / a.iters * 1e3
     fl = 2.0 * a.batch * ho * ho * cout * cin * k * k
     by = (x.numel() + dz.numel()) * 2
-    print(f"{sh:<18s} B={a.batch} dbg={os.environ.get('DYOLO_WGRAD3_DBG', '0')}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s  {by / us / 1e3:7.0f} GB/s (x + dz once)")
+    print(f"{sh:<18s} B={a.batch} dbg={os.environ.get('DYOLO_WGRAD3_DBG', '0')} pf2={os.environ.get('DYOLO_WGRAD3_PF2', '-')}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s  {by / us / 1e3:7.0f} GB/s (x + dz once)")
