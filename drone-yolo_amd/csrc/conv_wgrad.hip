@@ -521,6 +521,143 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* __restr
   }
 }
 
+// ---- 1x1 stride-1 layers, 16-bit storage -------------------------------------------------------------------------------
+// dW[co][ci] = sum_m dz[m][co] x[m][ci]: both operands are plain row-major (pixels x channels) matrices, so a lane's byte offsets
+// are launch constants plus the slab's running row.  Same structure as the 3x3 kernel above: branch-free buffer loads into two
+// register sets (two steps in flight, issued on every trip; rows past the slab read zeros), two LDS stages and ONE barrier per
+// 32-pixel step, the slab's partial sums STORED in its own workspace copy (wgrad3_reduce_kernel adds the copies; the waves that
+// split the pixel range inside a workgroup take one copy each).  conv_wgrad_kernel remains for fp32, strided and k x k layers.
+struct Wgrad1Args {
+  const void* x;
+  const void* dz;
+  float* dw;
+  float* part;  // workspace or null (atomics on dw)
+  int Cin, ldx, Cout, lddz, tilesCo, tilesCi, rows_per_block;
+  unsigned x_bytes, dz_bytes;
+  long long M;
+};
+
+template <typename T, int WCO, int WCI>
+__global__ __launch_bounds__(256, 2) void conv_wgrad1x1_kernel(const Wgrad1Args p) {
+  constexpr int E = Elem<T>::EPC;
+  constexpr int WK = 4 / (WCO * WCI);
+  constexpr int TCO = 64 * WCO, TCI = 64 * WCI;
+  constexpr int PA = TCO * (int)sizeof(T) + 32, PB = TCI * (int)sizeof(T) + 32;  // row pitches (bytes)
+  constexpr int TILE = 32 * (PA + PB);                                            // one 32-pixel step of both operands
+  constexpr int CA = TCO / E, CB = TCI / E;                                       // 16-byte chunks per row
+  constexpr int NCH = WK * 32 * (CA + CB);                                        // chunks per iteration: 1024 for every shape
+  constexpr int PER = NCH / 256;
+  static_assert(NCH % 256 == 0, "chunks must divide among the threads");
+  constexpr int STEP = 32 * WK;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WK * TILE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int wk = wave / (WCO * WCI), wco = (wave / WCI) % WCO, wci = wave % WCI;
+  const int tci = blockIdx.y % p.tilesCi, tco = blockIdx.y / p.tilesCi;
+  const int co0 = tco * TCO, ci0 = tci * TCI;
+  const int m_begin = (int)((long long)blockIdx.x * p.rows_per_block);  // M < 2^31 (host check)
+  const int m_end = (int)min((long long)m_begin + p.rows_per_block, p.M);
+
+  constexpr unsigned kOob = 0xfffffff0u;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dzrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dz), 0, p.dz_bytes, 0x00020000);
+  // chunk id -> (pixel split, operand, row, chunk): id = k * 256 + tid; the operand of a chunk is uniform per (k, wave) because
+  // 32 * CA is a multiple of 64
+  unsigned rel[PER], row_of[PER], lds_of[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int id = k * 256 + tid;
+    const int ws = id / (32 * (CA + CB)), rem = id - ws * 32 * (CA + CB);
+    if (rem < 32 * CA) {
+      const int row = rem / CA, ch = rem - row * CA, co = co0 + ch * E;
+      row_of[k] = ws * 32 + row;
+      rel[k] = co < p.Cout ? (unsigned)(row_of[k] * p.lddz + co) * 2u : kOob;
+      lds_of[k] = ws * TILE + row * PA + ch * 16;
+    } else {
+      const int rem2 = rem - 32 * CA, row = rem2 / CB, ch = rem2 - row * CB, ci = ci0 + ch * E;
+      row_of[k] = ws * 32 + row;
+      rel[k] = ci < p.Cin ? (unsigned)(row_of[k] * p.ldx + ci) * 2u : kOob;
+      lds_of[k] = ws * TILE + 32 * PA + row * PB + ch * 16;
+    }
+  }
+  const int wvu = __builtin_amdgcn_readfirstlane(wave);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 stage[2][PER];
+  auto load_step = [&](int m0, u32x4 (&stg)[PER]) {
+    // the whole offset goes into the VECTOR operand (range-checked against num_records whatever the hardware does with soffset);
+    // rows of the next slab and of steps past the end are switched off per lane
+    const unsigned base_dz = (unsigned)m0 * (unsigned)p.lddz * 2u, base_x = (unsigned)m0 * (unsigned)p.ldx * 2u;
+    const unsigned left = m0 < m_end ? (unsigned)(m_end - m0) : 0u;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int rem0 = (k * 256 + wvu * 64) % (32 * (CA + CB));
+      const bool role_dz = rem0 < 32 * CA;  // scalar
+      const unsigned off = (rel[k] != kOob && row_of[k] < left) ? rel[k] + (role_dz ? base_dz : base_x) : kOob;
+      stg[k] = __builtin_amdgcn_raw_buffer_load_b128(role_dz ? dzrs : xrs, (int)off, 0, 0);
+    }
+  };
+  auto store_step = [&](int buf, const u32x4 (&stg)[PER]) {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) *reinterpret_cast<u32x4*>(smem + buf * (WK * TILE) + lds_of[k]) = stg[k];
+  };
+
+  const int q4 = lr >> 2, pp = lr & 3;
+  const unsigned lane_a = (unsigned)((lq * 4 + q4) * PA + pp * 8 + wco * 64 * (int)sizeof(T));
+  const unsigned lane_b = (unsigned)(32 * PA + (lq * 4 + q4) * PB + pp * 8 + wci * 64 * (int)sizeof(T));
+  auto step_body = [&](int m0, int buf, u32x4 (&stg)[PER]) {
+    store_step(buf, stg);  // stage `buf` was last read two steps ago: the barrier of the previous step covers it
+    __syncthreads();
+    load_step(m0 + 2 * STEP, stg);
+    const unsigned tile = (unsigned)(uintptr_t)(smem + buf * (WK * TILE) + wk * TILE);
+    u32x2 ra[8], rb[8];
+    tr_issue8<0, 16 * PA>(tile + lane_a, ra);
+    tr_issue8<0, 16 * PB>(tile + lane_b, rb);
+    tr_wait<8>(ra);
+    u32x4 a[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = u32x4{ra[2 * i][0], ra[2 * i][1], ra[2 * i + 1][0], ra[2 * i + 1][1]};
+    tr_wait<0>(rb);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32x4 b = u32x4{rb[2 * j][0], rb[2 * j][1], rb[2 * j + 1][0], rb[2 * j + 1][1]};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = Elem<T>::mma(a[i], b, acc[i][j]);
+    }
+  };
+  load_step(m_begin, stage[0]);
+  load_step(m_begin + STEP, stage[1]);
+  for (int m0 = m_begin; m0 < m_end; m0 += 2 * STEP) {
+    step_body(m0, 0, stage[0]);
+    step_body(m0 + STEP, 1, stage[1]);  // an odd slab's last trip runs one step of zeros
+  }
+
+  // D[co][ci]: lane holds rows co = 4*lq + reg, column ci = lr of every 16 x 16 fragment
+  float* __restrict__ dst = p.part ? p.part + ((size_t)blockIdx.x * WK + wk) * ((size_t)p.Cout * p.Cin) : p.dw;
+  const bool plain = p.part != nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ci = ci0 + wci * 64 + j * 16 + lr;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = co0 + wco * 64 + i * 16 + lq * 4 + e;
+        if (co < p.Cout && ci < p.Cin) {
+          float* at = dst + (size_t)co * p.Cin + ci;
+          if (plain) *at = acc[i][j][e];
+          else atomicAdd(at, acc[i][j][e]);
+        }
+      }
+    }
+}
+
 // Launch geometry of the 3x3 kernel: output rows per step, steps, pixel slabs (= gridDim.x = copies in the workspace).
 struct Wgrad3Plan {
   int rs, stepsX, stepsY, nSteps, ny, steps_per_block, gx;
@@ -659,8 +796,56 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* z, float* out, lon
 
 using namespace dy;
 
+// Launch geometry of the 1x1 kernel: waves per tile side, pixel slabs, workspace copies (slabs x pixel splits inside a workgroup).
+struct Wgrad1Plan {
+  int wco, wci, wk, ny, rows_per_block, gx;
+};
+static Wgrad1Plan wgrad1_plan(const WgradArgs& a) {
+  Wgrad1Plan g{};
+  g.wco = a.Cout > 64 ? 2 : 1, g.wci = a.Cin > 64 ? 2 : 1, g.wk = 4 / (g.wco * g.wci);
+  g.ny = ((a.Cout + 64 * g.wco - 1) / (64 * g.wco)) * ((a.Cin + 64 * g.wci - 1) / (64 * g.wci));
+  const int step = 32 * g.wk;
+  static const int tgt = dy_ablate("DYOLO_WGRAD1_TARGET");  // probe: workgroups overall
+  long long slabs = ((tgt ? tgt : 512) + g.ny - 1) / g.ny;  // two workgroups per CU, every slab at least 8 steps
+  const long long max_slabs = (a.M + 8LL * step - 1) / (8LL * step);
+  if (slabs > max_slabs) slabs = max_slabs;
+  if (slabs < 1) slabs = 1;
+  long long rpb = (a.M + slabs - 1) / slabs;
+  rpb = (rpb + step - 1) / step * step;
+  g.rows_per_block = (int)rpb;
+  g.gx = (int)((a.M + rpb - 1) / rpb);
+  return g;
+}
+static size_t wgrad1_workspace_bytes(const WgradArgs& a) {
+  const Wgrad1Plan g = wgrad1_plan(a);
+  return g.gx * g.wk > 1 ? (size_t)g.gx * g.wk * a.Cout * a.Cin * sizeof(float) : 0;
+}
+template <typename T>
+static int launch_wgrad1(const WgradArgs& a, hipStream_t st) {
+  const Wgrad1Plan g = wgrad1_plan(a);
+  Wgrad1Args p{};
+  p.x = a.x, p.dz = a.dz, p.dw = a.dw, p.Cin = a.Cin, p.ldx = a.ldx, p.Cout = a.Cout, p.lddz = a.lddz, p.M = a.M;
+  p.tilesCo = (a.Cout + 64 * g.wco - 1) / (64 * g.wco), p.tilesCi = (a.Cin + 64 * g.wci - 1) / (64 * g.wci);
+  p.rows_per_block = g.rows_per_block, p.x_bytes = (unsigned)a.x_bytes, p.dz_bytes = (unsigned)a.dz_bytes;
+  const size_t n = (size_t)a.Cout * a.Cin;
+  const int copies = g.gx * g.wk;
+  static const int no_part = dy_ablate("DYOLO_WGRAD3_ATOMICS");
+  p.part = (!no_part && copies > 1 && a.ws && a.ws_bytes >= (size_t)copies * n * sizeof(float)) ? reinterpret_cast<float*>(a.ws) : nullptr;
+  const dim3 grid((unsigned)g.gx, (unsigned)g.ny);
+  if (g.wco == 2 && g.wci == 2) hipLaunchKernelGGL((conv_wgrad1x1_kernel<T, 2, 2>), grid, dim3(256), 0, st, p);
+  else if (g.wco == 2) hipLaunchKernelGGL((conv_wgrad1x1_kernel<T, 2, 1>), grid, dim3(256), 0, st, p);
+  else if (g.wci == 2) hipLaunchKernelGGL((conv_wgrad1x1_kernel<T, 1, 2>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((conv_wgrad1x1_kernel<T, 1, 1>), grid, dim3(256), 0, st, p);
+  if (const int rc = check_launch("conv_wgrad1x1_kernel")) return rc;
+  if (p.part) {
+    hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3((unsigned)((n / 4 + 256) / 256), (unsigned)((copies + 15) / 16)), dim3(256), 0, st, p.part, a.dw, (int)n, copies);
+    return check_launch("wgrad3_reduce_kernel");
+  }
+  return 0;
+}
+
 // validation + geometry shared by the entry points; `uses3` = the 3x3 kernel takes this call
-static int wgrad_setup(const dy_conv_desc* d, const void* dz, int32_t ld_dz, float* dw, bool need_ptrs, WgradArgs& a, bool& uses3) {
+static int wgrad_setup(const dy_conv_desc* d, const void* dz, int32_t ld_dz, float* dw, bool need_ptrs, WgradArgs& a, bool& uses3, bool& uses1) {
   DY_REQUIRE(d && (!need_ptrs || (d->x && dz && dw)), DY_ERR_INVALID_ARG, "dy_conv2d_wgrad_nhwc: null pointer");
   const int es = dtype_size_no_fp8(d->dtype);
   DY_REQUIRE(es != 0 && d->batch > 0 && d->h > 0 && d->w_in > 0 && d->cin > 0 && d->cout > 0 && d->ksize >= 1 && d->stride >= 1 && d->pad >= 0,
@@ -687,21 +872,23 @@ static int wgrad_setup(const dy_conv_desc* d, const void* dz, int32_t ld_dz, flo
   static const int no3 = dy_ablate("DYOLO_NO_WGRAD3");
   // all nine taps from one staged halo (32-bit byte offsets in its buffer loads: views of 2 GiB and more take the per-tap kernel)
   uses3 = !no3 && d->ksize == 3 && d->pad == 1 && (d->stride == 1 || d->stride == 2) && es == 2 && a.x_bytes < (1ll << 31) && a.dz_bytes < (1ll << 31);
+  static const int no1 = dy_ablate("DYOLO_NO_WGRAD1");
+  uses1 = !no1 && d->ksize == 1 && d->pad == 0 && d->stride == 1 && es == 2 && a.x_bytes < (1ll << 31) && a.dz_bytes < (1ll << 31);
   return 0;
 }
 
 extern "C" int64_t dy_conv2d_wgrad_workspace_bytes(const dy_conv_desc* d, int32_t ld_dz) {
   WgradArgs a{};
-  bool uses3 = false;
-  if (const int rc = wgrad_setup(d, nullptr, ld_dz, nullptr, false, a, uses3)) return rc;
-  return uses3 ? (int64_t)wgrad3_workspace_bytes(a, d->batch, d->stride) : 0;
+  bool uses3 = false, uses1 = false;
+  if (const int rc = wgrad_setup(d, nullptr, ld_dz, nullptr, false, a, uses3, uses1)) return rc;
+  return uses3 ? (int64_t)wgrad3_workspace_bytes(a, d->batch, d->stride) : uses1 ? (int64_t)wgrad1_workspace_bytes(a) : 0;
 }
 
 extern "C" int32_t dy_conv2d_wgrad_nhwc_ws(const dy_conv_desc* d, const void* dz, int32_t ld_dz, float* dw, void* workspace, int64_t workspace_bytes,
                                            dy_stream_t stream) {
   WgradArgs a{};
-  bool uses3 = false;
-  if (const int rc = wgrad_setup(d, dz, ld_dz, dw, true, a, uses3)) return rc;
+  bool uses3 = false, uses1 = false;
+  if (const int rc = wgrad_setup(d, dz, ld_dz, dw, true, a, uses3, uses1)) return rc;
   DY_REQUIRE(!workspace || (aligned16(workspace) && workspace_bytes >= 0), DY_ERR_INVALID_ARG, "dy_conv2d_wgrad_nhwc_ws: workspace must be 16-byte aligned");
   a.ws = workspace, a.ws_bytes = workspace ? (size_t)workspace_bytes : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -709,6 +896,7 @@ extern "C" int32_t dy_conv2d_wgrad_nhwc_ws(const dy_conv_desc* d, const void* dz
     if (d->dtype == DY_BF16) return d->stride == 1 ? launch_wgrad3<bf16_t, 1>(a, d->batch, st) : launch_wgrad3<bf16_t, 2>(a, d->batch, st);
     return d->stride == 1 ? launch_wgrad3<f16_t, 1>(a, d->batch, st) : launch_wgrad3<f16_t, 2>(a, d->batch, st);
   }
+  if (uses1) return d->dtype == DY_BF16 ? launch_wgrad1<bf16_t>(a, st) : launch_wgrad1<f16_t>(a, st);
   switch (d->dtype) {
     case DY_BF16: return launch_wgrad_dtype<bf16_t>(a, st);
     case DY_F16: return launch_wgrad_dtype<f16_t>(a, st);

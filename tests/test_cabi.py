@@ -85,7 +85,9 @@ def test_new_entry_points_validate_without_gpu():
     d = L.ConvDesc()  # 64 -> 64 3x3 at 160x160, batch 64, bf16: 256 pixel slabs x (64 x 9 x 64) fp32 partial sums
     d.batch, d.h, d.w_in, d.cin, d.ld_x, d.ho, d.wo, d.cout, d.ksize, d.stride, d.pad, d.groups, d.dtype = 64, 160, 160, 64, 64, 160, 160, 64, 3, 1, 1, 1, L.DY_BF16
     assert h.dy_conv2d_wgrad_workspace_bytes(ctypes.byref(d), 64) == 256 * 64 * 9 * 64 * 4
-    d.ksize, d.pad = 1, 0  # the per-tap kernel (1x1 layers) keeps its atomics
+    d.ksize, d.pad = 1, 0  # 1x1 stride 1: 512 slabs x 4 pixel splits inside a workgroup x (64 x 64)
+    assert h.dy_conv2d_wgrad_workspace_bytes(ctypes.byref(d), 64) == 512 * 4 * 64 * 64 * 4
+    d.dtype = L.DY_F32  # the per-tap kernel (fp32, strided, k x k layers) keeps its atomics
     assert h.dy_conv2d_wgrad_workspace_bytes(ctypes.byref(d), 64) == 0
     assert h.dy_letterbox_u8_to_nchw_f32(null, null, 1, 8, 8, 8, 8, 0, 0, 8, 8, 1, 114.0, null) == -1
     assert h.dy_sgd_step(null, null, null, 10, 0.1, 0.9, 0.0, 1, 1, null, 10.0, null, null) == -1

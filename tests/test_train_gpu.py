@@ -126,9 +126,11 @@ def test_conv_wgrad_dgrad_match_autograd(case, dtype, device):
         close(dx2, x.grad + prev, dtype, f"dgrad+accumulate {tag}")
 
 
-@pytest.mark.parametrize("cin,cout,s,b,h,w", [(64, 64, 1, 8, 80, 80), (64, 128, 2, 6, 84, 76), (192, 64, 1, 4, 40, 44), (32, 32, 1, 5, 66, 62)])
-def test_wgrad_workspace_path_matches_atomics_and_autograd(cin, cout, s, b, h, w, device):
-    """dy_conv2d_wgrad_nhwc_ws (per-slab partial sums + reduce launch) against the atomics form of the same kernel and against autograd,
+@pytest.mark.parametrize("cin,cout,k,s,b,h,w", [(64, 64, 3, 1, 8, 80, 80), (64, 128, 3, 2, 6, 84, 76), (192, 64, 3, 1, 4, 40, 44), (32, 32, 3, 1, 5, 66, 62),
+                                                (64, 64, 1, 1, 5, 81, 79), (96, 64, 1, 1, 7, 50, 46), (192, 128, 1, 1, 6, 41, 39), (768, 512, 1, 1, 9, 20, 20),
+                                                (40, 24, 1, 1, 3, 33, 31)])
+def test_wgrad_workspace_path_matches_atomics_and_autograd(cin, cout, k, s, b, h, w, device):
+    """dy_conv2d_wgrad_nhwc_ws (3x3 and 1x1 kernels: per-slab partial sums + reduce launch) against the atomics form of the same kernel and against autograd,
     at sizes with many pixel slabs, odd step counts (a slab's last trip runs a step of zeros) and ragged edges."""
     import ctypes as C
     from drone_yolo_amd import _lib as L
@@ -136,18 +138,18 @@ def test_wgrad_workspace_path_matches_atomics_and_autograd(cin, cout, s, b, h, w
     dtype = torch.bfloat16
     g = torch.Generator().manual_seed(cin + cout + h)
     x = quantize(torch.randn(b, cin, h, w, generator=g), dtype).requires_grad_(True)
-    wt = quantize(torch.randn(cout, cin, 3, 3, generator=g) * 0.05, dtype).requires_grad_(True)
-    z = F.conv2d(x, wt, None, s, 1)
+    wt = quantize(torch.randn(cout, cin, k, k, generator=g) * 0.05, dtype).requires_grad_(True)
+    z = F.conv2d(x, wt, None, s, k // 2)
     dz = quantize(torch.randn(z.shape, generator=g), dtype)
     z.backward(dz)
     xd, dzd = nhwc(x.detach(), dtype, device), nhwc(dz, dtype, device)
-    dw = H.conv_wgrad(xd, dzd, 3, s, 1)  # workspace path
+    dw = H.conv_wgrad(xd, dzd, k, s, k // 2)  # workspace path
     d = L.ConvDesc()
     (d.x, d.ld_x), (dzp, lddz) = H.view_params(xd), H.view_params(dzd)
     d.batch, d.h, d.w_in, d.cin, d.ho, d.wo, d.cout = b, h, w, cin, z.shape[2], z.shape[3], cout
-    d.ksize, d.stride, d.pad, d.groups, d.dtype = 3, s, 1, 1, L.DY_BF16
+    d.ksize, d.stride, d.pad, d.groups, d.dtype = k, s, k // 2, 1, L.DY_BF16
     assert L.lib().dy_conv2d_wgrad_workspace_bytes(C.byref(d), lddz) > 0
-    ref = torch.zeros(cout, 3, 3, cin, device=device)
+    ref = torch.zeros(cout, k, k, cin, device=device)
     assert L.lib().dy_conv2d_wgrad_nhwc(C.byref(d), dzp, lddz, ref.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
     torch.cuda.synchronize()
     scale = float(ref.abs().max())
