@@ -103,6 +103,24 @@ __device__ __forceinline__ void tr_issue4(unsigned base, u32x2 (&r)[4]) {
       : "v"(base), "n"(OFF), "n"(OFF + ROW2), "n"(OFF + 32), "n"(OFF + 32 + ROW2)
       : "memory");
 }
+// three taps of one kernel row, one 16-channel fragment each: reads at OFF + q * STEP + {0, ROW2}
+template <int OFF, int ROW2, int STEP>
+__device__ __forceinline__ void tr_issue6(unsigned base, u32x2 (&r)[6]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %6 offset:%7\n\t"
+      "ds_read_b64_tr_b16 %1, %6 offset:%8\n\t"
+      "ds_read_b64_tr_b16 %2, %6 offset:%9\n\t"
+      "ds_read_b64_tr_b16 %3, %6 offset:%10\n\t"
+      "ds_read_b64_tr_b16 %4, %6 offset:%11\n\t"
+      "ds_read_b64_tr_b16 %5, %6 offset:%12"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5])
+      : "v"(base), "n"(OFF), "n"(OFF + ROW2), "n"(OFF + STEP), "n"(OFF + STEP + ROW2), "n"(OFF + 2 * STEP), "n"(OFF + 2 * STEP + ROW2)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void tr_wait(u32x2 (&r)[6]) {
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]) : "n"(N));
+}
 template <int N>
 __device__ __forceinline__ void tr_wait(u32x2 (&r)[8]) {
   asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "n"(N));
@@ -113,10 +131,17 @@ __device__ __forceinline__ void tr_wait(u32x2 (&r)[4]) {
 }
 // reads a group of the 3x3 kernel's schedule issues (group g = (k-step g / 3, tap column g % 3): the tap's four x fragments, and the
 // k-step's dz fragments with its first tap), and how many reads of the younger groups are in flight after issuing DEPTH groups ahead
-constexpr int wg3_reads(int g, int cw) { return 8 + (g % 3 == 0 ? 2 * cw : 0); }
-constexpr int wg3_pending(int g, int depth, int ng, int cw) {
+constexpr int wg3_reads(int g, int cw) { return 6 + (g % 3 == 0 ? 2 * cw : 0); }
+constexpr int wg3_writes(int g, int wpg, int per) {
+  const int lo = g * wpg, hi = (g + 1) * wpg < per ? (g + 1) * wpg : per;
+  return g >= 0 && hi > lo ? hi - lo : 0;
+}
+// LDS operations younger than group g's reads at the point where its MFMAs wait: the reads of groups g + 1, g + 2 and the staging
+// stores placed behind the reads of groups g, g + 1, g + 2 (those were issued in the runs of groups g - 2, g - 1, g)
+constexpr int wg3_pending(int g, int ng, int cw, int wpg, int per) {
   int n = 0;
-  for (int j = g + 1; j <= g + depth && j < ng; ++j) n += wg3_reads(j, cw);
+  for (int j = g + 1; j <= g + 2 && j < ng; ++j) n += wg3_reads(j, cw);
+  for (int j = (g >= 2 ? g - 2 : 0); j <= g; ++j) n += wg3_writes(j, wpg, per);
   return n > 15 ? 15 : n;
 }
 
@@ -284,32 +309,37 @@ struct Wgrad3Args {
   int dbg;  // timing probes (-DDYOLO_ABLATE builds, DYOLO_WGRAD3_DBG): 1 no global loads, 32 no atomics
 };
 
-// CW = cout fragments (of 16) per wave: 4 -> three waves (one per kernel row) with 3 x 64 x 64 accumulators each = 192 registers of
-// accumulators, ONE workgroup per CU: < 1 wave per SIMD, 95-270 TFLOP/s (r01).  2 -> six waves (kernel row x cout half), 96
-// accumulator registers, two workgroups per CU = three waves per SIMD: the dz fragment reads halve, the x reads stay.
-// RS = output rows per step (2 or 4): a step of 4 rows does twice the MFMAs per staged halo row pair and per barrier, and the one
-// step of global-load prefetch then covers twice the time (the kernel is latency bound: one step of 32 pixels is ~0.2 us of MFMAs).
-// PF = steps of global loads in flight in registers (1 or 2).  One step is ~0.4 us of MFMAs per workgroup, a load from HBM ~1-2 us:
-// without any global load the 64 -> 64 @160 launch takes 249 us instead of 513 (probes, ablate build).  PF = 2 costs 16 more
-// registers (two waves per SIMD instead of three), so it runs where the launch has one workgroup per CU anyway (see the slab rule).
-template <typename T, int S, int CW, int RS, int PF>
-__global__ __launch_bounds__(192 * (4 / CW), (CW == 2 && PF == 1 ? 2 : 1)) void conv_wgrad3x3_kernel(const Wgrad3Args p) {
-  constexpr int NT = 192 * (4 / CW);
-  constexpr int E = Elem<T>::EPC;                // 8
+// Eight waves = (cout half h, 16-channel cin fragment c): a wave owns all nine taps x 32 couts x 16 cins = 72 accumulator registers,
+// 18 MFMAs per 32-pixel k-step -- two waves on every SIMD (r02's six waves, one per (kernel row, cout half), left two SIMDs with one
+// wave and two with two: the barrier waited for the pair).  ONE workgroup per CU (256 overall), so everything that hides latency is
+// software:
+//  * RS output rows per step (4 where the map's height allows, stride 1): two 32-pixel k-steps per staged halo and barrier;
+//  * two register sets of global loads: the set stored during step t holds step t + 1 and is re-issued for step t + 3 as soon as it
+//    is stored, so a load has two steps to arrive.  The loads are branch-free buffer loads and are issued on EVERY trip (past the
+//    slab's end they read zeros) -- the number in flight is then the same on every path and the compiler's s_waitcnt vmcnt in front
+//    of the stores leaves the other set flying.  (r02's loader chose between the dz and the x branch per lane and so read p.lddz /
+//    p.ldx through a per-lane SELECTED ADDRESS into the kernel-argument segment: a global_load_dword + s_waitcnt vmcnt(0) in front of
+//    every 16-byte load, i.e. a step's loads ran one after the other and nothing stayed in flight: 64 -> 64 @160 349 -> 195 us.)
+//  * two LDS stages and ONE barrier per step: the stores of step t + 1's stage are spread over the MFMA groups of step t (their
+//    stage was last read in step t - 1, behind the previous barrier) instead of standing between two barriers;
+//  * the transposed fragment reads run two groups ahead of the MFMAs that use them (tr_issue* / tr_wait above; the staging stores
+//    are part of the same in-order LDS queue and are counted in the waits).
+template <typename T, int S, int RS>
+__global__ __launch_bounds__(512, 1) void conv_wgrad3x3_kernel(const Wgrad3Args p) {
+  constexpr int NT = 512, CW = 2;
+  constexpr int E = Elem<T>::EPC;                  // 8
   constexpr int PITCH = 64 * (int)sizeof(T) + 32;  // 160 B rows: 64 channels + pad (conflict-free transposed reads)
-  constexpr int HH = (RS - 1) * S + 3, HW = 15 * S + 3;  // x halo of an RS x 16 output step: 4 x 18 (S = 1, RS = 2), 5 x 33 (S = 2, RS = 2), 6 x 18 (S = 1, RS = 4)
+  constexpr int HH = (RS - 1) * S + 3, HW = 15 * S + 3;  // x halo of an RS x 16 output step: 5 x 33 (S = 2, RS = 2), 6 x 18 (S = 1, RS = 4)
   constexpr int NPX = HH * HW;
   constexpr int NDZ = RS * 16;
-  constexpr int NCHK = (NDZ + NPX) * 8;          // 16-byte chunks per step
+  constexpr int NCHK = (NDZ + NPX) * 8;  // 16-byte chunks per step
   constexpr int PER = (NCHK + NT - 1) / NT;
-  // PF = 2 (a workgroup alone on its CU): the stage is padded to PER * NT chunks so that every thread stores every chunk -- with no
-  // exec-masked store in the loop the compiler's vmcnt counts are exact and the other register set's loads stay in flight
-  constexpr bool FULL = PF == 2;
-  constexpr int DZ_BYTES = NDZ * PITCH, X_BYTES = NPX * PITCH, STAGE = FULL ? PER * NT / 8 * PITCH : DZ_BYTES + X_BYTES;
+  // the stage is padded to PER * NT chunks: every thread stores every chunk (no exec-masked store in the loop)
+  constexpr int DZ_BYTES = NDZ * PITCH, STAGE = PER * NT / 8 * PITCH;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int r_ = wv % 3, chf = wv / 3;  // wave = (kernel row, cout part of CW fragments)
+  const int cf = wv & 3, chf = wv >> 2;  // wave = (cin fragment, cout half)
   const int lr = lane & 15, lq = lane >> 4;
   int t = blockIdx.y;
   const int tci = t % p.tilesCi, tco = t / p.tilesCi;
@@ -317,19 +347,15 @@ __global__ __launch_bounds__(192 * (4 / CW), (CW == 2 && PF == 1 ? 2 : 1)) void 
   const int s_begin = blockIdx.x * p.steps_per_block;
   int s_end = s_begin + p.steps_per_block;
   if (s_end > p.nSteps) s_end = p.nSteps;
-  f32x4 acc[3][CW][4];
-#pragma unroll
-  for (int q = 0; q < 3; ++q)
-#pragma unroll
-    for (int i = 0; i < CW; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // Loader: branch-free buffer loads.  (The first form of this loader chose between the dz and the x branch per lane and read
-  // p.lddz / p.ldx, p.Ho / p.H through a per-lane SELECTED ADDRESS into the kernel-argument segment: a global_load_dword followed by
-  // s_waitcnt vmcnt(0) in front of every 16-byte load, i.e. the loads of a step were serialised and nothing stayed in flight.)
-  // A chunk's role (dz or x) is uniform per (k, wave) -- NDZ * 8 is a multiple of 64 -- so the descriptor and the step's base offset
-  // are scalars; the lane's byte offset inside the step is a launch constant; rows / columns outside the image and dead channel
+  f32x4 acc[9][CW];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int i = 0; i < CW; ++i) acc[tp][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Loader.  A chunk's role (dz or x) is uniform per (k, wave) -- NDZ * 8 is a multiple of 64 -- so the descriptor and the step's base
+  // offset are scalars; the lane's byte offset inside the step is a launch constant; rows / columns outside the image and dead channel
   // chunks take an offset beyond num_records and read zeros.  The x descriptor starts (W + 1) pixels early so no offset is negative.
   constexpr unsigned kOob = 0xfffffff0u;
   const unsigned pre = (unsigned)((p.W + 1) * p.ldx) * 2u;
@@ -352,15 +378,16 @@ __global__ __launch_bounds__(192 * (4 / CW), (CW == 2 && PF == 1 ? 2 : 1)) void 
       ryx[k] = hy | (hx << 8);
     }
   }
+  const unsigned st_lane = (unsigned)((tid >> 3) * PITCH + (tid & 7) * 16);  // chunk id -> stage byte: dz rows first, the halo rows follow in the same pitch
 
-  u32x4 stage[PF][PER];
+  u32x4 stage[2][PER];
   auto load_step = [&](int step, u32x4 (&stg)[PER]) {
     const int bx = step % p.stepsX;
     int rest = step / p.stepsX;
     const int by = rest % p.stepsY, n = rest / p.stepsY;
     const int y0 = by * RS, x0 = bx * 16;
-    // steps past the slab's end (the PF = 2 loop issues its loads unconditionally, see below) read zeros: every offset out of range
-    // (a mask the compiler cannot see through: a visible condition is threaded into two copies of the loads behind a scalar branch)
+    // steps past the slab's end read zeros: every offset out of range (a mask the compiler cannot see through -- a visible condition
+    // is threaded into two copies of the loads behind a scalar branch)
     unsigned dead = step < s_end ? 0u : 0xffffffffu;
     asm volatile("" : "+v"(dead));
     dead = __builtin_amdgcn_readfirstlane(dead);  // (asm results count as divergent)
@@ -383,69 +410,55 @@ __global__ __launch_bounds__(192 * (4 / CW), (CW == 2 && PF == 1 ? 2 : 1)) void 
       stg[k] = __builtin_amdgcn_raw_buffer_load_b128(role_dz ? dzrs : xrs, (int)off, (int)(role_dz ? dz_base : x_base), 0);
     }
   };
-  auto store_step = [&](int buf, const u32x4 (&stg)[PER]) {
-    unsigned char* base = smem + buf * STAGE;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      const int id = k * NT + tid;
-      if (FULL || id < NCHK) {
-        const int px = id >> 3, ch = id & 7;  // dz rows first, the halo rows follow in the same pitch
-        *reinterpret_cast<u32x4*>(base + px * PITCH + ch * 16) = stg[k];
-      }
-    }
+  auto store_chunk = [&](int buf, int k, const u32x4 (&stg)[PER]) {
+    *reinterpret_cast<u32x4*>(smem + buf * STAGE + st_lane + k * (NT / 8 * PITCH)) = stg[k];
+    asm volatile("" ::: "memory");  // stays where it is written: the LDS queue is counted by hand in this section
   };
 
   // lane part of the transposed-read addresses: lane 4q+p of a 16-lane group addresses pixel row q of the 4-pixel block,
   // channels 4p..4p+3; lane group lq takes output columns 4lq..4lq+3 of output row 0 (first read) and row 1 (second read)
   const int q4 = lr >> 2, pp = lr & 3;
-  const int dz_lane = (lq * 4 + q4) * PITCH + pp * 8;
-  const int x_lane = ((lq * 4 + q4) * S) * PITCH + pp * 8;
+  const int dz_lane = (lq * 4 + q4) * PITCH + pp * 8 + chf * 64;  // channels [32 * chf, 32 * chf + 32) of the dz rows
+  const int x_lane = DZ_BYTES + ((lq * 4 + q4) * S) * PITCH + pp * 8 + cf * 32;  // channels [16 * cf, 16 * cf + 16) of the halo rows
 
-  auto step_body = [&](int st, int buf, u32x4 (&stg)[PER]) {
-    store_step(buf, stg);  // stage `buf` was last read two steps ago: the barrier of the previous step covers it
-    __syncthreads();
-    // in flight during the MFMAs of PF steps.  PF = 2: issued on every trip, also past the end (zeros, no memory access) -- the number
-    // of loads in flight is then the same on every path and the s_waitcnt in front of the staging stores lets the other set fly
-    if (PF == 2 || st + PF < s_end) load_step(st + PF, stg);
-    // MFMA section: NG = 3 * RS / 2 groups (k-step of 32 pixels = a pair of output rows, tap column); the transposed reads run
-    // DEPTH groups ahead of the MFMAs that use them
-#ifndef DYOLO_WG3_DEPTH
-#define DYOLO_WG3_DEPTH 2
-#endif
-    constexpr int NHH = RS / 2, NG = 3 * NHH, DEPTH = DYOLO_WG3_DEPTH;
-    const unsigned bdz = (unsigned)(uintptr_t)(smem + buf * STAGE) + (unsigned)dz_lane + (CW == 2 ? (unsigned)chf * 64u : 0u);
-    const unsigned bx = (unsigned)(uintptr_t)(smem + buf * STAGE) + (unsigned)(DZ_BYTES + x_lane + r_ * HW * PITCH);
+  // One step: MFMAs on stage `buf` (step st) in NG = 3 * RS / 2 groups (k-step of 32 pixels = a pair of output rows, kernel row: three
+  // taps, six MFMAs); `nxt` holds step st + 1: it is stored into the other stage, WPG chunks behind each of the first groups' reads,
+  // and re-issued for step st + 3.
+  constexpr int NHH = RS / 2, NG = 3 * NHH, WPG = (PER + NG - 1) / NG;
+  auto step_body = [&](int st, int buf, u32x4 (&nxt)[PER]) {
+    const unsigned bdz = (unsigned)(uintptr_t)(smem + buf * STAGE) + (unsigned)dz_lane;
+    const unsigned bx = (unsigned)(uintptr_t)(smem + buf * STAGE) + (unsigned)x_lane;
     u32x2 ra[NHH][2 * CW];
-    u32x2 rb[NG][8];
+    u32x2 rb[NG][6];
     u32x4 a[NHH][CW];
     auto issue = [&](auto G) {
-      constexpr int g = decltype(G)::value, hh = g / 3, q = g % 3;
-      if constexpr (q == 0) {
-        if constexpr (CW == 4) tr_issue8<hh * 32 * PITCH, 16 * PITCH>(bdz, ra[hh]);
-        else tr_issue4<hh * 32 * PITCH, 16 * PITCH>(bdz, ra[hh]);  // channels [32 * chf, 32 * chf + 32) of the dz rows
-      }
-      // tap (r_, q): halo pixel of output (row, col) is ((row*S + r_) * HW + col*S + q); the second output row is S halo rows below
-      tr_issue8<(hh * 2 * S * HW + q) * PITCH, S * HW * PITCH>(bx, rb[g]);
+      constexpr int g = decltype(G)::value, hh = g / 3, r = g % 3;
+      if constexpr (r == 0) tr_issue4<hh * 32 * PITCH, 16 * PITCH>(bdz, ra[hh]);
+      // tap (r, q): halo pixel of output (row, col) is ((row*S + r) * HW + col*S + q); the second output row is S halo rows below
+      tr_issue6<((hh * 2 * S + r) * HW) * PITCH, S * HW * PITCH, PITCH>(bx, rb[g]);
     };
     auto run = [&](auto G) {
-      constexpr int g = decltype(G)::value, hh = g / 3, q = g % 3;
-      if constexpr (g + DEPTH < NG) issue(std::integral_constant<int, g + DEPTH>{});
-      constexpr int N = wg3_pending(g, DEPTH, NG, CW);
-      if constexpr (q == 0) {
+      constexpr int g = decltype(G)::value, hh = g / 3, r = g % 3;
+      if constexpr (g + 2 < NG) issue(std::integral_constant<int, g + 2>{});
+#pragma unroll
+      for (int k = g * WPG; k < (g + 1) * WPG && k < PER; ++k) store_chunk(buf ^ 1, k, nxt);
+      if constexpr ((g + 1) * WPG >= PER && g * WPG < PER) load_step(st + 3, nxt);  // the set is free: two steps to arrive
+      constexpr int N = wg3_pending(g, NG, CW, WPG, PER);
+      if constexpr (r == 0) {
         tr_wait<N>(ra[hh]);
 #pragma unroll
         for (int i = 0; i < CW; ++i) a[hh][i] = u32x4{ra[hh][2 * i][0], ra[hh][2 * i][1], ra[hh][2 * i + 1][0], ra[hh][2 * i + 1][1]};
       }
       tr_wait<N>(rb[g]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const u32x4 b = u32x4{rb[g][2 * j][0], rb[g][2 * j][1], rb[g][2 * j + 1][0], rb[g][2 * j + 1][1]};
+      for (int q = 0; q < 3; ++q) {
+        const u32x4 b = u32x4{rb[g][2 * q][0], rb[g][2 * q][1], rb[g][2 * q + 1][0], rb[g][2 * q + 1][1]};
 #pragma unroll
-        for (int i = 0; i < CW; ++i) acc[q][i][j] = Elem<T>::mma(a[hh][i], b, acc[q][i][j]);
+        for (int i = 0; i < CW; ++i) acc[r * 3 + q][i] = Elem<T>::mma(a[hh][i], b, acc[r * 3 + q][i]);
       }
     };
     issue(std::integral_constant<int, 0>{});
-    if constexpr (DEPTH == 2) issue(std::integral_constant<int, 1>{});
+    issue(std::integral_constant<int, 1>{});
     run(std::integral_constant<int, 0>{});
     run(std::integral_constant<int, 1>{});
     run(std::integral_constant<int, 2>{});
@@ -454,18 +467,19 @@ __global__ __launch_bounds__(192 * (4 / CW), (CW == 2 && PF == 1 ? 2 : 1)) void 
       run(std::integral_constant<int, 4>{});
       run(std::integral_constant<int, 5>{});
     }
+    __syncthreads();  // stage buf ^ 1 is complete, stage buf is free for the stores of the next step
   };
+  static_assert(NG * WPG >= PER, "every chunk of the next stage has a group to be stored behind");
+
+  load_step(s_begin, stage[0]);
+  load_step(s_begin + 1, stage[1]);
 #pragma unroll
-  for (int d = 0; d < PF; ++d)
-    if (PF == 2 || s_begin + d < s_end) load_step(s_begin + d, stage[d]);
-  if constexpr (PF == 1) {
-    int buf = 0;
-    for (int st = s_begin; st < s_end; ++st, buf ^= 1) step_body(st, buf, stage[0]);
-  } else {
-    for (int st = s_begin; st < s_end; st += 2) {  // two steps per trip: LDS stage and register set by the step's parity
-      step_body(st, 0, stage[0]);
-      step_body(st + 1, 1, stage[1]);  // an odd slab's last trip runs one step of zeros
-    }
+  for (int k = 0; k < PER; ++k) store_chunk(0, k, stage[0]);
+  load_step(s_begin + 2, stage[0]);
+  __syncthreads();
+  for (int st = s_begin; st < s_end; st += 2) {  // two steps per trip: LDS stage and register set by the step's parity
+    step_body(st, 0, stage[1]);
+    step_body(st + 1, 1, stage[0]);  // an odd slab's last trip runs one step of zeros
   }
 
   // Epilogue.  Every slab ends with Cout x Cin x 9 partial sums.  fp32 atomics on dw take 30-50 us of a launch (9.4 M lane-atomics
@@ -474,26 +488,23 @@ __global__ __launch_bounds__(192 * (4 / CW), (CW == 2 && PF == 1 ? 2 : 1)) void 
   float* __restrict__ dst = p.part ? p.part + (size_t)blockIdx.x * ((size_t)p.Cout * 9 * p.Cin) : p.dw;
   const bool plain = p.part != nullptr;
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const int tap = r_ * 3 + q;
+  for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
-    for (int i = 0; i < CW; ++i)
+    for (int i = 0; i < CW; ++i) {
+      const int ci = ci0 + cf * 16 + lr;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int ci = ci0 + j * 16 + lr;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int co = co0 + (chf * CW + i) * 16 + lq * 4 + e;
+      for (int e = 0; e < 4; ++e) {
+        const int co = co0 + (chf * CW + i) * 16 + lq * 4 + e;
 #ifdef DYOLO_ABLATE
-          if (p.dbg & 32) continue;  // no atomics at all
+        if (p.dbg & 32) continue;  // no atomics at all
 #endif
-          if (co < p.Cout && ci < p.Cin) {
-            float* at = dst + ((size_t)co * 9 + tap) * p.Cin + ci;
-            if (plain) *at = acc[q][i][j][e];
-            else atomicAdd(at, acc[q][i][j][e]);
-          }
+        if (co < p.Cout && ci < p.Cin) {
+          float* at = dst + ((size_t)co * 9 + tap) * p.Cin + ci;
+          if (plain) *at = acc[tap][i][e];
+          else atomicAdd(at, acc[tap][i][e]);
         }
       }
+    }
   }
 }
 
@@ -674,8 +685,7 @@ static Wgrad3Plan wgrad3_plan(const WgradArgs& a, int batch, int stride) {
   // Pixel slabs: ONE six-wave workgroup per CU (256 overall) with two steps of loads in flight (PF = 2), every slab at least 8 steps.
   // (r02 ran stride-2 layers with 512 workgroups and one step in flight: that was the loader's serialised loads, see the kernel;
   // B = 64, 512 + PF 1 -> 256 + PF 2: 64 -> 128 s2 @160 222 -> 182 us, 128 -> 256 s2 235 -> 190, 64 -> 64 s2 176 -> 131.)
-  static const int force_pf2 = dy_ablate("DYOLO_WGRAD3_PF2");  // probe: 2 = 512 workgroups with one step of loads in flight
-  const int target = force_pf2 == 2 ? 512 : 256;
+  const int target = 256;
   int slabs = (target + g.ny - 1) / g.ny;
   const int max_slabs = (g.nSteps + 7) / 8;
   if (slabs > max_slabs) slabs = max_slabs;
@@ -704,11 +714,7 @@ static int launch_wgrad3_rs(const WgradArgs& a, const Wgrad3Plan& g, hipStream_t
   p.part = (!no_part && g.gx > 1 && a.ws && a.ws_bytes >= (size_t)g.gx * n * sizeof(float)) ? reinterpret_cast<float*>(a.ws) : nullptr;
   p.dbg = dy_ablate("DYOLO_WGRAD3_DBG");
   const dim3 grid((unsigned)g.gx, (unsigned)g.ny);
-  static const int cw4 = dy_ablate("DYOLO_WGRAD3_CW4");
-  static const int force_pf2 = dy_ablate("DYOLO_WGRAD3_PF2");
-  if (cw4) hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, S, 4, RS, 1>), grid, dim3(192), 0, st, p);
-  else if (force_pf2 != 2) hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, S, 2, RS, 2>), grid, dim3(384), 0, st, p);
-  else hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, S, 2, RS, 1>), grid, dim3(384), 0, st, p);
+  hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, S, RS>), grid, dim3(512), 0, st, p);
   if (const int rc = check_launch("conv_wgrad3x3_kernel")) return rc;
   if (p.part) {
     hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3((unsigned)((n / 4 + 256) / 256), (unsigned)((g.gx + 15) / 16)), dim3(256), 0, st, p.part, a.dw, (int)n, g.gx);

@@ -1,6 +1,6 @@
 #!/bin/bash
-# GPU box: weight-gradient kernels, product build against the per-tap kernel with atomics for 1x1 layers (ablate build, DYOLO_NO_WGRAD1)
+# GPU box: weight-gradient kernels (product build); second block: the 3x3 kernel without its epilogue (ablate build, DYOLO_WGRAD3_DBG=32)
 L=drone-yolo_amd/lib_ablate/libdyolo.so
-SH="64,64,1,1,160 96,64,1,1,160 128,128,1,1,80 192,128,1,1,80 256,128,1,1,80 384,256,1,1,40 256,256,1,1,40 512,512,1,1,20 768,512,1,1,20 1024,512,1,1,20 384,128,1,1,80"
+SH="8,32,3,2,640 32,64,3,2,320 64,64,3,1,160 32,32,3,1,160 64,128,3,2,160 128,256,3,2,80 256,512,3,2,40 64,64,3,2,160 128,128,3,2,80 64,64,3,1,80 128,128,3,1,40 256,256,3,1,20 128,64,3,1,80 64,128,3,1,160"
 python tools/bench_wgrad.py $SH
-DYOLO_NO_WGRAD1=1 python tools/bench_wgrad.py --lib $L $SH
+DYOLO_WGRAD3_DBG=32 python tools/bench_wgrad.py --lib $L $SH

@@ -7,6 +7,7 @@ from drone_yolo_amd import hip_ops as H
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--eager", action="store_true", help="no hipGraph around the iterations (counter collection)")
 ap.add_argument("--lib", default="", help="another build of libdyolo.so (make ABLATE=1 OUT=...): reads DYOLO_WGRAD3_* probes")
 ap.add_argument("shapes", nargs="*", default=["32,64,3,2,320", "64,64,3,1,160", "32,32,3,1,160", "64,128,3,2,160", "64,64,3,1,80", "128,128,3,1,40",
                                                "256,256,3,1,20", "128,64,3,1,80", "192,128,1,1,80", "96,64,1,1,160", "768,512,1,1,20"])
@@ -26,15 +27,22 @@ for sh in a.shapes:
     H.conv_wgrad(x, dz, k, s, k // 2, out=buf)
     torch.cuda.synchronize()
     # the iterations are replayed from a hipGraph: a call costs ~80-100 us of Python + allocator time, more than most of these launches
-    gr = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(gr):
+    def run():
         for _ in range(a.iters):
             H.conv_wgrad(x, dz, k, s, k // 2, out=buf)
-    gr.replay()
+
+    if a.eager:
+        replay = run
+    else:
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            run()
+        replay = gr.replay
+    replay()
     torch.cuda.synchronize()
     st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     st.record()
-    gr.replay()
+    replay()
     en.record()
     torch.cuda.synchronize()
     us = st.elapsed_time(en) / a.iters * 1e3
