@@ -126,6 +126,24 @@ def test_conv_wgrad_dgrad_match_autograd(case, dtype, device):
         close(dx2, x.grad + prev, dtype, f"dgrad+accumulate {tag}")
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("n,c,h,w,k", [(3, 32, 20, 20, 5), (2, 16, 13, 17, 5), (2, 8, 9, 7, 3)])
+def test_maxpool_backward_matches_autograd(n, c, h, w, k, dtype, device):
+    """dy_maxpool_bwd_nhwc (SPPF's MaxPool2d(k, 1, k // 2), block.py:185-191) against autograd, on inputs FULL of ties (few distinct
+    values): the gradient goes to the first maximum of a window in scan order, as torch's kernel does; with and without accumulate."""
+    g = torch.Generator().manual_seed(n * 100 + h)
+    x = quantize(torch.randint(-3, 4, (n, c, h, w), generator=g).float() * 0.5, dtype).requires_grad_(True)
+    go = quantize(torch.randn(n, c, h, w, generator=g), dtype)
+    F.max_pool2d(x, k, 1, k // 2).backward(go)
+    prev = quantize(torch.randn(n, c, h, w, generator=g), dtype)
+    xd, god = nhwc(x.detach(), dtype, device), nhwc(go, dtype, device)
+    gi = H.maxpool_bwd(xd, god, H.alloc_nhwc(n, c, h, w, xd.dtype, device), k, False)
+    gi2 = H.maxpool_bwd(xd, god, nhwc(prev, dtype, device), k, True)
+    torch.cuda.synchronize()
+    close(gi, x.grad, dtype, "maxpool bwd", extra=4.0)
+    close(gi2, x.grad + prev, dtype, "maxpool bwd accumulate", extra=4.0)
+
+
 @pytest.mark.parametrize("cin,cout,k,s,b,h,w", [(64, 64, 3, 1, 8, 80, 80), (64, 128, 3, 2, 6, 84, 76), (192, 64, 3, 1, 4, 40, 44), (32, 32, 3, 1, 5, 66, 62),
                                                 (64, 64, 1, 1, 5, 81, 79), (96, 64, 1, 1, 7, 50, 46), (192, 128, 1, 1, 6, 41, 39), (768, 512, 1, 1, 9, 20, 20),
                                                 (40, 24, 1, 1, 3, 33, 31)])
