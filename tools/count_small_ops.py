@@ -32,8 +32,8 @@ batch = dict(img=torch.randint(0, 255, (B, 3, 640, 640), dtype=torch.uint8, gene
 tr.step(batch)
 tr.step(batch)
 torch.cuda.synchronize()
-with Count():
+with torch.autograd.set_multithreading_enabled(False), Count():  # backward on this thread: the mode sees its ops too
     tr.step(batch)
 torch.cuda.synchronize()
-for (name, where), c in counts.most_common(40):
+for (name, where), c in counts.most_common(70):
     print(f"{c:5d}  {name:40s} {where}")
