@@ -21,6 +21,13 @@ DY_WLAYOUT_ROWS, DY_WLAYOUT_HALO3X3, DY_WLAYOUT_FRAG1X1 = 0, 1, 2
 _vp, _i32, _f32, _i64 = C.c_void_p, C.c_int32, C.c_float, C.c_int64
 
 
+class PackJob(C.Structure):
+    """dy_pack_job: one convolution of dy_pack_conv_weights_batched (the arguments of dy_pack_conv_weights)."""
+    _fields_ = [("w", C.c_void_p), ("s_co", C.c_int64), ("s_ci", C.c_int64), ("s_r", C.c_int64), ("s_q", C.c_int64),
+                ("cout", C.c_int32), ("cin", C.c_int32), ("ksize", C.c_int32), ("transpose_flip", C.c_int32), ("cin_logical", C.c_int32),
+                ("w_layout", C.c_int32), ("dst", C.c_void_p), ("dst_elems", C.c_int64)]
+
+
 class ConvDesc(C.Structure):
     """Mirror of ``dy_conv_desc`` (include/dyolo.h)."""
 
@@ -147,6 +154,9 @@ SIGNATURES = {
     "dy_last_error_string": (C.c_char_p, []),
     "dy_last_kernel_name": (C.c_char_p, []),
     "dy_dtype_size": (_i32, [_i32]),
+    "dy_pack_conv_weights_table_bytes": (C.c_int64, [_i32]),
+    "dy_pack_conv_weights_table": (_i32, [C.POINTER(PackJob), _i32, _i32, _vp, C.c_int64, C.POINTER(C.c_int32)]),
+    "dy_pack_conv_weights_batched": (_i32, [_vp, _i32, _i32, _i32, _vp]),
     "dy_conv_k_pad": (_i32, [_i32, _i32, _i32]),
     "dy_conv_cout_pad": (_i32, [_i32]),
     "dy_conv2d_nhwc": (_i32, [C.POINTER(ConvDesc), _vp]),

@@ -181,46 +181,70 @@ struct PackArgs {
   long long total;
 };
 
+// the logical weight destination element i of the packed buffer holds (0 in the padding)
+__device__ __forceinline__ float pack_element(const PackArgs& p, long long i) {
+  const int lco = p.lco, lci = p.lci;
+  int co, ci, r, q;
+  if (p.layout == DY_WLAYOUT_ROWS) {
+    co = (int)(i / p.a);
+    const int kk = (int)(i - (long long)co * p.a);
+    const int tap = kk / lci;
+    ci = kk - tap * lci;
+    r = tap / p.k, q = tap - r * p.k;
+    if (tap >= p.k * p.k) co = 1 << 30;  // row padding
+  } else {  // fragment orders: (((nt * nch + c) * taps + tap) * NF + j) * 64 + lq * 16 + lr) * E + e
+    const int taps = p.layout == DY_WLAYOUT_HALO3X3 ? 9 : 1;
+    long long t = i;
+    const int e = (int)(t % p.e);
+    t /= p.e;
+    const int lr = (int)(t % 16);
+    t /= 16;
+    const int lq = (int)(t % 4);
+    t /= 4;
+    const int j = (int)(t % p.nf);
+    t /= p.nf;
+    const int tap = (int)(t % taps);
+    t /= taps;
+    const int c = (int)(t % p.a);
+    const int nt = (int)(t / p.a);
+    co = (nt * p.nf + j) * 16 + lr;
+    ci = c * 4 * p.e + lq * p.e + e;
+    r = tap / 3, q = tap - r * 3;
+    if (taps == 1) r = q = 0;
+  }
+  float v = 0.f;
+  if (co < lco && ci < p.lci_valid) {
+    const int sr = p.tf ? p.k - 1 - r : r, sq = p.tf ? p.k - 1 - q : q;
+    const int sco = p.tf ? ci : co, sci = p.tf ? co : ci;
+    v = p.w[sco * p.s_co + sci * p.s_ci + sr * p.s_r + sq * p.s_q];
+  }
+  return v;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs p, T* __restrict__ dst) {
-  const int lco = p.lco, lci = p.lci;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
-    int co, ci, r, q;
-    if (p.layout == DY_WLAYOUT_ROWS) {
-      co = (int)(i / p.a);
-      const int kk = (int)(i - (long long)co * p.a);
-      const int tap = kk / lci;
-      ci = kk - tap * lci;
-      r = tap / p.k, q = tap - r * p.k;
-      if (tap >= p.k * p.k) co = 1 << 30;  // row padding
-    } else {  // fragment orders: (((nt * nch + c) * taps + tap) * NF + j) * 64 + lq * 16 + lr) * E + e
-      const int taps = p.layout == DY_WLAYOUT_HALO3X3 ? 9 : 1;
-      long long t = i;
-      const int e = (int)(t % p.e);
-      t /= p.e;
-      const int lr = (int)(t % 16);
-      t /= 16;
-      const int lq = (int)(t % 4);
-      t /= 4;
-      const int j = (int)(t % p.nf);
-      t /= p.nf;
-      const int tap = (int)(t % taps);
-      t /= taps;
-      const int c = (int)(t % p.a);
-      const int nt = (int)(t / p.a);
-      co = (nt * p.nf + j) * 16 + lr;
-      ci = c * 4 * p.e + lq * p.e + e;
-      r = tap / 3, q = tap - r * 3;
-      if (taps == 1) r = q = 0;
-    }
-    float v = 0.f;
-    if (co < lco && ci < p.lci_valid) {
-      const int sr = p.tf ? p.k - 1 - r : r, sq = p.tf ? p.k - 1 - q : q;
-      const int sco = p.tf ? ci : co, sci = p.tf ? co : ci;
-      v = p.w[sco * p.s_co + sci * p.s_ci + sr * p.s_r + sq * p.s_q];
-    }
-    dst[i] = Elem<T>::from_f32(v);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) dst[i] = Elem<T>::from_f32(pack_element(p, i));
+}
+
+// Every convolution of a training step in ONE launch (dy_pack_conv_weights_batched): a device table of jobs; a workgroup finds its
+// job by its first-block number (the table is sorted by it) and walks the job's elements with the job's own block count.
+struct PackEntry {
+  PackArgs a;
+  void* dst;
+  int block0, nblocks;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackEntry* __restrict__ tab, int n) {
+  int lo = 0, hi = n - 1;  // last entry with block0 <= blockIdx.x (uniform: scalar loads)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].block0 <= (int)blockIdx.x) lo = mid;
+    else hi = mid - 1;
   }
+  const PackArgs p = tab[lo].a;
+  T* __restrict__ dst = reinterpret_cast<T*>(tab[lo].dst);
+  const long long stride = (long long)tab[lo].nblocks * 256;
+  for (long long i = (long long)((int)blockIdx.x - tab[lo].block0) * 256 + threadIdx.x; i < p.total; i += stride) dst[i] = Elem<T>::from_f32(pack_element(p, i));
 }
 
 static inline int grid_for(long long items) {
@@ -377,8 +401,8 @@ extern "C" int32_t dy_quantize_fp8_nhwc(const void* src, void* dst, int64_t rows
   return check_launch("quantize_fp8_kernel");
 }
 
-extern "C" int32_t dy_pack_conv_weights(const float* w, int64_t s_co, int64_t s_ci, int64_t s_r, int64_t s_q, int32_t cout, int32_t cin, int32_t ksize,
-                                        int32_t transpose_flip, int32_t cin_logical, void* dst, int64_t dst_elems, int32_t dtype, int32_t w_layout, dy_stream_t stream) {
+static int pack_args(const float* w, int64_t s_co, int64_t s_ci, int64_t s_r, int64_t s_q, int32_t cout, int32_t cin, int32_t ksize, int32_t transpose_flip,
+                     int32_t cin_logical, const void* dst, int64_t dst_elems, int32_t dtype, int32_t w_layout, PackArgs& p) {
   const int es = dtype_size_no_fp8(dtype);
   DY_REQUIRE(w && dst && es && cout > 0 && cin > 0 && ksize >= 1 && dst_elems > 0 && aligned16(dst), DY_ERR_INVALID_ARG, "dy_pack_conv_weights: bad arguments");
   const int e = 16 / es;
@@ -388,7 +412,7 @@ extern "C" int32_t dy_pack_conv_weights(const float* w, int64_t s_co, int64_t s_
     DY_REQUIRE(!transpose_flip && cin_logical >= cin, DY_ERR_INVALID_ARG, "dy_pack_conv_weights: cin_logical");
     lci = cin_logical;
   }
-  PackArgs p{};
+  p = PackArgs{};
   p.w = w, p.s_co = s_co, p.s_ci = s_ci, p.s_r = s_r, p.s_q = s_q, p.k = ksize, p.tf = transpose_flip ? 1 : 0, p.layout = w_layout, p.e = e;
   p.lco = lco, p.lci_valid = transpose_flip ? cout : cin, p.lci = lci;
   long long need = 0;
@@ -410,10 +434,50 @@ extern "C" int32_t dy_pack_conv_weights(const float* w, int64_t s_co, int64_t s_
   }
   DY_REQUIRE(dst_elems == need, DY_ERR_INVALID_ARG, "dy_pack_conv_weights: dst holds %lld elements, the layout needs %lld", (long long)dst_elems, need);
   p.total = need;
+  return 0;
+}
+
+extern "C" int32_t dy_pack_conv_weights(const float* w, int64_t s_co, int64_t s_ci, int64_t s_r, int64_t s_q, int32_t cout, int32_t cin, int32_t ksize,
+                                        int32_t transpose_flip, int32_t cin_logical, void* dst, int64_t dst_elems, int32_t dtype, int32_t w_layout, dy_stream_t stream) {
+  PackArgs p;
+  if (const int rc = pack_args(w, s_co, s_ci, s_r, s_q, cout, cin, ksize, transpose_flip, cin_logical, dst, dst_elems, dtype, w_layout, p)) return rc;
+  const long long need = p.total;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int grid = grid_for(need);
   if (dtype == DY_BF16) hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, p, (bf16_t*)dst);
   else if (dtype == DY_F16) hipLaunchKernelGGL((pack_weights_kernel<f16_t>), dim3(grid), dim3(256), 0, st, p, (f16_t*)dst);
   else hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(grid), dim3(256), 0, st, p, (float*)dst);
   return check_launch("pack_weights_kernel");
+}
+
+extern "C" int64_t dy_pack_conv_weights_table_bytes(int32_t n_jobs) { return n_jobs > 0 ? (int64_t)n_jobs * (int64_t)sizeof(PackEntry) : -1; }
+
+extern "C" int32_t dy_pack_conv_weights_table(const dy_pack_job* jobs, int32_t n_jobs, int32_t dtype, void* table_host, int64_t table_bytes, int32_t* total_blocks) {
+  DY_REQUIRE(jobs && n_jobs > 0 && table_host && total_blocks && table_bytes >= dy_pack_conv_weights_table_bytes(n_jobs), DY_ERR_INVALID_ARG,
+             "dy_pack_conv_weights_table: null pointer or table too small");
+  PackEntry* tab = reinterpret_cast<PackEntry*>(table_host);
+  int blocks = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const dy_pack_job& j = jobs[i];
+    PackEntry e{};
+    if (const int rc = pack_args(j.w, j.s_co, j.s_ci, j.s_r, j.s_q, j.cout, j.cin, j.ksize, j.transpose_flip, j.cin_logical, j.dst, j.dst_elems, dtype, j.w_layout, e.a)) return rc;
+    e.dst = j.dst;
+    long long nb = (e.a.total + 2047) / 2048;  // eight elements per thread, at most 64 workgroups per job
+    e.nblocks = (int)(nb < 1 ? 1 : (nb > 64 ? 64 : nb));
+    e.block0 = blocks;
+    blocks += e.nblocks;
+    tab[i] = e;
+  }
+  *total_blocks = blocks;
+  return 0;
+}
+
+extern "C" int32_t dy_pack_conv_weights_batched(const void* table_dev, int32_t n_jobs, int32_t total_blocks, int32_t dtype, dy_stream_t stream) {
+  DY_REQUIRE(table_dev && n_jobs > 0 && total_blocks > 0 && dtype_size_no_fp8(dtype), DY_ERR_INVALID_ARG, "dy_pack_conv_weights_batched: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const PackEntry* tab = reinterpret_cast<const PackEntry*>(table_dev);
+  if (dtype == DY_BF16) hipLaunchKernelGGL((pack_weights_batched_kernel<bf16_t>), dim3((unsigned)total_blocks), dim3(256), 0, st, tab, n_jobs);
+  else if (dtype == DY_F16) hipLaunchKernelGGL((pack_weights_batched_kernel<f16_t>), dim3((unsigned)total_blocks), dim3(256), 0, st, tab, n_jobs);
+  else hipLaunchKernelGGL((pack_weights_batched_kernel<float>), dim3((unsigned)total_blocks), dim3(256), 0, st, tab, n_jobs);
+  return check_launch("pack_weights_batched_kernel");
 }

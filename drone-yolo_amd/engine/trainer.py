@@ -505,10 +505,18 @@ class DetectionTrainer:
             else:
                 self.flat.flush_sink()
 
+        from .. import hip_ops as H
+
+        packs = self.__dict__.get("_pack_cache")
+        if packs is None and batch["img"].is_cuda and os.environ.get("DYOLO_PACK_BATCH", "1") != "0":
+            packs = self._pack_cache = H.PackCache(self.model.train_dtype, batch["img"].device, self.flat.P)  # every layer's weights packed by ONE launch per step
         if not use:
-            with sink_armed():
-                loss, items = self.model(batch)
-            backward(loss)
+            with H.batched_weight_packing(packs):
+                if packs is not None:
+                    packs.pack_all()
+                with sink_armed():
+                    loss, items = self.model(batch)
+                backward(loss)
             # detached: a caller that keeps the loss must not keep the autograd graph alive — its AccumulateGrad nodes would stay bound to
             # this stream, and the next capture (another stream) then breaks inside hipStreamEndCapture (seen as a segfault on ROCm 7.0)
             return loss.detach(), items.detach()
@@ -540,7 +548,9 @@ class DetectionTrainer:
                 bk.arm(armed, capturing=True)
             torch.cuda.synchronize(img.device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g), H.batched_weight_packing(packs):
+                if packs is not None:
+                    packs.pack_all()
                 with sink_armed():
                     loss, items = model.criterion.from_gt(model.forward_train(gs["img"]), gs["gt"])
                 backward(loss)

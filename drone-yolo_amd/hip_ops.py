@@ -11,6 +11,7 @@ later forwards with the same shapes replay the launches without re-running the P
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import List, Optional, Sequence, Tuple
 
@@ -241,6 +242,82 @@ def _act_code(act) -> int:
     return int(act) if isinstance(act, int) and not isinstance(act, bool) else (DY_ACT_SILU if act else DY_ACT_NONE)
 
 
+class PackCache:
+    """Weight packing of a whole training step in one launch.  A step packs every convolution's fp32 master weights twice (forward
+    and input-gradient form): ~160 ``dy_pack_conv_weights`` launches of ~5 us.  The first step under ``batched_weight_packing`` packs
+    one by one and remembers each job with a PERSISTENT destination; from then on ``pack_all()`` (the trainer calls it at the start of
+    a step, i.e. after the optimizer changed the weights) runs all of them as ONE ``dy_pack_conv_weights_batched`` launch and the
+    ``PackedConv`` constructors of that step take the packed buffers as they are.  Sources are the flat parameter buffer's views
+    (stable addresses); a job that first appears later is packed on its own and joins the table at the next ``pack_all`` outside a
+    stream capture (the table is uploaded with a host-to-device copy)."""
+
+    def __init__(self, dtype: torch.dtype, device, stable: torch.Tensor):
+        """``stable``: the buffer whose views may be cached (the trainer's flat parameter buffer) -- weights built per step
+        (a padded copy, a folded RepVGG kernel) have another address every time and are packed on their own."""
+        self.dtype, self.device = dtype, torch.device(device)
+        self.lo, self.hi = stable.data_ptr(), stable.data_ptr() + stable.numel() * stable.element_size()
+        self.jobs: dict = {}      # job tuple -> [destination, generation packed, keep-alive source]
+        self.table = None         # (device table, n_jobs, total_blocks, job order)
+        self.dirty = False
+        self.gen = 0
+
+    def lookup(self, job):
+        e = self.jobs.get(job)
+        return e[0] if e is not None and e[1] == self.gen else None
+
+    def slot(self, job, src) -> torch.Tensor:
+        e = self.jobs.get(job)
+        if e is None:
+            e = self.jobs[job] = [torch.empty(job[11], dtype=self.dtype, device=self.device), -1, src]
+            self.dirty = True
+        e[1] = self.gen  # the caller packs it now
+        return e[0]
+
+    def _build(self) -> None:
+        L = lib()
+        order = list(self.jobs)
+        n = len(order)
+        arr = (_lib.PackJob * n)()
+        for i, j in enumerate(order):
+            a = arr[i]
+            a.w, a.s_co, a.s_ci, a.s_r, a.s_q, a.cout, a.cin, a.ksize, a.transpose_flip, a.cin_logical, a.w_layout = j[:11]
+            a.dst, a.dst_elems = self.jobs[j][0].data_ptr(), j[11]
+        nbytes = int(L.dy_pack_conv_weights_table_bytes(n))
+        host = torch.empty(nbytes, dtype=torch.uint8)
+        blocks = C.c_int32(0)
+        check(L.dy_pack_conv_weights_table(arr, n, dy_dtype(self.dtype), host.data_ptr(), nbytes, C.byref(blocks)), "dy_pack_conv_weights_table")
+        self.table = (host.to(self.device), n, int(blocks.value), order)
+        self.dirty = False
+
+    def pack_all(self) -> None:
+        """Start of a step: everything known is packed again from the current weights."""
+        if not self.jobs:
+            return
+        if (self.dirty or self.table is None) and not torch.cuda.is_current_stream_capturing():
+            self._build()
+        self.gen += 1
+        if self.table is None:
+            return
+        tab, n, blocks, order = self.table
+        _launch(lib().dy_pack_conv_weights_batched, (tab.data_ptr(), n, blocks, dy_dtype(self.dtype)), record=False)
+        for j in order:
+            self.jobs[j][1] = self.gen
+
+
+_PACK_CACHE = {"active": None}
+
+
+@contextlib.contextmanager
+def batched_weight_packing(cache: Optional[PackCache]):
+    """``PackedConv`` constructions of device-resident fp32 weights inside this block go through ``cache`` (see PackCache)."""
+    prev = _PACK_CACHE["active"]
+    _PACK_CACHE["active"] = cache
+    try:
+        yield cache
+    finally:
+        _PACK_CACHE["active"] = prev
+
+
 class PackedConv:
     """Folded + packed weights of one convolution in the layout ``dy_conv2d_nhwc`` expects.
 
@@ -273,10 +350,17 @@ class PackedConv:
             weight = torch.empty(lshape, device="meta")  # shape carrier for the layout decision below; data moves in _device_pack
 
             def _device_pack(layout: int, n_elems: int) -> torch.Tensor:
-                out = torch.empty(n_elems, dtype=dtype, device=src.device)
                 st = src.stride()
-                _launch(L.dy_pack_conv_weights, (src.data_ptr(), st[0], st[1], st[2], st[3], src.shape[0], src.shape[1], src.shape[2], int(transpose_flip), cin_logical,
-                                                 out.data_ptr(), n_elems, dy_dtype(dtype), layout), record=False)
+                job = (src.data_ptr(), st[0], st[1], st[2], st[3], src.shape[0], src.shape[1], src.shape[2], int(transpose_flip), cin_logical, layout, n_elems)
+                cache = _PACK_CACHE["active"]
+                if cache is not None and cache.dtype == dtype and cache.lo <= job[0] < cache.hi:
+                    hit = cache.lookup(job)
+                    if hit is not None:  # packed by this step's dy_pack_conv_weights_batched launch
+                        return hit
+                    out = cache.slot(job, src)
+                else:
+                    out = torch.empty(n_elems, dtype=dtype, device=src.device)
+                _launch(L.dy_pack_conv_weights, job[:10] + (out.data_ptr(), n_elems, dy_dtype(dtype), layout), record=False)
                 return out
 
             def _device_bias(n: int) -> torch.Tensor:

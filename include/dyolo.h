@@ -152,6 +152,20 @@ int32_t dy_quantize_fp8_nhwc(const void* src, void* dst, int64_t rows, int32_t c
  * at dy_conv_desc.w_layout), padding written as zeros. */
 int32_t dy_pack_conv_weights(const float* w, int64_t s_co, int64_t s_ci, int64_t s_r, int64_t s_q, int32_t cout, int32_t cin, int32_t ksize,
                              int32_t transpose_flip, int32_t cin_logical, void* dst, int64_t dst_elems, int32_t dtype, int32_t w_layout, dy_stream_t stream);
+/* The same for MANY convolutions in ONE launch (a training step re-packs every layer's weights twice: forward and input-gradient
+ * form, ~160 launches of ~5 us).  dy_pack_conv_weights_table validates the jobs (the arguments of dy_pack_conv_weights, one dtype)
+ * and writes the launch table into HOST memory (dy_pack_conv_weights_table_bytes(n) bytes) plus the grid size; the caller copies it to
+ * the device once; dy_pack_conv_weights_batched runs it (re-usable while the source / destination addresses stand; capturable). */
+typedef struct dy_pack_job {
+  const float* w;
+  int64_t s_co, s_ci, s_r, s_q;
+  int32_t cout, cin, ksize, transpose_flip, cin_logical, w_layout;
+  void* dst;
+  int64_t dst_elems;
+} dy_pack_job;
+int64_t dy_pack_conv_weights_table_bytes(int32_t n_jobs);
+int32_t dy_pack_conv_weights_table(const dy_pack_job* jobs, int32_t n_jobs, int32_t dtype, void* table_host, int64_t table_bytes, int32_t* total_blocks);
+int32_t dy_pack_conv_weights_batched(const void* table_dev, int32_t n_jobs, int32_t total_blocks, int32_t dtype, dy_stream_t stream);
 int32_t dy_conv_k_pad(int32_t cin, int32_t ksize, int32_t dtype);
 int32_t dy_conv_cout_pad(int32_t cout);
 int32_t dy_conv2d_nhwc(const dy_conv_desc* d, dy_stream_t stream);

@@ -126,6 +126,52 @@ def test_conv_wgrad_dgrad_match_autograd(case, dtype, device):
         close(dx2, x.grad + prev, dtype, f"dgrad+accumulate {tag}")
 
 
+def test_batched_weight_packing_equals_single_launches(device):
+    """dy_pack_conv_weights_batched (one launch for a step's ~160 packings) against dy_pack_conv_weights job by job: forward and
+    input-gradient (transposed, flipped) forms, 1x1 / 3x3, every layout PackedConv picks, the padded image stem; then the cache protocol:
+    second-generation constructions take the batched buffers, weights changed in between are re-packed, foreign tensors are not cached."""
+    g = torch.Generator().manual_seed(7)
+    shapes = [(64, 64, 3), (128, 64, 3), (32, 3, 3), (64, 32, 3), (128, 192, 1), (256, 128, 1), (16, 64, 1), (512, 256, 3), (64, 64, 1)]
+    flat = torch.empty(sum(a * b * k * k for a, b, k in shapes), device=device)
+    ws, off = [], 0
+    for a, b, k in shapes:
+        n = a * b * k * k
+        ws.append(flat[off : off + n].view(a, b, k, k))
+        ws[-1].copy_(torch.randn(a, b, k, k, generator=g))
+        off += n
+    dt = torch.bfloat16
+
+    def build():
+        out = []
+        for wt in ws:
+            k = wt.shape[2]
+            out.append(H.PackedConv(wt, H.zero_bias(wt.shape[0], device), 1, k // 2, 1, False, dt, device, cin_pad=8 if wt.shape[1] == 3 else None))
+            if wt.shape[1] != 3:
+                out.append(H.pack_dgrad(wt, 1, dt, device))
+        return out
+
+    ref = [pc.w.clone() for pc in build()]  # no cache: single launches
+    cache = H.PackCache(dt, device, flat)
+    with H.batched_weight_packing(cache):
+        first = build()  # generation 0: single launches into the cache's persistent buffers
+        assert len(cache.jobs) == len(first) and cache.dirty
+        cache.pack_all()  # builds the table, one launch
+        second = build()
+        assert all(a.w.data_ptr() == b.w.data_ptr() for a, b in zip(first, second)) and not cache.dirty
+        torch.cuda.synchronize()
+        for r, pc in zip(ref, second):
+            assert torch.equal(r, pc.w)
+        flat.mul_(-0.5)  # "optimizer step"
+        cache.pack_all()
+        third = build()
+        foreign = H.PackedConv(ws[0].clone(), H.zero_bias(64, device), 1, 1, 1, False, dt, device)  # not a view of the flat buffer
+        assert len(cache.jobs) == len(first) and foreign.w.data_ptr() not in {pc.w.data_ptr() for pc in third}
+    ref2 = [pc.w for pc in build()]
+    torch.cuda.synchronize()
+    for r, pc in zip(ref2, third):
+        assert torch.equal(r, pc.w)
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("n,c,h,w,k", [(3, 32, 20, 20, 5), (2, 16, 13, 17, 5), (2, 8, 9, 7, 3)])
 def test_maxpool_backward_matches_autograd(n, c, h, w, k, dtype, device):
