@@ -117,6 +117,33 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
   }
 }
 
+// ---- gradient of the Detect head's fp32 training map, split for the two 1x1 convolutions behind it ------------------------------
+// g: (rows, nb + nc) fp32, pitch ld_g -- what the loss hands back for cat(box logits, class logits) (head.py:69-72).  One pass writes
+// the 16-bit operands of the weight / input gradient kernels: dzb = scale * g[:, :nb], dzc = scale * g[:, nb : nb + nc] zero-padded
+// to ncp channels.  scale: optional DEVICE scalar (the seed of backward(): the loss scale under fp16).  Replaces a torch multiply,
+// two casting copies and a zero fill per level.
+template <typename T>
+__global__ __launch_bounds__(256) void head_grad_split_kernel(const float* __restrict__ g, int ld_g, long long rows, int nb, int nc, int ncp, const float* __restrict__ scale,
+                                                              T* __restrict__ dzb, int ld_b, T* __restrict__ dzc, int ld_c) {
+  constexpr int E = Elem<T>::EPC;
+  const int cb = nb / E, cc = ncp / E, per_row = cb + cc;
+  const float sc = scale ? *scale : 1.0f;
+  const long long total = rows * per_row;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / per_row;
+    const int k = (int)(i - r * per_row);
+    const bool box = k < cb;
+    const int c0 = box ? k * E : (k - cb) * E;       // first channel of this chunk inside its slot
+    const int lim = box ? nb : nc;                   // channels of the slot that exist
+    const float* src = g + r * ld_g + (box ? 0 : nb) + c0;
+    float f[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) f[e] = c0 + e < lim ? src[e] * sc : 0.f;
+    T* dst = box ? dzb + r * ld_b + c0 : dzc + r * ld_c + c0;
+    *reinterpret_cast<u32x4*>(dst) = Chunk<T>::pack(f);
+  }
+}
+
 // ---- out = a + b on (rows, c) views ----------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, long long rows, int cchunks, int lda, int ldb, int ldo) {
@@ -358,6 +385,21 @@ extern "C" int32_t dy_maxpool_bwd_nhwc(const void* x, const void* g_out, void* g
   else DY_MPB(float);
 #undef DY_MPB
   return check_launch("dy_maxpool_bwd_nhwc");
+}
+
+extern "C" int32_t dy_head_grad_split(const float* g, int32_t ld_g, int64_t rows, int32_t nb, int32_t nc, int32_t ncp, const float* scale, void* dzb, int32_t ld_b,
+                                      void* dzc, int32_t ld_c, int32_t dtype, dy_stream_t stream) {
+  const int es = dtype_size_no_fp8(dtype);
+  DY_REQUIRE(g && dzb && dzc && rows > 0 && nb > 0 && nc > 0 && ncp >= nc && (es == 2 || es == 4), DY_ERR_INVALID_ARG, "dy_head_grad_split: bad arguments");
+  const int epc = 16 / es;
+  DY_REQUIRE(nb % epc == 0 && ncp % epc == 0 && ld_g >= nb + nc && DY_VIEW_OK(dzb, ld_b, nb, es) && DY_VIEW_OK(dzc, ld_c, ncp, es), DY_ERR_INVALID_ARG,
+             "dy_head_grad_split: slots must be whole 16-byte chunks");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const unsigned grid = grid1(rows * ((nb + ncp) / epc));
+  if (dtype == DY_BF16) hipLaunchKernelGGL((head_grad_split_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, g, ld_g, (long long)rows, nb, nc, ncp, scale, (bf16_t*)dzb, ld_b, (bf16_t*)dzc, ld_c);
+  else if (dtype == DY_F16) hipLaunchKernelGGL((head_grad_split_kernel<f16_t>), dim3(grid), dim3(256), 0, st, g, ld_g, (long long)rows, nb, nc, ncp, scale, (f16_t*)dzb, ld_b, (f16_t*)dzc, ld_c);
+  else hipLaunchKernelGGL((head_grad_split_kernel<float>), dim3(grid), dim3(256), 0, st, g, ld_g, (long long)rows, nb, nc, ncp, scale, (float*)dzb, ld_b, (float*)dzc, ld_c);
+  return check_launch("dy_head_grad_split");
 }
 
 extern "C" int32_t dy_add_nhwc(const void* a, const void* b, void* out, int64_t rows, int32_t c, int32_t ld_a, int32_t ld_b, int32_t ld_o, int32_t dtype, dy_stream_t stream) {

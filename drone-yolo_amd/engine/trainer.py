@@ -492,14 +492,14 @@ class DetectionTrainer:
         runs under the backward kernels of buckets k+1.. — so the host still enqueues ~10 calls per step instead of ~2,400."""
         use = (self.graph_steps and self.iters >= 2 and batch["img"].is_cuda and self.model.training
                and (self.world == 1 or self.grad_sink))
-        from ..nn.autograd_ops import sink_armed
+        from ..nn.autograd_ops import lazy_head_seed, sink_armed
 
         bk = self.buckets
 
         def backward(loss):
             # scaler.scale(loss).backward() (trainer.py:389): the seed of the backward pass is the device-resident scale
-            with sink_armed(bk.note if bk is not None else None):
-                (loss * self.amp_state[0] if self.amp_state is not None else loss).backward()
+            with sink_armed(bk.note if bk is not None else None), lazy_head_seed():
+                loss.backward(gradient=self.amp_state[0] if self.amp_state is not None else self._unit_seed(loss))
             if bk is not None:
                 bk.end_backward()  # buckets backward did not run down (parameters without a gradient): flushed / issued in order
             else:
@@ -567,6 +567,13 @@ class DetectionTrainer:
         if bk is not None:
             bk.exchange_after_replay()
         return gs["loss"].clone(), gs["items"].clone()  # the static outputs are overwritten by the next replay (the epoch mean keeps them)
+
+    def _unit_seed(self, loss: torch.Tensor) -> torch.Tensor:
+        """ones_like(loss), allocated once (the seed autograd would create per call; a device fp32 scalar the head-gradient kernel reads)."""
+        u = self.__dict__.get("_unit")
+        if u is None or u.device != loss.device or u.dtype != loss.dtype or u.shape != loss.shape:
+            u = self._unit = torch.ones_like(loss)
+        return u
 
     def step_form(self) -> str:
         """How a step is issued (for the bench line): eager launches, one hipGraph, or one hipGraph with the bucket exchange behind it."""

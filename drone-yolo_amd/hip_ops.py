@@ -1148,6 +1148,21 @@ def maxpool_bwd(x: torch.Tensor, g_out: torch.Tensor, g_in: torch.Tensor, k: int
     return g_in
 
 
+def head_grad_split(g: torch.Tensor, nb: int, nc: int, ncp: int, dtype: torch.dtype, scale: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(dzb, dzc) of ``dy_head_grad_split``: ``g`` an fp32 NHWC view (n, nb + nc, h, w); ``scale`` a device fp32 scalar or None."""
+    n, c, h, w = g.shape
+    if g.dtype != torch.float32 or c != nb + nc or g.stride(1) != 1:
+        raise ValueError("head_grad_split: g must be an fp32 NHWC view of nb + nc channels")
+    gp, ldg = view_params(g)
+    dzb, dzc = alloc_nhwc(n, nb, h, w, dtype, g.device), alloc_nhwc(n, ncp, h, w, dtype, g.device)
+    (bp, ldb), (cp, ldc) = view_params(dzb), view_params(dzc)
+    if scale is not None and (scale.dtype != torch.float32 or not scale.is_cuda or scale.numel() != 1):
+        raise ValueError("head_grad_split: scale must be one fp32 value on the device")
+    _launch(lib().dy_head_grad_split, (gp, ldg, _rows(g), nb, nc, ncp, scale.data_ptr() if scale is not None else None, bp, ldb, cp, ldc, dy_dtype(dtype)),
+            keep=(g, dzb, dzc, scale))
+    return dzb, dzc
+
+
 def add_nhwc(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     n, c, h, w = a.shape
     if out is None:

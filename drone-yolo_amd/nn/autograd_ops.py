@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from typing import List, Sequence
 
+import os
+
 import torch
 
 from .. import hip_ops as H
@@ -38,6 +40,28 @@ def conv_bn_fwd(x, weight, gamma, beta, bn, stride, pad, act, out=None):
     st = H.BnState(weight.shape[0], dev)
     y = H.bn_train_fwd(z, gamma, beta, st, act, eps=bn.eps, momentum=bn.momentum, running_mean=bn.running_mean, running_var=bn.running_var, out=out)
     return z, st, y
+
+
+# Seed of the backward pass, deferred: under ``lazy_head_seed`` (the trainer's backward) DetectionLossFn.backward hands its stored
+# gradients on without the multiply by d loss_out / d total and leaves the factor here, keyed by the gradient's address; the consumer
+# (HeadTail.backward) takes it out again.  The trainer checks that nothing is left over: an entry nobody consumed means a gradient
+# went on unscaled.
+LAZY_SEED: dict = {}
+_LAZY = [False]
+
+
+class lazy_head_seed:
+    def __enter__(self):
+        _LAZY[0] = os.environ.get("DYOLO_LAZY_SEED", "1") != "0"
+        LAZY_SEED.clear()
+
+    def __exit__(self, et, ev, tb):
+        _LAZY[0] = False
+        left = len(LAZY_SEED)
+        LAZY_SEED.clear()
+        if et is None and left:
+            raise RuntimeError(f"lazy_head_seed: {left} head gradient(s) were passed on without their scale (no HeadTail consumed them)")
+        return False
 
 
 _SINK_ARMED = [False]  # set by the trainer around ITS forward + backward only: a backward run by anybody else keeps autograd's gradients
@@ -283,11 +307,10 @@ class HeadTail(torch.autograd.Function):
         nb, nc, ncp = ctx.dims
         dtype, dev = xb.dtype, xb.device
         n, _, h, w = xb.shape
-        dzb = H.alloc_nhwc(n, nb, h, w, dtype, dev)
-        dzb.copy_(dy[:, :nb])
-        dzc = H.alloc_nhwc(n, ncp, h, w, dtype, dev)
-        dzc.zero_()
-        dzc[:, :nc].copy_(dy[:, nb:])
+        # one pass: cast, split, zero padding and -- when the gradient comes straight from DetectionLossFn under the trainer -- the seed
+        # of the backward pass (LAZY_SEED below), read on the device
+        seed = LAZY_SEED.pop(dy.data_ptr(), None)  # by the address DetectionLossFn.backward handed over, before any re-layout
+        dzb, dzc = H.head_grad_split(dy if dy.stride(1) == 1 else as_nhwc(dy), nb, nc, ncp, dtype, scale=seed)
         dwb = H.conv_wgrad(xb, dzb, 1, 1, 0)
         dwc = H.conv_wgrad(xc, dzc[:, :nc], 1, 1, 0)
         dbb, dbc = H.colsum(dzb), H.colsum(dzc[:, :nc])
@@ -408,5 +431,13 @@ class DetectionLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_total, g_items):
-        gs = [g[:, : ctx.nch] * g_total for g in ctx.grads] if g_total is not None else [None] * len(ctx.grads)
-        return (None, None, None, None, None, *gs)
+        if g_total is None:
+            return (None, None, None, None, None, *([None] * len(ctx.grads)))
+        gs = [g[:, : ctx.nch] for g in ctx.grads]
+        if _LAZY[0] and g_total.is_cuda and g_total.dtype == torch.float32 and g_total.numel() == 1:
+            # the trainer's own backward: d total / d level is handed on UNSCALED and HeadTail.backward multiplies by the seed inside its
+            # split kernel (a device read) -- a full-map torch multiply per level otherwise
+            for g in gs:
+                LAZY_SEED[g.data_ptr()] = g_total
+            return (None, None, None, None, None, *gs)
+        return (None, None, None, None, None, *[g * g_total for g in gs])

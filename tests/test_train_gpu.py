@@ -126,6 +126,23 @@ def test_conv_wgrad_dgrad_match_autograd(case, dtype, device):
         close(dx2, x.grad + prev, dtype, f"dgrad+accumulate {tag}")
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+def test_head_grad_split_matches_torch(dtype, device):
+    """dy_head_grad_split against the torch chain it replaces (multiply by the seed, cast, split, zero-pad), with and without a seed."""
+    g = torch.Generator().manual_seed(3)
+    n, h, w, nb, nc, ncp = 3, 13, 11, 64, 10, 16
+    buf = H.alloc_nhwc(n, nb + ncp, h, w, torch.float32, device)
+    buf.copy_(torch.randn(n, nb + ncp, h, w, generator=g))
+    gview = buf[:, : nb + nc]
+    seed = torch.tensor(1024.0, device=device)
+    for sc in (None, seed):
+        dzb, dzc = H.head_grad_split(gview, nb, nc, ncp, dtype, scale=sc)
+        torch.cuda.synchronize()
+        f = 1.0 if sc is None else float(sc)
+        assert torch.equal(dzb, (gview[:, :nb] * f).to(dtype)) and torch.equal(dzc[:, :nc], (gview[:, nb:] * f).to(dtype))
+        assert float(dzc[:, nc:].abs().max()) == 0.0
+
+
 def test_batched_weight_packing_equals_single_launches(device):
     """dy_pack_conv_weights_batched (one launch for a step's ~160 packings) against dy_pack_conv_weights job by job: forward and
     input-gradient (transposed, flipped) forms, 1x1 / 3x3, every layout PackedConv picks, the padded image stem; then the cache protocol:
