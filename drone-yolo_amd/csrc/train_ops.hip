@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict
 
 // ---- max-pool k x k, stride 1, pad k/2: gradient goes to the FIRST maximum of each window in (row, column) scan order,
 // as torch's max_pool2d does.  One workgroup per (image, 16-byte channel chunk): the plane of x and of the incoming
-// gradient sit in LDS; phase 1 finds the arg-max offset of every output, phase 2 gathers per input position.
+// gradient sit in LDS; phase 1 finds every output's arg-max (row segments first, then the rows), phase 2 scatters the gradients.
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ go, T* __restrict__ gi, int h, int w, int cchunks,
                                                           int ldx, int ldgo, int ldgi, int r, int accumulate) {
@@ -45,11 +45,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
   const int hw = h * w;
   // channel-major planes ([E][hw]: consecutive lanes walk consecutive positions of one channel -- the position-major form of r02 put
   // 8 lanes on every bank: 186 us for a 13 MB map)
-  float* xs = reinterpret_cast<float*>(dyn_smem);   // [E][hw]; phase 2 writes its sums here
+  float* xs = reinterpret_cast<float*>(dyn_smem);   // [E][hw]
   float* gs = xs + hw * E;                          // [E][hw]
-  unsigned char* am = reinterpret_cast<unsigned char*>(gs + hw * E);  // [E][hw] arg-max offset (dy+r)*(2r+1) + (dx+r)
   const int img = blockIdx.x / cchunks, cc = blockIdx.x - img * cchunks;
-  const int k = 2 * r + 1;
   for (int p = threadIdx.x; p < hw; p += 256) {
     float f[E], q[E];
     Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(x + ((size_t)img * hw + p) * (size_t)ldx + cc * E), f);
@@ -58,54 +56,53 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
     for (int e = 0; e < E; ++e) xs[e * hw + p] = f[e], gs[e * hw + p] = q[e];
   }
   __syncthreads();
+  // phase 1a: per position the maximum of its ROW segment (columns xx - r .. xx + r) and the first column that reaches it.
+  // The first maximum of a window in (row, column) scan order is then: the first ROW whose segment maximum equals the window maximum,
+  // at that segment's first column -- 2 (2r + 1) comparisons per output instead of (2r + 1)^2.
+  float* rowmax = gs + hw * E;                                        // [E][hw]
+  unsigned char* rowarg = reinterpret_cast<unsigned char*>(rowmax + hw * E);  // [E][hw] column offset dx + r of the segment's first maximum
   for (int i = threadIdx.x; i < hw * E; i += 256) {  // item = (channel, position)
     const int e = i / hw, p = i - e * hw;
     const int yy = p / w, xx = p - yy * w;
-    const float* xe = xs + e * hw;
+    const float* xr = xs + e * hw + yy * w;
     float best = -3.4e38f;
     int bo = 0;
     bool first = true;
-    for (int dyy = -r; dyy <= r; ++dyy) {
-      const int y2 = yy + dyy;
-      if ((unsigned)y2 >= (unsigned)h) continue;
-      for (int dxx = -r; dxx <= r; ++dxx) {
-        const int x2 = xx + dxx;
-        if ((unsigned)x2 >= (unsigned)w) continue;
-        const float v = xe[y2 * w + x2];
-        if (first || v > best) {
-          best = v;
-          bo = (dyy + r) * k + (dxx + r);
-          first = false;
-        }
-      }
+    for (int dxx = -r; dxx <= r; ++dxx) {
+      const int x2 = xx + dxx;
+      if ((unsigned)x2 >= (unsigned)w) continue;
+      const float v = xr[x2];
+      if (first || v > best) best = v, bo = dxx + r, first = false;
     }
-    am[i] = (unsigned char)bo;
+    rowmax[i] = best, rowarg[i] = (unsigned char)bo;
   }
+  __syncthreads();
+  // phase 1b + 2: the window's arg-max from the row segments, then the output's gradient ADDED at that input position (LDS float atomic:
+  // one per output instead of (2r + 1)^2 look-ups per input; outputs that share a target add in arrival order)
+  float* sums = rowmax + hw * E + (hw * E + 3) / 4;  // [E][hw] sums, behind rowarg (rounded up to a float boundary)
+  for (int i = threadIdx.x; i < hw * E; i += 256) sums[i] = 0.f;
   __syncthreads();
   for (int i = threadIdx.x; i < hw * E; i += 256) {
     const int e = i / hw, p = i - e * hw;
     const int yy = p / w, xx = p - yy * w;
-    const float* ge = gs + e * hw;
-    const unsigned char* ae = am + e * hw;
-    float acc = 0.f;
-    // output o = (yy - dyy, xx - dxx) sees this position at window offset (dyy, dxx)
+    const float* rm = rowmax + e * hw;
+    float best = -3.4e38f;
+    int by = 0;
+    bool first = true;
     for (int dyy = -r; dyy <= r; ++dyy) {
-      const int y2 = yy - dyy;
+      const int y2 = yy + dyy;
       if ((unsigned)y2 >= (unsigned)h) continue;
-      for (int dxx = -r; dxx <= r; ++dxx) {
-        const int x2 = xx - dxx;
-        if ((unsigned)x2 >= (unsigned)w) continue;
-        const int o = y2 * w + x2;
-        if (ae[o] == (unsigned char)((dyy + r) * k + (dxx + r))) acc += ge[o];
-      }
+      const float v = rm[y2 * w + xx];
+      if (first || v > best) best = v, by = y2, first = false;
     }
-    xs[i] = acc;  // (x is not read after phase 1)
+    const int bx = xx + (int)rowarg[e * hw + by * w + xx] - r;
+    atomicAdd(sums + e * hw + by * w + bx, gs[i]);
   }
   __syncthreads();
   for (int p = threadIdx.x; p < hw; p += 256) {
     float acc[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) acc[e] = xs[e * hw + p];
+    for (int e = 0; e < E; ++e) acc[e] = sums[e * hw + p];
     T* dst = gi + ((size_t)img * hw + p) * (size_t)ldgi + cc * E;
     if (accumulate) {
       float f[E];
@@ -128,6 +125,7 @@ __global__ __launch_bounds__(256) void head_grad_split_kernel(const float* __res
   constexpr int E = Elem<T>::EPC;
   const int cb = nb / E, cc = ncp / E, per_row = cb + cc;
   const float sc = scale ? *scale : 1.0f;
+  const bool vec = ld_g >= nb + ncp && ld_g % 4 == 0 && nb % 4 == 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0;
   const long long total = rows * per_row;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long r = i / per_row;
@@ -137,8 +135,17 @@ __global__ __launch_bounds__(256) void head_grad_split_kernel(const float* __res
     const int lim = box ? nb : nc;                   // channels of the slot that exist
     const float* src = g + r * ld_g + (box ? 0 : nb) + c0;
     float f[E];
+    if (vec) {  // whole 16-byte loads: the slot's padding lies inside the row pitch (host check)
 #pragma unroll
-    for (int e = 0; e < E; ++e) f[e] = c0 + e < lim ? src[e] * sc : 0.f;
+      for (int e = 0; e < E; e += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[e + j] = c0 + e + j < lim ? v[j] * sc : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) f[e] = c0 + e < lim ? src[e] * sc : 0.f;
+    }
     T* dst = box ? dzb + r * ld_b + c0 : dzc + r * ld_c + c0;
     *reinterpret_cast<u32x4*>(dst) = Chunk<T>::pack(f);
   }
@@ -370,7 +377,7 @@ extern "C" int32_t dy_maxpool_bwd_nhwc(const void* x, const void* g_out, void* g
   const int epc = 16 / es;
   DY_REQUIRE(c % epc == 0 && DY_VIEW_OK(x, ld_x, c, es) && DY_VIEW_OK(g_out, ld_go, c, es) && DY_VIEW_OK(g_in, ld_gi, c, es), DY_ERR_INVALID_ARG,
              "dy_maxpool_bwd_nhwc: views must be whole 16-byte chunks");
-  const size_t smem = (size_t)h * w * epc * 9;
+  const size_t smem = (size_t)h * w * epc * 17 + 16;  // x, g, row maxima, sums (fp32) + row arg-max (bytes)
   DY_REQUIRE(smem <= 160 * 1024, DY_ERR_UNSUPPORTED, "dy_maxpool_bwd_nhwc: plane %dx%d too large for LDS", h, w);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const unsigned grid = (unsigned)(n * (c / epc));

@@ -526,7 +526,7 @@ int32_t dy_silu_bwd(const void* u, const void* dy, void* du, int64_t rows, int32
  *   dx (n,h,w,c) = sum of the 2x2 blocks of g (n,2h,2w,c).
  * dy_maxpool_bwd_nhwc: gradient of MaxPool2d(k, 1, k//2) inside SPPF (nn/modules/block.py:185-191): every output's
  *   gradient goes to the FIRST maximum of its window in (row, column) order (torch semantics); g_in = (accumulate ?
- *   g_in : 0) + that.  h*w*(16/elem_size)*9 bytes of LDS per workgroup (h*w <= ~2200).
+ *   g_in : 0) + that.  h*w*(16/elem_size)*17 bytes of LDS per workgroup (h*w <= ~1200).
  * dy_add_nhwc: out = a + b, (rows, c) views (Bottleneck's shortcut, block.py:348-350).  c % one 16-byte chunk == 0.
  * dy_head_grad_split: the gradient of Detect's fp32 training map cat(box, cls) (head.py:69-72; g: (rows, nb + nc) fp32, pitch ld_g) as the
  *   `dtype` operands of the two 1x1 convolutions' gradient kernels in one pass: dzb = s * g[:, :nb]; dzc = s * g[:, nb:nb+nc], zero-padded
