@@ -39,7 +39,7 @@ class ConvDesc(C.Structure):
         ("groups", _i32), ("act", _i32), ("dtype", _i32), ("out_f32", _i32),
         ("k_pad", _i32), ("cout_pad", _i32), ("up2x", _i32),
         ("x2", _vp), ("ld_x2", _i32), ("cin_split", _i32), ("w_layout", _i32),
-        ("w_scale", _vp), ("act_scale", _f32),
+        ("w_scale", _vp), ("act_scale", _f32), ("bn_stats", _vp),
     ]  # fmt: skip
 
 
@@ -143,7 +143,7 @@ class BnDesc(C.Structure):
         ("c", _i32), ("ld_z", _i32), ("ld_y", _i32), ("ld_add", _i32), ("ld_dy", _i32), ("ld_dz", _i32), ("dtype", _i32), ("act", _i32),
         ("gamma", _vp), ("beta", _vp), ("mean", _vp), ("rstd", _vp), ("running_mean", _vp), ("running_var", _vp),
         ("eps", _f32), ("momentum", _f32),
-        ("dgamma", _vp), ("dbeta", _vp), ("workspace", _vp), ("workspace_bytes", _i64),
+        ("dgamma", _vp), ("dbeta", _vp), ("workspace", _vp), ("workspace_bytes", _i64), ("partial_slabs", _i32),
     ]  # fmt: skip
 
 
@@ -160,6 +160,7 @@ SIGNATURES = {
     "dy_conv_k_pad": (_i32, [_i32, _i32, _i32]),
     "dy_conv_cout_pad": (_i32, [_i32]),
     "dy_conv2d_nhwc": (_i32, [C.POINTER(ConvDesc), _vp]),
+    "dy_conv_stats_written": (_i32, []),
     "dy_c2f_fused_supported": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "dy_c2f_fused": (_i32, [C.POINTER(C2fDesc), _vp]),
     "dy_stem2_fused_supported": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32]),

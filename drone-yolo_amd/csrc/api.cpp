@@ -7,7 +7,10 @@
 namespace dy {
 
 static thread_local char g_err[512] = {0};
+static thread_local int g_stats = 0;              // dy_conv_stats_written()
 static thread_local const char* g_kernel = "";  // name the last launching call passed to check_launch (static storage)
+
+void note_stats(int written) { g_stats = written; }
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -44,6 +47,8 @@ extern "C" int32_t dy_version(void) { return (DYOLO_VERSION_MAJOR << 16) | DYOLO
 extern "C" const char* dy_last_error_string(void) { return dy::g_err; }
 
 extern "C" const char* dy_last_kernel_name(void) { return dy::g_kernel; }
+
+extern "C" int32_t dy_conv_stats_written(void) { return dy::g_stats; }
 
 extern "C" int32_t dy_dtype_size(int32_t dtype) {
   switch (dtype) {

@@ -34,6 +34,7 @@ struct BnArgs {
   float* dgamma;
   float* dbeta;
   double* acc;  // [2][c]
+  int partial_slabs;  // forward: > 0 = that many slab partials are already in the workspace (a convolution epilogue's)
   int nch, R, rows_per_block;
 };
 
@@ -278,6 +279,8 @@ static int bn_prepare(const dy_bn_desc* d, BnArgs* a, const char* who, bool bwd)
   a->running_mean = d->running_mean, a->running_var = d->running_mean ? d->running_var : nullptr;
   a->eps = d->eps, a->momentum = d->momentum, a->dgamma = d->dgamma, a->dbeta = d->dbeta;
   a->acc = reinterpret_cast<double*>(d->workspace);
+  a->partial_slabs = bwd ? 0 : d->partial_slabs;
+  DY_REQUIRE(a->partial_slabs >= 0 && a->partial_slabs <= kBnMaxSlabs, DY_ERR_INVALID_ARG, "%s: partial_slabs out of range", who);
   a->nch = d->c / epc;
   int R = 256 / a->nch;
   if (R < 1) R = 1;
@@ -294,8 +297,8 @@ template <typename T>
 static int bn_fwd_t(const BnArgs& a, hipStream_t st) {
   const unsigned blocks = (unsigned)((a.rows + a.rows_per_block - 1) / a.rows_per_block);
   const size_t smem = (size_t)2 * a.R * a.c * 4;
-  hipLaunchKernelGGL((bn_reduce_kernel<T, 0>), dim3(blocks), dim3(256), smem, st, a);
-  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((unsigned)((2 * a.c + 31) / 32), kBnSumY), dim3(256), 0, st, a, (int)blocks);
+  if (a.partial_slabs <= 0) hipLaunchKernelGGL((bn_reduce_kernel<T, 0>), dim3(blocks), dim3(256), smem, st, a);
+  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((unsigned)((2 * a.c + 31) / 32), kBnSumY), dim3(256), 0, st, a, a.partial_slabs > 0 ? a.partial_slabs : (int)blocks);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((a.c + 255) / 256)), dim3(256), 0, st, a);
   const long long nb = (a.rows + a.R - 1) / a.R;
   const unsigned ab = (unsigned)(nb < 4096 ? nb : 4096);

@@ -26,11 +26,13 @@ int check_launch(const char* what);
 // memset becomes a memset NODE, and on ROCm 7.0 such a node was seen to lose its order against the kernels around it — replays of a
 // captured training step returned a doubled BCE sum (the accumulators were cleared at the wrong time).
 void zero_async(void* p, size_t bytes, hipStream_t stream);
+void note_stats(int written);  // dy_conv_stats_written(): set by a convolution launch that fills dy_conv_desc.bn_stats
 }  // namespace dy
 
 namespace DY_NS {
 #ifdef DYOLO_L2E_BUILD
 using ::dy::check_launch;
+using ::dy::note_stats;
 using ::dy::set_error;
 using ::dy::zero_async;
 #endif

@@ -42,6 +42,7 @@ struct HregArgs {
   int N, H, W, Cin, ldx, Cout, ldy, ldres, act;
   int tilesX, tilesY, tilesN, nSpatial;  // spatial tiles (n, ty, tx) and 64-cout groups
   unsigned x_bytes, y_bytes, r_bytes;
+  double* stats;  // optional: a dy_bn_train_fwd workspace; spatial block sb stores its per-channel sum / sum of squares of the STORED outputs in slot sb (dy_conv_desc.bn_stats)
   int dbg;  // -DDYOLO_ABLATE builds only (DYOLO_DBG): 1 no output stores, 2 no MFMAs, 4 no DMA after the prologue, 8 no fragment reads
 };
 
@@ -55,7 +56,13 @@ constexpr int kHrTH = 8, kHrTW = 16, kHrHH = 10, kHrHW = 24;  // 10 x 18 halo pi
 constexpr int kHrStage = 16 * 1024;  // one (tile, chunk) halo image: 10 x 24 x 64 = 15,360 B, padded to the 16 wave-instructions (4 per wave) that fill it
 constexpr int kHrStages = 3;
 
-template <typename T, int NCH, bool RES>
+// STATS: training forward (the convolution in front of a train-mode BatchNorm, conv.py:49-51): the batch statistics of the stored
+// output come out of the epilogue -- a lane always holds the same four output channels, so it keeps their sums over all of its tiles
+// in 8 registers and the kernel ends with one shuffle reduction over the 16 pixel lanes and 32 plain stores per wave into the
+// workgroup's slot of the BatchNorm workspace (dy_bn_train_fwd adds the slots up as it does for its own reduction pass; atomics on
+// the 2 x Cout totals from ~770 workgroups serialise: +0.7 ms per step, measured) -- instead of a separate pass that reads the whole
+// map again (dy_bn_train_fwd's reduction: 1.4 of 10 ms of BatchNorm per step at B = 64).
+template <typename T, int NCH, bool RES, bool STATS = false>
 __global__ __launch_bounds__(256, 3) void conv3x3_hreg_kernel(const HregArgs p) {
   constexpr int EPC = Elem<T>::EPC;  // 8
   __shared__ __attribute__((aligned(1024))) unsigned char smem[kHrStages * kHrStage];
@@ -71,6 +78,14 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hreg_kernel(const HregArgs p) 
   const int nt = logical % p.tilesN;
   const int sb = logical / p.tilesN, Gs = G / p.tilesN;
   const int myTiles = sb < p.nSpatial ? (p.nSpatial - sb + Gs - 1) / Gs : 0;
+  if constexpr (STATS) {
+    if (blockIdx.x == 0)  // the totals the BatchNorm's partial-sum launch adds into
+      for (int i = tid; i < 2 * p.Cout; i += 256) p.stats[i] = 0.0;
+    if (myTiles <= 0 && tid < 128) {  // a slot is summed whether its workgroup had tiles or not
+      const int co = nt * 64 + (tid & 63);
+      if (co < p.Cout) p.stats[(size_t)(1 + sb) * 2 * p.Cout + (tid >> 6) * p.Cout + co] = 0.0;
+    }
+  }
   if (myTiles <= 0) return;
   const int nItems = myTiles * NCH;
 
@@ -203,6 +218,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hreg_kernel(const HregArgs p) 
 #pragma unroll
     for (int o = 0; o < kHrTH; o += 2) lane_out[o / 2] = (unsigned)(((o + (lq & 1)) * p.W + lr) * p.ldy + co16) * (unsigned)sizeof(T);
   }
+  float st_sum[4] = {0.f, 0.f, 0.f, 0.f}, st_sq[4] = {0.f, 0.f, 0.f, 0.f};  // STATS: this lane's four channels, all its tiles
   auto epilogue = [&](int tile) {
     const int tx = tile % p.tilesX;
     const int r = tile / p.tilesX;
@@ -231,6 +247,15 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hreg_kernel(const HregArgs p) 
       t4 ov;
 #pragma unroll
       for (int e = 0; e < 4; ++e) ov[e] = Elem<T>::from_f32(v[e]);
+      if constexpr (STATS) {
+        if (whole || (y0 + o < p.H && x0 + lr < p.W)) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float f = Elem<T>::to_f32(ov[e]);  // what BatchNorm will read back
+            st_sum[e] += f, st_sq[e] += f * f;
+          }
+        }
+      }
       pk[o] = __builtin_bit_cast(u32x2, ov);
       acc[o] = bias4;
     }
@@ -273,6 +298,19 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hreg_kernel(const HregArgs p) 
       }
       __builtin_amdgcn_s_barrier();
       stage = stage + 1 == kHrStages ? 0 : stage + 1;
+    }
+  }
+  if constexpr (STATS) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a = st_sum[e], b = st_sq[e];
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) a += __shfl_xor(a, m, 64), b += __shfl_xor(b, m, 64);  // over the 16 pixel lanes of a quarter
+      const int co = nt * 64 + wave * 16 + lq * 4 + e;
+      if (lr == 0 && co < p.Cout) {
+        double* slot = p.stats + (size_t)(1 + sb) * 2 * p.Cout;
+        slot[co] = (double)a, slot[p.Cout + co] = (double)b;
+      }
     }
   }
 }
@@ -481,6 +519,12 @@ static int launch_hreg(const HregArgs& a, hipStream_t st) {
   const int q = 8 * p.tilesN;
   grid = (grid + q - 1) / q * q;  // the XCD remap and the fixed cout group per block need G % (8 * tilesN) == 0
   const bool res = p.res != nullptr;
+  if (p.stats) {  // conv3x3_hreg_try admits it without a residual only
+    if (nch == 1) hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 1, false, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 2, false, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    note_stats(grid / p.tilesN);  // slots written: one per spatial block
+    return check_launch("conv3x3_hreg_kernel");
+  }
   if (nch == 1) {
     if (res) hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 1, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 1, false>), dim3((unsigned)grid), dim3(256), 0, st, p);
@@ -541,6 +585,7 @@ int conv3x3_hreg_try(const dy_conv_desc* d, hipStream_t st) {
   a.tilesN = d->cout / 64;
   a.nSpatial = d->batch * a.tilesY * a.tilesX;
   a.x_bytes = (unsigned)xb, a.y_bytes = (unsigned)yb, a.r_bytes = (unsigned)rb;
+  a.stats = d->bn_stats;  // (at most 768 + 8 * tilesN - 1 workgroups: the slot count stays below the workspace's 1024)
   a.dbg = dy_ablate("DYOLO_DBG");
   return d->dtype == DY_BF16 ? launch_hreg<bf16_t>(a, st) : launch_hreg<f16_t>(a, st);
 }

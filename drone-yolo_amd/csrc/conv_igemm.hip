@@ -354,6 +354,7 @@ int32_t conv2d_entry(const dy_conv_desc* d, dy_stream_t stream);
 }
 // DY_ACT_SILU_L2E runs the second compilation of the kernels (namespace dy_l2e: silu_f32 is the scaled-domain formula there)
 extern "C" int32_t dy_conv2d_nhwc(const dy_conv_desc* d, dy_stream_t stream) {
+  dy::note_stats(0);
   if (d != nullptr && d->act == DY_ACT_SILU_L2E) {
     dy_conv_desc c = *d;
     c.act = DY_ACT_SILU;

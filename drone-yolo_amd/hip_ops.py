@@ -481,13 +481,21 @@ def conv_out_hw(h: int, w: int, k: int, s: int, p: int) -> Tuple[int, int]:
     return (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
 
 
+def conv_stats_written() -> int:
+    """Partial-sum slots this thread's last ``dy_conv2d_nhwc`` left in ``bn_stats`` (0: the launched kernel has no statistics epilogue)."""
+    return int(lib().dy_conv_stats_written())
+
+
 def conv2d(x: torch.Tensor, pc: PackedConv, out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-           out_f32: bool = False, up2x: bool = False, x2: Optional[torch.Tensor] = None, dil2: bool = False) -> torch.Tensor:
+           out_f32: bool = False, up2x: bool = False, x2: Optional[torch.Tensor] = None, dil2: bool = False,
+           bn_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
     """act(conv(x) + bias) (+ residual) through ``dy_conv2d_nhwc``.
 
     ``x2``: optional second input whose channels follow x's (Concat folded into the gather);
     ``up2x``: x is consumed through a fused 2x nearest upsample.
     ``dil2``: x is consumed zero-dilated by 2 (value at even (h, w) only): the gather of a stride-2 transposed conv.
+    ``bn_stats``: the ``BnState`` of the train-mode BatchNorm that follows: a kernel with the statistics epilogue leaves the output's
+    per-channel partial sums in its workspace (``conv_stats_written()`` = how many slots; hand that to ``bn_train_fwd(partial_slabs=)``).
     """
     require_device(x, "conv2d input")
     if x.dtype != pc.dtype:
@@ -513,6 +521,10 @@ def conv2d(x: torch.Tensor, pc: PackedConv, out: Optional[torch.Tensor] = None, 
     d.ksize, d.stride, d.pad, d.groups = pc.k, pc.stride, pc.pad, pc.groups
     d.act, d.dtype, d.out_f32 = pc.act, dy_dtype(x.dtype), int(out_f32)
     d.k_pad, d.cout_pad, d.up2x, d.w_layout = pc.k_pad, pc.cout_pad, (2 if dil2 else int(up2x)), pc.layout
+    if bn_stats is not None:
+        if bn_stats.c != pc.cout:
+            raise ValueError("conv2d: bn_stats must be the BnState of a BatchNorm over the output channels")
+        d.bn_stats = bn_stats.ws.data_ptr()
     if residual is not None:
         if tuple(residual.shape) != tuple(out.shape) or residual.dtype != x.dtype:
             raise ValueError("conv2d: residual must match the output shape and the input dtype")
@@ -922,6 +934,7 @@ class BnState:
     """Saved batch statistics + workspace of one BatchNorm layer for one training step."""
 
     def __init__(self, c: int, device):
+        self.c = c
         self.mean = torch.empty(c, dtype=torch.float32, device=device)
         self.rstd = torch.empty(c, dtype=torch.float32, device=device)
         self.ws = torch.empty(lib().dy_bn_workspace_bytes(c), dtype=torch.uint8, device=device)
@@ -933,8 +946,9 @@ def _rows(t: torch.Tensor) -> int:
 
 def bn_train_fwd(z: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, state: BnState, act: bool, eps: float = 1e-3,
                  momentum: float = 0.03, running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None,
-                 addend: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = act(BN_batchstats(z) (+ addend)) through ``dy_bn_train_fwd``; z, y, addend: NHWC views (N, C, H, W)."""
+                 addend: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, partial_slabs: int = 0) -> torch.Tensor:
+    """y = act(BN_batchstats(z) (+ addend)) through ``dy_bn_train_fwd``; z, y, addend: NHWC views (N, C, H, W).
+    ``partial_slabs``: > 0 = ``state``'s workspace already holds that many partial-sum slots of z (``conv2d(bn_stats=state)``): no reduction pass."""
     require_device(z, "bn input")
     n, c, h, w = z.shape
     if out is None:
@@ -949,6 +963,7 @@ def bn_train_fwd(z: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, state
         d.running_mean, d.running_var = running_mean.data_ptr(), running_var.data_ptr()
     d.eps, d.momentum = eps, momentum
     d.workspace, d.workspace_bytes = state.ws.data_ptr(), state.ws.numel()
+    d.partial_slabs = int(partial_slabs)
     _launch(lib().dy_bn_train_fwd, (C.byref(d),), keep=(d, z, out, addend, gamma, beta, state, running_mean, running_var))
     return out
 

@@ -31,14 +31,21 @@ def as_nhwc(t: torch.Tensor) -> torch.Tensor:
     return out
 
 
+CONV_STATS = [os.environ.get("DYOLO_CONV_STATS", "1") != "0"]  # BatchNorm statistics from convolution epilogues (conv_bn_fwd)
+
+
 def conv_bn_fwd(x, weight, gamma, beta, bn, stride, pad, act, out=None):
     """z = conv2d(x, weight), y = act(BN_batchstats(z)) (y into ``out`` when given): returns (z, BnState, y)."""
     dtype, dev = x.dtype, x.device
     cin_pad = x.shape[1] if x.shape[1] != weight.shape[1] else None  # image padded to one chunk
     pc = H.PackedConv(weight, H.zero_bias(weight.shape[0], dev), stride, pad, 1, False, dtype, dev, cin_pad=cin_pad)
-    z = H.conv2d(x, pc)
+    # batch statistics from the convolution's epilogue where the launched kernel has one (dy_conv_desc.bn_stats): partial sums straight
+    # into the BatchNorm's workspace, no reduction pass over z
     st = H.BnState(weight.shape[0], dev)
-    y = H.bn_train_fwd(z, gamma, beta, st, act, eps=bn.eps, momentum=bn.momentum, running_mean=bn.running_mean, running_var=bn.running_var, out=out)
+    z = H.conv2d(x, pc, bn_stats=st if CONV_STATS[0] else None)
+    slabs = H.conv_stats_written() if CONV_STATS[0] else 0
+    y = H.bn_train_fwd(z, gamma, beta, st, act, eps=bn.eps, momentum=bn.momentum, running_mean=bn.running_mean, running_var=bn.running_var, out=out,
+                       partial_slabs=slabs)
     return z, st, y
 
 

@@ -137,6 +137,12 @@ typedef struct dy_conv_desc {
    * DY_WLAYOUT_ROWS only.  Ignored (may be NULL / 0) for the other dtypes. */
   const float* w_scale;
   float act_scale;
+  /* Training forward in front of a train-mode BatchNorm (conv.py:49-51): optional pointer to that BatchNorm's dy_bn_desc.workspace.
+   * A kernel built for it stores, from its epilogue, per-channel partial sums and sums of squares of the STORED output values there
+   * (one slot per spatial workgroup, in the layout of dy_bn_train_fwd's own reduction pass, totals zeroed), so the batch statistics
+   * need no pass of their own: dy_conv_stats_written() returns the number of slots the calling thread's last dy_conv2d_nhwc wrote
+   * (0: the dispatched kernel has no such epilogue, nothing was touched) -- hand it to dy_bn_desc.partial_slabs.  NULL = off. */
+  double* bn_stats;
 } dy_conv_desc;
 
 /* Quantise a 16-bit / fp32 NHWC view to DY_FP8: dst_q = sat_e4m3(src / act_scale).  c % 16 == 0, views 16-byte aligned.
@@ -169,6 +175,7 @@ int32_t dy_pack_conv_weights_batched(const void* table_dev, int32_t n_jobs, int3
 int32_t dy_conv_k_pad(int32_t cin, int32_t ksize, int32_t dtype);
 int32_t dy_conv_cout_pad(int32_t cout);
 int32_t dy_conv2d_nhwc(const dy_conv_desc* d, dy_stream_t stream);
+int32_t dy_conv_stats_written(void); /* > 0: slots of d->bn_stats the last dy_conv2d_nhwc of this thread filled */
 
 /* ---- one Detect branch from its second 3x3 convolution to the decoded output ------------------------------
  * Replaces in ONE kernel per (level, branch), 16-bit storage: Detect.forward's cv2[i][1] -> cv2[i][2] (kind 1, box) or cv3[i][1] ->
@@ -512,6 +519,9 @@ typedef struct dy_bn_desc {
   float* dbeta;
   void* workspace;
   int64_t workspace_bytes;
+  /* Forward only: > 0 = the workspace ALREADY holds that many partial-sum slots of z (a convolution epilogue wrote them:
+   * dy_conv_desc.bn_stats / dy_conv_stats_written): the reduction pass over z is skipped.  0: the pass runs. */
+  int32_t partial_slabs;
 } dy_bn_desc;
 int64_t dy_bn_workspace_bytes(int32_t c);
 int32_t dy_bn_train_fwd(const dy_bn_desc* d, dy_stream_t stream);

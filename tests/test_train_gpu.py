@@ -143,6 +143,40 @@ def test_head_grad_split_matches_torch(dtype, device):
         assert float(dzc[:, nc:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("cin,cout,b,h,w", [(64, 64, 3, 40, 48), (64, 128, 2, 23, 37), (64, 64, 5, 8, 16)])
+def test_conv_epilogue_batchnorm_statistics(cin, cout, b, h, w, dtype, device):
+    """dy_conv_desc.bn_stats: the register-weight 3x3 kernel leaves per-workgroup sums / sums of squares of its STORED output per channel
+    (ragged tiles masked) in the BatchNorm workspace; dy_bn_train_fwd with partial_slabs then gives what its own reduction pass gives."""
+    g = torch.Generator().manual_seed(cout + h)
+    x = nhwc(quantize(torch.randn(b, cin, h, w, generator=g), dtype), dtype, device)
+    wt = quantize(torch.randn(cout, cin, 3, 3, generator=g) * 0.06, dtype).to(device)
+    pc = H.PackedConv(wt, H.zero_bias(cout, device), 1, 1, 1, False, dtype, device)
+    gamma, beta = torch.rand(cout, device=device) + 0.5, torch.randn(cout, device=device) * 0.2
+    s1, s2 = H.BnState(cout, device), H.BnState(cout, device)
+    s2.ws.fill_(0xFF)  # whatever the workspace held
+    z = H.conv2d(x, pc, bn_stats=s2)
+    slabs = H.conv_stats_written()
+    assert slabs > 0
+    torch.cuda.synchronize()
+    part = s2.ws.view(torch.float64)[2 * cout : (1 + slabs) * 2 * cout].view(slabs, 2 * cout).sum(0)
+    zf = z.double()
+    ref = torch.cat([zf.sum((0, 2, 3)), (zf * zf).sum((0, 2, 3))])
+    assert float((part - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    y1 = H.bn_train_fwd(z, gamma, beta, s1, True)
+    y2 = H.bn_train_fwd(z, gamma, beta, s2, True, partial_slabs=slabs)
+    torch.cuda.synchronize()
+    assert float((s1.mean - s2.mean).abs().max()) <= 1e-5 * float(s1.mean.abs().max()) + 1e-7
+    assert float((s1.rstd - s2.rstd).abs().max()) <= 1e-5 * float(s1.rstd.abs().max())
+    assert float((y1.float() - y2.float()).abs().max()) <= TOL[dtype] * float(y1.float().abs().max())
+    # a kernel without the epilogue (1x1 here) leaves the workspace alone and says so
+    pc1 = H.PackedConv(quantize(torch.randn(cout, cin, 1, 1, generator=g) * 0.1, dtype).to(device), H.zero_bias(cout, device), 1, 0, 1, False, dtype, device)
+    before = s1.ws.clone()
+    H.conv2d(x, pc1, bn_stats=s1)
+    torch.cuda.synchronize()
+    assert H.conv_stats_written() == 0 and torch.equal(before, s1.ws)
+
+
 def test_batched_weight_packing_equals_single_launches(device):
     """dy_pack_conv_weights_batched (one launch for a step's ~160 packings) against dy_pack_conv_weights job by job: forward and
     input-gradient (transposed, flipped) forms, 1x1 / 3x3, every layout PackedConv picks, the padded image stem; then the cache protocol:
