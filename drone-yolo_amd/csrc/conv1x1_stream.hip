@@ -38,9 +38,14 @@ struct Conv1Args {
   int Cout, ldy, act;
   int tilesN, nMT;
   FastDiv div_hw, div_w;  // m / (H*W) and r / W of the up2x pixel decode
+  double* stats;  // optional: a dy_bn_train_fwd workspace, pixel group g's per-channel sums / sums of squares of the STORED output go to slot g (dy_conv_desc.bn_stats)
 };
 
-template <typename T, int NKG, int MF, int NF, bool OUTF32>
+// STATS (training forward in front of a train-mode BatchNorm): in the row-store pass of the epilogue a lane always holds the same 8
+// output channels (chunk lane % CPR of the tile's rows), so it keeps their sum / sum of squares over all of its wave's tiles in 16
+// registers; the kernel ends with a shuffle reduction over the lanes of a chunk, a sum over the 8 waves through LDS and plain stores
+// into the workgroup's slot of the BatchNorm workspace (see conv3x3_hreg.hip: same protocol).
+template <typename T, int NKG, int MF, int NF, bool OUTF32, bool STATS = false>
 __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const Conv1Args p) {
   constexpr int NT = 512;
   constexpr int EPC = Elem<T>::EPC;
@@ -83,7 +88,16 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const Conv1Args p) 
   OutT* __restrict__ yg = reinterpret_cast<OutT*>(p.y);
   const int stride = groups * 8;
   int mt = group * 8 + wave;
-  if (mt >= p.nMT) return;
+  if (!STATS && mt >= p.nMT) return;
+  constexpr int CPR_S = BN * (int)sizeof(OutT) / 16;  // 16-byte chunks per output row of the tile (STATS: a lane's chunk is lane % CPR_S)
+  float st_sum[STATS ? 8 : 1], st_sq[STATS ? 8 : 1];
+  if constexpr (STATS) {
+    static_assert(!STATS || (sizeof(OutT) == 2 && 64 % CPR_S == 0), "STATS: 16-bit output, the chunk of a lane must not depend on the round");
+#pragma unroll
+    for (int e = 0; e < 8; ++e) st_sum[e] = 0.f, st_sq[e] = 0.f;
+    if (blockIdx.x == 0)  // the totals the BatchNorm's partial-sum launch adds into
+      for (int i = tid; i < 2 * p.Cout; i += NT) p.stats[i] = 0.0;
+  }
 
   // measured per layer (B = 256): K = 128 -10 %, K = 192 -2 %, K = 256 +4 %, K = 384 +11 %: the crossbar passes grow with K, the
   // saved L1 requests do not pay for them from K = 256 up
@@ -169,6 +183,14 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const Conv1Args p) 
       const int co = nt * BN + cc * VE;
       if ((MF * 16 * CPR) % 64 != 0 && pixl >= MF * 16) continue;
       const u32x4 val = *reinterpret_cast<const u32x4*>(escr + pixl * EP_PITCH + cc * 16);
+      if constexpr (STATS) {
+        if (m < p.M) {  // (channels past Cout hold zeros: zero weights and bias)
+          float f[8];
+          Chunk<T>::unpack(val, f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) st_sum[e] += f[e], st_sq[e] += f[e] * f[e];
+        }
+      }
       if (m < p.M && co < p.Cout) {
         OutT* yp = yg + (size_t)m * (size_t)p.ldy + co;
         if (co + VE <= p.Cout) {
@@ -188,8 +210,8 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const Conv1Args p) 
   // (a_cur, a register copy) is multiplied.  One load body and one compute body keep the kernel inside
   // the 256-VGPR budget of a 512-thread workgroup.
   u32x4 a_cur[MF][NKG], a_nxt[MF][NKG];
-  load_tile(mt, a_nxt);
-  while (true) {
+  if (mt < p.nMT) load_tile(mt, a_nxt);
+  while (mt < p.nMT) {
 #pragma unroll
     for (int i = 0; i < MF; ++i)
 #pragma unroll
@@ -202,6 +224,27 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const Conv1Args p) 
     process(mt, a_cur);
     if (nx >= p.nMT) break;
     mt = nx;
+  }
+  if constexpr (STATS) {
+    // lanes of one chunk (lane % CPR_S) -> the wave's sums; the wave leaves them in ITS scratch, then 2 * BN threads add the 8 waves up
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int msk = CPR_S; msk < 64; msk <<= 1) st_sum[e] += __shfl_xor(st_sum[e], msk, 64), st_sq[e] += __shfl_xor(st_sq[e], msk, 64);
+    }
+    float* wsum = reinterpret_cast<float*>(escr);  // [2][BN]
+    if (lane < CPR_S) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wsum[lane * 8 + e] = st_sum[e], wsum[BN + lane * 8 + e] = st_sq[e];
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, ch = tid - which * BN, co = nt * BN + ch;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += reinterpret_cast<const float*>(dyn_smem + W_CHUNKS * 16 + BN * 4 + w * EP_BYTES)[which * BN + ch];
+      if (co < p.Cout) p.stats[(size_t)(1 + group) * 2 * p.Cout + which * p.Cout + co] = (double)t;
+    }
   }
 }
 
@@ -221,6 +264,18 @@ static int launch_1x1(const Conv1Args& a, hipStream_t st) {
   if (groups < 1) groups = 1;
   const int need = (p.nMT + 7) / 8;  // groups that still get at least one tile per wave-slot
   if (groups > need) groups = need;
+#ifndef DYOLO_L2E_BUILD
+  if constexpr (!OUTF32 && sizeof(T) == 2 && NF >= 4) {
+    if (p.stats) {
+      auto kern_s = conv1x1_stream_kernel<T, NKG, MF, NF, OUTF32, true>;
+      static const hipError_t once_s = hipFuncSetAttribute((const void*)kern_s, hipFuncAttributeMaxDynamicSharedMemorySize, kLds1);
+      (void)once_s;
+      hipLaunchKernelGGL(kern_s, dim3((unsigned)(groups * p.tilesN)), dim3(512), smem, st, p);
+      note_stats(groups);  // slots written: one per pixel group
+      return check_launch("conv1x1_stream_kernel");
+    }
+  }
+#endif
   auto kern = conv1x1_stream_kernel<T, NKG, MF, NF, OUTF32>;
   static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLds1);
   (void)once;
@@ -295,6 +350,7 @@ int conv1x1_stream_dispatch(const dy_conv_desc* d, hipStream_t st) {
   a.act = d->act;
   a.div_hw = make_fastdiv((unsigned)(d->h * d->w_in));
   a.div_w = make_fastdiv((unsigned)d->w_in);
+  a.stats = d->bn_stats;
   if (d->x2) {
     DY_REQUIRE(d->cin_split > 0 && d->cin_split < d->cin && d->cin_split % epc == 0, DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: bad cin_split %d", d->cin_split);
     DY_REQUIRE(aligned16(d->x2) && (d->ld_x2 * es) % 16 == 0, DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: x2 view misaligned");

@@ -144,14 +144,15 @@ def test_head_grad_split_matches_torch(dtype, device):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
-@pytest.mark.parametrize("cin,cout,b,h,w", [(64, 64, 3, 40, 48), (64, 128, 2, 23, 37), (64, 64, 5, 8, 16)])
-def test_conv_epilogue_batchnorm_statistics(cin, cout, b, h, w, dtype, device):
-    """dy_conv_desc.bn_stats: the register-weight 3x3 kernel leaves per-workgroup sums / sums of squares of its STORED output per channel
+@pytest.mark.parametrize("cin,cout,k,b,h,w", [(64, 64, 3, 3, 40, 48), (64, 128, 3, 2, 23, 37), (64, 64, 3, 5, 8, 16), (64, 64, 1, 3, 40, 48), (192, 128, 1, 2, 23, 37),
+                                               (96, 64, 1, 1, 7, 9), (384, 256, 1, 4, 20, 20), (128, 128, 1, 2, 33, 31), (256, 128, 1, 2, 16, 16)])
+def test_conv_epilogue_batchnorm_statistics(cin, cout, k, b, h, w, dtype, device):
+    """dy_conv_desc.bn_stats: the register-weight 3x3 kernel and the streaming 1x1 kernel leave per-workgroup sums / sums of squares of its STORED output per channel
     (ragged tiles masked) in the BatchNorm workspace; dy_bn_train_fwd with partial_slabs then gives what its own reduction pass gives."""
     g = torch.Generator().manual_seed(cout + h)
     x = nhwc(quantize(torch.randn(b, cin, h, w, generator=g), dtype), dtype, device)
-    wt = quantize(torch.randn(cout, cin, 3, 3, generator=g) * 0.06, dtype).to(device)
-    pc = H.PackedConv(wt, H.zero_bias(cout, device), 1, 1, 1, False, dtype, device)
+    wt = quantize(torch.randn(cout, cin, k, k, generator=g) * 0.06, dtype).to(device)
+    pc = H.PackedConv(wt, H.zero_bias(cout, device), 1, k // 2, 1, False, dtype, device)
     gamma, beta = torch.rand(cout, device=device) + 0.5, torch.randn(cout, device=device) * 0.2
     s1, s2 = H.BnState(cout, device), H.BnState(cout, device)
     s2.ws.fill_(0xFF)  # whatever the workspace held
@@ -169,10 +170,10 @@ def test_conv_epilogue_batchnorm_statistics(cin, cout, b, h, w, dtype, device):
     assert float((s1.mean - s2.mean).abs().max()) <= 1e-5 * float(s1.mean.abs().max()) + 1e-7
     assert float((s1.rstd - s2.rstd).abs().max()) <= 1e-5 * float(s1.rstd.abs().max())
     assert float((y1.float() - y2.float()).abs().max()) <= TOL[dtype] * float(y1.float().abs().max())
-    # a kernel without the epilogue (1x1 here) leaves the workspace alone and says so
-    pc1 = H.PackedConv(quantize(torch.randn(cout, cin, 1, 1, generator=g) * 0.1, dtype).to(device), H.zero_bias(cout, device), 1, 0, 1, False, dtype, device)
+    # a kernel without the epilogue (3x3 from 32 channels: the LDS-weight kernel) leaves the workspace alone and says so
+    pc1 = H.PackedConv(quantize(torch.randn(cout, 32, 3, 3, generator=g) * 0.1, dtype).to(device), H.zero_bias(cout, device), 1, 1, 1, False, dtype, device)
     before = s1.ws.clone()
-    H.conv2d(x, pc1, bn_stats=s1)
+    H.conv2d(x[:, :32], pc1, bn_stats=s1)
     torch.cuda.synchronize()
     assert H.conv_stats_written() == 0 and torch.equal(before, s1.ws)
 
