@@ -676,7 +676,7 @@ struct Wgrad3Plan {
 static Wgrad3Plan wgrad3_plan(const WgradArgs& a, int batch, int stride) {
   Wgrad3Plan g{};
   // four output rows per step where the map is tall enough to fill them (stride 1: the 6 x 18 halo + 64 dz pixels are 27 KB a stage);
-  // stride 2 keeps two rows (its halo is 5 x 33 already)
+  // stride 2 keeps two rows (its halo is 5 x 33 already; four rows -- 9 x 33, 58 KB a stage -- measured 25-60 % slower on every stride-2 layer)
   static const int rs2 = dy_ablate("DYOLO_WGRAD3_RS2");
   g.rs = (stride == 1 && !rs2 && a.Ho % 4 == 0) ? 4 : 2;
   g.stepsX = (a.Wo + 15) / 16, g.stepsY = (a.Ho + g.rs - 1) / g.rs;
