@@ -195,6 +195,7 @@ SIGNATURES = {
     "dy_upsample2x_bwd_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dy_maxpool_bwd_nhwc": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dy_add_nhwc": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "dy_add_dilated2_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dy_head_grad_split": (_i32, [_vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _vp]),
     "dy_sumsq_f32": (_i32, [_vp, _i64, _vp, _vp]),
     "dy_sgd_step": (_i32, [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _i32, _i32, _vp, _f32, _vp, _vp]),

@@ -151,6 +151,29 @@ __global__ __launch_bounds__(256) void head_grad_split_kernel(const float* __res
   }
 }
 
+// ---- dx[n][2y][2x][:] += t[n][y][x][:]: the input gradient of a 1x1 STRIDE-2 convolution (RepVGGBlock's side branch, block.py:1480-1490)
+// reaches only the even positions.  t = the 1x1 stride-1 convolution of dz with the transposed weights (a quarter of the pixels of
+// dx); the zero-dilated gather it replaces ran the generic implicit-GEMM kernel over ALL pixels of dx, three quarters of them for zeros.
+template <typename T>
+__global__ __launch_bounds__(256) void add_dilated2_kernel(const T* __restrict__ t, T* __restrict__ dx, int n, int h, int w, int H2, int W2, int cchunks, int ld_t, int ld_dx) {
+  constexpr int E = Elem<T>::EPC;
+  const long long total = (long long)n * h * w * cchunks;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cc = (int)(i % cchunks);
+    long long r = i / cchunks;
+    const int x = (int)(r % w);
+    r /= w;
+    const int y = (int)(r % h), img = (int)(r / h);
+    float a[E], b[E];
+    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(t + (((long long)img * h + y) * w + x) * ld_t + cc * E), a);
+    T* dst = dx + (((long long)img * H2 + 2 * y) * W2 + 2 * x) * ld_dx + cc * E;
+    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(dst), b);
+#pragma unroll
+    for (int e = 0; e < E; ++e) a[e] += b[e];
+    *reinterpret_cast<u32x4*>(dst) = Chunk<T>::pack(a);
+  }
+}
+
 // ---- out = a + b on (rows, c) views ----------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, long long rows, int cchunks, int lda, int ldb, int ldo) {
@@ -407,6 +430,20 @@ extern "C" int32_t dy_head_grad_split(const float* g, int32_t ld_g, int64_t rows
   else if (dtype == DY_F16) hipLaunchKernelGGL((head_grad_split_kernel<f16_t>), dim3(grid), dim3(256), 0, st, g, ld_g, (long long)rows, nb, nc, ncp, scale, (f16_t*)dzb, ld_b, (f16_t*)dzc, ld_c);
   else hipLaunchKernelGGL((head_grad_split_kernel<float>), dim3(grid), dim3(256), 0, st, g, ld_g, (long long)rows, nb, nc, ncp, scale, (float*)dzb, ld_b, (float*)dzc, ld_c);
   return check_launch("dy_head_grad_split");
+}
+
+extern "C" int32_t dy_add_dilated2_nhwc(const void* t, void* dx, int32_t n, int32_t h, int32_t w, int32_t H2, int32_t W2, int32_t c, int32_t ld_t, int32_t ld_dx,
+                                        int32_t dtype, dy_stream_t stream) {
+  const int es = dtype_size_no_fp8(dtype);
+  DY_REQUIRE(es && t && dx && n > 0 && h > 0 && w > 0 && c > 0 && H2 >= 2 * h - 1 && W2 >= 2 * w - 1, DY_ERR_INVALID_ARG, "dy_add_dilated2_nhwc: bad arguments");
+  const int epc = 16 / es;
+  DY_REQUIRE(c % epc == 0 && DY_VIEW_OK(t, ld_t, c, es) && DY_VIEW_OK(dx, ld_dx, c, es), DY_ERR_INVALID_ARG, "dy_add_dilated2_nhwc: views must be whole 16-byte chunks");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const unsigned grid = grid1((long long)n * h * w * (c / epc));
+  if (dtype == DY_BF16) hipLaunchKernelGGL((add_dilated2_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)t, (bf16_t*)dx, n, h, w, H2, W2, c / epc, ld_t, ld_dx);
+  else if (dtype == DY_F16) hipLaunchKernelGGL((add_dilated2_kernel<f16_t>), dim3(grid), dim3(256), 0, st, (const f16_t*)t, (f16_t*)dx, n, h, w, H2, W2, c / epc, ld_t, ld_dx);
+  else hipLaunchKernelGGL((add_dilated2_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)t, (float*)dx, n, h, w, H2, W2, c / epc, ld_t, ld_dx);
+  return check_launch("dy_add_dilated2_nhwc");
 }
 
 extern "C" int32_t dy_add_nhwc(const void* a, const void* b, void* out, int64_t rows, int32_t c, int32_t ld_a, int32_t ld_b, int32_t ld_o, int32_t dtype, dy_stream_t stream) {

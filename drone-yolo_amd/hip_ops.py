@@ -1163,6 +1163,16 @@ def maxpool_bwd(x: torch.Tensor, g_out: torch.Tensor, g_in: torch.Tensor, k: int
     return g_in
 
 
+def add_dilated2_(dx: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """dx[:, :, ::2, ::2] += t in place (``dy_add_dilated2_nhwc``): NHWC views of one dtype, t (n, c, ceil(H/2), ceil(W/2))."""
+    n, c, h2, w2 = dx.shape
+    if t.shape[0] != n or t.shape[1] != c or t.shape[2] != (h2 + 1) // 2 or t.shape[3] != (w2 + 1) // 2 or t.dtype != dx.dtype:
+        raise ValueError("add_dilated2_: t must be the half-resolution map of dx")
+    (tp, ldt), (xp, ldx) = view_params(t), view_params(dx)
+    _launch(lib().dy_add_dilated2_nhwc, (tp, xp, n, t.shape[2], t.shape[3], h2, w2, c, ldt, ldx, dy_dtype(dx.dtype)), keep=(t, dx))
+    return dx
+
+
 def head_grad_split(g: torch.Tensor, nb: int, nc: int, ncp: int, dtype: torch.dtype, scale: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """(dzb, dzc) of ``dy_head_grad_split``: ``g`` an fp32 NHWC view (n, nb + nc, h, w); ``scale`` a device fp32 scalar or None."""
     n, c, h, w = g.shape

@@ -538,6 +538,8 @@ int32_t dy_silu_bwd(const void* u, const void* dy, void* du, int64_t rows, int32
  *   gradient goes to the FIRST maximum of its window in (row, column) order (torch semantics); g_in = (accumulate ?
  *   g_in : 0) + that.  h*w*(16/elem_size)*17 bytes of LDS per workgroup (h*w <= ~1200).
  * dy_add_nhwc: out = a + b, (rows, c) views (Bottleneck's shortcut, block.py:348-350).  c % one 16-byte chunk == 0.
+ * dy_add_dilated2_nhwc: dx (n, H2, W2, c)[:, 2y, 2x] += t (n, h, w, c)[:, y, x] -- the input gradient of a 1x1 STRIDE-2 convolution
+ *   (RepVGGBlock's 1x1 branch, block.py:1480-1490) from t = the 1x1 stride-1 convolution of dz with the transposed weights.
  * dy_head_grad_split: the gradient of Detect's fp32 training map cat(box, cls) (head.py:69-72; g: (rows, nb + nc) fp32, pitch ld_g) as the
  *   `dtype` operands of the two 1x1 convolutions' gradient kernels in one pass: dzb = s * g[:, :nb]; dzc = s * g[:, nb:nb+nc], zero-padded
  *   to ncp channels; s = *scale (optional DEVICE scalar: the seed loss.backward() starts from, the loss scale under fp16) or 1. */
@@ -545,6 +547,8 @@ int32_t dy_upsample2x_bwd_nhwc(const void* g, void* dx, int32_t n, int32_t h, in
                                int32_t dtype, dy_stream_t stream);
 int32_t dy_maxpool_bwd_nhwc(const void* x, const void* g_out, void* g_in, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ld_x,
                             int32_t ld_go, int32_t ld_gi, int32_t k, int32_t accumulate, int32_t dtype, dy_stream_t stream);
+int32_t dy_add_dilated2_nhwc(const void* t, void* dx, int32_t n, int32_t h, int32_t w, int32_t H2, int32_t W2, int32_t c, int32_t ld_t, int32_t ld_dx,
+                             int32_t dtype, dy_stream_t stream);
 int32_t dy_head_grad_split(const float* g, int32_t ld_g, int64_t rows, int32_t nb, int32_t nc, int32_t ncp, const float* scale, void* dzb, int32_t ld_b,
                            void* dzc, int32_t ld_c, int32_t dtype, dy_stream_t stream);
 int32_t dy_add_nhwc(const void* a, const void* b, void* out, int64_t rows, int32_t c, int32_t ld_a, int32_t ld_b, int32_t ld_o,

@@ -178,6 +178,25 @@ def test_conv_epilogue_batchnorm_statistics(cin, cout, k, b, h, w, dtype, device
     assert H.conv_stats_written() == 0 and torch.equal(before, s1.ws)
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("cin,cout,b,h,w", [(32, 64, 2, 40, 40), (64, 128, 2, 21, 27), (128, 256, 1, 10, 10)])
+def test_1x1_stride2_input_gradient_by_scatter(cin, cout, b, h, w, dtype, device):
+    """RepVGG's 1x1 stride-2 branch: dx = scatter of (1x1 stride-1 convolution of dz with the transposed weights) to the even positions,
+    added onto a gradient already held (dy_add_dilated2_nhwc), against autograd; odd map sizes included."""
+    g = torch.Generator().manual_seed(cin + h)
+    x = quantize(torch.randn(b, cin, h, w, generator=g), dtype).requires_grad_(True)
+    wt = quantize(torch.randn(cout, cin, 1, 1, generator=g) * 0.1, dtype).requires_grad_(True)
+    z = F.conv2d(x, wt, None, 2, 0)
+    dz = quantize(torch.randn(z.shape, generator=g), dtype)
+    z.backward(dz)
+    prev = quantize(torch.randn(x.shape, generator=g), dtype)
+    dx = nhwc(prev, dtype, device)
+    t = H.conv2d(nhwc(dz, dtype, device), H.pack_dgrad(wt.detach().to(device), 1, dtype, device))
+    H.add_dilated2_(dx, t)
+    torch.cuda.synchronize()
+    close(dx, x.grad + prev, dtype, "1x1 s2 dgrad scatter", extra=2.0)
+
+
 def test_batched_weight_packing_equals_single_launches(device):
     """dy_pack_conv_weights_batched (one launch for a step's ~160 packings) against dy_pack_conv_weights job by job: forward and
     input-gradient (transposed, flipped) forms, 1x1 / 3x3, every layout PackedConv picks, the padded image stem; then the cache protocol:
