@@ -77,45 +77,76 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// Sum of v over the 256-thread workgroup, in thread 0 (callers add it to a global accumulator: ONE atomic per workgroup and value.
+// The first form ended every WAVE with its own double atomics on the same few addresses -- 16 k waves x 5 values in loss_fg_kernel --
+// and those serialise: 505 us for a kernel whose work is 3 % of the anchors).
+__device__ __forceinline__ double block_sum(double v, double* red /* [4] in LDS */) {
+  v = wave_sum(v);
+  __syncthreads();  // red may still be read from the previous call
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
 // ---- K1 -------------------------------------------------------------------------------------------------------
+// Thread = (anchor, side): the side's 16 bins are ONE 64-byte run, read as four 16-byte loads (one thread per anchor read its 296-byte
+// row a float at a time, twice: 374 us at B = 64); lane `side` writes its own corner; side 0 also sums the class softplus terms.
 __global__ __launch_bounds__(256) void loss_decode_kernel(const LossArgs p) {
-  const long long total = (long long)p.batch * p.A;
+  __shared__ double red[4];
   double sp = 0.0;
-  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    const int b = (int)(idx / p.A), a = (int)(idx - (long long)b * p.A);
-    int l, gx, gy;
-    const float* r = row_ptr(p, b, a, &l, &gx, &gy);
-    float d[4];
+  for (int l = 0; l < p.n_levels; ++l) {  // level by level: per-level arguments are scalars (see loss_grad_dense_kernel)
+    const unsigned w = (unsigned)p.w[l], hw = (unsigned)p.h[l] * w, total = (unsigned)p.batch * hw * 4u;
+    const float* __restrict__ lv = p.level[l];
+    const size_t ld = (size_t)p.ld[l];
+    const unsigned a0 = (unsigned)p.a0[l];
+    const float st = p.stride[l];
+    for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
+      const unsigned row = t >> 2;  // b * hw + anchor of the level
+      const int sd = (int)(t & 3);
+      const unsigned b = row / hw, al = row - b * hw;
+      const unsigned gy = al / w, gx = al - gy * w;
+      const size_t idx = (size_t)b * p.A + a0 + al;
+      const float* r = lv + (size_t)row * ld;
+      float q[kRegMax];
+      const float* src = r + sd * kRegMax;
+      if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      float mx = r[s * kRegMax];
-      for (int i = 1; i < kRegMax; ++i) mx = fmaxf(mx, r[s * kRegMax + i]);
+        for (int i = 0; i < kRegMax; i += 4) {
+          const float4 v = *reinterpret_cast<const float4*>(src + i);
+          q[i] = v.x, q[i + 1] = v.y, q[i + 2] = v.z, q[i + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < kRegMax; ++i) q[i] = src[i];
+      }
+      float mx = q[0];
+#pragma unroll
+      for (int i = 1; i < kRegMax; ++i) mx = fmaxf(mx, q[i]);
       float den = 0.f, num = 0.f;
+#pragma unroll
       for (int i = 0; i < kRegMax; ++i) {
-        const float e = expf(r[s * kRegMax + i] - mx);
+        const float e = expf(q[i] - mx);
         den += e;
         num += e * (float)i;
       }
-      d[s] = num / den;
+      const float d = num / den;
+      const float ac = (float)((sd & 1) ? gy : gx) + 0.5f;
+      p.pbox[idx * 4 + sd] = (sd < 2 ? ac - d : ac + d) * st;
+      if (sd == 0) {
+        const float* cl = r + 4 * kRegMax;
+        float sm = 0.f;
+        for (int c = 0; c < p.nc; ++c) {
+          const float x = cl[c];
+          sm += fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));  // BCEWithLogits against target 0
+        }
+        sp += (double)sm;
+        p.claims[idx] = 0;
+        p.owner[idx] = -1;
+      }
     }
-    const float ax = (float)gx + 0.5f, ay = (float)gy + 0.5f, st = p.stride[l];
-    float* o = p.pbox + (size_t)idx * 4;
-    o[0] = (ax - d[0]) * st;
-    o[1] = (ay - d[1]) * st;
-    o[2] = (ax + d[2]) * st;
-    o[3] = (ay + d[3]) * st;
-    const float* cl = r + 4 * kRegMax;
-    float s = 0.f;
-    for (int c = 0; c < p.nc; ++c) {
-      const float x = cl[c];
-      s += fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));  // BCEWithLogits against target 0
-    }
-    sp += (double)s;
-    p.claims[idx] = 0;
-    p.owner[idx] = -1;
   }
-  sp = wave_sum(sp);
-  if ((threadIdx.x & 63) == 0 && sp != 0.0) atomicAdd(p.acc + 0, sp);
+  sp = block_sum(sp, red);
+  if (threadIdx.x == 0 && sp != 0.0) atomicAdd(p.acc + 0, sp);
 }
 
 // metric and overlap of (gt box g of image b, anchor a); 0 when the anchor centre is not strictly inside the box
@@ -231,6 +262,7 @@ __global__ __launch_bounds__(256) void tal_gtmax_kernel(const LossArgs p) {
 }
 
 __global__ __launch_bounds__(256) void loss_fg_kernel(const LossArgs p) {
+  __shared__ double red[4];
   const long long total = (long long)p.batch * p.A;
   double s_t = 0.0, s_xt = 0.0, s_box = 0.0, s_dfl = 0.0, s_n = 0.0;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -273,8 +305,8 @@ __global__ __launch_bounds__(256) void loss_fg_kernel(const LossArgs p) {
     s_dfl += (double)(dfl * t);
     s_n += 1.0;
   }
-  s_t = wave_sum(s_t), s_xt = wave_sum(s_xt), s_box = wave_sum(s_box), s_dfl = wave_sum(s_dfl), s_n = wave_sum(s_n);
-  if ((threadIdx.x & 63) == 0 && s_n != 0.0) {
+  s_t = block_sum(s_t, red), s_xt = block_sum(s_xt, red), s_box = block_sum(s_box, red), s_dfl = block_sum(s_dfl, red), s_n = block_sum(s_n, red);
+  if (threadIdx.x == 0 && s_n != 0.0) {
     atomicAdd(p.acc + 1, s_t);
     atomicAdd(p.acc + 2, s_xt);
     atomicAdd(p.acc + 3, s_box);
@@ -333,37 +365,80 @@ __device__ __forceinline__ D4 ciou_dual(const float* pb, const float* tb) {
   return iou - (rho2 / c2 + dscale(v, alpha));
 }
 
+// Two launches.  DENSE: thread = one 16-byte chunk of a BACKGROUND anchor's row of the gradient map (97 % of the rows): zeros in the
+// 64 box bins, sigmoid(x) * gain in the class slots -- consecutive lanes write consecutive 16 bytes.  SPARSE: thread = anchor, foreground
+// anchors only: box / DFL bins and the class slots with the soft target.  (One thread per anchor for everything wrote its 74 floats one at a
+// time, each store instruction touching 64 different lines: 591 us at B = 64.)
+// Rows whose pitch leaves fewer than 8 floats of alignment padding behind the 4 * reg_max + nc values are written WHOLE (zeros in the
+// padding): a row with holes makes the L2 fetch every partly written line from HBM before it can write it back (389 -> 2xx us).
+__global__ __launch_bounds__(256) void loss_grad_dense_kernel(const LossArgs p, unsigned chunks_values) {
+  const double tss_d = p.acc[1] > 1.0 ? p.acc[1] : 1.0;
+  const float inv = (float)((double)p.batch / tss_d);  // d total / d (sum of a loss term's numerator)
+  // level by level: everything that depends on the level is then a SCALAR (indexing the per-level arrays of the kernel arguments with a
+  // per-lane level makes every access a vector load from the argument segment, one dependent round trip each: 485 us for this kernel)
+  for (int l = 0; l < p.n_levels; ++l) {
+    const unsigned hw = (unsigned)(p.h[l] * p.w[l]);
+    const float* __restrict__ lv = p.level[l];
+    float* __restrict__ gl = p.glevel[l];
+    const size_t ld = (size_t)p.ld[l], gld = (size_t)p.gld[l];
+    const unsigned a0 = (unsigned)p.a0[l];
+    const int nval = 4 * kRegMax + p.nc;
+    const bool whole = gld % 4 == 0 && (int)gld - nval < 8;  // scalar
+    const unsigned chunks = whole ? (unsigned)(gld / 4) : chunks_values;
+    const int lim = whole ? (int)gld : nval;  // floats of a row this kernel writes
+    const unsigned total = (unsigned)p.batch * hw * chunks;
+    for (unsigned tt = blockIdx.x * 256u + threadIdx.x; tt < total; tt += gridDim.x * 256u) {
+      const unsigned row = tt / chunks;  // b * hw + anchor of the level
+      const int ch = (int)(tt - row * chunks);
+      const unsigned b = row / hw, al = row - b * hw;
+      if (p.owner[(size_t)b * p.A + a0 + al] >= 0) continue;  // the sparse launch writes that row
+      float* go = gl + (size_t)row * gld;
+      if (ch < kRegMax) {
+        float* gs = go + ch * 4;
+        if ((reinterpret_cast<uintptr_t>(gs) & 15) == 0) *reinterpret_cast<float4*>(gs) = float4{0.f, 0.f, 0.f, 0.f};
+        else gs[0] = 0.f, gs[1] = 0.f, gs[2] = 0.f, gs[3] = 0.f;
+      } else {
+        const int c0 = (ch - kRegMax) * 4;
+        const float* cl = lv + (size_t)row * ld + 4 * kRegMax;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = c0 + j < p.nc ? (1.0f / (1.0f + expf(-cl[c0 + j])) - 0.f) * p.cls_gain * inv : 0.f;
+        float* gs = go + 4 * kRegMax + c0;
+        if (4 * kRegMax + c0 + 4 <= lim && (reinterpret_cast<uintptr_t>(gs) & 15) == 0) {
+          *reinterpret_cast<float4*>(gs) = float4{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (4 * kRegMax + c0 + j < lim) gs[j] = v[j];
+        }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void loss_grad_kernel(const LossArgs p) {
   const long long total = (long long)p.batch * p.A;
   const double tss_d = p.acc[1] > 1.0 ? p.acc[1] : 1.0;
   const float inv = (float)((double)p.batch / tss_d);  // d total / d (sum of a loss term's numerator)
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int g = p.owner[idx];
+    if (g < 0) continue;  // background rows: loss_grad_dense_kernel
     const int b = (int)(idx / p.A), a = (int)(idx - (long long)b * p.A);
     int l, gx, gy;
     const float* r = row_ptr(p, b, a, &l, &gx, &gy);
     const int al = a - p.a0[l];
     float* go = p.glevel[l] + ((size_t)b * p.h[l] * p.w[l] + al) * (size_t)p.gld[l];
-    const int g = p.owner[idx];
-    float t = 0.f;
-    int tc = -1;
-    const float* g5 = nullptr;
-    if (g >= 0) {
-      g5 = p.gt + ((size_t)b * p.gmax + g) * 5;
-      float m, ov;
-      pair_metric(p, b, g5, a, &m, &ov);
-      const float pal = __uint_as_float(p.gmax_al[(size_t)b * p.gmax + g]), pov = __uint_as_float(p.gmax_ov[(size_t)b * p.gmax + g]);
-      t = m * pov / (pal + 1e-9f);
-      tc = (int)g5[0];
-    }
+    const float* g5 = p.gt + ((size_t)b * p.gmax + g) * 5;
+    float m, ov;
+    pair_metric(p, b, g5, a, &m, &ov);
+    const float pal = __uint_as_float(p.gmax_al[(size_t)b * p.gmax + g]), pov = __uint_as_float(p.gmax_ov[(size_t)b * p.gmax + g]);
+    const float t = m * pov / (pal + 1e-9f);
+    const int tc = (int)g5[0];
     // class logits: d BCE / dx = sigmoid(x) - target
     const float* cl = r + 4 * kRegMax;
     for (int c = 0; c < p.nc; ++c) {
       const float sg = 1.0f / (1.0f + expf(-cl[c]));
       go[4 * kRegMax + c] = (sg - (c == tc ? t : 0.f)) * p.cls_gain * inv;
-    }
-    if (g < 0) {  // background anchor: no box / DFL term
-      for (int i = 0; i < 4 * kRegMax; ++i) go[i] = 0.f;
-      continue;
     }
     // box bins of a foreground anchor
     const float st = p.stride[l];
@@ -486,7 +561,8 @@ extern "C" int32_t dy_detection_loss(const dy_loss_desc* d, dy_stream_t stream) 
   zero_async(a.gmax_al, 2 * lalign(bg * 4) + lalign(6 * 8), st);  // a kernel, never a memset node (common_hip.h)
   const long long tot = (long long)d->batch * A;
   const unsigned blocks = (unsigned)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
-  hipLaunchKernelGGL(loss_decode_kernel, dim3(blocks), dim3(256), 0, st, a);
+  const unsigned blocks4 = (unsigned)((tot * 4 + 255) / 256 < 8192 ? (tot * 4 + 255) / 256 : 8192);
+  hipLaunchKernelGGL(loss_decode_kernel, dim3(blocks4), dim3(256), 0, st, a);
   if (d->gmax > 0) {
     hipLaunchKernelGGL(tal_pick_kernel, dim3((unsigned)(d->batch * d->gmax)), dim3(64), 0, st, a);
     const long long np = (long long)d->batch * d->gmax * d->topk;
@@ -501,6 +577,10 @@ extern "C" int32_t dy_detection_loss(const dy_loss_desc* d, dy_stream_t stream) 
       a.glevel[i] = d->grad_level[i];
       a.gld[i] = d->ld_grad[i];
     }
+    const unsigned chunks = (unsigned)(kRegMax + (d->nc + 3) / 4);  // 16-byte chunks of a row that carry values
+    DY_REQUIRE(tot * chunks < (1ll << 32), DY_ERR_UNSUPPORTED, "dy_detection_loss: gradient map too large for 32-bit chunk indices");
+    const long long nb = (tot * (chunks + 2) + 255) / 256;
+    hipLaunchKernelGGL(loss_grad_dense_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, st, a, chunks);
     hipLaunchKernelGGL(loss_grad_kernel, dim3(blocks), dim3(256), 0, st, a);
   }
   if (d->out_owner) {

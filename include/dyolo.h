@@ -436,7 +436,8 @@ int32_t dy_scale_boxes(float* boxes, const int32_t* counts, const float* params,
  * out_owner: optional int32 (batch, A): index of the ground-truth box each anchor is assigned to, or -1.
  * Assignment is sparse (no (batch, gmax, A) tensors).
  * grad_level[l] (optional, all or none): fp32 NHWC (batch, h_l, w_l, 4*reg_max + nc), pitch ld_grad[l]; receives
- * d total / d level[l] — what loss.backward() hands to the Detect head in the reference trainer (engine/trainer.py:381-389);
+ * d total / d level[l] — what loss.backward() hands to the Detect head in the reference trainer (engine/trainer.py:381-389)
+ * (alignment padding of a row — ld_grad[l] − (4*reg_max + nc) < 8 floats — may be overwritten with zeros: whole-line stores);
  * the assignment, soft targets, target_scores_sum and CIoU's alpha are constants exactly as under autograd
  * (tal.py:60 no_grad, metrics.py:127-128). */
 typedef struct dy_loss_desc {
