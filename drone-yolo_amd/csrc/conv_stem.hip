@@ -21,6 +21,8 @@ namespace DY_NS {
 
 struct StemArgs {
   const float* x;
+  const unsigned char* x8;  // U8 kernels: uint8 NCHW image, value = x8 / divisor (the training input: preprocess_batch's float() / 255)
+  float divisor;
   const void* w;      // [cout_pad16][32] T, k = c*9 + r*3 + q, zero padded
   const float* bias;  // [cout_pad16]
   void* y;
@@ -34,7 +36,7 @@ constexpr int kStemPH = 2 * kStemTH + 1, kStemPW = 2 * kStemTW + 1;  // 17 x 65 
 constexpr int kStemPitch = 68;  // floats per patch row: 17 aligned float4 = image columns gx0-3 .. gx0+64 (column px at index px+3)
 constexpr int kStemShift = 3;
 
-template <typename T, int NF>
+template <typename T, int NF, bool U8 = false>
 __global__ __launch_bounds__(256) void conv_stem_kernel(const StemArgs p) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr int NKG = 32 / (4 * EPC);  // k-groups covering K padded to 32: 1 (16-bit) or 2 (fp32)
@@ -69,8 +71,14 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const StemArgs p) {
       const int c = row / kStemPH, py = row - c * kStemPH;
       const int gy = gy0 + py, gx = gx0 - kStemShift + 4 * j;
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-        v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(n * p.Cin + c) * p.H + gy) * p.W + gx);
+      if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) {
+        if constexpr (U8) {
+          const unsigned u = *reinterpret_cast<const unsigned*>(p.x8 + ((size_t)(n * p.Cin + c) * p.H + gy) * p.W + gx);
+          v = f32x4{(float)(u & 255u) / p.divisor, (float)((u >> 8) & 255u) / p.divisor, (float)((u >> 16) & 255u) / p.divisor, (float)(u >> 24) / p.divisor};
+        } else {
+          v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(n * p.Cin + c) * p.H + gy) * p.W + gx);
+        }
+      }
       *reinterpret_cast<f32x4*>(patch + c * PLANE + py * kStemPitch + 4 * j) = v;
     }
   } else {
@@ -80,8 +88,10 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const StemArgs p) {
       const int py = r2 / kStemPW, px = r2 - py * kStemPW;
       const int gy = gy0 + py, gx = gx0 + px;
       float v = 0.f;
-      if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-        v = p.x[((size_t)(n * p.Cin + c) * p.H + gy) * p.W + gx];
+      if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) {
+        const size_t at = ((size_t)(n * p.Cin + c) * p.H + gy) * p.W + gx;
+        v = U8 ? (float)p.x8[at] / p.divisor : p.x[at];
+      }
       patch[c * PLANE + py * kStemPitch + px + kStemShift] = v;
     }
   }
@@ -175,14 +185,14 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const StemArgs p) {
   }
 }
 
-template <typename T, int NF>
+template <typename T, int NF, bool U8 = false>
 static int launch_stem(const StemArgs& a, hipStream_t st) {
   StemArgs p = a;
   p.tilesX = (p.Wo + kStemTW - 1) / kStemTW;
   p.tilesY = (p.Ho + kStemTH - 1) / kStemTH;
-  p.vec4 = (p.W % 4 == 0 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0) ? 1 : 0;
+  p.vec4 = U8 ? (p.W % 4 == 0 && (reinterpret_cast<uintptr_t>(p.x8) & 3) == 0 && ((size_t)p.H * p.W) % 4 == 0) : (p.W % 4 == 0 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
   const int smem = ((p.Cin * kStemPH * kStemPitch * 4 + 15) / 16) * 16 + 4 * 4 * 16 * (NF * 16 * (int)sizeof(T) + 16);
-  auto kern = conv_stem_kernel<T, NF>;
+  auto kern = conv_stem_kernel<T, NF, U8>;
   static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)once;
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.N * p.tilesY * p.tilesX)), dim3(256), smem, st, p);
@@ -221,6 +231,32 @@ extern "C" int32_t dy_stem_conv3x3s2_nchw(const float* x, const void* w, const f
                                           dy_stream_t stream) {
   if (act == DY_ACT_SILU_L2E) return dy_l2e::stem_entry(x, w, bias, y, n, cin, h, w_in, cout, ld_y, DY_ACT_SILU, dtype, stream);
   return dy::stem_entry(x, w, bias, y, n, cin, h, w_in, cout, ld_y, act, dtype, stream);
+}
+
+// uint8 source (training: DetectionTrainer.preprocess_batch's `img.float() / 255`, models/yolo/detect/train.py:57-60, folded into the stem):
+// 32 output channels, 16-bit storage -- the Drone-YOLO / YOLOv8 stem of the s scale.
+extern "C" int32_t dy_stem_conv3x3s2_nchw_u8(const uint8_t* x, float divisor, const void* w, const float* bias, void* y, int32_t n, int32_t cin, int32_t h,
+                                             int32_t w_in, int32_t cout, int32_t ld_y, int32_t act, int32_t dtype, dy_stream_t stream) {
+  DY_REQUIRE(x && w && bias && y && divisor > 0.f, DY_ERR_INVALID_ARG, "dy_stem_conv3x3s2_nchw_u8: null pointer or bad divisor");
+  DY_REQUIRE((dtype == DY_BF16 || dtype == DY_F16) && n > 0 && h > 0 && w_in > 0 && cin >= 1 && cin * 9 <= 32 && cout > 0 && cout <= 80 && cout % 16 == 0 &&
+                 act != DY_ACT_SILU_L2E, DY_ERR_UNSUPPORTED, "dy_stem_conv3x3s2_nchw_u8: 16-bit storage, cin <= 3, cout a multiple of 16 up to 80");
+  DY_REQUIRE(ld_y >= cout && (ld_y * 2) % 16 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0, DY_ERR_INVALID_ARG,
+             "dy_stem_conv3x3s2_nchw_u8: y / w must be 16-byte aligned, ld_y whole chunks");
+  dy::StemArgs a{};
+  a.x = nullptr, a.x8 = x, a.divisor = divisor, a.w = w, a.bias = bias, a.y = y;
+  a.N = n, a.Cin = cin, a.H = h, a.W = w_in, a.Ho = (h - 1) / 2 + 1, a.Wo = (w_in - 1) / 2 + 1, a.Cout = cout, a.ldy = ld_y, a.act = act;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define DY_STEM_U8(T)                                               \
+  switch (cout / 16) {                                               \
+    case 1: return dy::launch_stem<T, 1, true>(a, st);               \
+    case 2: return dy::launch_stem<T, 2, true>(a, st);               \
+    case 3: return dy::launch_stem<T, 3, true>(a, st);               \
+    case 4: return dy::launch_stem<T, 4, true>(a, st);               \
+    default: return dy::launch_stem<T, 5, true>(a, st);              \
+  }
+  if (dtype == DY_BF16) { DY_STEM_U8(dy::bf16_t) }
+  DY_STEM_U8(dy::f16_t)
+#undef DY_STEM_U8
 }
 #endif
 

@@ -596,6 +596,31 @@ def stem_conv(src: torch.Tensor, ps: PackedStem, out: Optional[torch.Tensor] = N
 
 
 
+_STEM_TRAIN_W: dict = {}
+
+
+def stem_conv_u8(img: torch.Tensor, weight: torch.Tensor, dtype: torch.dtype, divisor: float = 255.0) -> torch.Tensor:
+    """Training stem: uint8 NCHW image -> conv3x3 s2 p1 (no bias, no activation) as an NHWC view of ``dtype`` through
+    ``dy_stem_conv3x3s2_nchw_u8``.  ``weight``: the fp32 master weight (cout, cin <= 3, 3, 3) on the device — its OIHW rows ARE the
+    kernel's k order, so packing is one casting copy into a persistent zero-padded [cout][32] buffer."""
+    require_device(img, "training image")
+    cout, cin = weight.shape[0], weight.shape[1]
+    if img.dtype != torch.uint8 or not img.is_contiguous() or img.shape[1] != cin or tuple(weight.shape[2:]) != (3, 3) or cout % 16 or cout > 80:
+        raise ValueError("stem_conv_u8: contiguous uint8 (N, cin, H, W) image, (cout % 16 == 0, cin, 3, 3) weights")
+    key = (weight.data_ptr(), dtype, str(img.device))
+    ent = _STEM_TRAIN_W.get(key)
+    if ent is None:
+        ent = _STEM_TRAIN_W[key] = (torch.zeros((cout, 32), dtype=dtype, device=img.device), zero_bias(cout, img.device))
+    wp, bp = ent
+    wp[:, : cin * 9].copy_(weight.detach().reshape(cout, cin * 9))
+    n, _, h, w = img.shape
+    out = alloc_nhwc(n, cout, (h - 1) // 2 + 1, (w - 1) // 2 + 1, dtype, img.device)
+    op, ld = view_params(out)
+    _launch(lib().dy_stem_conv3x3s2_nchw_u8, (img.data_ptr(), float(divisor), wp.data_ptr(), bp.data_ptr(), op, n, cin, h, w, cout, ld, DY_ACT_NONE, dy_dtype(dtype)),
+            keep=(img, wp, bp, out))
+    return out
+
+
 class PackedStem2:
     """Weights of layers 0 + 1 for ``dy_stem2_fused``: the stem rows as in :class:`PackedStem` and the stride-2 3x3
     layer as [64][288] rows with k = (r*3 + q)*32 + c (include/dyolo.h)."""

@@ -34,16 +34,19 @@ def as_nhwc(t: torch.Tensor) -> torch.Tensor:
 CONV_STATS = [os.environ.get("DYOLO_CONV_STATS", "1") != "0"]  # BatchNorm statistics from convolution epilogues (conv_bn_fwd)
 
 
-def conv_bn_fwd(x, weight, gamma, beta, bn, stride, pad, act, out=None):
+def conv_bn_fwd(x, weight, gamma, beta, bn, stride, pad, act, out=None, stem_u8=None):
     """z = conv2d(x, weight), y = act(BN_batchstats(z)) (y into ``out`` when given): returns (z, BnState, y)."""
     dtype, dev = x.dtype, x.device
-    cin_pad = x.shape[1] if x.shape[1] != weight.shape[1] else None  # image padded to one chunk
-    pc = H.PackedConv(weight, H.zero_bias(weight.shape[0], dev), stride, pad, 1, False, dtype, dev, cin_pad=cin_pad)
     # batch statistics from the convolution's epilogue where the launched kernel has one (dy_conv_desc.bn_stats): partial sums straight
     # into the BatchNorm's workspace, no reduction pass over z
     st = H.BnState(weight.shape[0], dev)
-    z = H.conv2d(x, pc, bn_stats=st if CONV_STATS[0] else None)
-    slabs = H.conv_stats_written() if CONV_STATS[0] else 0
+    if stem_u8 is not None:  # the image stem straight from the uint8 batch (x, its NHWC form, only serves the weight gradient)
+        z, slabs = H.stem_conv_u8(stem_u8, weight, dtype), 0
+    else:
+        cin_pad = x.shape[1] if x.shape[1] != weight.shape[1] else None  # image padded to one chunk
+        pc = H.PackedConv(weight, H.zero_bias(weight.shape[0], dev), stride, pad, 1, False, dtype, dev, cin_pad=cin_pad)
+        z = H.conv2d(x, pc, bn_stats=st if CONV_STATS[0] else None)
+        slabs = H.conv_stats_written() if CONV_STATS[0] else 0
     y = H.bn_train_fwd(z, gamma, beta, st, act, eps=bn.eps, momentum=bn.momentum, running_mean=bn.running_mean, running_var=bn.running_var, out=out,
                        partial_slabs=slabs)
     return z, st, y
@@ -146,8 +149,8 @@ class ConvBnAct(torch.autograd.Function):
     """y = act(BN_train(conv2d(x, w))) — dy_conv2d_nhwc + dy_bn_train_fwd; backward: dy_bn_train_bwd + wgrad + dgrad."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, bn, stride, pad, act, need_dx):
-        z, st, y = conv_bn_fwd(x, weight, gamma, beta, bn, stride, pad, act)
+    def forward(ctx, x, weight, gamma, beta, bn, stride, pad, act, need_dx, stem_u8=None):
+        z, st, y = conv_bn_fwd(x, weight, gamma, beta, bn, stride, pad, act, stem_u8=stem_u8)
         ctx.save_for_backward(x, z, weight, gamma, beta)
         ctx.st, ctx.stride, ctx.pad, ctx.act, ctx.need_dx = st, stride, pad, act, need_dx
         return y
@@ -156,7 +159,7 @@ class ConvBnAct(torch.autograd.Function):
     def backward(ctx, dy):
         x, z, weight, gamma, beta = ctx.saved_tensors
         dx, dw, dgamma, dbeta = conv_bn_bwd(dy, x, z, weight, gamma, beta, ctx.st, ctx.stride, ctx.pad, ctx.act, need_dx=ctx.need_dx)
-        return dx, dw, dgamma, dbeta, None, None, None, None, None
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None
 
 
 class C2fTrain(torch.autograd.Function):

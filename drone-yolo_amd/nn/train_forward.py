@@ -10,15 +10,23 @@ from typing import List
 import torch
 import torch.nn as nn
 
+import os
+
 from .. import hip_ops as H
 from . import autograd_ops as A
 
+_STEM_U8 = os.environ.get("DYOLO_STEM_U8", "1") != "0"  # training: layer 0 straight from the uint8 batch
 
-def conv_train(m, x, need_dx: bool = True):
+
+def conv_train(m, x, need_dx: bool = True, img_u8=None):
     c = m.conv
     if c.groups != 1:  # DWConv of the -sf YAML
         return A.GroupedConvBnAct.apply(x, c.weight, m.bn.weight, m.bn.bias, m.bn, c.stride[0], c.padding[0], c.groups, isinstance(m.act, nn.SiLU))
-    return A.ConvBnAct.apply(x, c.weight, m.bn.weight, m.bn.bias, m.bn, c.stride[0], c.padding[0], isinstance(m.act, nn.SiLU), need_dx)
+    stem = None
+    if (img_u8 is not None and _STEM_U8 and c.kernel_size[0] == 3 and c.stride[0] == 2 and c.padding[0] == 1 and c.weight.shape[1] <= 3
+            and c.weight.shape[0] % 16 == 0 and c.weight.shape[0] <= 80 and x.dtype in (torch.bfloat16, torch.float16) and c.weight.is_cuda):
+        stem = img_u8  # the first layer reads the uint8 batch itself (dy_stem_conv3x3s2_nchw_u8)
+    return A.ConvBnAct.apply(x, c.weight, m.bn.weight, m.bn.bias, m.bn, c.stride[0], c.padding[0], isinstance(m.act, nn.SiLU), need_dx, stem)
 
 
 def repvgg_train(m, x):
@@ -65,7 +73,7 @@ def detect_train(m, xs: List[torch.Tensor]) -> List[torch.Tensor]:
     return out
 
 
-def module_train(m, x, first: bool = False):
+def module_train(m, x, first: bool = False, img_u8=None):
     from .modules import C2f, Concat, Conv, Detect, RepVGGBlock, SPPF, Upsample
 
     if isinstance(m, nn.Sequential):
@@ -73,7 +81,7 @@ def module_train(m, x, first: bool = False):
             x = module_train(mm, x)
         return x
     if isinstance(m, Conv):
-        return conv_train(m, x, need_dx=not first)
+        return conv_train(m, x, need_dx=not first, img_u8=img_u8 if first else None)
     if isinstance(m, RepVGGBlock):
         return repvgg_train(m, x)
     if isinstance(m, C2f):
@@ -92,14 +100,16 @@ def module_train(m, x, first: bool = False):
 def model_train_forward(model, img: torch.Tensor, dtype: torch.dtype):
     """img: (N, 3, H, W) uint8 or float on the device -> Detect's per-level training outputs."""
     H.require_device(img, "training image")
+    img_u8 = None
     if img.dtype == torch.uint8:
-        x = H.u8_to_nhwc(img.contiguous(), dtype)  # preprocess_batch's float() / 255 (detect/train.py:59) + layout, one kernel
+        img_u8 = img.contiguous()
+        x = H.u8_to_nhwc(img_u8, dtype)  # preprocess_batch's float() / 255 (detect/train.py:59) + layout, one kernel
     else:
         x = H.to_nhwc(img.float().contiguous(), dtype)
     ys = []
     for m in model.model:
         if m.f != -1:
             x = ys[m.f] if isinstance(m.f, int) else [x if j == -1 else ys[j] for j in m.f]
-        x = module_train(m, x, first=(m.i == 0))
+        x = module_train(m, x, first=(m.i == 0), img_u8=img_u8 if m.i == 0 else None)
         ys.append(x if m.i in model.save else None)
     return x

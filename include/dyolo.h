@@ -247,6 +247,12 @@ int32_t dy_stem_conv3x3s2_nchw(const float* x, const void* w, const float* bias,
                                int32_t h, int32_t w_in, int32_t cout, int32_t ld_y, int32_t act, int32_t dtype,
                                dy_stream_t stream);
 
+/* The same from a uint8 NCHW image, value = x / divisor: the training input (DetectionTrainer.preprocess_batch's `img.float() / 255`,
+ * models/yolo/detect/train.py:57-60) consumed by the stem directly.  16-bit storage, cout a multiple of 16 (<= 80); the operand values
+ * are exactly those of dy_nchw_u8_to_nhwc followed by dy_conv2d_nhwc (same division, same rounding to `dtype`). */
+int32_t dy_stem_conv3x3s2_nchw_u8(const uint8_t* x, float divisor, const void* w, const float* bias, void* y, int32_t n, int32_t cin,
+                                  int32_t h, int32_t w_in, int32_t cout, int32_t ld_y, int32_t act, int32_t dtype, dy_stream_t stream);
+
 /* Fused first TWO layers.  Replaces in one kernel: the layout step + Conv(3, 32, 3, 2) (yolov8-p2-repvgg.yaml layer 0,
  * nn/modules/conv.py:37-55) + RepVGGBlock(32, 64, stride 2) in deploy form (layer 1, nn/modules/block.py:1393-1490:
  * get_equivalent_kernel_bias folds the three branches into one 3x3 kernel), each followed by SiLU.  The 1/2-resolution

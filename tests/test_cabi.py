@@ -94,6 +94,7 @@ def test_new_entry_points_validate_without_gpu():
     assert h.dy_adamw_step(null, null, null, null, 10, 0.1, 0.9, 0.999, 1e-8, 0.0, 0, null, 10.0, null, null) == -1
     assert h.dy_amp_update(null, null, 2.0, 0.5, 2000, null) == -1 and b"dy_amp_update" in h.dy_last_error_string()
     assert h.dy_last_kernel_name() is not None
+    assert h.dy_stem_conv3x3s2_nchw_u8(null, 255.0, null, null, null, 1, 3, 8, 8, 32, 32, 0, L.DY_BF16, null) == -1
     assert h.dy_add_dilated2_nhwc(null, null, 1, 4, 4, 8, 8, 64, 64, 64, L.DY_BF16, null) == -1
     assert h.dy_head_grad_split(null, 80, 10, 64, 10, 16, null, null, 64, null, 16, L.DY_BF16, null) == -1
     assert h.dy_pack_conv_weights_table_bytes(0) == -1 and h.dy_pack_conv_weights_table_bytes(3) % 3 == 0

@@ -197,6 +197,24 @@ def test_1x1_stride2_input_gradient_by_scatter(cin, cout, b, h, w, dtype, device
     close(dx, x.grad + prev, dtype, "1x1 s2 dgrad scatter", extra=2.0)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("n,h,w", [(2, 64, 96), (3, 70, 54), (1, 33, 37)])
+def test_training_stem_from_uint8(n, h, w, dtype, device):
+    """dy_stem_conv3x3s2_nchw_u8 (layer 0 straight from the uint8 batch) against F.conv2d on the image / 255 rounded to the storage type —
+    the operand the layout kernel + convolution pair it replaces sees; ragged sizes take the scalar loader."""
+    g = torch.Generator().manual_seed(h)
+    img = torch.randint(0, 256, (n, 3, h, w), generator=g, dtype=torch.uint8)
+    wt = (torch.randn(32, 3, 3, 3, generator=g) * 0.2).to(device)
+    z = H.stem_conv_u8(img.to(device), wt, dtype)
+    torch.cuda.synchronize()
+    ref = F.conv2d(quantize(img.float() / 255.0, dtype), quantize(wt.cpu(), dtype), None, 2, 1)
+    assert tuple(z.shape) == tuple(ref.shape)
+    close(z, ref, dtype, "stem u8")
+    two = H.conv2d(H.u8_to_nhwc(img.to(device), dtype), H.PackedConv(wt, H.zero_bias(32, device), 2, 1, 1, False, dtype, device, cin_pad=8))
+    torch.cuda.synchronize()
+    close(z, two.float().cpu(), dtype, "stem u8 vs layout + conv", extra=2.0)
+
+
 def test_batched_weight_packing_equals_single_launches(device):
     """dy_pack_conv_weights_batched (one launch for a step's ~160 packings) against dy_pack_conv_weights job by job: forward and
     input-gradient (transposed, flipped) forms, 1x1 / 3x3, every layout PackedConv picks, the padded image stem; then the cache protocol:
