@@ -305,7 +305,7 @@ __global__ __launch_bounds__(BM * WN) void conv_gemm_glds_kernel(const ConvArgs 
           }
           if (rg != nullptr) {
             const int m = out_px(m0 + i * 16 + lr);
-            if (m >= 0) {
+            if (m >= 0 && n0 + j * 16 + lq * 4 < p.Cout) {  // (a tile may be wider than a narrow layer's Cout: weights / bias are zero-padded)
               typedef __attribute__((ext_vector_type(4))) T t4;
               const t4 rv = *reinterpret_cast<const t4*>(rg + (size_t)m * (size_t)p.ldres + (size_t)(n0 + j * 16 + lq * 4));
 #pragma unroll
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(BM * WN) void conv_gemm_glds_kernel(const ConvArgs 
         const int idx = k * 64 + lane;
         const int px = idx / CPP, cc = idx % CPP;
         const int m = px < PXP ? out_px(m0 + half * PXP + px) : -1;
-        if (m >= 0) {
+        if (m >= 0 && n0 + g * EG * 16 + cc * EPC < p.Cout) {
           const u32x4 val = *reinterpret_cast<const u32x4*>(escr + px * EP_PITCH + cc * 16);
           *reinterpret_cast<u32x4*>(yg + (size_t)m * (size_t)p.ldy + (size_t)(n0 + g * EG * 16 + cc * EPC)) = val;
         }
@@ -573,7 +573,7 @@ static int launch_glds(const ConvArgs& a, hipStream_t st) {
     p.tilesPerClass = (p.Mq + BM - 1) / BM;
     tilesM = 4 * p.tilesPerClass;
   }
-  p.tilesN = p.Cout / BN;
+  p.tilesN = (p.Cout + BN - 1) / BN;  // (a narrow layer -- Cout < 64, whole chunks -- runs one masked 64-wide tile)
   p.nblk = tilesM * p.tilesN;
   auto kern = conv_gemm_glds_kernel<T, BM, BN, STAGES, WN>;
   hipLaunchKernelGGL(kern, dim3((unsigned)p.nblk), dim3(BM * WN), 0, st, p);  // static LDS only (up to 144 KiB)
@@ -586,7 +586,7 @@ static int launch_glds_dtype(const ConvArgs& a, hipStream_t st) {
   static const int big = dy_ablate("DYOLO_GLDS_BIG");  // 1: 256x128 three-stage, 2: never persistent, 3: always persistent
   // short K (<= 9 steps, the 64-channel stride-2 layers on 160x160 maps: thousands of tiles) measured faster one tile per
   // workgroup; everything else gains 3-14 % from the persistent walk with the next tile's first K-step prefetched
-  const bool persist = big != 2 && !a.dil_cls && (big == 3 || a.Kpad > 9 * 8 * (16 / (int)sizeof(T)));  // (the parity-class tiling lives in the plain kernel)
+  const bool persist = big != 2 && !a.dil_cls && a.Cout % 64 == 0 && (big == 3 || a.Kpad > 9 * 8 * (16 / (int)sizeof(T)));  // (the parity-class tiling lives in the plain kernel)
   // 256 x 256 tiles (one workgroup per CU; sixteen waves of 64 x 64 = four per SIMD measured 5-14 % faster than eight of 64 x 128:
   // the kernels are wait-bound, not LDS-bound) halve the gathered-operand bytes per flop: 4-19 % faster on
   // the wide 1x1 layers and the 256-cout stride-2 layers at throughput batch sizes (512->256 @40x40: 241 -> 204 us); slower on
@@ -629,7 +629,10 @@ int conv_gemm_glds_try(const ConvArgs& a0, int dtype, bool out_f32, hipStream_t 
   const int es = dtype_size_no_fp8(dtype);
   const int bke = 8 * (16 / es);
   if (off || out_f32 || !a.vec_store) return 1;
-  if (a.Cin % bke || a.split % bke || a.Cout % 64 || a.Kpad != a.ks * a.ks * a.Cin) return 1;
+  // Cout: multiples of 64, or -- for the parity-class tiling of a stride-2 input gradient only (layer 1's 64 -> 32 at 320 x 320: the
+  // zero-dilated gather on the generic kernel took 0.7 ms of a training step) -- a narrower layer on one masked 64-wide tile
+  const bool narrow = a.dil_cls && a.Cout < 64 && a.Cout % (16 / es) == 0;
+  if (a.Cin % bke || a.split % bke || (a.Cout % 64 && !narrow) || a.Kpad != a.ks * a.ks * a.Cin) return 1;
   // no threshold on M: which kernel runs must not depend on the batch size, so that an image's result is bit-identical
   // whatever batch it arrives in (tests/test_model_gpu.py::test_full_size_properties)
   if (a.res && a.ldres % 4) return 1;

@@ -1145,13 +1145,14 @@ def colsum(z: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def pack_dgrad(weight: torch.Tensor, stride: int, dtype: torch.dtype, device) -> PackedConv:
+def pack_dgrad(weight: torch.Tensor, stride: int, dtype: torch.dtype, device, no_accumulate: bool = False) -> PackedConv:
     """Weights of the convolution that computes dx from dz: w'[ci][co][r][q] = w[co][ci][k-1-r][k-1-q], stride 1,
     pad k-1-pad (= pad for the 'same' convolutions of this model); stride-2 layers run on the generic / LDS-DMA kernels
     (zero-dilated gather), stride-1 3x3 layers may take the halo kernel.  Device-resident fp32 weights (training) are
     transposed, flipped, cast and laid out by one ``dy_pack_conv_weights`` launch."""
     k = weight.shape[2]
-    halo = None if (stride == 1 and k == 3) else False  # the streaming 1x1 kernel has no residual (accumulate) input
+    # the streaming 1x1 kernel has no residual (accumulate) input: 1x1 layers take it only when the caller adds nothing in the epilogue
+    halo = None if (stride == 1 and (k == 3 or (k == 1 and no_accumulate))) else False
     if weight.is_cuda and weight.dtype == torch.float32 and dtype != FP8 and weight.device == torch.device(device):
         return PackedConv(weight, zero_bias(weight.shape[1], weight.device), 1, k // 2, 1, False, dtype, device, halo=halo, transpose_flip=True)
     wt = weight.detach().permute(1, 0, 2, 3)  # a view: the packing copy below does the layout change

@@ -288,7 +288,7 @@ class RepVGGTrain(torch.autograd.Function):
         dx = H.conv_dgrad(dz3, H.pack_dgrad(w3, ctx.stride, x.dtype, x.device), ctx.stride)
         if ctx.stride == 2 and w1.shape[2] == 1 and os.environ.get("DYOLO_DGRAD1_SCATTER", "1") != "0":
             # 1x1 stride 2: the gradient reaches the even positions only -- a 1x1 stride-1 convolution at dz's resolution, then a scatter-add
-            dx = H.add_dilated2_(dx, H.conv2d(dz1, H.pack_dgrad(w1, 1, x.dtype, x.device)))
+            dx = H.add_dilated2_(dx, H.conv2d(dz1, H.pack_dgrad(w1, 1, x.dtype, x.device, no_accumulate=True)))
         else:
             dx = H.conv_dgrad(dz1, H.pack_dgrad(w1, ctx.stride, x.dtype, x.device), ctx.stride, accumulate=dx)
         return dx, dw3, dg3, db3, dw1, dg1, db1, None, None, None

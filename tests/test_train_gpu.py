@@ -191,7 +191,7 @@ def test_1x1_stride2_input_gradient_by_scatter(cin, cout, b, h, w, dtype, device
     z.backward(dz)
     prev = quantize(torch.randn(x.shape, generator=g), dtype)
     dx = nhwc(prev, dtype, device)
-    t = H.conv2d(nhwc(dz, dtype, device), H.pack_dgrad(wt.detach().to(device), 1, dtype, device))
+    t = H.conv2d(nhwc(dz, dtype, device), H.pack_dgrad(wt.detach().to(device), 1, dtype, device, no_accumulate=True))
     H.add_dilated2_(dx, t)
     torch.cuda.synchronize()
     close(dx, x.grad + prev, dtype, "1x1 s2 dgrad scatter", extra=2.0)
