@@ -850,8 +850,188 @@ static int launch_wgrad1(const WgradArgs& a, hipStream_t st) {
   return 0;
 }
 
+// ---- the image stem: 3x3 stride 2, at most 8 input channels (the 3-channel image padded to one 16-byte chunk), at most 32 couts ----
+// On the tiled kernel above this layer uses 3 of the 64 x 64 tile's input channels and half of its couts (6 % of the MFMAs), and seven
+// of every eight staged x chunks are padding: 0.7 ms per training step.  Here the x rows sit in LDS at their natural 16-byte pixel
+// pitch, and ONE transposed fragment read covers TWO taps: output pixel k of a 32-pixel row segment sees taps (q, q + 1) of kernel row r
+// as the 32 contiguous bytes of input pixels (2k + q, 2k + q + 1) -- B[k][n = t * 8 + ci] -- with a row stride of two pixels (32 B: eight
+// rows x 32 B are 64 distinct banks).  Per segment and kernel row: fragments (q = 0, 1) and (q = 2, [3 = unused]) x two cout fragments
+// = 12 MFMAs on 5 KB of staged data -- the kernel is a stream.  A WAVE is the unit: its own LDS region (no workgroup barriers), the next
+// segment's loads in registers while the current one is multiplied, 48 accumulator registers summed over the workgroup's four waves
+// at the end and stored as ONE partial per workgroup (wgrad3_reduce_kernel adds them up).
+struct WgradStemArgs {
+  const void* x;
+  const void* dz;
+  float* dw;    // [cout][9][cin]
+  float* part;  // workspace or null (atomics on dw)
+  int N, H, W, Cin, ldx, Ho, Wo, Cout, lddz, segX, nSeg;
+  unsigned x_bytes, dz_bytes;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 3) void conv_wgrad_stem_kernel(const WgradStemArgs p) {
+  constexpr int PDZ = 96;                    // dz tile: 32 pixels x (32 couts = 64 B + 32 B pad): conflict-free transposed reads
+  constexpr int XROW = 68 * 16;              // one halo row: 68 pixels x 16 B (pixels 2 xo0 - 1 .. 2 xo0 + 66)
+  constexpr int DZ_BYTES = 32 * PDZ, WAVE_LDS = DZ_BYTES + 3 * XROW;  // 3,072 + 3,264
+  constexpr int RED_BYTES = 4 * 12 * 4 * 64 * 4;  // the final sum over the four waves (49 KB) reuses the staging space
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RED_BYTES > 4 * WAVE_LDS ? RED_BYTES : 4 * WAVE_LDS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  unsigned char* const my = smem + wave * WAVE_LDS;
+  constexpr unsigned kOob = 0xfffffff0u;
+  const unsigned pre = (unsigned)((p.W + 1) * p.ldx) * 2u;  // the x descriptor starts one row + one pixel early: no negative offsets
+  const __amdgpu_buffer_rsrc_t xrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) - pre, 0, p.x_bytes + pre, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dzrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dz), 0, p.dz_bytes, 0x00020000);
+
+  // lane constants of the loader.  dz: chunks c = lane, lane + 64 -> pixel c >> 2, 16-byte part c & 3 (8 couts).
+  // x: ids lane + 64 i (i < 4) of 3 rows x 68 pixels -> (row, pixel); one chunk (8 channels) per pixel.
+  unsigned dz_rel[2], dz_lds[2];
+  int dz_px[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = lane + 64 * i, px = c >> 2, part = c & 3;
+    dz_px[i] = px;
+    dz_rel[i] = part * 8 < p.Cout ? (unsigned)(px * p.lddz + part * 8) * 2u : kOob;
+    dz_lds[i] = (unsigned)(px * PDZ + part * 16);
+  }
+  unsigned x_rel[4], x_lds[4];
+  int x_rc[4];  // row | pixel << 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = lane + 64 * i, row = id / 68, px = id - row * 68;
+    x_rc[i] = row | (px << 8);
+    x_rel[i] = id < 3 * 68 ? (unsigned)((row * p.W + px) * p.ldx) * 2u : kOob;
+    x_lds[i] = (unsigned)(DZ_BYTES + (id < 3 * 68 ? row * XROW + px * 16 : 0));
+  }
+
+  f32x4 acc[3][2][2];  // [kernel row][tap pair][cout fragment]
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) acc[r][j][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int gw = (int)blockIdx.x * 4 + wave, GW = (int)gridDim.x * 4;
+  u32x4 rdz[2], rx[4];
+  auto load_seg = [&](int seg) {  // seg = (image, output row, 32-pixel segment): scalars of the wave
+    unsigned dead = seg < p.nSeg ? 0u : 0xffffffffu;
+    asm volatile("" : "+v"(dead));
+    dead = __builtin_amdgcn_readfirstlane(dead);
+    const int sx = seg % p.segX;
+    const int t = seg / p.segX;
+    const int yo = t % p.Ho, n = t / p.Ho;
+    const int xo0 = sx * 32;
+    const unsigned dz_base = (unsigned)(((n * p.Ho + yo) * p.Wo + xo0) * p.lddz) * 2u & ~dead;
+    const unsigned x_base = (unsigned)(((n * p.H + 2 * yo) * p.W + 2 * xo0) * p.ldx) * 2u & ~dead;  // halo origin (2 yo - 1, 2 xo0 - 1) in the shifted descriptor's terms
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned off = (xo0 + dz_px[i] < p.Wo ? dz_rel[i] : kOob) | dead;
+      rdz[i] = __builtin_amdgcn_raw_buffer_load_b128(dzrs, (int)off, (int)dz_base, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gy = 2 * yo - 1 + (x_rc[i] & 255), gx = 2 * xo0 - 1 + (x_rc[i] >> 8);
+      const unsigned off = (((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) ? x_rel[i] : kOob) | dead;
+      rx[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, (int)x_base, 0);
+    }
+  };
+
+  const int q4 = lr >> 2, pp = lr & 3;
+  const unsigned la = (unsigned)(uintptr_t)my + (unsigned)((lq * 4 + q4) * PDZ + pp * 8);                 // dz: pixel rows of 96 B
+  const unsigned lb = (unsigned)(uintptr_t)my + (unsigned)(DZ_BYTES + (lq * 4 + q4) * 32 + pp * 8);       // x: output pixel k at 2 k input pixels = 32 B
+
+  load_seg(gw);
+  for (int seg = gw; seg < p.nSeg; seg += GW) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(my + dz_lds[i]) = rdz[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (lane + 64 * i < 3 * 68) *reinterpret_cast<u32x4*>(my + x_lds[i]) = rx[i];
+    load_seg(seg + GW);  // in flight during this segment's MFMAs (zeros past the end)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own stores are in LDS (one wave: no barrier)
+    // one call = four transposed reads at {0, 16 rows, +32 B, +32 B + 16 rows}: for dz the two cout fragments, for an x row the tap pairs
+    // (q = 0, 1) and (q = 2, [3]) -- "+32 B" is the next 16 couts there and the next two input pixels here
+    u32x2 ra[4], rb[3][4];
+    tr_issue4<0, 16 * PDZ>(la, ra);
+    tr_issue4<0 * XROW, 16 * 32>(lb, rb[0]);
+    tr_issue4<1 * XROW, 16 * 32>(lb, rb[1]);
+    tr_issue4<2 * XROW, 16 * 32>(lb, rb[2]);
+    tr_wait<12>(ra);
+    u32x4 a[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) a[f] = u32x4{ra[2 * f][0], ra[2 * f][1], ra[2 * f + 1][0], ra[2 * f + 1][1]};
+    auto taps = [&](auto R) {
+      constexpr int r = decltype(R)::value;
+      tr_wait<(2 - r) * 4>(rb[r]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const u32x4 b = u32x4{rb[r][2 * j][0], rb[r][2 * j][1], rb[r][2 * j + 1][0], rb[r][2 * j + 1][1]};
+#pragma unroll
+        for (int f = 0; f < 2; ++f) acc[r][j][f] = Elem<T>::mma(a[f], b, acc[r][j][f]);
+      }
+    };
+    taps(std::integral_constant<int, 0>{});
+    taps(std::integral_constant<int, 1>{});
+    taps(std::integral_constant<int, 2>{});
+  }
+
+  // sum over the workgroup's waves (through the staging space), then one partial per workgroup
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);  // [wave][12 tiles][4][64]
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[((wave * 12 + (r * 2 + j) * 2 + f) * 4 + e) * 64 + lane] = acc[r][j][f][e];
+  __syncthreads();
+  float* __restrict__ dst = p.part ? p.part + (size_t)blockIdx.x * ((size_t)p.Cout * 9 * p.Cin) : p.dw;
+  for (int i = tid; i < 12 * 4 * 64; i += 256) {
+    const int ln = i & 63, e = (i >> 6) & 3, tile = i >> 8;
+    const int f = tile & 1, j = (tile >> 1) & 1, r = tile >> 2;
+    const int n16 = ln & 15, t = n16 >> 3, ci = n16 & 7;
+    const int co = f * 16 + (ln >> 4) * 4 + e, q = 2 * j + t;
+    if (q > 2 || co >= p.Cout || ci >= p.Cin) continue;
+    const float v = red[i] + red[i + 12 * 256] + red[i + 2 * 12 * 256] + red[i + 3 * 12 * 256];
+    float* at = dst + ((size_t)co * 9 + r * 3 + q) * p.Cin + ci;
+    if (p.part) *at = v;
+    else atomicAdd(at, v);
+  }
+}
+
+static int wgrad_stem_blocks(const WgradArgs& a, int batch) {
+  const long long segs = (long long)batch * a.Ho * ((a.Wo + 31) / 32);
+  const long long want = (segs + 4 * 8 - 1) / (4 * 8);  // at least 8 segments per wave
+  return (int)(want < 768 ? (want < 1 ? 1 : want) : 768);  // three 256-thread workgroups per CU
+}
+static size_t wgrad_stem_workspace_bytes(const WgradArgs& a, int batch) {
+  const int g = wgrad_stem_blocks(a, batch);
+  return g > 1 ? (size_t)g * a.Cout * 9 * a.Cin * sizeof(float) : 0;
+}
+template <typename T>
+static int launch_wgrad_stem(const WgradArgs& a, int batch, hipStream_t st) {
+  WgradStemArgs p{};
+  p.x = a.x, p.dz = a.dz, p.dw = a.dw, p.N = batch, p.H = a.H, p.W = a.W, p.Cin = a.Cin, p.ldx = a.ldx, p.Ho = a.Ho, p.Wo = a.Wo, p.Cout = a.Cout, p.lddz = a.lddz;
+  p.segX = (a.Wo + 31) / 32, p.nSeg = batch * a.Ho * p.segX;
+  p.x_bytes = (unsigned)a.x_bytes, p.dz_bytes = (unsigned)a.dz_bytes;
+  const int grid = wgrad_stem_blocks(a, batch);
+  const size_t n = (size_t)a.Cout * 9 * a.Cin;
+  p.part = (grid > 1 && a.ws && a.ws_bytes >= (size_t)grid * n * sizeof(float)) ? reinterpret_cast<float*>(a.ws) : nullptr;
+  hipLaunchKernelGGL((conv_wgrad_stem_kernel<T>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  if (const int rc = check_launch("conv_wgrad_stem_kernel")) return rc;
+  if (p.part) {
+    hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3((unsigned)((n / 4 + 256) / 256), (unsigned)((grid + 15) / 16)), dim3(256), 0, st, p.part, a.dw, (int)n, grid);
+    return check_launch("wgrad3_reduce_kernel");
+  }
+  return 0;
+}
+
 // validation + geometry shared by the entry points; `uses3` = the 3x3 kernel takes this call
-static int wgrad_setup(const dy_conv_desc* d, const void* dz, int32_t ld_dz, float* dw, bool need_ptrs, WgradArgs& a, bool& uses3, bool& uses1) {
+static int wgrad_setup(const dy_conv_desc* d, const void* dz, int32_t ld_dz, float* dw, bool need_ptrs, WgradArgs& a, bool& uses3, bool& uses1, bool& uses_stem) {
   DY_REQUIRE(d && (!need_ptrs || (d->x && dz && dw)), DY_ERR_INVALID_ARG, "dy_conv2d_wgrad_nhwc: null pointer");
   const int es = dtype_size_no_fp8(d->dtype);
   DY_REQUIRE(es != 0 && d->batch > 0 && d->h > 0 && d->w_in > 0 && d->cin > 0 && d->cout > 0 && d->ksize >= 1 && d->stride >= 1 && d->pad >= 0,
@@ -878,6 +1058,9 @@ static int wgrad_setup(const dy_conv_desc* d, const void* dz, int32_t ld_dz, flo
   static const int no3 = dy_ablate("DYOLO_NO_WGRAD3");
   // all nine taps from one staged halo (32-bit byte offsets in its buffer loads: views of 2 GiB and more take the per-tap kernel)
   uses3 = !no3 && d->ksize == 3 && d->pad == 1 && (d->stride == 1 || d->stride == 2) && es == 2 && a.x_bytes < (1ll << 31) && a.dz_bytes < (1ll << 31);
+  static const int no_stem = dy_ablate("DYOLO_NO_WGRAD_STEM");
+  uses_stem = uses3 && !no_stem && d->stride == 2 && d->cin <= 8 && d->cout <= 32;  // the image stem (conv_wgrad_stem_kernel)
+  if (uses_stem) uses3 = false;
   static const int no1 = dy_ablate("DYOLO_NO_WGRAD1");
   uses1 = !no1 && d->ksize == 1 && d->pad == 0 && d->stride == 1 && es == 2 && a.x_bytes < (1ll << 31) && a.dz_bytes < (1ll << 31);
   return 0;
@@ -885,16 +1068,17 @@ static int wgrad_setup(const dy_conv_desc* d, const void* dz, int32_t ld_dz, flo
 
 extern "C" int64_t dy_conv2d_wgrad_workspace_bytes(const dy_conv_desc* d, int32_t ld_dz) {
   WgradArgs a{};
-  bool uses3 = false, uses1 = false;
-  if (const int rc = wgrad_setup(d, nullptr, ld_dz, nullptr, false, a, uses3, uses1)) return rc;
+  bool uses3 = false, uses1 = false, uses_stem = false;
+  if (const int rc = wgrad_setup(d, nullptr, ld_dz, nullptr, false, a, uses3, uses1, uses_stem)) return rc;
+  if (uses_stem) return (int64_t)wgrad_stem_workspace_bytes(a, d->batch);
   return uses3 ? (int64_t)wgrad3_workspace_bytes(a, d->batch, d->stride) : uses1 ? (int64_t)wgrad1_workspace_bytes(a) : 0;
 }
 
 extern "C" int32_t dy_conv2d_wgrad_nhwc_ws(const dy_conv_desc* d, const void* dz, int32_t ld_dz, float* dw, void* workspace, int64_t workspace_bytes,
                                            dy_stream_t stream) {
   WgradArgs a{};
-  bool uses3 = false, uses1 = false;
-  if (const int rc = wgrad_setup(d, dz, ld_dz, dw, true, a, uses3, uses1)) return rc;
+  bool uses3 = false, uses1 = false, uses_stem = false;
+  if (const int rc = wgrad_setup(d, dz, ld_dz, dw, true, a, uses3, uses1, uses_stem)) return rc;
   DY_REQUIRE(!workspace || (aligned16(workspace) && workspace_bytes >= 0), DY_ERR_INVALID_ARG, "dy_conv2d_wgrad_nhwc_ws: workspace must be 16-byte aligned");
   a.ws = workspace, a.ws_bytes = workspace ? (size_t)workspace_bytes : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -902,6 +1086,7 @@ extern "C" int32_t dy_conv2d_wgrad_nhwc_ws(const dy_conv_desc* d, const void* dz
     if (d->dtype == DY_BF16) return d->stride == 1 ? launch_wgrad3<bf16_t, 1>(a, d->batch, st) : launch_wgrad3<bf16_t, 2>(a, d->batch, st);
     return d->stride == 1 ? launch_wgrad3<f16_t, 1>(a, d->batch, st) : launch_wgrad3<f16_t, 2>(a, d->batch, st);
   }
+  if (uses_stem) return d->dtype == DY_BF16 ? launch_wgrad_stem<bf16_t>(a, d->batch, st) : launch_wgrad_stem<f16_t>(a, d->batch, st);
   if (uses1) return d->dtype == DY_BF16 ? launch_wgrad1<bf16_t>(a, st) : launch_wgrad1<f16_t>(a, st);
   switch (d->dtype) {
     case DY_BF16: return launch_wgrad_dtype<bf16_t>(a, st);

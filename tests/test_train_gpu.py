@@ -97,6 +97,9 @@ GRAD_CASES = [
     (256, 256, 3, 1, 2, 10, 10, "3x3 s1 256->256"),
     (64, 16, 3, 1, 2, 16, 16, "3x3 cout=16"),
     (8, 32, 3, 2, 2, 32, 32, "stem (cin padded to 8)"),
+    (8, 32, 3, 2, 3, 70, 54, "stem, ragged segments"),
+    (8, 16, 3, 2, 2, 33, 37, "stem, odd map, cout 16"),
+    (8, 32, 3, 2, 5, 128, 160, "stem, many segments per wave"),
 ]
 
 
