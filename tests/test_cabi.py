@@ -87,6 +87,9 @@ def test_new_entry_points_validate_without_gpu():
     assert h.dy_conv2d_wgrad_workspace_bytes(ctypes.byref(d), 64) == 256 * 64 * 9 * 64 * 4
     d.ksize, d.pad = 1, 0  # 1x1 stride 1: 512 slabs x 4 pixel splits inside a workgroup x (64 x 64)
     assert h.dy_conv2d_wgrad_workspace_bytes(ctypes.byref(d), 64) == 512 * 4 * 64 * 64 * 4
+    s = L.ConvDesc()  # the image stem (8 <- 3 padded channels, 32 couts, 3x3 stride 2 at 640x640, batch 64): one partial per workgroup of conv_wgrad_stem_kernel
+    s.batch, s.h, s.w_in, s.cin, s.ld_x, s.ho, s.wo, s.cout, s.ksize, s.stride, s.pad, s.groups, s.dtype = 64, 640, 640, 8, 8, 320, 320, 32, 3, 2, 1, 1, L.DY_BF16
+    assert h.dy_conv2d_wgrad_workspace_bytes(ctypes.byref(s), 32) == 768 * 32 * 9 * 8 * 4
     d.dtype = L.DY_F32  # the per-tap kernel (fp32, strided, k x k layers) keeps its atomics
     assert h.dy_conv2d_wgrad_workspace_bytes(ctypes.byref(d), 64) == 0
     assert h.dy_letterbox_u8_to_nchw_f32(null, null, 1, 8, 8, 8, 8, 0, 0, 8, 8, 1, 114.0, null) == -1

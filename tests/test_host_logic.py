@@ -315,3 +315,19 @@ def test_optimizer_groups_enumerate_frozen_parameters_like_the_reference():
             full = f"{mn}.{pn}" if mn else pn
             (ref2 if "bias" in full else ref1 if isinstance(mod, bn) else ref0).append(full)
     assert (f0, f1, f2) == (ref0, ref1, ref2) and len(ref0) + len(ref1) + len(ref2) == len(list(m.parameters()))
+
+
+def test_lazy_head_seed_refuses_unconsumed_scales():
+    """nn/autograd_ops.lazy_head_seed: a head gradient handed on without its backward seed must be consumed (HeadTail.backward pops
+    it); anything left at the end of the trainer's backward is an error, not a silently unscaled gradient."""
+    import pytest
+
+    from drone_yolo_amd.nn import autograd_ops as A
+
+    with A.lazy_head_seed():
+        A.LAZY_SEED[1234] = object()
+        assert A.LAZY_SEED.pop(1234, None) is not None  # consumed: fine
+    with pytest.raises(RuntimeError, match="without their scale"):
+        with A.lazy_head_seed():
+            A.LAZY_SEED[5678] = object()
+    assert not A.LAZY_SEED and not A._LAZY[0]
