@@ -35,74 +35,78 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict
 }
 
 // ---- max-pool k x k, stride 1, pad k/2: gradient goes to the FIRST maximum of each window in (row, column) scan order,
-// as torch's max_pool2d does.  One workgroup per (image, 16-byte channel chunk): the plane of x and of the incoming
-// gradient sit in LDS; phase 1 finds every output's arg-max (row segments first, then the rows), phase 2 scatters the gradients.
+// as torch's max_pool2d does.  One workgroup per (image, 16-byte channel chunk); the plane of x and of the incoming gradient sit in LDS
+// as they come -- one 16-byte chunk (8 or 4 channels) per position -- and a thread handles a POSITION with its channels in registers:
+//   1a. per position the maximum of its ROW segment (columns xx - r .. xx + r) and the first column that reaches it (4 bits a channel);
+//   1b. the window's arg-max from the row segments: the first ROW whose segment maximum equals the window maximum, at that segment's
+//       first column -- 2 (2r + 1) chunk reads per output instead of (2r + 1)^2 scalar ones; then the output's gradient ADDED at that
+//       input position (LDS float atomics; outputs that share a target add in arrival order);
+//   2.  sums (+ the gradient already held) -> g_in.
+// (r02: scalar fp32 planes, a thread per (position, channel) with dependent LDS reads per tap, 54 KB of LDS: two workgroups per CU and
+// 126-190 us for a 13 MB map.)
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ go, T* __restrict__ gi, int h, int w, int cchunks,
                                                           int ldx, int ldgo, int ldgi, int r, int accumulate) {
   constexpr int E = Elem<T>::EPC;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
   const int hw = h * w;
-  // channel-major planes ([E][hw]: consecutive lanes walk consecutive positions of one channel -- the position-major form of r02 put
-  // 8 lanes on every bank: 186 us for a 13 MB map)
-  float* xs = reinterpret_cast<float*>(dyn_smem);   // [E][hw]
-  float* gs = xs + hw * E;                          // [E][hw]
+  u32x4* xs = reinterpret_cast<u32x4*>(dyn_smem);  // [hw] chunks of x
+  u32x4* gs = xs + hw;                             // [hw] chunks of the incoming gradient
+  u32x4* rm = gs + hw;                             // [hw] row-segment maxima (values of x: exact in T)
+  float* sums = reinterpret_cast<float*>(rm + hw); // [hw][E]
+  unsigned* ra = reinterpret_cast<unsigned*>(sums + (size_t)hw * E);  // [hw] 4 bits per channel: column offset dx + r of the segment's first maximum
   const int img = blockIdx.x / cchunks, cc = blockIdx.x - img * cchunks;
   for (int p = threadIdx.x; p < hw; p += 256) {
-    float f[E], q[E];
-    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(x + ((size_t)img * hw + p) * (size_t)ldx + cc * E), f);
-    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(go + ((size_t)img * hw + p) * (size_t)ldgo + cc * E), q);
+    xs[p] = *reinterpret_cast<const u32x4*>(x + ((size_t)img * hw + p) * (size_t)ldx + cc * E);
+    gs[p] = *reinterpret_cast<const u32x4*>(go + ((size_t)img * hw + p) * (size_t)ldgo + cc * E);
 #pragma unroll
-    for (int e = 0; e < E; ++e) xs[e * hw + p] = f[e], gs[e * hw + p] = q[e];
+    for (int e = 0; e < E; ++e) sums[p * E + e] = 0.f;
   }
   __syncthreads();
-  // phase 1a: per position the maximum of its ROW segment (columns xx - r .. xx + r) and the first column that reaches it.
-  // The first maximum of a window in (row, column) scan order is then: the first ROW whose segment maximum equals the window maximum,
-  // at that segment's first column -- 2 (2r + 1) comparisons per output instead of (2r + 1)^2.
-  float* rowmax = gs + hw * E;                                        // [E][hw]
-  unsigned char* rowarg = reinterpret_cast<unsigned char*>(rowmax + hw * E);  // [E][hw] column offset dx + r of the segment's first maximum
-  for (int i = threadIdx.x; i < hw * E; i += 256) {  // item = (channel, position)
-    const int e = i / hw, p = i - e * hw;
+  for (int p = threadIdx.x; p < hw; p += 256) {
     const int yy = p / w, xx = p - yy * w;
-    const float* xr = xs + e * hw + yy * w;
-    float best = -3.4e38f;
-    int bo = 0;
+    float best[E];
+    unsigned arg = 0;
     bool first = true;
     for (int dxx = -r; dxx <= r; ++dxx) {
       const int x2 = xx + dxx;
       if ((unsigned)x2 >= (unsigned)w) continue;
-      const float v = xr[x2];
-      if (first || v > best) best = v, bo = dxx + r, first = false;
+      float v[E];
+      Chunk<T>::unpack(xs[yy * w + x2], v);
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (first || v[e] > best[e]) best[e] = v[e], arg = (arg & ~(15u << (4 * e))) | ((unsigned)(dxx + r) << (4 * e));
+      first = false;
     }
-    rowmax[i] = best, rowarg[i] = (unsigned char)bo;
+    rm[p] = Chunk<T>::pack(best);
+    ra[p] = arg;
   }
   __syncthreads();
-  // phase 1b + 2: the window's arg-max from the row segments, then the output's gradient ADDED at that input position (LDS float atomic:
-  // one per output instead of (2r + 1)^2 look-ups per input; outputs that share a target add in arrival order)
-  float* sums = rowmax + hw * E + (hw * E + 3) / 4;  // [E][hw] sums, behind rowarg (rounded up to a float boundary)
-  for (int i = threadIdx.x; i < hw * E; i += 256) sums[i] = 0.f;
-  __syncthreads();
-  for (int i = threadIdx.x; i < hw * E; i += 256) {
-    const int e = i / hw, p = i - e * hw;
+  for (int p = threadIdx.x; p < hw; p += 256) {
     const int yy = p / w, xx = p - yy * w;
-    const float* rm = rowmax + e * hw;
-    float best = -3.4e38f;
-    int by = 0;
+    float best[E], g[E];
+    int tgt[E];  // input position of the channel's arg-max
     bool first = true;
     for (int dyy = -r; dyy <= r; ++dyy) {
       const int y2 = yy + dyy;
       if ((unsigned)y2 >= (unsigned)h) continue;
-      const float v = rm[y2 * w + xx];
-      if (first || v > best) best = v, by = y2, first = false;
+      float v[E];
+      Chunk<T>::unpack(rm[y2 * w + xx], v);
+      const unsigned arg = ra[y2 * w + xx];
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (first || v[e] > best[e]) best[e] = v[e], tgt[e] = y2 * w + xx + (int)((arg >> (4 * e)) & 15u) - r;
+      first = false;
     }
-    const int bx = xx + (int)rowarg[e * hw + by * w + xx] - r;
-    atomicAdd(sums + e * hw + by * w + bx, gs[i]);
+    Chunk<T>::unpack(gs[p], g);
+#pragma unroll
+    for (int e = 0; e < E; ++e) atomicAdd(sums + tgt[e] * E + e, g[e]);
   }
   __syncthreads();
   for (int p = threadIdx.x; p < hw; p += 256) {
     float acc[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) acc[e] = sums[e * hw + p];
+    for (int e = 0; e < E; ++e) acc[e] = sums[p * E + e];
     T* dst = gi + ((size_t)img * hw + p) * (size_t)ldgi + cc * E;
     if (accumulate) {
       float f[E];
@@ -400,7 +404,8 @@ extern "C" int32_t dy_maxpool_bwd_nhwc(const void* x, const void* g_out, void* g
   const int epc = 16 / es;
   DY_REQUIRE(c % epc == 0 && DY_VIEW_OK(x, ld_x, c, es) && DY_VIEW_OK(g_out, ld_go, c, es) && DY_VIEW_OK(g_in, ld_gi, c, es), DY_ERR_INVALID_ARG,
              "dy_maxpool_bwd_nhwc: views must be whole 16-byte chunks");
-  const size_t smem = (size_t)h * w * epc * 17 + 16;  // x, g, row maxima, sums (fp32) + row arg-max (bytes)
+  const size_t smem = (size_t)h * w * (3 * 16 + epc * 4 + 4);  // chunks of x, g, row maxima; fp32 sums; packed row arg-max
+  DY_REQUIRE(k <= 15, DY_ERR_UNSUPPORTED, "dy_maxpool_bwd_nhwc: k <= 15 (4-bit column offsets)");
   DY_REQUIRE(smem <= 160 * 1024, DY_ERR_UNSUPPORTED, "dy_maxpool_bwd_nhwc: plane %dx%d too large for LDS", h, w);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const unsigned grid = (unsigned)(n * (c / epc));

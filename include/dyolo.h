@@ -543,7 +543,7 @@ int32_t dy_silu_bwd(const void* u, const void* dy, void* du, int64_t rows, int32
  *   dx (n,h,w,c) = sum of the 2x2 blocks of g (n,2h,2w,c).
  * dy_maxpool_bwd_nhwc: gradient of MaxPool2d(k, 1, k//2) inside SPPF (nn/modules/block.py:185-191): every output's
  *   gradient goes to the FIRST maximum of its window in (row, column) order (torch semantics); g_in = (accumulate ?
- *   g_in : 0) + that.  h*w*(16/elem_size)*17 bytes of LDS per workgroup (h*w <= ~1200).
+ *   g_in : 0) + that.  h*w*(52 + 64/elem_size) bytes of LDS per workgroup (16-bit: h*w <= ~1900), k <= 15.
  * dy_add_nhwc: out = a + b, (rows, c) views (Bottleneck's shortcut, block.py:348-350).  c % one 16-byte chunk == 0.
  * dy_add_dilated2_nhwc: dx (n, H2, W2, c)[:, 2y, 2x] += t (n, h, w, c)[:, y, x] -- the input gradient of a 1x1 STRIDE-2 convolution
  *   (RepVGGBlock's 1x1 branch, block.py:1480-1490) from t = the 1x1 stride-1 convolution of dz with the transposed weights.
