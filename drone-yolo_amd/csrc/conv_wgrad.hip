@@ -1120,7 +1120,7 @@ extern "C" int32_t dy_colsum(const void* z, float* out, int64_t rows, int32_t c,
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int R = 256 / nch;
   long long blocks = (rows + 8LL * R - 1) / (8LL * R);
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 256) blocks = 256;  // every workgroup ends with one atomic per channel on the same addresses: they serialise (1024: 20 us a call)
   const int rpb = (int)((rows + blocks - 1) / blocks);
   const unsigned gx = (unsigned)((rows + rpb - 1) / rpb);
   const size_t smem = (size_t)R * nch * epc * 4;

@@ -198,11 +198,18 @@ __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const
 // ---- optimizer over ONE flat fp32 tensor ------------------------------------------------------------------------------
 // sum of squares (double) for clip_grad_norm_
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, double* out) {
+  __shared__ double red[4];
   double s = 0.0;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += (double)g[i] * (double)g[i];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-  if ((threadIdx.x & 63) == 0 && s != 0.0) atomicAdd(out, s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  // ONE atomic per workgroup, 256 workgroups: 4,096 wave atomics on the one address took most of the kernel's 60 us
+  if (threadIdx.x == 0) {
+    const double t = red[0] + red[1] + red[2] + red[3];
+    if (t != 0.0) atomicAdd(out, t);
+  }
 }
 
 // Loss-scaling state of torch.cuda.amp.GradScaler kept on the device (reference: engine/trainer.py:271, 389, 591-599):
@@ -518,7 +525,7 @@ extern "C" int32_t dy_conv2d_grouped_bwd_nhwc(const dy_conv_desc* d, const void*
 
 extern "C" int32_t dy_sumsq_f32(const float* g, int64_t n, double* out, dy_stream_t stream) {
   DY_REQUIRE(g && out && n > 0, DY_ERR_INVALID_ARG, "dy_sumsq_f32: bad arguments");
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid1(n) > 1024 ? 1024 : grid1(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, (long long)n, out);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid1(n) > 256 ? 256 : grid1(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, (long long)n, out);
   return check_launch("dy_sumsq_f32");
 }
 
