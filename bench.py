@@ -320,14 +320,18 @@ def train_record(a, dt, t_enq, loss, tr, batch, world, steps, warmup, dtype):
            "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": dtype, "data": "synthetic", "host_enqueue_ms_per_step": round(t_enq / steps * 1e3, 3),
            "config": {"workload": "Drone-YOLO-s training step 640x640: uint8 batch -> forward (batch-stat BN) -> v8DetectionLoss -> backward -> "
-                                  "bucketed SUM all-reduce (RCCL, overlapped with backward) -> clip -> SGD nesterov -> EMA"
+                                  "bucketed SUM all-reduce of the gradients over RCCL (placement relative to backward: `step_form`) -> clip -> SGD nesterov -> EMA"
                                   + (" under a device-side GradScaler (fp16 storage)" if dtype == "fp16" else ""),
                       "batch_per_gpu": batch, "global_batch": batch * world, "labels_per_image": "Poisson(50)",
                       "parallelism": f"data parallel x{world}" + (f", {len(tr.buckets.buckets)} gradient buckets all-reduced as backward produces them" if tr.buckets is not None else ", single rank (no exchange)"),
                       "step_form": tr.step_form(), "loss": round(loss, 3)},
            "flops_per_image_G": 111.2, "mfma_frac": round(111.2e9 * total / dt / 1e12 / MFMA_PEAK_TFLOPS.get(dtype, 2500.0), 4)}
     if tr.amp_state is not None:
-        rec["config"]["grad_scaler"] = tr.scaler_state_dict()
+        sc, tracker, _, skipped = tr.amp_state.cpu().tolist()
+        rec["config"]["grad_scaler"] = {"scale": sc, "growth_tracker": int(tracker), "skipped_steps": int(skipped)}
+    if tr.buckets is not None:
+        rec["config"]["exchange"] = {"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(), "buckets": len(tr.buckets.buckets),
+                                     "event_path_verified": tr.buckets.event_path_verified}
     return rec
 
 
@@ -335,7 +339,7 @@ def train_bench(a):
     """Secondary line: Drone-YOLO-s training step, B images per GPU, bf16 storage, SGD nesterov."""
     from drone_yolo_amd import parallel as P
 
-    rank, local_rank, world = P.init_distributed()
+    rank, local_rank, world = P.init_distributed(single_rank=True)  # one rank too: barrier / MAX go through the collective
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
     if os.environ.get("DYOLO_FORCE_DEVICE"):
@@ -373,12 +377,12 @@ def time_breakdown(plan, iters: int = 5):
 
 def batch_sweep(model, dtype, device_index, batches=(1, 8, 64), steps: int = 20):
     """B in {1, 8, 64, 256} (256 is the headline itself): hipGraph replay on one stream.  One more row runs
-    fp32 storage at B = 64 — the precision that meets the north-star bar EXACTLY (kept sets identical to the reference's) — with its
-    own parity gate, so that one bar-exact throughput stands in the record beside the fp16 headline."""
+    fp32 storage at B = 64 and at the headline's B = 256 — the precision that meets the north-star bar EXACTLY (kept sets identical to the
+    reference's) — with its own parity gate, so that a bar-exact full-batch throughput stands in the record beside the fp16 headline."""
     from drone_yolo_amd.engine.predictor import DetectionPredictor
 
     out = []
-    for b, dt_name in [(b, dtype) for b in batches] + [(64, "fp32")]:
+    for b, dt_name in [(b, dtype) for b in batches] + [(64, "fp32"), (256, "fp32")]:
         p = DetectionPredictor(model, dict(conf=0.25, iou=0.7, max_det=300, dtype=dt_name, device=device_index, graph=True))
         x = torch.rand(b, 3, 640, 640, generator=torch.Generator().manual_seed(2000 + b)).to(torch.device("cuda", device_index))
         cf = p.forward_device(x)
@@ -396,7 +400,8 @@ def batch_sweep(model, dtype, device_index, batches=(1, 8, 64), steps: int = 20)
         del p, cf
         torch.cuda.empty_cache()
         if dt_name != dtype:
-            g = parity_gate(dt_name, device_index)
+            gates = batch_sweep.__dict__.setdefault("_gates", {})
+            g = gates.get(dt_name) or gates.setdefault(dt_name, parity_gate(dt_name, device_index))
             row["parity"] = {k: g[k] for k in ("match_rate", "missed", "extra", "iou_min", "counts_equal", "kept_sets_identical")}
             row["note"] = "bar-exact precision (class / index identical to the reference, IoU >= 0.999)"
         out.append(row)
@@ -406,8 +411,8 @@ def batch_sweep(model, dtype, device_index, batches=(1, 8, 64), steps: int = 20)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200 for infer: ~2.7 s of GPU time, long enough for a 1 Hz utilisation sampler; 30 for train)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps first (default 10 infer / 5 train)")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 256 for infer, SURVEY §8d config 2; 64 for train, config 3)")
     ap.add_argument("--imgsz", type=int, default=640, help="square input size (BASELINE config 5: --model yolov8x-p2-repvgg.yaml --imgsz 1536 --dtype fp8 --batch 8)")
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32", "fp8"],
@@ -429,6 +434,10 @@ def main():
         a.batch = 64 if a.mode == "train" else int(os.environ.get("DYOLO_BENCH_BATCH", 256))
     if a.dtype is None:
         a.dtype = "bf16" if a.mode == "train" else "fp16"
+    if a.steps is None:
+        a.steps = 30 if a.mode == "train" else 200
+    if a.warmup is None:
+        a.warmup = 5 if a.mode == "train" else 10
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this process becomes the launcher (reference: utils/dist.py:56-66 + trainer.py:185-205).
         # It has not touched the GPU (device_count() only reads the topology) and starts the ranks as CHILD processes — one per
@@ -447,7 +456,9 @@ def main():
     from drone_yolo_amd import parallel as P
     from drone_yolo_amd.engine.predictor import DetectionPredictor
 
-    rank, local_rank, world = P.init_distributed()
+    # a ONE-rank job initialises a (one-rank) RCCL group as well, so that the barrier, the MAX over ranks and `ranks_seen` below are what
+    # the N-rank job runs, not a host shortcut
+    rank, local_rank, world = P.init_distributed(single_rank=True)
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: refusing to report a {a.gpus}-GPU number from {world} rank(s)")
     if os.environ.get("DYOLO_FORCE_DEVICE"):  # rehearsal of N ranks on one GPU (with DYOLO_DIST_BACKEND=gloo)
@@ -455,6 +466,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     ranks_seen = int(round(P.sum_over_ranks(1.0, dev)))  # every rank contributes 1 through the collective itself
+    collective = {"initialized": torch.distributed.is_initialized(), "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None}
 
     model = D.DetectionModel(a.model, nc=10, verbose=False)
     sd = synthetic_state_dict(model, seed=0)
@@ -535,7 +547,7 @@ def main():
                 e["share_csv_pct_of_base_symbol"] = round(shares[base], 2)
             e["us"], e["gflop"] = round(e["us"], 1), round(e["gflop"], 1)
         roof["by_kernel"] = dict(sorted(by.items(), key=lambda kv: -kv[1]["us"]))
-        if by and a.dtype in ("bf16", "fp16"):
+        if by:
             sym, e = max(by.items(), key=lambda kv: kv[1]["us"])
             roof["dominant_kernel"] = {"symbol": f"dy::{sym}", "launches_per_pass": e["launches_per_pass"], "avg_us": e["avg_us"],
                                        "avg_gflop": round(e["gflop"] / e["launches_per_pass"], 2), "achieved": e["achieved_TFLOPs"], "unit": "TFLOP/s",
@@ -587,7 +599,7 @@ def main():
                                       "fp32": "fp32 storage (bar-exact)", "fp8": "fp8 e4m3fn storage / fp32 accumulate (BASELINE config 5)"}[a.dtype], "batch_per_gpu": a.batch, "global_batch": a.batch * world,
                        "parallelism": f"batch-split x{world}, no collective", "hipgraph": not a.no_graph, "streams": ns,
                        "conf": 0.25, "iou": 0.7, "max_det": 300, "candidates_frac": round(cand, 4), "kept_per_image": round(kept, 1)},
-            "ranks_seen": ranks_seen, "parity": parity, "breakdown": breakdown, "batch_sweep": sweep,
+            "ranks_seen": ranks_seen, "collective": collective, "parity": parity, "breakdown": breakdown, "batch_sweep": sweep,
             "roofline": roof, "train": train, "cpu_baseline": cpu}))
 
 

@@ -399,7 +399,7 @@ class DetectionTrainer:
         self.batch_size = int(a["batch"])  # GLOBAL batch, as in the reference; each rank sees batch // world
         self.weight_decay = a["weight_decay"] * self.batch_size * max(round(a["nbs"] / max(self.batch_size, 1)), 1) / a["nbs"]  # trainer.py:254-256
         self.flat = FlatState(self.model, self.device)
-        if self.world > 1 and torch.distributed.is_initialized():
+        if P.exchange_on():
             # DDP broadcasts rank 0's parameters and buffers at construction; so do we (replicas must not rely on equal seeds)
             for t in (self.flat.P, self.flat.B):
                 if torch.distributed.get_backend() == "nccl":
@@ -426,7 +426,8 @@ class DetectionTrainer:
         self.opt_steps = 0
         self.iters = 0
         self.last_opt_step = -1
-        self.buckets = P.GradBuckets(self.flat, n_buckets=int(os.environ.get("DYOLO_GRAD_BUCKETS", 4))) if self.world > 1 else None
+        # (a one-rank group under DYOLO_DDP_SINGLE_RANK=1 exchanges too: every RCCL call of the N-rank job on one GPU)
+        self.buckets = P.GradBuckets(self.flat, n_buckets=int(os.environ.get("DYOLO_GRAD_BUCKETS", 4))) if P.exchange_on() else None
         if self.grad_sink:
             self.flat.enable_sink()
             if self.buckets is not None:
@@ -491,7 +492,7 @@ class DetectionTrainer:
         replay is launched the bucket all-reduces are issued on a second stream, each behind its bucket's event — bucket k's ring
         runs under the backward kernels of buckets k+1.. — so the host still enqueues ~10 calls per step instead of ~2,400."""
         use = (self.graph_steps and self.iters >= 2 and batch["img"].is_cuda and self.model.training
-               and (self.world == 1 or self.grad_sink))
+               and (self.buckets is None or self.grad_sink))
         from ..nn.autograd_ops import lazy_head_seed, sink_armed
 
         bk = self.buckets
@@ -542,7 +543,10 @@ class DetectionTrainer:
             gs["img"].copy_(img)
             armed = bk.armed if bk is not None else False
             if bk is not None:
-                if bk.events is None and os.environ.get("DYOLO_DDP_OVERLAP", "1") != "0" and external_events_work(img.device):
+                # external events inside the graph are OPT-IN (DYOLO_DDP_OVERLAP=1): this image's ROCm refuses them ("External events are
+                # disallowed in rocm"), so the shipped form issues the bucket all-reduces after the graph; where a runtime takes them the
+                # timing probe below and the first-replay check in exchange_after_replay guard the path
+                if bk.events is None and os.environ.get("DYOLO_DDP_OVERLAP", "0") == "1" and external_events_work(img.device):
                     bk.make_events()
                 self._graph_events = bk.events is not None
                 bk.arm(armed, capturing=True)
@@ -578,13 +582,14 @@ class DetectionTrainer:
     def step_form(self) -> str:
         """How a step is issued (for the bench line): eager launches, one hipGraph, or one hipGraph with the bucket exchange behind it."""
         graphed = getattr(self, "_graph", None) is not None
-        if self.world == 1:
+        if self.buckets is None:
             return "forward + loss + backward replayed as ONE hipGraph, gradients through the sink (one flush)" if graphed else "eager launches"
         if graphed:
             return ("forward + loss + backward replayed as ONE hipGraph; per-bucket sink flush + external event inside the graph, bucket all-reduces "
                     "issued behind those events (overlap with the remaining backward)" if getattr(self, "_graph_events", False) else
-                    "forward + loss + backward replayed as ONE hipGraph; bucket all-reduces issued after it")
-        return "eager launches, bucket all-reduces from autograd hooks"
+                    "forward + loss + backward replayed as ONE hipGraph with a per-bucket sink flush; the bucket all-reduces are issued AFTER the graph "
+                    "(no overlap with backward)")
+        return "eager launches, bucket all-reduces issued from backward as each bucket's last gradient lands (overlap with the remaining backward)"
 
     def optimizer_step(self) -> None:
         """scaler.unscale_, clip 10, scaler.step, scaler.update, zero_grad, EMA — trainer.py:591-599.  The scaler exists for fp16
@@ -610,13 +615,6 @@ class DetectionTrainer:
             H.amp_update_(self.amp_state, self.sumsq)
         G.zero_()
         self.ema.update()
-
-    def scaler_state_dict(self) -> Optional[dict]:
-        """GradScaler.state_dict() of the device state (host read: checkpoint time only)."""
-        if self.amp_state is None:
-            return None
-        sc, tr, _, _ = self.amp_state.cpu().tolist()
-        return {"scale": sc, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "_growth_tracker": int(tr)}
 
     # ---- the loop --------------------------------------------------------------------------------------------------------
     def train(self):
@@ -739,6 +737,9 @@ class DetectionTrainer:
         g0, g1, g2 = param_group_names(self.model, include_frozen=True)  # the reference's enumeration: frozen parameters keep their index
         order = list(g2) + list(g0) + list(g1)
         state = {}
+        # torch.optim.AdamW counts the steps that RAN: a GradScaler skips the optimizer on overflow (the reference saves no scaler state,
+        # trainer.py:514-545), and the step kernels' bias correction uses opt_steps - skipped likewise (amp_state[3]; checkpoint-time host read)
+        ran = self.opt_steps - (int(self.amp_state[3].item()) if self.amp_state is not None else 0)
         for i, k in enumerate(order):
             if k not in self.flat.offsets:
                 continue  # frozen (dfl.conv.weight): never received a gradient, so torch.optim holds no state entry for it
@@ -747,7 +748,7 @@ class DetectionTrainer:
             if self.opt_name == "SGD":
                 state[i] = {"momentum_buffer": self.buf1[off : off + c].view(shape).clone()}
             else:
-                state[i] = {"step": torch.tensor(float(self.opt_steps)), "exp_avg": self.buf1[off : off + c].view(shape).clone(),
+                state[i] = {"step": torch.tensor(float(ran)), "exp_avg": self.buf1[off : off + c].view(shape).clone(),
                             "exp_avg_sq": self.buf2[off : off + c].view(shape).clone()}
         groups, s = [], 0
         for names, lr, wd in ((g2, self.cur_lrs[2], 0.0), (g0, self.cur_lrs[0], self.weight_decay), (g1, self.cur_lrs[1], 0.0)):

@@ -335,6 +335,9 @@ class PackedConv:
         fp32 weights that already live on the device (training: the master weights, every step) are packed by ONE
         ``dy_pack_conv_weights`` launch instead of the pad / permute / flip / cast chain below."""
         L = lib()
+        # what a DY_WLAYOUT_ROWS pack of the same layer is built from (``rows()``: calls the special layout's kernels refuse)
+        self._rows_args = (weight, bias, stride, pad, groups, act, dtype, device, cin_pad, for_out_f32, transpose_flip)
+        self._rows_pack = None
         dev_pack = weight.is_cuda and weight.dtype == torch.float32 and dtype != FP8 and groups == 1 and weight.device == torch.device(device)
         if transpose_flip and not dev_pack:
             raise ValueError("PackedConv(transpose_flip=True) needs fp32 weights on the target device")
@@ -401,6 +404,7 @@ class PackedConv:
             sp[:cout] = ws * self.act_scale
             self.w = wp.to(FP8).contiguous().to(device)
             self.b, self.wscale = bp.contiguous().to(device), sp.contiguous().to(device)
+            self._rows_args = None
             return
         # stride-2 halo tiles are 17x33 pixels (2 x 45 KB of LDS): only a weight set of <= 36 KB fits beside them
         s2_fits = self.cin <= 4 * elems_per_chunk(dtype) and cout > 32 or self.cin <= 8 * elems_per_chunk(dtype) and cout <= 32
@@ -476,9 +480,39 @@ class PackedConv:
         self.w = wp.to(dtype).contiguous().to(device)
         self.b = bp.contiguous().to(device)
 
+    def rows(self) -> "PackedConv":
+        """The same layer packed in DY_WLAYOUT_ROWS (built on first use, kept): the layout every call shape has a kernel for.
+        ``conv2d`` takes it when a call does not meet the preconditions of the kernels behind this pack's special layout."""
+        if self.layout == _lib.DY_WLAYOUT_ROWS:
+            return self
+        if self._rows_pack is None:
+            w, b, stride, pad, groups, act, dtype, device, cin_pad, for_out_f32, tf = self._rows_args
+            self._rows_pack = PackedConv(w, b, stride, pad, groups, act, dtype, device, cin_pad=cin_pad, halo=False, for_out_f32=for_out_f32, transpose_flip=tf)
+        return self._rows_pack
+
+    def for_call(self, x_bytes: int, y_bytes: int, ld_y: int, y_ptr: int, residual: bool, out_f32: bool, gathered: bool) -> "PackedConv":
+        """This pack, or its DY_WLAYOUT_ROWS twin when the call is outside what the special layout's kernels take (mirrors
+        csrc/conv3x3_halo.hip::conv3x3_halo_dispatch and conv3x3_hreg.hip::conv3x3_hreg_try): a second source / upsampled or dilated
+        gather, an input view beyond the 4 GiB a buffer descriptor addresses, and -- stride-2 64-channel layers, which have no kernel
+        but conv3x3_hreg_s2 behind DY_WLAYOUT_HALO3X3 -- a residual, fp32 output, an output pitch / base that rules out 16-byte
+        stores or an input view beyond 2 GiB."""
+        if self.layout != _lib.DY_WLAYOUT_HALO3X3:
+            return self
+        if gathered or x_bytes >= (1 << 32) - 64:
+            return self.rows()
+        if self.stride == 2 and self.cin == 64 and self.cout > 32:
+            if residual or out_f32 or ld_y % 8 or y_ptr % 16 or x_bytes >= (1 << 31) or y_bytes >= (1 << 32) - 64 or self.dtype == torch.float32:
+                return self.rows()
+        return self
+
 
 def conv_out_hw(h: int, w: int, k: int, s: int, p: int) -> Tuple[int, int]:
     return (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+
+
+def last_kernel_name() -> str:
+    """Device kernel the calling thread's last libdyolo launch dispatched to (``dy_last_kernel_name``)."""
+    return (lib().dy_last_kernel_name() or b"").decode()
 
 
 def conv_stats_written() -> int:
@@ -514,6 +548,8 @@ def conv2d(x: torch.Tensor, pc: PackedConv, out: Optional[torch.Tensor] = None, 
         raise ValueError(f"conv2d: out has shape {tuple(out.shape)}/{out.dtype}, expected {(n, pc.cout, ho, wo)}/{odt}")
     xp, ldx = view_params(x)
     yp, ldy = view_params(out)
+    pc = pc.for_call(n * hb * wb * ldx * x.element_size(), n * ho * wo * ldy * out.element_size(), ldy, yp, residual is not None, out_f32,
+                     x2 is not None or up2x or dil2)
     d = ConvDesc()
     d.x, d.w, d.bias, d.y = xp, pc.w.data_ptr(), pc.b.data_ptr(), yp
     d.batch, d.h, d.w_in, d.cin, d.ld_x = n, h, w, cin, ldx

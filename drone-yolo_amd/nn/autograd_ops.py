@@ -126,16 +126,22 @@ def conv_bn_bwd(dy, x, z, weight, gamma, beta, st, stride, pad, act, need_dx=Tru
     contribution), added in the dgrad epilogue; ``dx_out`` may be that same view (in place: a lane reads what it then overwrites).
     Parameter gradients that went to the trainer's sink come back as None."""
     cout, cin, k, _ = weight.shape
-    # (the image stem's input is padded to one chunk: its weight gradient is sliced below and goes through autograd — its sink slot must
-    #  not be taken, or a listener would count the parameter done before AccumulateGrad has added it)
-    sg, sb, sw = grad_sink(gamma), grad_sink(beta), (grad_sink(weight) if x.shape[1] == cin else None)
+    sg, sb, sw = grad_sink(gamma), grad_sink(beta), grad_sink(weight)
     dz, dgamma, dbeta = H.bn_train_bwd(as_nhwc(dy), z, gamma, beta, st, act, dgamma=sg, dbeta=sb)
     if sg is not None:
         dgamma = None
     if sb is not None:
         dbeta = None
-    if sw is not None:
+    if sw is not None and x.shape[1] == cin:
         H.conv_wgrad_into(x, dz, k, stride, pad, sw.view(cout, k, k, cin))  # on the side stream: overlaps the input gradient below
+        dw = None
+    elif sw is not None:
+        # the image stem: its input is padded to one chunk, so the kernel's (cout, k, k, cin_pad) result is sliced into the sink slot.
+        # r04: this gradient used to go back through autograd — the one AccumulateGrad node of a training step, created on the eager
+        # warm-up step's stream and met again under hipGraph capture on another (PyTorch's "AccumulateGrad node's stream does not
+        # match" warning, and the precondition of round 3's hipStreamEndCapture crash).  Now no parameter gradient passes through autograd.
+        dwp = H.conv_wgrad(x, dz, k, stride, pad)  # (cout, cin_pad, k, k) view of the kernel's (cout, k, k, cin_pad) buffer
+        sw.view(cout, k, k, cin).add_(dwp.permute(0, 2, 3, 1)[..., :cin])
         dw = None
     else:
         dw = H.conv_wgrad(x, dz, k, stride, pad)[:, :cin]

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from ... import hip_ops as H
-from .conv import Conv, _PackedMixin, _require_eval, fold_conv_bn
+from .conv import Conv, _PackedMixin, _train_forward, fold_conv_bn
 
 __all__ = ("DFL", "SPPF", "C2f", "Bottleneck", "RepVGGBlock", "SEBlock", "conv_bn")
 
@@ -43,6 +43,8 @@ class Bottleneck(nn.Module):
         self.add = shortcut and c1 == c2
 
     def forward(self, x, out=None):
+        if self.training:
+            return _train_forward(self, "bottleneck_train", x, out=out)
         # the residual add rides in cv2's epilogue (after its SiLU, as in the reference expression)
         return self.cv2(self.cv1(x), out=out, residual=x if self.add else None)
 
@@ -76,7 +78,9 @@ class C2f(nn.Module):
         ``kw`` (x2= / up2x=) is forwarded to cv1 so that a Concat(+Upsample) in front of this block
         can be folded into cv1's gather.
         """
-        if self.fuse_block and len(self.m) == 1 and not self.training:
+        if self.training:
+            return _train_forward(self, "c2f_train", x, out=out, **kw)
+        if self.fuse_block and len(self.m) == 1:
             cout = self.cv2.conv.out_channels
             if not kw and H.c2f_fused_supported(x.shape[1], self.c, cout, 1, x.dtype):
                 return H.c2f_fused(x, self._packed_block(x.dtype, x.device), out=out)
@@ -105,6 +109,8 @@ class SPPF(nn.Module):
         self.m = nn.MaxPool2d(kernel_size=k, stride=1, padding=k // 2)  # kept for repr / state parity only
 
     def forward(self, x, out=None):
+        if self.training:
+            return _train_forward(self, "sppf_train", x, out=out)
         n, _, h, w = x.shape
         c_ = self.cv1.conv.out_channels
         ybuf = H.alloc_nhwc(n, 4 * c_, h, w, x.dtype, x.device)
@@ -210,7 +216,8 @@ class RepVGGBlock(_PackedMixin, nn.Module):
         return H.PackedConv(w, b, self.stride, self.padding, self.groups, act, dtype, device, cin_pad=cin_pad)
 
     def forward(self, inputs, out=None):
-        _require_eval(self)
         if not isinstance(self.se, nn.Identity):
             return self.se(inputs)  # raises: no SE kernel
+        if self.training:
+            return _train_forward(self, "repvgg_train", inputs, out=out)
         return H.conv2d(inputs, self._packed_for(inputs), out=out)

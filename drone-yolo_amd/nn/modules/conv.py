@@ -84,12 +84,16 @@ class _PackedMixin:
         return out
 
 
-def _require_eval(m: nn.Module) -> None:
-    if m.training:
-        raise NotImplementedError(
-            f"{type(m).__name__}: training-mode forward (batch-statistics BatchNorm + autograd) is not built "
-            "yet on the HIP path; call model.eval(). There is deliberately no eager-PyTorch fallback."
-        )
+def _train_forward(m: nn.Module, fn_name: str, x, **kw):
+    """``module.train()(x)`` on a module of its own (reference conv.py:49-51, block.py:1480-1490, :237-242: batch-statistics BatchNorm,
+    running statistics updated, autograd graph): the same autograd ops the model-level executor uses (nn/train_forward.py).  ``x`` is an
+    NHWC view on the device, as for eval; the eval-only launch options (out= slices, fused residual / Concat gathers) do not exist here."""
+    extra = {k: v for k, v in kw.items() if v is not None and v is not False}
+    if extra:
+        raise NotImplementedError(f"{type(m).__name__}: {sorted(extra)} are launch options of the eval path; a training-mode forward takes the input only")
+    from .. import train_forward as TF
+
+    return getattr(TF, fn_name)(m, x)
 
 
 class Conv(_PackedMixin, nn.Module):
@@ -118,7 +122,8 @@ class Conv(_PackedMixin, nn.Module):
         return H.PackedConv(w, b, c.stride[0], c.padding[0], c.groups, act, dtype, device, cin_pad=cin_pad)
 
     def forward(self, x, out=None, residual=None, **kw):
-        _require_eval(self)
+        if self.training:
+            return _train_forward(self, "conv_train", x, out=out, residual=residual, **kw)
         return H.conv2d(x, self._packed_for(x), out=out, residual=residual, **kw)
 
     forward_fuse = forward  # BN is always folded on this path
@@ -131,7 +136,8 @@ class Conv(_PackedMixin, nn.Module):
 
     def forward_stem(self, im, dtype, out=None, mark_input=False):
         """fp32 NCHW image -> this layer's NHWC output in ``dtype`` (layout cast + conv + BN + SiLU in one kernel)."""
-        _require_eval(self)
+        if self.training:
+            raise NotImplementedError("Conv.forward_stem is the eval path's fused image kernel; training reads the image through model.forward_train")
         cache = self._pack_cache()
         key = ("stem", dtype, im.device, H.scaled_domain())
         ps = cache.get(key)

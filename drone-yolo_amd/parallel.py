@@ -21,15 +21,35 @@ def dist_env() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
-    """Initialise the default process group when launched by torch.distributed.run; "nccl" is RCCL."""
+def single_rank_exchange() -> bool:
+    """DYOLO_DDP_SINGLE_RANK=1: a ONE-rank process group still runs the whole exchange path (bucket all-reduces on device slices, the
+    communication stream, the control-plane reductions) — every RCCL call of the N-rank job on one GPU (tests/test_train_gpu.py)."""
+    return os.environ.get("DYOLO_DDP_SINGLE_RANK", "0") == "1"
+
+
+def exchange_on() -> bool:
+    """Whether gradients are exchanged at all: a process group of several ranks, or of one under ``single_rank_exchange()``."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or single_rank_exchange())
+
+
+def init_distributed(backend: Optional[str] = None, single_rank: bool = False) -> Tuple[int, int, int]:
+    """Initialise the default process group when launched by torch.distributed.run; "nccl" is RCCL.  ``single_rank``: also for a
+    world of one (bench.py --gpus 1 and the one-rank RCCL test: the barrier / MAX / SUM of the measurement go through the collective)."""
     rank, local_rank, world = dist_env()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank or single_rank_exchange()) and not dist.is_initialized():
         if backend is None:
             # DYOLO_DIST_BACKEND=gloo: rehearse an N-rank run on fewer GPUs than ranks (RCCL refuses two ranks on one device)
             backend = os.environ.get("DYOLO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            if world > 1:
+                os.environ["MASTER_PORT"] = "29500"
+            else:  # a lone rank picks a free port (nothing else has to find it)
+                import socket
+
+                with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -80,7 +100,7 @@ def allreduce_gradients(flat_grad: torch.Tensor) -> torch.Tensor:
     """In-place SUM all-reduce of the flat gradient buffer over all ranks (reference: loss *= world_size, trainer.py:382-383,
     then DistributedDataParallel's gradient mean — the product is the plain sum).  One bucket: for Drone-YOLO-s 43 MB fp32,
     a single ring pass over the xGMI links; BatchNorm statistics stay per rank (no SyncBN in the reference)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if exchange_on():
         if flat_grad.is_cuda and dist.get_backend() != "nccl":  # gloo rehearsal: through host memory
             h = flat_grad.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM)
@@ -108,6 +128,7 @@ class GradBuckets:
     def __init__(self, flat, n_buckets: int = 4):
         self.flat = flat
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.exchange = exchange_on()
         bounds, off = [], 0
         for s in flat.sizes:
             bounds.append((off, off + s))
@@ -150,6 +171,8 @@ class GradBuckets:
         self.capturing = False  # inside a hipGraph capture: a ready bucket is flushed and marked by an event, exchanged after the replay
         self.events: Optional[list] = None
         self.comm_stream = None
+        self._events_checked = False
+        self.event_path_verified: Optional[bool] = None
         self._noted: dict = {}
         self._seen: set = set()
         self._done: set = set()
@@ -189,7 +212,7 @@ class GradBuckets:
         """Call before a backward: ``on`` when that backward is followed by the optimizer step (the last micro-batch of an
         accumulation window) — earlier micro-batches only accumulate locally.  ``capturing``: the backward is being captured into a
         hipGraph — ready buckets are flushed and marked (``events``), ``exchange_after_replay`` issues the all-reduces."""
-        self.armed = bool(on) and self.world > 1
+        self.armed = bool(on) and self.exchange
         self.capturing = capturing
         self.pending = [len(b["names"]) for b in self.buckets]
         self.next, self.works, self.issued_during_backward = 0, [], 0
@@ -260,6 +283,15 @@ class GradBuckets:
         if not self.armed:
             return
         self.works = []
+        check = None
+        if self.events is not None and not self._events_checked:
+            # first armed replay on the event path: the same exchange once more the plain way (a copy of G taken behind the WHOLE graph,
+            # all-reduced on the current stream); finish() compares.  An event wait that ordered nothing would let a ring read G before
+            # its bucket's flush — silently wrong gradients — so a mismatch turns the event path off for good and keeps the plain result.
+            check = self._event_check = self.flat.G.clone()
+            for bi in range(len(self.buckets)):
+                for lo, hi in self.buckets[bi]["ranges"]:
+                    self._all_reduce(check[lo:hi])
         for bi in range(len(self.buckets)):
             if self.events is None:
                 self._issue(bi)
@@ -269,17 +301,30 @@ class GradBuckets:
                 self._issue(bi)
 
     def finish(self) -> None:
-        if self.world <= 1:
+        if not self.exchange:
             return
         if not self.armed:  # a step without an armed backward (should not happen): one plain all-reduce
             dist.all_reduce(self.flat.G, op=dist.ReduceOp.SUM)
             return
         self.end_backward()  # (a no-op after the trainer's own end_backward / exchange_after_replay)
         for w in self.works:
-            w.wait()
+            if w is not None:
+                w.wait()
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.works, self.armed = [], False
+        check = self.__dict__.pop("_event_check", None)
+        if check is not None:
+            self._events_checked = True
+            same = bool(torch.allclose(check, self.flat.G, rtol=1e-5, atol=1e-10))  # (one host read, on the first armed replay only; a missed flush is off by whole gradients)
+            if not same:
+                import logging
+
+                logging.getLogger("drone_yolo_amd").error("GradBuckets: the event-ordered bucket exchange disagrees with the exchange behind the whole graph; "
+                                                          "external events do not order streams on this runtime -> exchange after the graph from now on")
+                self.flat.G.copy_(check)
+                self.events = None
+            self.event_path_verified = same
 
 
 def gather_detections(rows: torch.Tensor, counts: torch.Tensor) -> Optional[List[Tuple[torch.Tensor, torch.Tensor]]]:

@@ -248,6 +248,41 @@ def per_op(R):
     np.savez_compressed(OUT / "per_op.npz", **out)
 
 
+# ---- 2b. per-operator vectors in TRAINING mode (module.train(): batch-statistics BatchNorm, running statistics updated) ------------
+def per_op_train(R):
+    """Outputs of the real reference modules called on their own in ``train()`` mode (conv.py:49-51, block.py:1480-1490, :237-242,
+    :337-350, :172-191) and the BatchNorm running statistics they leave behind — the vectors tests/test_train_gpu.py holds the
+    module-level training forward of this package against (tests/golden/per_op_train.npz)."""
+    out = {}
+    g = torch.Generator().manual_seed(4321)
+
+    def rnd(*s):
+        return torch.randn(*s, generator=g)
+
+    def run(tag, m, seed, x, **extra):
+        sd = O.seeded_state_dict({k: v for k, v in m.state_dict().items()}, seed)
+        m.load_state_dict(sd)
+        R.tu.initialize_weights(m)  # BatchNorm eps 1e-3 / momentum 0.03 (torch_utils.py:423-433)
+        m.train()
+        y = m(x)
+        after = m.state_dict()
+        out.update({f"{tag}_x": tnp(x), f"{tag}_y": tnp(y), f"{tag}_seed": seed, **{f"{tag}_{k}": v for k, v in extra.items()}})
+        for k, v in after.items():
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                out[f"{tag}_stat__{k}"] = tnp(v)
+        print(f"  train-mode reference vector  {tag:<10s} y {tuple(y.shape)}  |y|max {float(y.abs().max()):.3f}  {sum(1 for k in after if k.endswith('running_mean'))} BatchNorm layers")
+
+    with torch.no_grad():
+        run("conv", R.conv.Conv(16, 32, 3, 2), 111, rnd(4, 16, 20, 24), args=np.array([16, 32, 3, 2]))
+        run("conv1", R.conv.Conv(24, 16, 1, 1), 112, rnd(3, 24, 9, 7), args=np.array([24, 16, 1, 1]))
+        run("rep_s2", R.block.RepVGGBlock(16, 32, 3, 2), 121, rnd(4, 16, 16, 12), args=np.array([16, 32, 3, 2]))
+        run("bott", R.block.Bottleneck(16, 16, True, 1, k=((3, 3), (3, 3)), e=1.0), 131, rnd(4, 16, 10, 10))
+        run("c2f_a", R.block.C2f(32, 32, 2, True), 141, rnd(4, 32, 12, 8), args=np.array([32, 32, 2, 1]))
+        run("c2f_b", R.block.C2f(48, 16, 1, False), 142, rnd(4, 48, 12, 8), args=np.array([48, 16, 1, 0]))
+        run("sppf", R.block.SPPF(32, 32, 5), 151, rnd(4, 32, 20, 20))
+    np.savez_compressed(OUT / "per_op_train.npz", **out)
+
+
 # ---- NMS vectors: the reference's non_max_suppression code over our nms primitive -----------------------------
 def nms_cases(R):
     g = torch.Generator().manual_seed(77)
@@ -699,6 +734,8 @@ if __name__ == "__main__":
     print("reference imported from", REF)
     if "--ckpt-only" in sys.argv:
         checkpoint_fixture(R)
+    elif "--train-ops-only" in sys.argv:
+        per_op_train(R)
     elif "--train-only" in sys.argv:
         train_vectors(R)
     elif "--loss-only" in sys.argv:
@@ -708,6 +745,7 @@ if __name__ == "__main__":
         big_vectors(R, only=only[0] if only else None)
     else:
         per_op(R)
+        per_op_train(R)
         nms_cases(R)
         e2e(R)
         loss_vectors(R)

@@ -100,9 +100,11 @@ def test_no_cpu_fallback():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             D.YOLO("yolov8n-p2-repvgg.yaml").train(data="synthetic:4", epochs=1)
-    m.train()
-    with pytest.raises(NotImplementedError):
-        m.model[0](torch.zeros(1, 8, 8, 8))
+    m.train()  # a module called on its own in training mode runs the device training forward (r04) — and has no CPU fallback either
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.model[0](torch.zeros(1, 8, 8, 8).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2))
+    with pytest.raises(NotImplementedError):  # eval-path launch options have no training form
+        m.model[0](torch.zeros(1, 8, 8, 8), residual=torch.zeros(1))
 
 
 def test_view_params_and_alloc():

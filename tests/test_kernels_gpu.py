@@ -5,6 +5,7 @@ CPU result on identically rounded inputs the error budget is one output rounding
 bf16, 2^-11 for fp16) plus accumulation-order noise; fp32 storage must agree to ~1e-5 relative.
 Integer / index outputs (NMS kept indices, classes, counts) are compared exactly.
 """
+import zlib
 import ast
 
 import numpy as np
@@ -77,7 +78,7 @@ CONV_CASES = [
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[-1] for c in CONV_CASES])
 def test_conv_matches_cpu(case, dtype, device):
     cin, cout, k, s, b, h, w, act, tag = case
-    g = torch.Generator().manual_seed(hash(tag) % 1000)
+    g = torch.Generator().manual_seed(zlib.crc32(tag.encode()) % 1000)
     x = quantize(torch.randn(b, cin, h, w, generator=g), dtype)
     wt = quantize(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5, dtype)
     bias = torch.randn(cout, generator=g) * 0.2
@@ -89,6 +90,45 @@ def test_conv_matches_cpu(case, dtype, device):
     torch.cuda.synchronize()
     assert tuple(y.shape) == tuple(ref.shape)
     check_close(back(y), ref, dtype, f"conv {tag}")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("how", ["residual", "out_f32", "unaligned_out", "x2", "up2x"])
+def test_halo_layout_pack_falls_back_to_rows_for_calls_its_kernels_refuse(how, dtype, device):
+    """A 16-bit 3x3 stride-2 layer with 64 input channels is packed in DY_WLAYOUT_HALO3X3 and has ONE kernel behind that layout
+    (conv3x3_hreg_s2: no residual, no fp32 output, 16-byte output rows, one plain source).  A call outside that must run on the
+    pack's DY_WLAYOUT_ROWS twin (PackedConv.for_call), not fail: every such call against the fp32 CPU convolution."""
+    g = torch.Generator().manual_seed(zlib.crc32(how.encode()) % 1000)
+    b, cin, cout, h, w = 2, 64, 128, 24, 20
+    wt = quantize(torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5, dtype)
+    bias = torch.randn(cout, generator=g) * 0.2
+    pc = H.PackedConv(wt, bias, 2, 1, 1, True, dtype, device)
+    assert pc.layout == H._lib.DY_WLAYOUT_HALO3X3
+    kw, res = {}, None
+    if how == "x2":
+        xa, xb = quantize(torch.randn(b, 32, h, w, generator=g), dtype), quantize(torch.randn(b, 32, h, w, generator=g), dtype)
+        x, xin, kw = torch.cat([xa, xb], 1), nhwc(xa, dtype, device), {"x2": nhwc(xb, dtype, device)}
+    elif how == "up2x":
+        xl = quantize(torch.randn(b, cin, h // 2, w // 2, generator=g), dtype)
+        x, xin, kw = F.interpolate(xl, scale_factor=2, mode="nearest"), nhwc(xl, dtype, device), {"up2x": True}
+    else:
+        x = quantize(torch.randn(b, cin, h, w, generator=g), dtype)
+        xin = nhwc(x, dtype, device)
+    ref = F.silu(F.conv2d(x, wt, bias, 2, 1))
+    if how == "residual":
+        r = quantize(torch.randn(ref.shape, generator=g), dtype)
+        ref, kw = ref + r, {"residual": nhwc(r, dtype, device)}
+    elif how == "out_f32":
+        kw = {"out_f32": True}
+    elif how == "unaligned_out":  # a channel slice whose pitch is not a multiple of eight elements: no 16-byte row stores
+        kw = {"out": nhwc(torch.zeros(ref.shape), dtype, device, ld=cout + 4)}
+    y = H.conv2d(xin, pc, **kw)
+    torch.cuda.synchronize()
+    assert pc._rows_pack is not None and pc._rows_pack.layout == H._lib.DY_WLAYOUT_ROWS
+    check_close(back(y), ref, dtype, f"hreg_s2 fallback {how}", extra=2.0 if how == "residual" else 1.0)
+    y2 = H.conv2d(nhwc(quantize(torch.randn(b, cin, h, w, generator=g), dtype), dtype, device), pc)  # the plain call still takes the fast kernel
+    torch.cuda.synchronize()
+    assert H.last_kernel_name().startswith("conv3x3_hreg_s2") and tuple(y2.shape) == (b, cout, h // 2, w // 2)
 
 
 GLDS_CASES = [
@@ -119,7 +159,7 @@ def test_conv_silu_in_the_log2e_scaled_domain(case, dtype, device):
     """DY_ACT_SILU_L2E (include/dyolo.h): the accumulator is t = log2(e) * z and the epilogue returns t / (1 + 2^-t) = log2(e) * silu(z).
     Against the CPU: conv on the same rounded operands, t * sigmoid(t / log2 e) — every conv kernel's epilogue (the shapes pick them)."""
     cin, cout, k, s, b, h, w, tag = case
-    g = torch.Generator().manual_seed(hash(tag) % 1013)
+    g = torch.Generator().manual_seed(zlib.crc32(tag.encode()) % 1013)
     x = quantize(torch.randn(b, cin, h, w, generator=g), dtype)
     wt = quantize(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5, dtype)
     bias = torch.randn(cout, generator=g) * 0.2
@@ -156,7 +196,7 @@ def test_scaled_activation_domain_folds(device):
 @pytest.mark.parametrize("case", GLDS_CASES, ids=[c[-1] for c in GLDS_CASES])
 def test_conv_glds_big_tile_matches_cpu(case, dtype, device):
     cin, cout, k, s, b, h, w, tag = case
-    g = torch.Generator().manual_seed(hash(tag) % 1000)
+    g = torch.Generator().manual_seed(zlib.crc32(tag.encode()) % 1000)
     x = quantize(torch.randn(b, cin, h, w, generator=g), dtype)
     wt = quantize(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5, dtype)
     bias = torch.randn(cout, generator=g) * 0.2

@@ -2,6 +2,7 @@
 optimizer) against PyTorch CPU autograd in fp32 on the same (dtype-rounded) inputs.
 Tolerances: fp32 1e-4 of the output scale; bf16 / f16 storage: outputs are rounded once to the storage type, so
 2^-8 / 2^-10 of the scale (arithmetic is fp32 / double inside the kernels)."""
+import zlib
 import pytest
 import torch
 import torch.nn.functional as F
@@ -107,7 +108,7 @@ GRAD_CASES = [
 @pytest.mark.parametrize("case", GRAD_CASES, ids=[c[-1] for c in GRAD_CASES])
 def test_conv_wgrad_dgrad_match_autograd(case, dtype, device):
     cin, cout, k, s, b, h, w, tag = case
-    g = torch.Generator().manual_seed(hash(tag) % 997)
+    g = torch.Generator().manual_seed(zlib.crc32(tag.encode()) % 997)
     x = quantize(torch.randn(b, cin, h, w, generator=g), dtype).requires_grad_(True)
     wt = quantize(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5, dtype).requires_grad_(True)
     z = F.conv2d(x, wt, None, s, k // 2)
@@ -809,10 +810,16 @@ def test_config3_batch64_graph_and_sink_step(device):
     parameter gradients are finite and non-zero; (2) against the SAME batch stepped eagerly in fp32 storage: loss within 3 %, gradient
     norm within 10 %, cosine of the head-tail gradients > 0.98; (3) permuting the images of the batch (labels re-indexed) leaves the
     graphed loss and gradient norm unchanged up to atomics order; (4) a replay with other labels equals the eager step on them."""
+    import warnings
+
     import bench
     import drone_yolo_amd as D
     from drone_yolo_amd.engine.trainer import DetectionTrainer, synthetic_dataset
 
+    # r04: no parameter gradient passes through autograd any more (the image stem's weight gradient goes through the sink too), so no
+    # AccumulateGrad node is created in the eager steps and met again under capture on another stream — round 3's capture crash began
+    # with exactly this warning.  It is an error here.
+    warnings.filterwarnings("error", message=".*AccumulateGrad.*stream.*")
     B = 64
     data = synthetic_dataset(B, 640, seed=1000)
     other = synthetic_dataset(B, 640, seed=1001)
@@ -882,6 +889,51 @@ def test_external_event_inside_a_graph_orders_a_side_stream(device):
     assert isinstance(ok, bool)
 
 
+def test_one_rank_rccl_group_runs_the_exchange_path(device, tmp_path):
+    """every line of the RCCL branch runs once on hardware.  ONE rank is started as a child process by the launcher
+    (before any GPU call of its own) with backend "nccl" and DYOLO_DDP_SINGLE_RANK=1: ``init_process_group("nccl", device_id=...)``, the
+    parameter broadcast, ``GradBuckets`` armed, the bucket all-reduces as asynchronous RCCL calls on device slices of G — issued from
+    backward (eager steps) and behind the replayed hipGraph (graphed steps) —, ``finish()``, and ``max_over_ranks`` / ``sum_over_ranks`` /
+    ``barrier`` on device tensors.  A SUM over one rank is the identity, so the parameters after six steps must equal a run of the
+    same trainer without any process group (in this process) up to fp32 atomics order."""
+    import os
+
+    import drone_yolo_amd as D
+    from drone_yolo_amd.engine.trainer import DetectionTrainer, synthetic_dataset
+    from drone_yolo_amd.utils.dist import launch_ranks
+    from drone_yolo_amd.utils.parity import seeded_state_dict
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode in ("0", "1"):
+        out = tmp_path / f"rccl_{mode}.pt"
+        rc = launch_ranks(1, os.path.join(root, "tests", "_ddp_train_worker.py"), [str(out)],
+                          env={"DYOLO_DDP_SINGLE_RANK": "1", "DYOLO_TRAIN_GRAPH": mode, "DYOLO_DIST_BACKEND": None, "DYOLO_FORCE_DEVICE": None})
+        assert rc == 0, f"one-rank RCCL run (DYOLO_TRAIN_GRAPH={mode}) exited with {rc}"
+        outs[mode] = torch.load(out, weights_only=False)
+    for mode, o in outs.items():
+        assert o["backend"] == "nccl" and o["world"] == 1 and o["ranks_sum"] == 1.0 and o["replicas_identical"] and o["buckets"] == 4, o
+    assert not outs["0"]["graphed"] and outs["0"]["issued_during_backward"] >= 1  # eager: buckets leave while backward still runs
+    assert outs["1"]["graphed"] and "AFTER the graph" in outs["1"]["step_form"], outs["1"]["step_form"]
+    # the same six steps without a process group
+    steps, per_rank = 6, 4
+    model = D.DetectionModel("yolov8n-p2-repvgg.yaml", nc=10, verbose=False)
+    model.load_state_dict(seeded_state_dict(model.state_dict(), 5, cls_bias=-1.6))
+    tr = DetectionTrainer(model, dict(optimizer="SGD", lr0=0.01, momentum=0.9, batch=per_rank, nbs=per_rank, dtype="fp32", warmup_epochs=0.0))
+    assert tr.buckets is None
+    data = synthetic_dataset(per_rank * steps, 64, seed=100)
+    for it in range(steps):
+        sel = torch.arange(it * per_rank, (it + 1) * per_rank)
+        rows = torch.isin(data["batch_idx"].long(), sel)
+        tr.step(dict(img=data["img"][sel].to(device), batch_idx=data["batch_idx"][rows] - it * per_rank, cls=data["cls"][rows], bboxes=data["bboxes"][rows]))
+    torch.cuda.synchronize()
+    ref = tr.flat.P.cpu()
+    for mode, o in outs.items():
+        for k, (off, c) in tr.flat.offsets.items():
+            a, b = o["P"][off : off + c], ref[off : off + c]
+            assert float((a - b).abs().max()) <= 2e-3 * max(float(b.abs().max()), 1e-3), (mode, k)
+
+
 def test_two_rank_graphed_steps_equal_eager_steps(device, tmp_path):
     """with several ranks the trainer no longer falls back to ~2,400 eager launches per step.  Two ranks on ONE GPU
     (the launcher, DYOLO_FORCE_DEVICE=0, gloo) take six steps of the real DetectionTrainer twice: eagerly (gradient sink flushed and
@@ -910,3 +962,49 @@ def test_two_rank_graphed_steps_equal_eager_steps(device, tmp_path):
         assert abs(a - b) <= 2e-3 * abs(a), (e["losses"], g["losses"])
     err = float((e["P"] - g["P"]).abs().max()) / float(e["P"].abs().max())
     assert err <= 2e-3, err
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+def test_modules_in_train_mode_match_the_reference_modules(dtype, device):
+    """``Conv(...).train()(x)``, ``RepVGGBlock``, ``Bottleneck``, ``C2f``, ``SPPF`` called on their own in training mode (reference
+    conv.py:49-51, block.py:1480-1490, :337-350, :237-242, :172-191): outputs and the BatchNorm running statistics they leave behind
+    against tests/golden/per_op_train.npz — the REAL reference modules in ``train()`` mode on the same seeded weights and inputs
+    (oracle/make_golden.py::per_op_train).  Round 3 raised NotImplementedError here; the reference does not."""
+    from drone_yolo_amd.nn import modules as M
+    from drone_yolo_amd.nn.tasks import initialize_weights
+    from oracle import drone_yolo_oracle as O
+    from tests._util import golden
+
+    g = golden("per_op_train.npz")
+    t = lambda k: torch.from_numpy(g[k])  # noqa: E731
+
+    def build(tag, m):
+        m.load_state_dict(O.seeded_state_dict(m.state_dict(), int(g[f"{tag}_seed"])))
+        initialize_weights(m)  # BatchNorm eps 1e-3 / momentum 0.03 (torch_utils.py:423-433)
+        return m.to(device).train()
+
+    cases = {"conv": lambda a: M.Conv(*a), "conv1": lambda a: M.Conv(*a), "rep_s2": lambda a: M.RepVGGBlock(a[0], a[1], 3, a[3]),
+             "bott": lambda a: M.Bottleneck(16, 16, True, 1, k=((3, 3), (3, 3)), e=1.0), "c2f_a": lambda a: M.C2f(a[0], a[1], a[2], bool(a[3])),
+             "c2f_b": lambda a: M.C2f(a[0], a[1], a[2], bool(a[3])), "sppf": lambda a: M.SPPF(32, 32, 5)}
+    for tag, make in cases.items():
+        args = [int(v) for v in g[f"{tag}_args"]] if f"{tag}_args" in g.files else None
+        m = build(tag, make(args))
+        x = quantize(t(f"{tag}_x"), dtype)
+        y = m(nhwc(x, dtype, device))
+        torch.cuda.synchronize()
+        assert m.training and tuple(y.shape) == tuple(t(f"{tag}_y").shape)
+        # against outputs of fp32 modules: one storage rounding per layer boundary of the block (tests/test_model_gpu.py::RTOL)
+        rtol = {torch.float32: 1e-4, torch.bfloat16: 4e-2, torch.float16: 6e-3}[dtype]
+        err, scale = float((y.detach().float().cpu() - t(f"{tag}_y")).abs().max()), float(t(f"{tag}_y").abs().max())
+        assert err <= rtol * scale, f"train-mode {tag} [{dtype}]: max|err| {err:.3e}, scale {scale:.3f}"
+        sd = m.state_dict()
+        stats = [k for k in g.files if k.startswith(f"{tag}_stat__")]
+        assert stats
+        for k in stats:  # running_mean / running_var after ONE training forward (momentum 0.03, unbiased variance)
+            name = k.split("__", 1)[1]
+            ref = t(k)
+            tol = {torch.float32: 2e-5, torch.bfloat16: 4e-3, torch.float16: 6e-4}[dtype]  # (the statistics move by 3 % of the batch's per step)
+            assert torch.allclose(sd[name].float().cpu(), ref, rtol=0, atol=tol * max(1.0, float(ref.abs().max()))), (tag, name)
+    with pytest.raises(NotImplementedError):  # launch options of the eval path have no training form
+        m = build("conv", M.Conv(16, 32, 3, 2))
+        m(nhwc(quantize(t("conv_x"), dtype), dtype, device), residual=torch.zeros(1, device=device))
