@@ -39,7 +39,7 @@ class ConvDesc(C.Structure):
         ("groups", _i32), ("act", _i32), ("dtype", _i32), ("out_f32", _i32),
         ("k_pad", _i32), ("cout_pad", _i32), ("up2x", _i32),
         ("x2", _vp), ("ld_x2", _i32), ("cin_split", _i32), ("w_layout", _i32),
-        ("w_scale", _vp), ("act_scale", _f32), ("bn_stats", _vp),
+        ("w_scale", _vp), ("act_scale", _f32), ("bn_stats", _vp), ("y_dtype1", _i32),
     ]  # fmt: skip
 
 

@@ -1,0 +1,421 @@
+// Flat-K implicit-GEMM convolution with LDS-DMA staging for the channel counts the tap-aligned kernels cannot tile, and the fp8
+// kernel of BASELINE config 5 on the block-scaled MFMA.
+//
+// conv_gemm_glds.hip cuts K = (r, q, c) into steps of 128 bytes of ONE tap, so it needs Cin % 64 == 0 (16-bit) and Cout % 64 == 0.
+// The widths of the n / m / x scales of the model YAMLs are multiples of 8 or 16 only (scale x: 80, 160, 320, 640 and 5 c / 8 c
+// concatenations); those layers ran on the generic register-staged kernel (conv_igemm.hip, ~310 TFLOP/s).  Here K is walked FLAT:
+// step s covers the 16-byte chunks 8 s .. 8 s + 7 of the (r, q, c) axis, whichever taps they fall into (93-98 % of the MFMA K
+// slots carry data for Cin = 80 m, against 62-83 % when every tap is padded to whole steps).  The price is a per-lane (tap, channel)
+// state in the loader: a lane's chunk column is fixed over the K loop (cc = (lane & 7) ^ swizzle(row)), so its state advances by
+// exactly one step per step -- an add and at most two wrap-arounds -- and only two such states exist per lane (the swizzle of a
+// piece's rows depends on the piece's parity only).  Zero padding and the K tail are out-of-range buffer offsets (the range check
+// of buffer_load ... lds feeds zeros); weights are DY_WLAYOUT_ROWS rows, whose k order IS the flat axis.
+//
+// Tile: (WM x MFR x 16) pixels x (WN x NFR x 16) couts, waves as WM x WN, wave tile (MFR x 16) x (NFR x 16): NFR = 5 makes 80 / 160
+// wide tiles for the x scale, masked on the last cout tile for anything else.  LDS image, swizzle, MFMA operand order (weights as
+// the A operand: a lane holds 4 consecutive couts of one pixel) and the transposing epilogue follow conv_gemm_glds.hip.
+//
+// DY_FP8 (e4m3fn): a K-step is 128 channels = ONE v_mfma_f32_16x16x128_f8f6f4 per fragment pair (unscaled form: E8M0 scale 2^0 on
+// both operands; the per-output-channel weight scales and the network-wide activation scale multiply the fp32 accumulator in the
+// epilogue, include/dyolo.h).  That opcode retires 4x the K of v_mfma_f32_16x16x32_fp8_fp8 in 2x its cycles: the 5 PFLOP/s rate.
+// Lane (lr, lq) of a 16x16x128 operand holds row lr and k = 32 lq .. 32 lq + 31 (tools/mx_probe.hip checks the map on the device
+// with exact integer data); A and B only have to AGREE on which k a (lane quarter, byte) pair means, so a lane's 32 bytes are the
+// two 16-byte chunks lq and 4 + lq of the 128-byte row -- the same two ds_read_b128 the 16-bit path issues for its two 32-deep
+// sub-steps.  The output type is a template parameter: fp8 -> fp8, fp8 -> f16 (a precision-critical tail behind an fp8 trunk) and
+// 16-bit -> fp8 (the hand-over into an fp8 trunk) besides the plain same-type form (dy_conv_desc.y_dtype1).
+//
+// Reference semantics: nn/modules/conv.py:37-55 (Conv), block.py:337-350 (Bottleneck residual), block.py:1480-1490 (RepVGGBlock,
+// folded), head.py:43-57 (Detect convs).
+#include "common_hip.h"
+#include <type_traits>
+
+namespace DY_NS {
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+struct FkArgs {
+  const void* x;
+  const void* x2;
+  const void* w;
+  const float* bias;
+  const float* wscale;  // fp8 input: act_scale * weight scale per output channel; else nullptr
+  const void* res;
+  void* y;
+  int H, W, Cin, ldx, ldx2, split;  // channels [0, split) from x, the rest from x2 (1x1 only, split a multiple of the K-step)
+  int HB, WB;                        // buffer dims of x (H/2, W/2 with up2x)
+  int Ho, Wo, Cout, ldy, ldres;
+  int ks, stride, pad;
+  int Kpad, M, HoWo, up2x;
+  int act;
+  int tilesN, nblk;
+  int cout_pad;
+  unsigned xb, x2b, wb;  // bytes addressable from x / x2 / w (buffer descriptor ranges)
+  float res_scale;        // fp8 residual: real value of one quantum (act_scale); 1 otherwise
+  float out_scale;        // fp8 output: 1 / act_scale; 1 otherwise
+};
+
+template <typename T> struct FkIsFp8 { static constexpr bool v = std::is_same<T, fp8_t>::value; };
+
+// pack 4 fp32 -> 4 OT at `sp` (8 bytes for 16-bit, 4 bytes for fp8)
+template <typename OT>
+__device__ __forceinline__ void fk_store4(unsigned char* sp, const float (&v)[4]) {
+  if constexpr (FkIsFp8<OT>::v) {
+    float c[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c[e] = __builtin_fminf(__builtin_fmaxf(v[e], -448.f), 448.f);
+    int r = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], r, true);
+    *reinterpret_cast<int*>(sp) = r;
+  } else {
+    typedef __attribute__((ext_vector_type(4))) OT t4;
+    t4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = Elem<OT>::from_f32(v[e]);
+    *reinterpret_cast<u32x2*>(sp) = __builtin_bit_cast(u32x2, o);
+  }
+}
+
+template <typename T, typename OT, int MFR, int NFR, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs p) {
+  constexpr bool MX = FkIsFp8<T>::v;
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int NW = WM * WN;
+  constexpr int BM = WM * MFR * 16, BN = WN * NFR * 16;
+  constexpr int BKE = 8 * EPC;  // K elements per step (128 bytes)
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int PA = BM / 8 / NW;                  // A pieces per wave per step
+  constexpr int PBT = BN / 8;                      // W pieces per step (all waves)
+  constexpr int PB = (PBT + NW - 1) / NW;          // ... per wave (the last ones may not exist: wave-uniform skip)
+  static_assert(PA >= 1 && BM % (8 * NW) == 0, "every wave stages whole A pieces");
+  constexpr int OES = (int)sizeof(OT);
+  constexpr int EP_PITCH = NFR * 16 * OES + 16;    // one pixel row of the wave tile + a 16-byte skew
+  constexpr int CPP = NFR * OES;                   // 16-byte chunks per pixel row of the wave tile
+  constexpr int NH = (MFR * 16 * EP_PITCH * NW <= 2 * STAGE) ? 1 : ((MFR * 8 * EP_PITCH * NW <= 2 * STAGE) ? 2 : 4);  // epilogue passes per wave tile
+  constexpr int PXP = MFR * 16 / NH;               // pixels per wave and pass
+  constexpr int MPP = MFR / NH;                    // pixel fragments per pass
+  static_assert(MFR % NH == 0 && PXP * EP_PITCH * NW <= 2 * STAGE, "epilogue scratch must fit the stage memory");
+
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lq = lane >> 4, lr = lane & 15;
+  const unsigned L = xcd_remap(blockIdx.x, (unsigned)p.nblk);
+  const int tileN = (int)(L % (unsigned)p.tilesN);
+  const int tileM = (int)(L / (unsigned)p.tilesN);
+  constexpr unsigned ES = (unsigned)sizeof(T);
+  constexpr unsigned kOob = 0xfffffff0u;
+
+  // ---- buffer descriptors: the base is moved back by `pre` so that the (negative) tap (0, 0) offset of a border pixel stays >= 0 ----
+  const unsigned pre1 = (unsigned)((p.pad * p.WB + p.pad) * p.ldx) * ES, pre2 = (unsigned)((p.pad * p.W + p.pad) * p.ldx2) * ES;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) - pre1, 0, p.xb + pre1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t x2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x2)) - pre2, 0, p.x2b + pre2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.wb, 0x00020000);
+
+  // ---- per-lane gather bookkeeping (constant over the K loop) ----
+  const int prow = lane >> 3;
+  int a_hi0[PA], a_wi0[PA];
+  unsigned av1[PA], av2[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int row = (wave * PA + i) * 8 + prow;
+    const int m = tileM * BM + row;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    const int n = mm / p.HoWo;
+    const int rem = mm - n * p.HoWo;
+    const int ho = rem / p.Wo;
+    const int wo = rem - ho * p.Wo;
+    const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+    a_hi0[i] = ok ? hi0 : -(1 << 28);  // never valid
+    a_wi0[i] = wi0;
+    const int hb = p.up2x ? (hi0 >> 1) : hi0, wb_ = p.up2x ? (wi0 >> 1) : wi0;
+    av1[i] = (unsigned)(((n * p.HB + hb) * p.WB + wb_) * p.ldx) * ES + pre1;
+    av2[i] = (unsigned)(((n * p.H + hi0) * p.W + wi0) * p.ldx2) * ES + pre2;
+  }
+  unsigned bv[PB];
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    const int row = (wave * PB + j) * 8 + prow;
+    bv[j] = (unsigned)((tileN * BN + row) * p.Kpad + (((lane & 7) ^ ((row >> 1) & 7)) * EPC)) * ES;  // rows beyond cout_pad: past p.wb -> zeros
+  }
+  // chunk column of this lane in an even / odd piece: (lane & 7) ^ ((row >> 1) & 7), row = 8 piece + prow  ->  bit 2 = piece parity
+  const int cc0 = (lane & 7) ^ (prow >> 1), cc1 = cc0 ^ 4;
+  // flat-K state of the NEXT step to issue, per parity: channel offset c inside tap (kr, kq)
+  int sc[2], skr[2], skq[2];
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    const int k0 = (v ? cc1 : cc0) * EPC;
+    const int tap = k0 / p.Cin;
+    sc[v] = k0 - tap * p.Cin;
+    skr[v] = tap / p.ks;
+    skq[v] = tap - skr[v] * p.ks;
+  }
+  int kstep = 0;
+
+  auto issue = [&](int stage) {
+    unsigned char* sa = smem + stage * STAGE;
+    unsigned char* sb = sa + A_BYTES;
+    if (p.ks == 1) {
+      // single tap: chunk f = 8 s + cc holds channels f EPC ..; the source (x through a fused 2x upsample, or x2) is wave-uniform per step
+      const int kbase = kstep * BKE;
+      const bool from_x = kbase < p.split;
+      const int c_e = kbase + cc0 * EPC, c_o = kbase + cc1 * EPC;
+      const unsigned oe = c_e < p.Cin ? (unsigned)(c_e - (from_x ? 0 : p.split)) * ES : kOob;
+      const unsigned oo = c_o < p.Cin ? (unsigned)(c_o - (from_x ? 0 : p.split)) * ES : kOob;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const unsigned o = ((wave * PA + i) & 1) ? oo : oe;
+        const bool ok = a_hi0[i] >= 0 && o != kOob;
+        const unsigned off = ok ? (from_x ? av1[i] : av2[i]) + o : kOob;
+        if (from_x)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(sa + (wave * PA + i) * 1024), 16, (int)off, 0, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(x2rs, (__attribute__((address_space(3))) void*)(sa + (wave * PA + i) * 1024), 16, (int)off, 0, 0, 0);
+      }
+    } else {
+      unsigned toff[2];
+      bool tok[2];
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        toff[v] = (unsigned)((skr[v] * p.W + skq[v]) * p.ldx + sc[v]) * ES;
+        tok[v] = skr[v] < p.ks;  // beyond the last tap: the zero-padded K tail
+      }
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int v = (wave * PA + i) & 1;
+        const bool ok = tok[v] && ((unsigned)(a_hi0[i] + skr[v]) < (unsigned)p.H) && ((unsigned)(a_wi0[i] + skq[v]) < (unsigned)p.W);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(sa + (wave * PA + i) * 1024), 16, (int)(ok ? av1[i] + toff[v] : kOob), 0, 0, 0);
+      }
+      // advance both states by one K-step (Cin >= BKE / 2: at most two wrap-arounds)
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        sc[v] += BKE;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const bool wrap = sc[v] >= p.Cin;
+          sc[v] -= wrap ? p.Cin : 0;
+          skq[v] += wrap ? 1 : 0;
+          const bool wq = skq[v] >= p.ks;
+          skq[v] = wq ? 0 : skq[v];
+          skr[v] += wq ? 1 : 0;
+        }
+      }
+    }
+    const unsigned soffw = (unsigned)(kstep * BKE) * ES;
+#pragma unroll
+    for (int j = 0; j < PB; ++j)
+      if (wave * PB + j < PBT)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(sb + (wave * PB + j) * 1024), 16, (int)bv[j], (int)soffw, 0, 0);
+    ++kstep;
+  };
+
+  // ---- accumulators ----
+  f32x4 acc[NFR][MFR];
+#pragma unroll
+  for (int j = 0; j < NFR; ++j)
+#pragma unroll
+    for (int i = 0; i < MFR; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int swz = lr >> 1;
+  auto compute = [&](int stage) {
+    const unsigned char* sa = smem + stage * STAGE + (wm * MFR * 16 + lr) * 128;
+    const unsigned char* sb = smem + stage * STAGE + A_BYTES + (wn * NFR * 16 + lr) * 128;
+    if constexpr (MX) {
+      const int s0 = ((0 + lq) ^ swz) * 16, s1 = ((4 + lq) ^ swz) * 16;
+      i32x8 a[MFR], b[NFR];
+#pragma unroll
+      for (int j = 0; j < NFR; ++j) {
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(sb + j * 16 * 128 + s0), hi = *reinterpret_cast<const u32x4*>(sb + j * 16 * 128 + s1);
+        b[j] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < MFR; ++i) {
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(sa + i * 16 * 128 + s0), hi = *reinterpret_cast<const u32x4*>(sa + i * 16 * 128 + s1);
+        a[i] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < NFR; ++j)
+#pragma unroll
+        for (int i = 0; i < MFR; ++i) {
+          // the SCALED opcode with E8M0 127 (2^0) on both operands: bit-identical results to the unscaled form, and 3-8 % more MFMAs per
+          // second in a bare issue loop (tools/mx_probe.hip: 4.88-4.99 against 4.51-4.85 PFLOP/s)
+          acc[j][i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b[j], a[i], acc[j][i], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int slot = ((s * 4 + lq) ^ swz) * 16;
+        u32x4 a[MFR], b[NFR];
+#pragma unroll
+        for (int j = 0; j < NFR; ++j) b[j] = *reinterpret_cast<const u32x4*>(sb + j * 16 * 128 + slot);
+#pragma unroll
+        for (int i = 0; i < MFR; ++i) a[i] = *reinterpret_cast<const u32x4*>(sa + i * 16 * 128 + slot);
+#pragma unroll
+        for (int j = 0; j < NFR; ++j)
+#pragma unroll
+          for (int i = 0; i < MFR; ++i) acc[j][i] = Elem<T>::mma(b[j], a[i], acc[j][i]);
+      }
+    }
+  };
+
+  // ---- main loop: one barrier per K-step, the next step's DMA runs under this step's MFMAs ----
+  const int nsteps = p.Kpad / BKE;
+  issue(0);
+  for (int s = 0; s < nsteps; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of step s has landed
+    __syncthreads();                                   // publishes stage s & 1; everyone is done with the other one
+    if (s + 1 < nsteps) issue((s + 1) & 1);
+    compute(s & 1);
+  }
+  __syncthreads();  // stage memory becomes the per-wave transpose scratch
+
+  // ---- epilogue: scale / bias / SiLU / residual in fp32, per-wave LDS transpose, 16-byte row stores ----
+  unsigned char* escr = smem + wave * (PXP * EP_PITCH);
+  OT* __restrict__ yg = reinterpret_cast<OT*>(p.y);
+  const T* __restrict__ rg = reinterpret_cast<const T*>(p.res);
+  const int n0 = tileN * BN + wn * NFR * 16;
+  constexpr int OEPC = 16 / OES;  // output elements per 16-byte chunk
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    const int m0 = tileM * BM + wm * MFR * 16 + h * PXP;
+#pragma unroll
+    for (int j = 0; j < NFR; ++j) {
+      const int co = n0 + j * 16 + lq * 4;
+      const bool cok = co + 3 < p.cout_pad;  // (a tile may reach past the padded rows of a narrow layer: its weights read as zeros)
+      const f32x4 bb = cok ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 sc4 = f32x4{1.f, 1.f, 1.f, 1.f};
+      if constexpr (MX) sc4 = cok ? *reinterpret_cast<const f32x4*>(p.wscale + co) : sc4;
+#pragma unroll
+      for (int ii = 0; ii < MPP; ++ii) {
+        const int i = h * MPP + ii;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = MX ? acc[j][i][e] * sc4[e] + bb[e] : acc[j][i][e] + bb[e];
+        if (p.act == DY_ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
+        }
+        if (rg != nullptr) {
+          const int m = m0 + ii * 16 + lr;
+          if (m < p.M && co < p.Cout) {
+            const T* rp = rg + (size_t)m * (size_t)p.ldres + (size_t)co;
+            if constexpr (MX) {
+              const int rv = *reinterpret_cast<const int*>(rp);  // four e4m3 quanta
+              v[0] += __builtin_amdgcn_cvt_f32_fp8(rv, 0) * p.res_scale;
+              v[1] += __builtin_amdgcn_cvt_f32_fp8(rv, 1) * p.res_scale;
+              v[2] += __builtin_amdgcn_cvt_f32_fp8(rv, 2) * p.res_scale;
+              v[3] += __builtin_amdgcn_cvt_f32_fp8(rv, 3) * p.res_scale;
+            } else {
+              typedef __attribute__((ext_vector_type(4))) T t4;
+              const t4 rv = *reinterpret_cast<const t4*>(rp);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += Elem<T>::to_f32(rv[e]);
+            }
+          }
+        }
+        if constexpr (FkIsFp8<OT>::v) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
+        }
+        fk_store4<OT>(escr + (ii * 16 + lr) * EP_PITCH + (j * 16 + lq * 4) * OES, v);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < (PXP * CPP + 63) / 64; ++k) {
+      const int idx = k * 64 + lane;
+      const int px = idx / CPP, cc = idx - px * CPP;
+      const int m = m0 + px;
+      if (px < PXP && m < p.M && n0 + cc * OEPC < p.Cout) {
+        const u32x4 val = *reinterpret_cast<const u32x4*>(escr + px * EP_PITCH + cc * 16);
+        *reinterpret_cast<u32x4*>(yg + (size_t)m * (size_t)p.ldy + (size_t)(n0 + cc * OEPC)) = val;
+      }
+    }
+    if (h + 1 < NH) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+}
+
+template <typename T, typename OT, int MFR, int NFR, int WM, int WN>
+static int launch_fk(const FkArgs& a, hipStream_t st, const char* name) {
+  FkArgs p = a;
+  constexpr int BM = WM * MFR * 16, BN = WN * NFR * 16;
+  const int tilesM = (p.M + BM - 1) / BM;
+  p.tilesN = (p.Cout + BN - 1) / BN;
+  p.nblk = tilesM * p.tilesN;
+  hipLaunchKernelGGL((conv_gemm_fk_kernel<T, OT, MFR, NFR, WM, WN>), dim3((unsigned)p.nblk), dim3(WM * WN * 64), 0, st, p);
+  return check_launch(name);
+}
+
+// Tile choice: the cout tile that covers Cout with the fewest padded columns (ties: the wider one); 128 pixels.  Measured and dropped
+// (tools/fk_ab.sh, r04): 256-pixel tiles — 256 x 160 as sixteen waves of 32 x 80 (LDS-read bound in fp8: 14 ds_read_b128 per 10 MFMAs)
+// 3-12 % slower, 256 x 320 as sixteen waves of 64 x 80 (128-register cap: spills) 2x slower; two 128-pixel workgroups per CU that
+// cover for each other's barriers beat one big one; eight waves of 32 x 80 on the 128 x 160 tile, two waves of 64 x 80 on 128 x 80: +-2 %.
+template <typename T, typename OT>
+static int launch_fk_tiles(const FkArgs& a, hipStream_t st) {
+  static const int force = dy_ablate("DYOLO_FK_BN");
+  const int cands[4] = {160, 128, 80, 64};
+  int best = 160;
+  long long bw = 1ll << 60;
+  for (int c : cands) {
+    const long long w = (long long)((a.Cout + c - 1) / c) * c;
+    if (w < bw) bw = w, best = c;
+  }
+  if (force) best = force;
+  switch (best) {
+    case 160: return launch_fk<T, OT, 4, 5, 2, 2>(a, st, "conv_gemm_fk_kernel<128,160>");
+    case 128: return launch_fk<T, OT, 4, 4, 2, 2>(a, st, "conv_gemm_fk_kernel<128,128>");
+    case 80: return launch_fk<T, OT, 2, 5, 4, 1>(a, st, "conv_gemm_fk_kernel<128,80>");
+    default: return launch_fk<T, OT, 2, 4, 4, 1>(a, st, "conv_gemm_fk_kernel<128,64>");
+  }
+}
+
+// Returns 1 when the call is not one this kernel is built for (the caller then runs the generic kernel), else the launch status.
+int conv_gemm_fk_try(const dy_conv_desc* d, hipStream_t st) {
+  static const int off = dy_ablate("DYOLO_NO_FK");
+  if (off) return 1;
+  const int es = dy_dtype_size(d->dtype);
+  if (d->dtype == DY_F32 || es == 0 || d->groups > 1 || d->out_f32 || d->w_layout != DY_WLAYOUT_ROWS) return 1;
+  const int ydt = d->y_dtype1 ? d->y_dtype1 - 1 : d->dtype;
+  const bool in8 = d->dtype == DY_FP8, out8 = ydt == DY_FP8;
+  if (!(ydt == d->dtype || (in8 && ydt == DY_F16) || (d->dtype == DY_F16 && out8))) return 1;
+  const int epc = 16 / es, bke = 8 * epc, oes = dy_dtype_size(ydt);
+  if (!((d->ksize == 1 && d->pad == 0) || (d->ksize == 3 && d->pad == 1)) || (d->stride != 1 && d->stride != 2)) return 1;
+  if (d->cin % epc || d->cout % (16 / oes) || d->k_pad % bke) return 1;
+  if (d->ksize == 3 && (d->cin < bke / 2 || d->x2 || d->up2x)) return 1;
+  if (d->up2x > 1 || (d->up2x && d->stride != 1)) return 1;
+  if (d->x2 && (d->cin_split % bke || d->cin_split <= 0 || d->cin_split >= d->cin)) return 1;
+  if (!aligned16(d->y) || (d->ld_y * oes) % 16 || (d->ld_x * es) % 16 || !aligned16(d->x)) return 1;
+  if (d->residual && ((d->ld_res * es) % 4 || (reinterpret_cast<uintptr_t>(d->residual) & 3))) return 1;
+  const int hb = d->up2x ? d->h / 2 : d->h, wb = d->up2x ? d->w_in / 2 : d->w_in;
+  const long long lim = (1ll << 32) - (1ll << 24);
+  const long long xb = (long long)d->batch * hb * wb * d->ld_x * es, x2b = d->x2 ? (long long)d->batch * d->h * d->w_in * d->ld_x2 * es : 0;
+  const long long wbytes = (long long)d->cout_pad * d->k_pad * es;
+  if (xb >= lim || x2b >= lim || wbytes >= lim) return 1;
+  if (in8 && (!d->w_scale || !(d->act_scale > 0.f))) return 1;
+  if (out8 && !(d->act_scale > 0.f)) return 1;
+
+  FkArgs a{};
+  a.x = d->x, a.x2 = d->x2 ? d->x2 : d->x, a.w = d->w, a.bias = d->bias, a.wscale = in8 ? d->w_scale : nullptr, a.res = d->residual, a.y = d->y;
+  a.H = d->h, a.W = d->w_in, a.Cin = d->cin, a.ldx = d->ld_x, a.ldx2 = d->x2 ? d->ld_x2 : d->ld_x, a.split = d->x2 ? d->cin_split : d->cin;
+  a.HB = hb, a.WB = wb;
+  a.Ho = d->ho, a.Wo = d->wo, a.Cout = d->cout, a.ldy = d->ld_y, a.ldres = d->ld_res;
+  a.ks = d->ksize, a.stride = d->stride, a.pad = d->pad;
+  a.Kpad = d->k_pad, a.M = d->batch * d->ho * d->wo, a.HoWo = d->ho * d->wo, a.up2x = d->up2x;
+  a.act = d->act;
+  a.cout_pad = d->cout_pad;
+  a.xb = (unsigned)xb, a.x2b = (unsigned)(d->x2 ? x2b : xb), a.wb = (unsigned)wbytes;
+  a.res_scale = in8 ? d->act_scale : 1.f;
+  a.out_scale = out8 ? 1.f / d->act_scale : 1.f;
+  if (in8) return out8 ? launch_fk_tiles<fp8_t, fp8_t>(a, st) : launch_fk_tiles<fp8_t, f16_t>(a, st);
+  if (d->dtype == DY_F16) return out8 ? launch_fk_tiles<f16_t, fp8_t>(a, st) : launch_fk_tiles<f16_t, f16_t>(a, st);
+  return launch_fk_tiles<bf16_t, bf16_t>(a, st);
+}
+
+}  // namespace DY_NS

@@ -329,6 +329,7 @@ static int launch_dtype(const ConvArgs& a, hipStream_t st) {
 }
 
 int conv3x3_halo_dispatch(const dy_conv_desc* d, hipStream_t st);    // conv3x3_halo.hip
+int conv_gemm_fk_try(const dy_conv_desc* d, hipStream_t st);         // conv_gemm_fk.hip: flat-K kernel (any channel count / fp8 on the block-scaled MFMA)
 int conv1x1_stream_dispatch(const dy_conv_desc* d, hipStream_t st);  // conv1x1_stream.hip
 
 }  // namespace DY_NS
@@ -422,6 +423,8 @@ int32_t conv2d_entry(const dy_conv_desc* d, dy_stream_t stream) {
     a.wscale = nullptr;
     a.act_scale = 1.f;
   }
+  DY_REQUIRE(!d->y_dtype1 || d->y_dtype1 - 1 == d->dtype || (d->w_layout == DY_WLAYOUT_ROWS && !d->out_f32), DY_ERR_UNSUPPORTED,
+             "dy_conv2d_nhwc: an output type other than the input's (y_dtype1) needs DY_WLAYOUT_ROWS and no out_f32");
   if (d->w_layout == DY_WLAYOUT_HALO3X3) return conv3x3_halo_dispatch(d, st);
   if (d->w_layout == DY_WLAYOUT_FRAG1X1) return conv1x1_stream_dispatch(d, st);
   DY_REQUIRE(d->w_layout == DY_WLAYOUT_ROWS, DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: unknown w_layout %d", d->w_layout);
@@ -475,12 +478,25 @@ int32_t conv2d_entry(const dy_conv_desc* d, dy_stream_t stream) {
   const int oes = d->out_f32 ? 4 : es;
   a.vec_store = (aligned16(d->y) && (d->ld_y * oes) % 16 == 0) ? 1 : 0;
 
-  {
+  // cout tiles of 80 / 160 (the x scale: 160, 320, 800 ... outputs) beat the 64-cout persistent tiles of the tap-aligned kernel:
+  // a layer whose Cout is no multiple of 128 but fills 160-wide tiles exactly goes to the flat-K kernel first
+  const bool fk_first = d->cout % 128 != 0 && d->cout % 80 == 0 && (d->dtype == DY_BF16 || d->dtype == DY_F16) && !d->out_f32 && !d->up2x;
+  if (fk_first) {
+    const int rf = conv_gemm_fk_try(d, st);
+    if (rf <= 0) return rf;
+  }
+  if (!d->y_dtype1 || d->y_dtype1 - 1 == d->dtype) {
     const int rv = conv3x3_vgemm_try(a, d->dtype, d->out_f32 != 0, st);  // deep 3x3 stride-1 layers: halo staged once per chunk
     if (rv <= 0) return rv;
     const int rc = conv_gemm_glds_try(a, d->dtype, d->out_f32 != 0, st);  // big-tile LDS-DMA kernel where it is built
     if (rc <= 0) return rc;
   }
+  {
+    const int rf = conv_gemm_fk_try(d, st);  // channel counts that are not whole tap-aligned K-steps / cout tiles; fp8 on the block-scaled MFMA
+    if (rf <= 0) return rf;
+  }
+  DY_REQUIRE(!d->y_dtype1 || d->y_dtype1 - 1 == d->dtype, DY_ERR_UNSUPPORTED,
+             "dy_conv2d_nhwc: y_dtype1 %d with dtype %d is built in the flat-K kernel only (dense 1x1 / 3x3, DY_WLAYOUT_ROWS, 16-byte aligned views)", d->y_dtype1, d->dtype);
   switch (d->dtype) {
     case DY_BF16:
       return d->out_f32 ? launch_dtype<bf16_t, true>(a, st) : launch_dtype<bf16_t, false>(a, st);

@@ -55,11 +55,14 @@ class DetectionPredictor:
 
     def __init__(self, model, overrides: Optional[dict] = None):
         a = dict(conf=0.25, iou=0.7, max_det=300, classes=None, agnostic_nms=False, half=False, dtype=None, device="",
-                 verbose=False, graph=False, max_nms=30000, max_wh=7680, imgsz=640)
+                 verbose=False, graph=False, max_nms=30000, max_wh=7680, imgsz=640, fp8_layers=None)
         a.update(overrides or {})
         self.args = a
         self.device = select_device(a["device"])
-        self.dtype = resolve_dtype(a["dtype"], a["half"])
+        # dtype="fp8-mixed" (BASELINE config 5): float16 storage with the layers the error budget allows in e4m3
+        # (BaseModel.fp8_plan_off_p2, or the set given as overrides["fp8_layers"]); dtype="fp8": the whole trunk in e4m3, Detect tail float16
+        self.mixed8 = isinstance(a["dtype"], str) and a["dtype"].lower().replace("_", "-") == "fp8-mixed"
+        self.dtype = torch.float16 if self.mixed8 else resolve_dtype(a["dtype"], a["half"])
         # setup_model (predictor.py:300-323): AutoBackend moves the graph to the device, fuses, picks the precision and freezes it
         self.backend = AutoBackend(model, device=self.device, fp16=bool(a["half"]), dtype=self.dtype, fuse=False, verbose=bool(a["verbose"]))
         self.model = self.backend.model
@@ -119,8 +122,12 @@ class DetectionPredictor:
     def _record(self, im: torch.Tensor) -> CompiledForward:
         cf = CompiledForward()
         a = self.args
-        if self.dtype == H.FP8:
+        if self.dtype == H.FP8 or self.mixed8:
             self._calibrate_fp8(im)
+        plan8 = None
+        if self.mixed8:
+            plan8 = frozenset(a["fp8_layers"]) if a.get("fp8_layers") is not None else self.model.fp8_plan_off_p2()
+            self.fp8_calibration["fp8_layers"] = sorted(plan8)
         n, _, h, w = im.shape
         params = torch.tensor([self._box_params(h, w)] * n, dtype=torch.float32, device=self.device)
         cf.box_params, cf.box_key = params, self._box_params(h, w)
@@ -133,6 +140,7 @@ class DetectionPredictor:
 
         det.fused_nms = (make_bufs, float(a["conf"]), self._classes_mask)
         det.fuse_tail = True  # branch tails + decode + filter in one launch where the shape is built
+        self.model.fp8_layers = plan8
         try:
             with H.record(cf.plan):
                 y, _ = self.model._predict_once(im, image_dtype=self.dtype)
@@ -146,6 +154,7 @@ class DetectionPredictor:
         finally:
             det.fused_nms = None
             det.fuse_tail = False
+            self.model.fp8_layers = None
         cf.plan.keep.append(params)
         return cf
 

@@ -305,6 +305,7 @@ class PackCache:
 
 
 _PACK_CACHE = {"active": None}
+FLAT_K_3X3 = [os.environ.get("DYOLO_FLAT_K_3X3", "1") != "0"]  # see PackedConv: odd-width 3x3 layers on the flat-K kernel (0: the halo kernel, for A/B runs)
 
 
 @contextlib.contextmanager
@@ -415,7 +416,15 @@ class PackedConv:
         kstep = 8 * elems_per_chunk(dtype)
         deep3x3 = halo is None and k == 3 and stride == 1 and self.cin % kstep == 0 and cout % 64 == 0 and \
             self.cin >= 128 and cout >= 128
-        if (halo is None or halo) and not deep3x3 and groups == 1 and k == 3 and pad == 1 and (stride == 1 or (stride == 2 and s2_fits)) \
+        # r04: ... unless cout is no multiple of 128 on a 16-bit type (scale x: 320 -> 320): neither the virtual-flat GEMM (cout % 128) nor
+        # the 256-wide LDS-DMA tiles apply, the 64-cout persistent tiles ran it at 536 TFLOP/s, the halo kernel at 857 (tools/fk_bench.sh)
+        if deep3x3 and cout % 128 != 0 and dtype in (torch.bfloat16, torch.float16) and self.cin * cout <= 320 * 320:
+            deep3x3 = False
+        # r04: 3x3 layers whose channel counts are not whole 64-channel K-steps / 64-cout tiles (the n / m / x scales: 80, 160, 320 ...)
+        # run on the flat-K LDS-DMA kernel behind DY_WLAYOUT_ROWS (conv_gemm_fk.hip) instead of the halo kernel's 32-channel chunks
+        flat3x3 = FLAT_K_3X3[0] and halo is None and k == 3 and pad == 1 and groups == 1 and dtype in (torch.bfloat16, torch.float16) and \
+            self.cin >= 64 and (self.cin % 64 != 0 or cout % 64 != 0) and self.cin % 8 == 0 and cout % 8 == 0
+        if (halo is None or halo) and not deep3x3 and not flat3x3 and groups == 1 and k == 3 and pad == 1 and (stride == 1 or (stride == 2 and s2_fits)) \
                 and cout % 4 == 0 and self.cin >= 4 * elems_per_chunk(dtype) // 2:
             # LDS-halo 3x3 kernel: MFMA-fragment-ordered weights (include/dyolo.h, DY_WLAYOUT_HALO3X3)
             self.layout = _lib.DY_WLAYOUT_HALO3X3
@@ -522,7 +531,7 @@ def conv_stats_written() -> int:
 
 def conv2d(x: torch.Tensor, pc: PackedConv, out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
            out_f32: bool = False, up2x: bool = False, x2: Optional[torch.Tensor] = None, dil2: bool = False,
-           bn_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+           bn_stats: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """act(conv(x) + bias) (+ residual) through ``dy_conv2d_nhwc``.
 
     ``x2``: optional second input whose channels follow x's (Concat folded into the gather);
@@ -530,6 +539,8 @@ def conv2d(x: torch.Tensor, pc: PackedConv, out: Optional[torch.Tensor] = None, 
     ``dil2``: x is consumed zero-dilated by 2 (value at even (h, w) only): the gather of a stride-2 transposed conv.
     ``bn_stats``: the ``BnState`` of the train-mode BatchNorm that follows: a kernel with the statistics epilogue leaves the output's
     per-channel partial sums in its workspace (``conv_stats_written()`` = how many slots; hand that to ``bn_train_fwd(partial_slabs=)``).
+    ``out_dtype``: storage type of the output when it differs from the input's (mixed-precision plans of BASELINE config 5: fp8 ->
+    float16 behind an fp8 trunk, float16 -> fp8 into one; ``dy_conv_desc.y_dtype1``, the flat-K kernel).
     """
     require_device(x, "conv2d input")
     if x.dtype != pc.dtype:
@@ -540,7 +551,9 @@ def conv2d(x: torch.Tensor, pc: PackedConv, out: Optional[torch.Tensor] = None, 
     if cin != pc.cin:
         raise ValueError(f"conv2d: input has {cin} channels, weights expect {pc.cin}")
     ho, wo = conv_out_hw(h, w, pc.k, pc.stride, pc.pad)
-    odt = torch.float32 if out_f32 else x.dtype
+    if out_dtype is not None and out_f32:
+        raise ValueError("conv2d: out_dtype and out_f32 exclude each other")
+    odt = torch.float32 if out_f32 else (out_dtype or x.dtype)
     if out is None:
         epc_o = elems_per_chunk(odt)  # keep every pixel row 16-byte aligned (vector stores in all kernels)
         out = alloc_nhwc(n, pc.cout, ho, wo, odt, x.device, ld=-(-pc.cout // epc_o) * epc_o)
@@ -572,6 +585,10 @@ def conv2d(x: torch.Tensor, pc: PackedConv, out: Optional[torch.Tensor] = None, 
         d.cin_split = c1
     if pc.wscale is not None:
         d.w_scale, d.act_scale = pc.wscale.data_ptr(), pc.act_scale
+    if odt != x.dtype and not out_f32:
+        d.y_dtype1 = dy_dtype(odt) + 1
+        if odt == FP8:
+            d.act_scale = fp8_act_scale()  # the output quantum (the input is 16-bit: no pack-time scale)
     _launch(lib().dy_conv2d_nhwc, (C.byref(d),), keep=(d, x, out, residual, x2, pc))
     if _absmax_log is not None and not out_f32:  # activations that WOULD be stored in fp8 (the fp32 head logits are not)
         _absmax_log.append(out.float().abs().amax())

@@ -202,7 +202,48 @@ class Detect(nn.Module):
             kw = dict(nms_bufs=make_bufs(xb[0].shape[0], A), conf_thres=conf, classes_mask=mask)
         return H.detect_head_decode(xb, xc, pb, pc, [float(s) for s in self.stride], self.nc, self.reg_max, **kw)
 
+    tail_dtype = torch.float16  # storage type of the Detect branches behind an fp8 trunk (DY_FP8 inputs): see _forward_fp8_trunk
+
+    def _forward_fp8_trunk(self, x):
+        """Levels that arrive in fp8 (BASELINE config 5: an e4m3 trunk): the FIRST 3x3 convolution of each branch reads the fp8 map on the
+        block-scaled MFMA and writes ``tail_dtype`` (float16) — from there the branch is the 16-bit path: second 3x3, then the 1x1 tails +
+        DFL / sigmoid decode + candidate filter in one launch where that kernel is built.  The scores and box bins, where a rounding step
+        decides a detection, never pass through a 3-bit mantissa.  Inference only."""
+        if self.training or not self.legacy:
+            raise NotImplementedError("Detect on fp8 inputs is built for inference with the v8 (legacy) class branch")
+        td = self.tail_dtype
+        xb, xc = [], []
+        for i in range(self.nl):
+            kw = {"out_dtype": td} if x[i].dtype == H.FP8 else {}
+            tb, tc = self.cv2[i][0](x[i], **kw), self.cv3[i][0](x[i], **kw)
+            for m in list(self.cv2[i])[1:-1]:
+                tb = m(tb)
+            for m in list(self.cv3[i])[1:-1]:
+                tc = m(tc)
+            xb.append(tb), xc.append(tc)
+        fused = getattr(self, "fused_nms", None)
+        kw = {}
+        if fused is not None:
+            make_bufs, conf, mask = fused
+            kw = dict(nms_bufs=make_bufs(xb[0].shape[0], sum(f.shape[2] * f.shape[3] for f in xb)), conf_thres=conf, classes_mask=mask)
+        if self.fuse_tail and H.head_decode_supported(self.cv2[0][-1].in_channels, self.cv3[0][-1].in_channels, self.nc, self.reg_max, td):
+            pb, pc = self._packed_tail(td, xb[0].device)
+            y = H.detect_head_decode(xb, xc, pb, pc, [float(s) for s in self.stride], self.nc, self.reg_max, **kw)
+            return y if self.export else (y, None)
+        nb, ld = self.reg_max * 4, (self.no + 3) // 4 * 4
+        feats = []
+        for i in range(self.nl):
+            n, _, h, w = xb[i].shape
+            buf = H.alloc_nhwc(n, self.no, h, w, torch.float32, xb[i].device, ld=ld)
+            self.cv2[i][-1](xb[i], out=buf[:, :nb], out_f32=True)
+            self.cv3[i][-1](xc[i], out=buf[:, nb:], out_f32=True)
+            feats.append(buf)
+        y = H.detect_decode(feats, [float(s) for s in self.stride], self.nc, self.reg_max, **kw)
+        return y if self.export else (y, feats)
+
     def forward(self, x):
+        if any(t.dtype == H.FP8 for t in x) and self.tail_dtype is not None:
+            return self._forward_fp8_trunk(x)
         if self.fuse_tail and not self.training and H.head_decode_supported(
                 self.cv2[0][-1].in_channels, self.cv3[0][-1].in_channels, self.nc, self.reg_max, x[0].dtype):
             y = self._forward_fused(x)

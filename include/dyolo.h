@@ -143,6 +143,11 @@ typedef struct dy_conv_desc {
    * need no pass of their own: dy_conv_stats_written() returns the number of slots the calling thread's last dy_conv2d_nhwc wrote
    * (0: the dispatched kernel has no such epilogue, nothing was touched) -- hand it to dy_bn_desc.partial_slabs.  NULL = off. */
   double* bn_stats;
+  /* Storage type of y when it differs from `dtype` (mixed-precision plans of BASELINE config 5: an fp8 trunk in front of a 16-bit
+   * Detect tail, a 16-bit layer handing over to the fp8 trunk).  0: y has type `dtype` (or fp32 with out_f32); k > 0: y has
+   * dy_dtype k - 1.  Built in the flat-K kernel (csrc/conv_gemm_fk.hip, DY_WLAYOUT_ROWS) for DY_FP8 -> DY_F16 and DY_F16 -> DY_FP8
+   * (act_scale > 0 then gives the output quantum: y_q = sat_e4m3(y_real / act_scale)); any other pair returns DY_ERR_UNSUPPORTED. */
+  int32_t y_dtype1;
 } dy_conv_desc;
 
 /* Quantise a 16-bit / fp32 NHWC view to DY_FP8: dst_q = sat_e4m3(src / act_scale).  c % 16 == 0, views 16-byte aligned.

@@ -131,6 +131,62 @@ def test_halo_layout_pack_falls_back_to_rows_for_calls_its_kernels_refuse(how, d
     assert H.last_kernel_name().startswith("conv3x3_hreg_s2") and tuple(y2.shape) == (b, cout, h // 2, w // 2)
 
 
+FK_CASES = [
+    # cin, cout, k, s, B, H, W, residual, tag — channel counts that are not whole 64-channel K-steps / 64-cout tiles (the n / m / x scales)
+    (80, 80, 3, 1, 2, 24, 20, False, "x-scale P2 bottleneck 80->80 (tile 128x80)"),
+    (160, 160, 3, 1, 2, 24, 20, False, "160->160 (tile 128x160)"),
+    (160, 160, 3, 1, 1, 13, 17, True, "160->160 + residual, M tail"),
+    (160, 320, 3, 2, 2, 25, 23, False, "RepVGG-like s2 160->320 odd dims"),
+    (400, 160, 1, 1, 2, 24, 20, False, "C2f.cv2 400->160 (K tail inside a step)"),
+    (160, 64, 3, 1, 1, 13, 17, False, "Detect box 160->64 (tile 128x64)"),
+    (48, 96, 3, 1, 2, 16, 16, False, "m-scale 48->96 (two wrap-arounds per step)"),
+    (240, 200, 1, 1, 1, 9, 7, False, "cout 200: masked last tile"),
+    (160, 320, 3, 1, 1, 12, 12, False, "160->320 (two cout tiles)"),
+    (96, 96, 1, 2, 2, 16, 16, False, "1x1 stride 2"),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("case", FK_CASES, ids=[c[-1] for c in FK_CASES])
+def test_conv_flat_k_kernel_matches_cpu(case, dtype, device):
+    """csrc/conv_gemm_fk.hip: K walked flat over (r, q, c) in 128-byte steps whatever taps they cross, cout tiles of 64 / 80 / 128 / 160
+    masked on the last tile — against the fp32 CPU convolution on the same rounded operands (DY_WLAYOUT_ROWS forced: the layers of the
+    n / m / x scales that used to fall to the generic kernel)."""
+    cin, cout, k, s, b, h, w, res, tag = case
+    g = torch.Generator().manual_seed(zlib.crc32(tag.encode()) % 1000)
+    x = quantize(torch.randn(b, cin, h, w, generator=g), dtype)
+    wt = quantize(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5, dtype)
+    bias = torch.randn(cout, generator=g) * 0.2
+    ref = F.silu(F.conv2d(x, wt, bias, s, k // 2))
+    kw = {}
+    if res:
+        r = quantize(torch.randn(ref.shape, generator=g), dtype)
+        ref, kw = ref + r, {"residual": nhwc(r, dtype, device)}
+    pc = H.PackedConv(wt, bias, s, k // 2, 1, True, dtype, device, halo=False)
+    y = H.conv2d(nhwc(x, dtype, device, ld=cin + 16, c_off=8), pc, **kw)  # a channel slice of a wider buffer
+    torch.cuda.synchronize()
+    assert H.last_kernel_name().startswith("conv_gemm_fk_kernel"), H.last_kernel_name()
+    check_close(back(y), ref, dtype, f"flat-K {tag}", extra=2.0 if res else 1.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_conv_flat_k_two_sources_through_upsample(dtype, device):
+    """Upsample + Concat folded into a 1x1 gather (C2f.cv1 of the neck) on the flat-K kernel: channels [0, 128) from a half-resolution
+    map through the fused 2x nearest upsample, [128, 208) from the skip map; the split is a whole K-step, the total is not."""
+    g = torch.Generator().manual_seed(11)
+    b, c_lo, c_sk, cout, h, w = 2, 128, 80, 160, 12, 10
+    lo = quantize(torch.randn(b, c_lo, h // 2, w // 2, generator=g), dtype)
+    sk = quantize(torch.randn(b, c_sk, h, w, generator=g), dtype)
+    wt = quantize(torch.randn(cout, c_lo + c_sk, 1, 1, generator=g) * (2.0 / (c_lo + c_sk)) ** 0.5, dtype)
+    bias = torch.randn(cout, generator=g) * 0.2
+    ref = F.silu(F.conv2d(torch.cat([F.interpolate(lo, scale_factor=2, mode="nearest"), sk], 1), wt, bias))
+    pc = H.PackedConv(wt, bias, 1, 0, 1, True, dtype, device, halo=False)
+    y = H.conv2d(nhwc(lo, dtype, device), pc, x2=nhwc(sk, dtype, device), up2x=True)
+    torch.cuda.synchronize()
+    assert H.last_kernel_name().startswith("conv_gemm_fk_kernel"), H.last_kernel_name()
+    check_close(back(y), ref, dtype, "flat-K two sources")
+
+
 GLDS_CASES = [
     # cin, cout, k, s, B, H, W, tag — ROWS layout, M >= 8192 and whole 128-byte K-steps: the LDS-DMA big-tile kernel
     (128, 128, 3, 1, 6, 40, 40, "3x3 s1 BN=128"),
@@ -818,7 +874,8 @@ def test_detect_branch_fused_matches_cpu_chain(shapes, dtype, device):
 
 
 @pytest.mark.parametrize("case", [(64, 64, 3, 1, 2, 24, 20, True), (160, 80, 1, 1, 2, 17, 19, True), (80, 160, 3, 2, 2, 24, 28, True), (640, 320, 1, 1, 1, 12, 12, False),
-                                  (96, 48, 3, 1, 3, 10, 10, True)], ids=["3x3 64->64", "1x1 160->80", "3x3 s2 80->160", "1x1 640->320 no act", "3x3 96->48"])
+                                  (96, 48, 3, 1, 3, 10, 10, True), (160, 160, 3, 1, 3, 33, 29, True), (320, 320, 3, 1, 1, 16, 16, True), (400, 160, 1, 1, 2, 24, 20, True)],
+                         ids=["3x3 64->64", "1x1 160->80", "3x3 s2 80->160", "1x1 640->320 no act", "3x3 96->48", "3x3 160->160", "3x3 320->320", "1x1 400->160"])
 def test_fp8_conv_matches_dequantised_reference(case, device):
     """DY_FP8 (BASELINE config 5): e4m3fn activations and per-output-channel-scaled e4m3fn weights on the fp8 MFMA, fp32 accumulate.
     The reference is the SAME arithmetic on the CPU: dequantise the fp8 input and the fp8 weights exactly, convolve in fp32.
@@ -856,6 +913,22 @@ def test_fp8_conv_matches_dequantised_reference(case, device):
             step = want_q.abs().clamp_min(2.0 ** -6) * 0.126  # one e4m3 quantum is <= 1/8 of the value (2^-9 below 2^-6)
             assert bool((diff <= step).all()), float((diff / step).max())
             assert float((diff > 0).float().mean()) <= 0.02
+        # r04: fp8 convolutions run on the flat-K kernel's block-scaled MFMA (v_mfma_f32_16x16x128_f8f6f4), and the output type may differ
+        # from the input's: fp8 -> float16 (a 16-bit Detect tail behind an fp8 trunk) is the fp32 result rounded once to float16
+        y16 = H.conv2d(xd, pc, out_dtype=torch.float16)
+        torch.cuda.synchronize()
+        assert H.last_kernel_name().startswith("conv_gemm_fk_kernel"), H.last_kernel_name()
+        assert y16.dtype == torch.float16 and float((y16.cpu().float() - ref).abs().max()) <= 1.2e-3 * scale
+        # float16 -> fp8 (the hand-over into the trunk): 16-bit operands, the output quantised at the activation scale
+        x16 = quantize(xq.float() * act_scale, torch.float16)
+        w16 = quantize(wt, torch.float16)
+        pc16 = H.PackedConv(w16, bias, s_, k // 2, 1, act, torch.float16, device, halo=False)
+        y8 = H.conv2d(x16.permute(0, 2, 3, 1).contiguous().to(device, torch.float16).permute(0, 3, 1, 2), pc16, out_dtype=FP8)
+        torch.cuda.synchronize()
+        z16 = F.conv2d(x16, w16, bias, s_, k // 2)
+        want_q = ((F.silu(z16) if act else z16) / act_scale).clamp(-448, 448).to(FP8).float()
+        diff = (y8.cpu().float() - want_q).abs()
+        assert y8.dtype == FP8 and bool((diff <= want_q.abs().clamp_min(2.0 ** -6) * 0.126).all()) and float((diff > 0).float().mean()) <= 0.02
     finally:
         H.set_fp8_act_scale(1.0)
 
