@@ -96,7 +96,7 @@ class NmsDesc(C.Structure):
         ("max_wh", _f32), ("agnostic", _i32),
         ("classes_mask", _vp),
         ("out", _vp), ("out_count", _vp), ("out_index", _vp),
-        ("workspace", _vp), ("workspace_bytes", _i64), ("prefiltered", _i32),
+        ("workspace", _vp), ("workspace_bytes", _i64), ("prefiltered", _i32), ("multi_label", _i32),
     ]  # fmt: skip
 
 

@@ -47,6 +47,8 @@ struct NmsArgs {
   unsigned short* cls;  // [batch][A] best class of every candidate anchor
   int P;                // per-image key capacity (power of two >= A)
   int SL;               // LDS sort capacity in keys (power of two)
+  int multi;            // multi_label (ops.py:286-288): a candidate is an (anchor, class) pair, key low word = anchor * nc + class
+  int cap;              // candidates an image can have: A, or A * nc with multi
 };
 
 __global__ __launch_bounds__(256) void nms_filter_kernel(const NmsArgs p) {
@@ -98,6 +100,43 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(const NmsArgs p) {
   }
 }
 
+// multi_label (the validator's NMS, ops.py:286-288: `i, j = torch.where(cls > conf_thres)`): every (anchor, class) pair scored above conf
+// is a candidate of its own.  Candidate order in the reference is row-major over (anchor, class), so the tie order of the stable
+// descending sort is ascending anchor * nc + class: that number is the key's low word.
+__global__ __launch_bounds__(256) void nms_filter_ml_kernel(const NmsArgs p) {
+  const int lane = threadIdx.x & 63;
+  const long long total = (long long)p.batch * p.A;
+  const long long nthreads = (long long)gridDim.x * 256;
+  const long long iters = (total + nthreads - 1) / nthreads;
+  for (long long it = 0; it < iters; ++it) {
+    const long long idx = it * nthreads + (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool in = idx < total;
+    const int b = in ? (int)(idx / p.A) : 0;
+    const int a = in ? (int)(idx - (long long)b * p.A) : 0;
+    const float* s = p.pred + ((size_t)b * p.nch + 4) * (size_t)p.A + a;
+    for (int c = 0; c < p.nc; ++c) {  // (wave-uniform trip count: the ballots below are well defined)
+      const float v = in ? s[(size_t)c * p.A] : 0.f;
+      bool pass = in && v > p.conf;
+      if (pass && p.cmask) pass = p.cmask[c] != 0;
+      u64 todo = __ballot(pass);
+      while (todo != 0ull) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int bb = __shfl(b, leader);
+        const bool mine = pass && b == bb;
+        const u64 m = __ballot(mine);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(p.counts + bb, __popcll(m));
+        base = __shfl(base, leader);
+        if (mine) {
+          const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+          p.keys[(size_t)bb * p.P + pos] = ((u64)(~__float_as_uint(v)) << 32) | (u64)((unsigned)a * (unsigned)p.nc + (unsigned)c);
+        }
+        todo &= ~m;
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ bool iou_gt(float ix1, float iy1, float ix2, float iy2, float iarea, float jx1, float jy1,
                                        float jx2, float jy2, float jarea, float thr) {
   const float xx1 = fmaxf(ix1, jx1), yy1 = fmaxf(iy1, jy1);
@@ -115,7 +154,7 @@ __global__ __launch_bounds__(1024) void nms_suppress_kernel(const NmsArgs p) {
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
   int n = p.counts[b];
-  if (n > p.A) n = p.A;
+  if (n > p.cap) n = p.cap;
   u64* gkeys = p.keys + (size_t)b * p.P;
 
   int P2 = 1;
@@ -171,7 +210,12 @@ __global__ __launch_bounds__(1024) void nms_suppress_kernel(const NmsArgs p) {
       const u64 key = in_lds ? skeys[i] : gkeys[i];
       anchor = (int)(unsigned)(key & 0xffffffffull);
       score = __uint_as_float(~(unsigned)(key >> 32));
-      cls = (int)p.cls[(size_t)b * p.A + anchor];
+      if (p.multi) {
+        cls = anchor % p.nc;
+        anchor = anchor / p.nc;
+      } else {
+        cls = (int)p.cls[(size_t)b * p.A + anchor];
+      }
       const float cx = pr[anchor], cy = pr[(size_t)p.A + anchor];
       const float hw = pr[(size_t)2 * p.A + anchor] / 2.f, hh = pr[(size_t)3 * p.A + anchor] / 2.f;
       x1 = cx - hw;
@@ -259,7 +303,11 @@ extern "C" int32_t dy_nms(const dy_nms_desc* d, dy_stream_t stream) {
   DY_REQUIRE(d->conf_thres >= 0.f && d->conf_thres <= 1.f && d->iou_thres >= 0.f && d->iou_thres <= 1.f,
              DY_ERR_INVALID_ARG, "dy_nms: thresholds must be in [0,1] (utils/ops.py:233-234)");
   DY_REQUIRE(d->max_det >= 1 && d->max_det <= 4096 && d->max_nms >= 1, DY_ERR_INVALID_ARG, "dy_nms: max_det must be in [1,4096]");
-  const int64_t need = dy_nms_workspace_bytes(d->batch, d->anchors);
+  const bool multi = d->multi_label != 0 && d->nc > 1;  // (ops.py:255: multi_label &= nc > 1)
+  DY_REQUIRE(!multi || (long long)d->anchors * d->nc < (1ll << 30), DY_ERR_UNSUPPORTED, "dy_nms: multi_label with anchors * nc >= 2^30");
+  DY_REQUIRE(!(multi && d->prefiltered), DY_ERR_UNSUPPORTED, "dy_nms: the fused candidate filter is single-label; multi_label filters here");
+  const int wcap = multi ? d->anchors * d->nc : d->anchors;
+  const int64_t need = dy_nms_workspace_bytes(d->batch, wcap);
   DY_REQUIRE(d->workspace_bytes >= need, DY_ERR_WORKSPACE, "dy_nms: workspace %lld < %lld bytes", (long long)d->workspace_bytes,
              (long long)need);
   DY_REQUIRE(aligned16(d->workspace), DY_ERR_INVALID_ARG, "dy_nms: workspace not 16-byte aligned");
@@ -281,7 +329,9 @@ extern "C" int32_t dy_nms(const dy_nms_desc* d, dy_stream_t stream) {
   a.out = d->out;
   a.out_count = d->out_count;
   a.out_index = d->out_index;
-  const NmsWs w = nms_ws_layout(d->workspace, d->batch, d->anchors);
+  const NmsWs w = nms_ws_layout(d->workspace, d->batch, wcap);
+  a.multi = multi ? 1 : 0;
+  a.cap = wcap;
   a.P = w.P;
   a.counts = w.counts;
   a.keys = reinterpret_cast<u64*>(w.keys);
@@ -293,8 +343,9 @@ extern "C" int32_t dy_nms(const dy_nms_desc* d, dy_stream_t stream) {
     const long long total = (long long)d->batch * d->anchors;
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(nms_filter_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
-    const int rc = check_launch("nms_filter_kernel");
+    if (multi) hipLaunchKernelGGL(nms_filter_ml_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(nms_filter_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    const int rc = check_launch(multi ? "nms_filter_ml_kernel" : "nms_filter_kernel");
     if (rc != DY_OK) return rc;
   }
   const size_t smem = (size_t)a.SL * 8 + align_up((size_t)d->max_det * 5 * 4, 16);

@@ -59,8 +59,8 @@ class DetectionPredictor:
         a.update(overrides or {})
         self.args = a
         self.device = select_device(a["device"])
-        # dtype="fp8-mixed" (BASELINE config 5): float16 storage with the layers the error budget allows in e4m3
-        # (BaseModel.fp8_plan_off_p2, or the set given as overrides["fp8_layers"]); dtype="fp8": the whole trunk in e4m3, Detect tail float16
+        # dtype="fp8-mixed" (BASELINE config 5): float16 storage with the internals of the C2f blocks the error budget allows in
+        # e4m3 (BaseModel.fp8_plan_off_p2, or the blocks given as overrides["fp8_layers"]); dtype="fp8": the whole trunk in e4m3, Detect tail float16
         self.mixed8 = isinstance(a["dtype"], str) and a["dtype"].lower().replace("_", "-") == "fp8-mixed"
         self.dtype = torch.float16 if self.mixed8 else resolve_dtype(a["dtype"], a["half"])
         # setup_model (predictor.py:300-323): AutoBackend moves the graph to the device, fuses, picks the precision and freezes it

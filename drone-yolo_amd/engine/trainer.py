@@ -19,7 +19,10 @@ What is kept from the reference, with the place it comes from:
   * gradient clipping max_norm 10 (trainer.py:594), ModelEMA (utils/torch_utils.py:515-545).
 Parameters, gradients, BatchNorm buffers and the EMA copy live in FLAT fp32 buffers (the module parameters are views), so
 the clip norm is one reduction, each optimizer group one kernel launch and the EMA one launch.
-Out of scope: dataset files, augmentation, validation / fitness, callbacks, plots.  The loader here serves
+  * validation inside the loop (trainer.py:427-442, 605-615; r04): rank 0 evaluates the EMA weights every epoch (``val: true``) with the
+    validator's NMS (multi_label, conf 0.001) — mAP50 / mAP50-95 / fitness into results.csv, ``best.pt`` beside ``last.pt``
+    (engine/validator.py).
+Out of scope: dataset files, augmentation, callbacks, plots, early stopping.  The loader here serves
 tensor datasets (uint8 images + labels in the reference's collate layout) or the synthetic VisDrone-shaped set of SURVEY §8(d).
 """
 from __future__ import annotations
@@ -352,7 +355,10 @@ class DetectionTrainer:
         self.iterations_hint = iterations_hint
         self.save_dir = Path(a.get("project") or "runs/detect") / (a.get("name") or "train")
         self.wdir = self.save_dir / "weights"
-        self.last, self.csv = self.wdir / "last.pt", self.save_dir / "results.csv"
+        self.last, self.best, self.csv = self.wdir / "last.pt", self.wdir / "best.pt", self.save_dir / "results.csv"
+        self.best_fitness, self.fitness, self.metrics = None, None, {}
+        self.validator = None
+        self.val_loader = None
         self.epochs = int(a["epochs"])
         self.start_epoch, self.epoch = 0, 0
         self.loss_names = ("box_loss", "cls_loss", "dfl_loss")
@@ -661,6 +667,14 @@ class DetectionTrainer:
         self.train_loader = TensorLoader(data, per_rank, self.rank if world > 1 else 0, max(world, 1), seed=int(a.get("seed", 0)))
         if self.rank == 0:
             self.wdir.mkdir(parents=True, exist_ok=True)
+            if a.get("val", True):
+                # _setup_train (trainer.py:288-296): the validation loader lives on rank 0 at twice the per-rank batch.  A tensor dataset
+                # carries its split as data["val"] (same layout); without one the training tensors are evaluated
+                from .validator import DetectionValidator
+
+                vd = data.get("val") if isinstance(data.get("val"), dict) else data
+                self.val_loader = TensorLoader({k: vd[k] for k in ("img", "batch_idx", "cls", "bboxes")}, per_rank * 2, 0, 1, shuffle=False)
+                self.validator = DetectionValidator(a)
 
     def _do_train(self, world: int = 1):
         if world > 1:
@@ -688,7 +702,9 @@ class DetectionTrainer:
             final_epoch = epoch + 1 >= self.epochs
             if self.rank == 0:
                 self.lr = {f"lr/pg{ir}": x for ir, x in enumerate((self.cur_lrs[2], self.cur_lrs[0], self.cur_lrs[1]))}  # reference group order
-                self.save_metrics({"time": time.time() - t_start, **self.label_loss_items(self.tloss), **self.lr})
+                if self.validator is not None and (self.args.get("val", True) or final_epoch):  # trainer.py:430-432
+                    self.metrics, self.fitness = self.validate()
+                self.save_metrics({"time": time.time() - t_start, **self.label_loss_items(self.tloss), **self.metrics, **self.lr})
                 if self.args.get("save", True) or final_epoch:
                     self.save_model()
                 LOGGER.info(f"{epoch + 1}/{self.epochs}  " + "  ".join(f"{k} {float(v):.4g}" for k, v in self.label_loss_items(self.tloss).items()))
@@ -701,6 +717,26 @@ class DetectionTrainer:
         if world > 1 and torch.distributed.is_initialized():
             torch.distributed.barrier()
         return {**self.label_loss_items(self.tloss), "save_dir": str(self.save_dir)}
+
+    def validate(self):
+        """trainer.py:605-615 + validator.py:109-221 (training branch): the EMA weights evaluated on the validation tensors; fitness =
+        0.1 mAP50 + 0.9 mAP50-95 (metrics.py ``Metric.fitness``), the best one remembered.  The EMA copy is swapped into the flat
+        parameter / BatchNorm buffers for the pass (the module parameters are views of them) and the live weights put back after."""
+        live_p, live_b = self.flat.P.clone(), self.flat.B.clone()
+        self.flat.P.copy_(self.ema.P)
+        self.flat.B.copy_(self.ema.B)
+        try:
+            metrics = self.validator(self.model, self.val_loader, self.device, self.model.train_dtype)
+        finally:
+            self.flat.P.copy_(live_p)
+            self.flat.B.copy_(live_b)
+            self.model.train()  # (drops the packs folded from the EMA weights)
+        fitness = metrics.pop("fitness", None)
+        if fitness is None:
+            fitness = -float(self.loss)
+        if not self.best_fitness or self.best_fitness < fitness:
+            self.best_fitness = fitness
+        return metrics, fitness
 
     def preprocess_batch(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """detect/train.py:57-74: images to the device (the /255 and the layout change ride in the first kernel)."""
@@ -765,7 +801,12 @@ class DetectionTrainer:
 
         from ..nn.checkpoint import save_reference_checkpoint
 
+        args = {k: v for k, v in self.args.items() if not isinstance(v, dict)}  # (a tensor dataset passed as a dict does not belong in the file)
         save_reference_checkpoint(self.last, self.model, self.ema.state_dict(self.model), extra={
-            "epoch": self.epoch, "best_fitness": None, "updates": self.ema.updates, "optimizer": self.optimizer_state_dict(),
-            "train_args": dict(self.args), "train_metrics": {**self.label_loss_items(self.tloss), "fitness": None},
+            "epoch": self.epoch, "best_fitness": self.best_fitness, "updates": self.ema.updates, "optimizer": self.optimizer_state_dict(),
+            "train_args": args, "train_metrics": {**self.metrics, "fitness": self.fitness},
             "train_results": self.read_results_csv(), "date": datetime.now().isoformat()})
+        if self.best_fitness is not None and self.best_fitness == self.fitness:  # trainer.py:541-542
+            import shutil
+
+            shutil.copyfile(self.last, self.best)

@@ -561,6 +561,8 @@ def conv2d(x: torch.Tensor, pc: PackedConv, out: Optional[torch.Tensor] = None, 
         raise ValueError(f"conv2d: out has shape {tuple(out.shape)}/{out.dtype}, expected {(n, pc.cout, ho, wo)}/{odt}")
     xp, ldx = view_params(x)
     yp, ldy = view_params(out)
+    if odt != x.dtype and not out_f32:
+        pc = pc.rows()  # another storage type on the output is built in the flat-K kernel only (DY_WLAYOUT_ROWS)
     pc = pc.for_call(n * hb * wb * ldx * x.element_size(), n * ho * wo * ldy * out.element_size(), ldy, yp, residual is not None, out_f32,
                      x2 is not None or up2x or dil2)
     d = ConvDesc()
@@ -919,9 +921,10 @@ def detect_head_decode(x_box: Sequence[torch.Tensor], x_cls: Sequence[torch.Tens
 class NmsBuffers:
     """Persistent outputs + workspace of ``dy_nms`` for one (batch, anchors, max_det)."""
 
-    def __init__(self, batch: int, anchors: int, max_det: int, device):
-        self.batch, self.anchors, self.max_det = batch, anchors, max_det
-        nbytes = lib().dy_nms_workspace_bytes(batch, anchors)
+    def __init__(self, batch: int, anchors: int, max_det: int, device, candidates_per_anchor: int = 1):
+        """``candidates_per_anchor``: nc for the validator's multi_label NMS (one candidate per (anchor, class) pair), else 1."""
+        self.batch, self.anchors, self.max_det, self.cpa = batch, anchors, max_det, candidates_per_anchor
+        nbytes = lib().dy_nms_workspace_bytes(batch, anchors * candidates_per_anchor)
         self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=device)
         self.out = torch.empty((batch, max_det, 6), dtype=torch.float32, device=device)
         self.count = torch.empty((batch,), dtype=torch.int32, device=device)
@@ -930,18 +933,20 @@ class NmsBuffers:
 
 def nms(pred: torch.Tensor, conf_thres: float, iou_thres: float, max_det: int = 300, max_nms: int = 30000,
         max_wh: float = 7680.0, agnostic: bool = False, nc: int = 0, classes_mask: Optional[torch.Tensor] = None,
-        bufs: Optional[NmsBuffers] = None, prefiltered: bool = False) -> NmsBuffers:
+        bufs: Optional[NmsBuffers] = None, prefiltered: bool = False, multi_label: bool = False) -> NmsBuffers:
     """Batched NMS on (N, 4+nc(+nm), A) fp32 predictions; results stay on the device.
-    ``prefiltered``: ``bufs.workspace`` already holds the candidates (detect_decode(nms_bufs=bufs))."""
+    ``prefiltered``: ``bufs.workspace`` already holds the candidates (detect_decode(nms_bufs=bufs)).
+    ``multi_label``: the validator's form (utils/ops.py:286-288): every (anchor, class) pair above conf is a candidate."""
     require_device(pred, "prediction")
     if pred.dtype != torch.float32 or not pred.is_contiguous() or pred.dim() != 3:
         raise ValueError("nms expects a contiguous fp32 (N, 4+nc, A) tensor")
     n, ch, A = pred.shape
     nc = nc or ch - 4
-    if bufs is None or (bufs.batch, bufs.anchors, bufs.max_det) != (n, A, max_det):
+    cpa = nc if (multi_label and nc > 1) else 1
+    if bufs is None or (bufs.batch, bufs.anchors, bufs.max_det) != (n, A, max_det) or getattr(bufs, "cpa", 1) < cpa:
         if prefiltered:
             raise ValueError("nms(prefiltered=True) needs the NmsBuffers that detect_decode filled")
-        bufs = NmsBuffers(n, A, max_det, pred.device)
+        bufs = NmsBuffers(n, A, max_det, pred.device, candidates_per_anchor=cpa)
     d = NmsDesc()
     d.pred, d.batch, d.nc, d.n_extra, d.anchors = pred.data_ptr(), n, nc, ch - 4 - nc, A
     d.conf_thres, d.iou_thres, d.max_det, d.max_nms = conf_thres, iou_thres, max_det, max_nms
@@ -949,7 +954,7 @@ def nms(pred: torch.Tensor, conf_thres: float, iou_thres: float, max_det: int = 
     d.classes_mask = classes_mask.data_ptr() if classes_mask is not None else None
     d.out, d.out_count, d.out_index = bufs.out.data_ptr(), bufs.count.data_ptr(), bufs.index.data_ptr()
     d.workspace, d.workspace_bytes = bufs.workspace.data_ptr(), bufs.workspace.numel()
-    d.prefiltered = int(prefiltered)
+    d.prefiltered, d.multi_label = int(prefiltered), int(bool(multi_label))
     _launch(lib().dy_nms, (C.byref(d),), keep=(d, pred, bufs, classes_mask))
     return bufs
 

@@ -80,6 +80,8 @@ class C2f(nn.Module):
         """
         if self.training:
             return _train_forward(self, "c2f_train", x, out=out, **kw)
+        if kw.pop("fp8_internal", False):
+            return self._forward_fp8_internal(x, out)
         if self.fuse_block and len(self.m) == 1:
             cout = self.cv2.conv.out_channels
             if not kw and H.c2f_fused_supported(x.shape[1], self.c, cout, 1, x.dtype):
@@ -95,6 +97,22 @@ class C2f(nn.Module):
         for i, m in enumerate(self.m):
             m(ybuf[:, (1 + i) * c : (2 + i) * c], out=ybuf[:, (2 + i) * c : (3 + i) * c])
         return self.cv2(ybuf, out=out)
+
+
+def _c2f_fp8_internal(self, x, out=None):
+    """C2f with its internals in e4m3 (mixed plan of BASELINE config 5, nn/tasks.py::_predict_layers): cv1 reads the 16-bit input and
+    writes fp8 ([y0 | y1] in ONE fp8 buffer), every Bottleneck convolution runs fp8 -> fp8 on the block-scaled MFMA, cv2 reads the
+    fp8 buffer and writes the 16-bit output — the block's boundary types are its caller's (csrc/conv_gemm_fk.hip, y_dtype1)."""
+    n, _, h, w = x.shape
+    c = self.c
+    ybuf = H.alloc_nhwc(n, (2 + len(self.m)) * c, h, w, H.FP8, x.device)
+    self.cv1(x, out=ybuf[:, : 2 * c], out_dtype=H.FP8)
+    for i, m in enumerate(self.m):
+        m(ybuf[:, (1 + i) * c : (2 + i) * c], out=ybuf[:, (2 + i) * c : (3 + i) * c])
+    return self.cv2(ybuf, out=out, out_dtype=x.dtype)
+
+
+C2f._forward_fp8_internal = _c2f_fp8_internal
 
 
 class SPPF(nn.Module):

@@ -191,11 +191,7 @@ class Concat(nn.Module):
         for t in x:
             c = t.shape[1]
             tp, tld = H.view_params(t)
-            if t.dtype != out.dtype:  # a 16-bit source of an fp8 Concat (mixed plan, nn/tasks.py::_predict_layers): quantised into its slice
-                if out.dtype != H.FP8:
-                    raise TypeError(f"Concat: input dtype {t.dtype} into a {out.dtype} buffer")
-                H.quantize_fp8(t, out=out[:, c0 : c0 + c])
-            elif not (tp == op + c0 * es and tld == ld):
+            if not (tp == op + c0 * es and tld == ld):
                 H.copy_nhwc(t, out[:, c0 : c0 + c])
             c0 += c
         return out

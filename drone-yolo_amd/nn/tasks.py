@@ -226,22 +226,12 @@ class BaseModel(nn.Module):
         y: List[Optional[torch.Tensor]] = []
         cat_bufs: Dict[int, torch.Tensor] = {}
         fused_stem2 = None
-        # mixed-precision plan (BASELINE config 5): the output buffers of the layers in ``fp8_layers`` are e4m3, everything
-        # else the pass's 16-bit type.  A layer of the set reads fp8 (a 16-bit source is quantised once, ``as8``), so its convolutions run
-        # on the block-scaled fp8 MFMA; the set must be closed under "consumer of" up to Detect, which takes either type per level.
+        # mixed-precision plan (BASELINE config 5): the C2f blocks in ``fp8_layers`` run their INTERNALS in e4m3 on the
+        # block-scaled fp8 MFMA — cv1 reads the 16-bit input and writes fp8, the Bottlenecks are fp8, cv2 reads fp8 and writes the 16-bit
+        # output — so every layer boundary, skip connection and Concat stays 16-bit and no plan can leave a consumer with the wrong type
         f8 = self.__dict__.get("fp8_layers") or frozenset()
-        if f8 and x.dtype not in (torch.float16,):
+        if f8 and x.dtype != torch.float16:
             raise NotImplementedError("a mixed fp8 plan (fp8_layers) runs on float16 storage")
-        q8: Dict[int, torch.Tensor] = {}
-
-        def as8(j):
-            t = y[j]
-            if t.dtype == H.FP8:
-                return t
-            if j not in q8:
-                q8[j] = H.quantize_fp8(t)
-            return q8[j]
-
         for m in self.model:
             i = m.i
             if i in self._skip:
@@ -249,28 +239,24 @@ class BaseModel(nn.Module):
                 continue
             src = self._srcs[i]
             kw = {}
-            pick = as8 if (i in f8 and not isinstance(m, Concat)) else (lambda j: y[j])  # (a Concat of the set quantises into its slices itself)
             if isinstance(m, C2f) and src[0] in self._virtual:
                 lo, skip = self._virtual[src[0]]
-                xin, kw = pick(lo), {"x2": pick(skip), "up2x": True}
+                xin, kw = y[lo], {"x2": y[skip], "up2x": True}
             elif isinstance(m.f, int):
-                xin = x if (i == 0) else pick(src[0])
+                xin = x if (i == 0) else y[src[0]]
             else:
-                xin = [pick(j) for j in src]
-            if f8 and i not in f8 and not isinstance(m, Detect) and i > 0:
-                ins = xin if isinstance(xin, list) else [xin] + ([kw["x2"]] if "x2" in kw else [])
-                if any(t.dtype == H.FP8 for t in ins):
-                    raise RuntimeError(f"fp8_layers is not closed under 'consumer of': layer {i} ({type(m).__name__}) is 16-bit and reads an fp8 buffer")
-            if i in self._place and ((self._place[i][0] in f8) == (i in f8)):  # (a producer of the other storage type keeps its own buffer)
+                xin = [y[j] for j in src]
+            if i in f8:
+                if not isinstance(m, C2f) or kw:
+                    raise NotImplementedError(f"fp8_layers: layer {i} ({type(m).__name__}) — fp8 internals are built for C2f blocks with one plain input")
+                kw["fp8_internal"] = True
+            if i in self._place:
                 ci, off = self._place[i]
                 if ci not in cat_bufs:
                     n = x.shape[0]
                     h, w = self._out_hw(ci, x.shape[2], x.shape[3])
-                    cat_bufs[ci] = H.alloc_nhwc(n, self._out_ch[ci], h, w, H.FP8 if ci in f8 else x.dtype, x.device)
+                    cat_bufs[ci] = H.alloc_nhwc(n, self._out_ch[ci], h, w, x.dtype, x.device)
                 kw["out"] = cat_bufs[ci][:, off : off + self._out_ch[i]]
-            if isinstance(m, Concat) and i in f8 and i not in cat_bufs:
-                h, w = self._out_hw(i, x.shape[2], x.shape[3])
-                cat_bufs[i] = H.alloc_nhwc(x.shape[0], self._out_ch[i], h, w, H.FP8, x.device)
             if isinstance(m, Concat) and i in cat_bufs:
                 kw["out"] = cat_bufs[i]
             if i == 0 and stem_image is not None:
@@ -293,10 +279,10 @@ class BaseModel(nn.Module):
     fuse_stem2 = True  # layers 0 + 1 in one kernel where dy_stem2_fused is built for the shapes
 
     def fp8_plan_off_p2(self) -> frozenset:
-        """The mixed plan the error budget allows on these models (profiles/r04_fp8_sensitivity_*.jsonl): every layer that does NOT feed the
-        highest-resolution Detect level.  Most detections of the P2 models live on that level (25,600 of 34,000 anchors at 640 x 640),
-        and ONE fp8 rounding anywhere on its path flips 7-15 % of the kept boxes of the synthetic-weight fixtures, while the whole deep
-        neck (the stride-8 / 16 / 32 outputs and what only they depend on) in fp8 flips < 1 %."""
+        """The mixed plan the error budget allows on these models (profiles/r04_fp8_sensitivity_*.jsonl): the C2f blocks that do NOT feed
+        the highest-resolution Detect level.  Most detections of the P2 models live on that level (25,600 of 34,000 anchors at 640 x
+        640), and ONE e4m3 rounding anywhere on its path flips 7-15 % of the kept boxes of the synthetic-weight fixtures, while the deep
+        neck blocks (stride 8 / 16 / 32 outputs) in fp8 flip < 1 %."""
         if not hasattr(self, "_srcs"):
             self._plan_graph()
         det = self.model[-1]
@@ -310,7 +296,8 @@ class BaseModel(nn.Module):
             anc.add(t)
             if t > 0:
                 todo += list(self._srcs[t])
-        return frozenset(m.i for m in self.model if m.i not in anc and m.i != det.i)
+        return frozenset(m.i for m in self.model if isinstance(m, C2f) and m.i not in anc and m.i not in self._skip
+                         and not (self._srcs[m.i][0] in self._virtual))
 
     def _stem2_pack(self, image, dtype, consumers0):
         """Packed weights for ``dy_stem2_fused`` when layers 0 / 1 are Conv(3, 32, 3, 2) -> RepVGGBlock(32, 64, stride 2),

@@ -130,7 +130,8 @@ def non_max_suppression(
     end2end=False,
     return_padded=False,
 ) -> List[torch.Tensor]:
-    """Reference ops.py:181-332, single-label detection path, on the device via ``dy_nms``.
+    """Reference ops.py:181-332 on the device via ``dy_nms``: the predictor's single-label path and the validator's ``multi_label``
+    path (one candidate per (anchor, class) pair above conf, ops.py:286-288; models/yolo/detect/val.py:93-106).
 
     Returns a list (one (n_i, 6) tensor [x1, y1, x2, y2, conf, cls] per image) like the reference;
     ``return_padded=True`` returns the device-resident ``NmsBuffers`` (out (N,max_det,6), count (N,),
@@ -141,8 +142,8 @@ def non_max_suppression(
     assert 0 <= iou_thres <= 1, f"Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0"
     if isinstance(prediction, (list, tuple)):
         prediction = prediction[0]
-    if multi_label or labels or rotated or end2end or prediction.shape[-1] == 6:
-        raise NotImplementedError("multi_label / labels / rotated / end2end NMS variants are not on the accelerated path")
+    if labels or rotated or end2end or prediction.shape[-1] == 6:
+        raise NotImplementedError("labels (autolabelling) / rotated / end2end NMS variants are not on the accelerated path")
     H.require_device(prediction, "prediction")
     nc = nc or (prediction.shape[1] - 4)
     mask = None
@@ -152,7 +153,7 @@ def non_max_suppression(
         mask = mask.to(prediction.device)
     pred = prediction if (prediction.dtype == torch.float32 and prediction.is_contiguous()) else prediction.float().contiguous()
     bufs = H.nms(pred, float(conf_thres), float(iou_thres), max_det=int(max_det), max_nms=int(max_nms),
-                 max_wh=float(max_wh), agnostic=bool(agnostic), nc=int(nc), classes_mask=mask)
+                 max_wh=float(max_wh), agnostic=bool(agnostic), nc=int(nc), classes_mask=mask, multi_label=bool(multi_label))
     if return_padded:
         return bufs
     counts = bufs.count.tolist()  # one device->host sync for the whole batch

@@ -397,7 +397,7 @@ int32_t dy_detect_head_decode_supported(int32_t c_box, int32_t c_cls, int32_t nc
 int32_t dy_detect_head_decode(const dy_head_decode_desc* d, dy_stream_t stream);
 
 /* ---- NMS --------------------------------------------------------------------
- * Replaces: ops.non_max_suppression single-label path (utils/ops.py:181-332)
+ * Replaces: ops.non_max_suppression (utils/ops.py:181-332; the predictor's single-label path and the validator's multi_label path)
  * including torchvision.ops.nms (called at ops.py:312): candidates = anchors
  * whose best class score > conf_thres; xywh -> xyxy; if more than max_nms keep the
  * max_nms best; boxes offset by cls*max_wh unless agnostic; greedy NMS in
@@ -425,6 +425,10 @@ typedef struct dy_nms_desc {
   int64_t workspace_bytes;
   int32_t prefiltered; /* 1: the workspace already holds the candidates (dy_detect_decode fused filter,
                           same conf_thres / classes_mask); only sort + suppress run */
+  int32_t multi_label; /* 1 (and nc > 1): the validator's NMS (utils/ops.py:255, 286-288; call site models/yolo/detect/val.py:93-106):
+                          every (anchor, class) pair scored above conf_thres is a candidate of its own (ties: ascending
+                          anchor * nc + class, the reference's row-major torch.where order); out_index still names the ANCHOR.
+                          The workspace is then dy_nms_workspace_bytes(batch, anchors * nc) bytes; not with prefiltered */
 } dy_nms_desc;
 int64_t dy_nms_workspace_bytes(int32_t batch, int32_t anchors);
 int32_t dy_nms(const dy_nms_desc* d, dy_stream_t stream);

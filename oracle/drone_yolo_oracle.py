@@ -318,14 +318,17 @@ def nms_greedy(boxes: np.ndarray, scores: np.ndarray, iou_threshold: float) -> n
 
 
 def non_max_suppression(prediction: Tensor, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, max_det=300,
-                        nc=0, max_nms=30000, max_wh=7680, return_index=False):
-    """utils/ops.py:181-332, single-label path, without the wall-clock break (ops.py:328-330)."""
+                        nc=0, max_nms=30000, max_wh=7680, return_index=False, multi_label=False):
+    """utils/ops.py:181-332 without the wall-clock break (ops.py:328-330): the single-label path (best class per anchor, ops.py:290-291)
+    and the validator's ``multi_label`` path (one candidate per (anchor, class) pair scored above conf, ops.py:286-288).
+    ``return_index``: also the anchor index of every kept row."""
     prediction = prediction.clone()
     bs = prediction.shape[0]
     nc = nc or (prediction.shape[1] - 4)
     nm = prediction.shape[1] - nc - 4
     mi = 4 + nc
     xc = prediction[:, 4:mi].amax(1) > conf_thres  # ops.py:250
+    multi_label &= nc > 1  # ops.py:255
     prediction = prediction.transpose(-1, -2)  # ops.py:257
     prediction[..., :4] = xywh2xyxy(prediction[..., :4])  # ops.py:259-260
     output = [torch.zeros((0, 6 + nm))] * bs
@@ -336,10 +339,15 @@ def non_max_suppression(prediction: Tensor, conf_thres=0.25, iou_thres=0.45, cla
         if not x.shape[0]:
             continue
         box, cls, mask = x.split((4, nc, nm), 1)
-        conf, j = cls.max(1, keepdim=True)  # ops.py:290
-        sel = conf.view(-1) > conf_thres
-        x = torch.cat((box, conf, j.float(), mask), 1)[sel]  # ops.py:291
-        aidx = aidx[sel]
+        if multi_label:  # ops.py:286-288
+            i, j = torch.where(cls > conf_thres)
+            x = torch.cat((box[i], x[i, 4 + j, None], j[:, None].float(), mask[i]), 1)
+            aidx = aidx[i]
+        else:
+            conf, j = cls.max(1, keepdim=True)  # ops.py:290
+            sel = conf.view(-1) > conf_thres
+            x = torch.cat((box, conf, j.float(), mask), 1)[sel]  # ops.py:291
+            aidx = aidx[sel]
         if classes is not None:
             sel = (x[:, 5:6] == torch.tensor(classes)).any(1)  # ops.py:294-295
             x, aidx = x[sel], aidx[sel]

@@ -336,6 +336,87 @@ def nms_cases(R):
     np.savez_compressed(OUT / "nms.npz", **out)
 
 
+def nms_multilabel_cases(R):
+    """The validator's NMS (``multi_label=True``, conf 0.001: one candidate per (anchor, class) pair, ops.py:286-288; call site
+    models/yolo/detect/val.py:93-106): the REAL reference's non_max_suppression over our nms primitive, on hand-built predictions."""
+    g = torch.Generator().manual_seed(78)
+    cases = {}
+    n, nc = 300, 5
+    xy = torch.rand(3, n, 2, generator=g) * 300 + 20
+    wh = torch.rand(3, n, 2, generator=g) * 60 + 4
+    sc = torch.rand(3, n, nc, generator=g) ** 4
+    crowd = torch.cat((xy, wh, sc), 2).transpose(1, 2).contiguous()
+    cases["val_crowd"] = (crowd, dict(conf_thres=0.001, iou_thres=0.7, multi_label=True, max_det=300))
+    cases["val_crowd_conf25"] = (crowd, dict(conf_thres=0.25, iou_thres=0.6, multi_label=True))
+    cases["val_agnostic"] = (crowd, dict(conf_thres=0.05, iou_thres=0.7, multi_label=True, agnostic=True))
+    cases["val_classes"] = (crowd, dict(conf_thres=0.05, iou_thres=0.7, multi_label=True, classes=[0, 3]))
+    cases["val_max_det"] = (crowd, dict(conf_thres=0.001, iou_thres=0.9, multi_label=True, max_det=25))
+    # one anchor, several labels above conf: every (anchor, class) pair is its own candidate and survives (class offset separates them)
+    b = torch.tensor([[50.0, 50, 20, 20], [52.0, 50, 20, 20], [200.0, 200, 30, 30]])
+    s_ = torch.tensor([[0.9, 0.8, 0.002], [0.85, 0.0005, 0.7], [0.3, 0.3, 0.3]])
+    cases["val_pairs"] = (torch.cat((b, s_), 1).t().unsqueeze(0).contiguous(), dict(conf_thres=0.001, iou_thres=0.5, multi_label=True))
+    # nc = 1: multi_label is switched off by the reference (ops.py:255)
+    cases["val_nc1"] = (torch.cat((xy[:1, :60], wh[:1, :60], sc[:1, :60, :1]), 2).transpose(1, 2).contiguous(), dict(conf_thres=0.01, iou_thres=0.7, multi_label=True))
+    # more candidates than max_nms: distinct scores, so the top-max_nms cut (an unstable argsort in the reference) is well defined
+    big = torch.cat((xy[:1], wh[:1], (torch.rand(1, n, nc, generator=g) * 0.9 + 0.05)), 2).transpose(1, 2).contiguous()
+    cases["val_max_nms"] = (big, dict(conf_thres=0.001, iou_thres=0.7, multi_label=True, max_nms=200, max_det=50))
+    out = {}
+    for name, (pred, kw) in cases.items():
+        ref = R.ops.non_max_suppression(pred.clone(), **kw)
+        ours, idx = O.non_max_suppression(pred.clone(), return_index=True, **kw)
+        for i, (a, b_) in enumerate(zip(ours, ref)):
+            assert a.shape == b_.shape and torch.equal(a, b_), f"nms case {name} image {i}: oracle != reference"
+        print(f"  oracle vs reference  nms/{name:<34s} identical ({[len(r) for r in ref]} boxes)")
+        out[f"{name}__pred"] = tnp(pred)
+        out[f"{name}__kw"] = np.array(repr(kw))
+        out[f"{name}__n"] = np.array([len(r) for r in ref])
+        out[f"{name}__out"] = np.concatenate([tnp(r) for r in ref], 0) if sum(len(r) for r in ref) else np.zeros((0, 6), np.float32)
+        out[f"{name}__idx"] = np.concatenate([tnp(t) for t in idx], 0).astype(np.int64) if sum(len(t) for t in idx) else np.zeros((0,), np.int64)
+    np.savez_compressed(OUT / "nms_ml.npz", **out)
+
+
+def val_metric_vectors(R):
+    """Inputs and outputs of the REAL reference's validation metrics — ``box_iou`` (utils/metrics.py:52-71), ``BaseValidator.
+    match_predictions`` (engine/validator.py:224-264), ``ap_per_class`` (metrics.py:537-623) and ``Metric.fitness`` (:748-751) — on
+    synthetic detections: what drone-yolo_amd/utils/metrics.py (the validation step of the training loop) is pinned against."""
+    from ultralytics.engine.validator import BaseValidator
+    from ultralytics.utils import metrics as rm
+
+    g = torch.Generator().manual_seed(555)
+    out = {}
+    iouv = torch.linspace(0.5, 0.95, 10)
+    holder = types.SimpleNamespace(iouv=iouv)
+    tps, confs, pcs, tcs = [], [], [], []
+    for img in range(12):
+        nl, nd, nc = int(torch.randint(0, 9, (1,), generator=g)), int(torch.randint(0, 40, (1,), generator=g)), 4
+        gt = torch.rand(nl, 2, generator=g) * 400
+        gtb = torch.cat((gt, gt + torch.rand(nl, 2, generator=g) * 80 + 8), 1)
+        gtc = torch.randint(0, nc, (nl,), generator=g).float()
+        # detections: jittered copies of ground-truth boxes plus clutter
+        if nl and nd:
+            pick = torch.randint(0, nl, (nd,), generator=g)
+            db = gtb[pick] + torch.randn(nd, 4, generator=g) * 6
+            dc = torch.where(torch.rand(nd, generator=g) < 0.8, gtc[pick], torch.randint(0, nc, (nd,), generator=g).float())
+        else:
+            d0 = torch.rand(nd, 2, generator=g) * 400
+            db, dc = torch.cat((d0, d0 + 30), 1), torch.randint(0, nc, (nd,), generator=g).float()
+        conf = torch.rand(nd, generator=g)
+        iou = rm.box_iou(gtb, db)
+        tp = BaseValidator.match_predictions(holder, dc, gtc, iou) if nl and nd else torch.zeros(nd, 10, dtype=torch.bool)
+        out[f"img{img}_gtb"], out[f"img{img}_gtc"], out[f"img{img}_db"], out[f"img{img}_dc"] = tnp(gtb), tnp(gtc), tnp(db), tnp(dc)
+        out[f"img{img}_iou"], out[f"img{img}_tp"] = tnp(iou), tnp(tp)
+        if nd or nl:
+            tps.append(tp.numpy()), confs.append(conf.numpy()), pcs.append(dc.numpy()), tcs.append(gtc.numpy())
+    tp, conf, pc, tc = np.concatenate(tps), np.concatenate(confs), np.concatenate(pcs), np.concatenate(tcs)
+    res = rm.ap_per_class(tp, conf, pc, tc, plot=False)
+    m = rm.Metric()
+    m.update(res[2:])  # (p, r, f1, all_ap, ap_class_index, curves ...) as DetMetrics.process hands them over
+    out.update(n_img=np.array(12), tp=tp, conf=conf, pred_cls=pc, target_cls=tc, ap_tp=res[0], ap_fp=res[1], ap_p=res[2], ap_r=res[3], ap_f1=res[4], ap_ap=res[5],
+               ap_classes=res[6], mean_results=np.array(m.mean_results()), fitness=np.array(m.fitness()))
+    print(f"  reference validation metrics: {len(tp)} detections, {len(tc)} labels, mean results {np.round(m.mean_results(), 4)}, fitness {m.fitness():.5f}")
+    np.savez_compressed(OUT / "val_metrics.npz", **out)
+
+
 # ---- end-to-end models ------------------------------------------------------------------------------------------
 def tune_cls_bias(d, template, seed, x, target=0.02):
     """Pick the class-branch bias so that ~2 % of anchors clear conf=0.25 (the stock bias_init
@@ -736,6 +817,10 @@ if __name__ == "__main__":
         checkpoint_fixture(R)
     elif "--train-ops-only" in sys.argv:
         per_op_train(R)
+    elif "--nms-ml-only" in sys.argv:
+        nms_multilabel_cases(R)
+    elif "--val-metrics-only" in sys.argv:
+        val_metric_vectors(R)
     elif "--train-only" in sys.argv:
         train_vectors(R)
     elif "--loss-only" in sys.argv:
@@ -747,6 +832,8 @@ if __name__ == "__main__":
         per_op(R)
         per_op_train(R)
         nms_cases(R)
+        nms_multilabel_cases(R)
+        val_metric_vectors(R)
         e2e(R)
         loss_vectors(R)
         train_vectors(R)

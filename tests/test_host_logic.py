@@ -333,3 +333,30 @@ def test_lazy_head_seed_refuses_unconsumed_scales():
         with A.lazy_head_seed():
             A.LAZY_SEED[5678] = object()
     assert not A.LAZY_SEED and not A._LAZY[0]
+
+
+def test_validation_metrics_match_the_reference_functions():
+    """utils/metrics.py (the host half of the validation step: box_iou, match_predictions, ap_per_class, fitness) against the REAL
+    reference's functions on synthetic detections (tests/golden/val_metrics.npz, oracle/make_golden.py::val_metric_vectors):
+    the matching is an exact boolean matrix; AP / precision / recall to 1e-12 (same numpy arithmetic in the same order)."""
+    import numpy as np
+
+    from drone_yolo_amd.utils import metrics as M
+    from tests._util import golden
+
+    g = golden("val_metrics.npz")
+    iouv = np.linspace(0.5, 0.95, 10)
+    for i in range(int(g["n_img"])):
+        gtb, gtc, db, dc = g[f"img{i}_gtb"], g[f"img{i}_gtc"], g[f"img{i}_db"], g[f"img{i}_dc"]
+        iou = M.box_iou(gtb, db)
+        assert iou.shape == g[f"img{i}_iou"].shape and np.allclose(iou, g[f"img{i}_iou"], rtol=1e-6, atol=1e-7)
+        if len(gtc) and len(dc):
+            tp = M.match_predictions(dc, gtc, g[f"img{i}_iou"], iouv)
+            assert np.array_equal(tp, g[f"img{i}_tp"]), i
+    res = M.ap_per_class(g["tp"], g["conf"], g["pred_cls"], g["target_cls"])
+    for got, key in zip(res, ("ap_tp", "ap_fp", "ap_p", "ap_r", "ap_f1", "ap_ap", "ap_classes")):
+        assert np.allclose(got, g[key], rtol=0, atol=1e-12), key
+    m = M.DetMetrics()
+    m.process(g["tp"], g["conf"], g["pred_cls"], g["target_cls"])
+    assert np.allclose(m.mean_results(), g["mean_results"], atol=1e-12) and abs(m.fitness - float(g["fitness"])) < 1e-12
+    assert set(m.results_dict) == {"metrics/precision(B)", "metrics/recall(B)", "metrics/mAP50(B)", "metrics/mAP50-95(B)", "fitness"}

@@ -535,7 +535,7 @@ def _run_nms(pred, device, **kw):
         mask[classes] = 1
         mask = mask.to(device)
     b = H.nms(pred.to(device).contiguous(), kw.get("conf_thres", 0.25), kw.get("iou_thres", 0.45), max_det=kw.get("max_det", 300),
-              max_nms=kw.get("max_nms", 30000), agnostic=kw.get("agnostic", False), classes_mask=mask)
+              max_nms=kw.get("max_nms", 30000), agnostic=kw.get("agnostic", False), classes_mask=mask, multi_label=kw.get("multi_label", False))
     torch.cuda.synchronize()
     counts = b.count.cpu().tolist()
     return [b.out[i, :c].cpu() for i, c in enumerate(counts)], [b.index[i, :c].cpu() for i, c in enumerate(counts)], b
@@ -554,6 +554,44 @@ def test_nms_golden_cases_bit_exact(device):
         md = bufs.max_det
         for i, c in enumerate(bufs.count.cpu().tolist()):
             assert float(bufs.out[i, c:].abs().sum()) == 0 and (c == md or int(bufs.index[i, c]) == -1)
+
+
+def test_nms_multilabel_golden_cases_bit_exact(device):
+    """The validator's NMS (``multi_label=True``: one candidate per (anchor, class) pair above conf, utils/ops.py:286-288; call site
+    models/yolo/detect/val.py:93-106) against the rows the REAL reference's non_max_suppression returned (tests/golden/nms_ml.npz):
+    rows bit-exact, kept ANCHOR indices identical — conf 0.001 crowds, agnostic, class filter, max_det, more candidates than max_nms,
+    several labels on one anchor, and nc = 1 (where the reference switches multi_label off)."""
+    g = golden("nms_ml.npz")
+    names = sorted({k.split("__")[0] for k in g.files})
+    assert len(names) >= 8
+    for name in names:
+        pred = torch.from_numpy(g[f"{name}__pred"])
+        kw = ast.literal_eval(str(g[f"{name}__kw"]))
+        rows, idx, bufs = _run_nms(pred, device, **kw)
+        exp = split_rows(g[f"{name}__out"], g[f"{name}__n"])
+        assert [len(r) for r in rows] == [len(e) for e in exp], f"{name}: counts {[len(r) for r in rows]} vs {[len(e) for e in exp]}"
+        for r, e in zip(rows, exp):
+            assert np.array_equal(r.numpy(), e), f"{name}: kept rows differ"
+        assert np.array_equal(torch.cat(idx).numpy().astype(np.int64), g[f"{name}__idx"]), f"{name}: kept anchor indices differ"
+
+
+def test_nms_multilabel_random_matches_oracle(device):
+    """34,000 anchors x 10 classes at conf 0.001 (the validator's setting): ~300k (anchor, class) candidates per image through the
+    global-memory sort and the max_nms cut; rows and anchor indices bit-exact vs the oracle (continuous scores: no ties at the cut)."""
+    g = torch.Generator().manual_seed(99)
+    batch, n_anchors, nc = 2, 34000, 10
+    xy = torch.rand(batch, 2, n_anchors, generator=g) * 600 + 20
+    wh = torch.rand(batch, 2, n_anchors, generator=g) * 80 + 2
+    # DISTINCT scores (a permutation of k / N): among 340,000 candidates per image random floats tie, and the reference cuts to max_nms
+    # with an unstable argsort (ops.py:302), which leaves the order of ties — and with it the kept set — undefined
+    N = nc * n_anchors
+    sc = torch.stack([(torch.randperm(N, generator=g).float() + 0.5) / N for _ in range(batch)]).view(batch, nc, n_anchors)
+    pred = torch.cat((xy, wh, sc), 1).contiguous()
+    exp, exp_idx = O.non_max_suppression(pred, 0.001, 0.7, max_det=300, nc=nc, max_nms=30000, return_index=True, multi_label=True)
+    rows, idx, _ = _run_nms(pred, device, conf_thres=0.001, iou_thres=0.7, max_det=300, max_nms=30000, multi_label=True)
+    for i in range(batch):
+        assert torch.equal(idx[i].long(), exp_idx[i]), f"image {i}: kept anchor indices differ"
+        assert torch.equal(rows[i], exp[i]), f"image {i}: rows differ"
 
 
 @pytest.mark.parametrize("n_anchors,batch,conf", [(34000, 3, 0.25), (2100, 5, 0.05), (40, 7, 0.2), (34000, 2, 0.001)])
@@ -588,8 +626,10 @@ def test_nms_public_api_list_and_errors(device):
     assert all(np.array_equal(o.cpu().numpy(), e) for o, e in zip(out, exp))
     with pytest.raises(AssertionError):
         ops.non_max_suppression(pred, 1.5, 0.7)
+    ml = ops.non_max_suppression(pred, 0.25, 0.7, multi_label=True)  # the validator's form: at least the single-label detections' count
+    assert len(ml) == len(out) and all(len(a) >= len(b) or len(a) == 300 for a, b in zip(ml, out))
     with pytest.raises(NotImplementedError):
-        ops.non_max_suppression(pred, 0.25, 0.7, multi_label=True)
+        ops.non_max_suppression(pred, 0.25, 0.7, rotated=True)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.non_max_suppression(pred.cpu(), 0.25, 0.7)
 

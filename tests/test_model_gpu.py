@@ -333,12 +333,12 @@ def _fp8_launches(cf):
 @pytest.mark.parametrize("tag", ["s640bench", "x1536"])
 def test_config5_fp8_mixed_plan_meets_the_gate(tag, device):
     """BASELINE config 5 as a DEPLOYABLE precision ("match >= 0.90 and IoU min >= 0.98, not lowered to fit"):
-    ``dtype="fp8-mixed"`` = float16 storage with every layer that does not feed the P2 Detect level in e4m3 on the block-scaled MFMA
-    (BaseModel.fp8_plan_off_p2: layers 19..27 of the P2 YAMLs; Detect levels 1..3 read fp8 through their first convolutions, the
-    branch tails are float16) — the set the error budget allows: profiles/r04_fp8_sensitivity_*.jsonl shows ONE e4m3 rounding on the P2
+    ``dtype="fp8-mixed"`` = float16 storage with the INTERNALS of every C2f block that does not feed the P2 Detect level in e4m3 on
+    the block-scaled MFMA (BaseModel.fp8_plan_off_p2: layers 21, 24, 27 of the P2 YAMLs — cv1 16-bit -> fp8, Bottlenecks fp8, cv2
+    fp8 -> 16-bit; every layer boundary and skip connection stays float16) — the set the error budget allows: profiles/r04_fp8_sensitivity_*.jsonl shows ONE e4m3 rounding on the P2
     path flipping 7-15 % of the kept boxes of these synthetic-weight fixtures, the whole deep neck < 1 %.  Against the rows the REAL
     reference computed in fp32 (tests/golden/big.npz): >= 90 % of the detections reproduced (same anchor AND class), <= 10 % extra,
-    min IoU of the matched boxes >= 0.98; and the plan really runs fp8 (>= 20 convolution launches on e4m3 operands)."""
+    min IoU of the matched boxes >= 0.98; and the plan really runs fp8 (the blocks' Bottleneck and cv2 launches are on e4m3 operands)."""
     from drone_yolo_amd.utils import parity as PR
 
     meta, x, exp_rows, exp_idx = PR.golden_case("big.npz", tag)
@@ -351,7 +351,8 @@ def test_config5_fp8_mixed_plan_meets_the_gate(tag, device):
         n8, nconv = _fp8_launches(cf)
         _report(f"config5 fp8-mixed {tag}", {"dtype": "fp16 + e4m3 off the P2 path", "fp8_conv_launches": n8, "conv_launches": nconv, **par, **pred.fp8_calibration})
         assert bool(torch.isfinite(cf.pred).all())
-        assert pred.fp8_calibration["fp8_layers"] == list(range(19, 28)) and n8 >= 20, (pred.fp8_calibration, n8)
+        nb = sum(2 * len(model.model[i].m) + 1 for i in (21, 24, 27))
+        assert pred.fp8_calibration["fp8_layers"] == [21, 24, 27] and n8 == nb, (pred.fp8_calibration, n8, nb)
         assert par["match_rate"] >= 0.90 and par["extra_frac"] <= 0.10 and par["iou_min"] >= 0.98, par
         cf2 = pred.forward_device(pred.preprocess(x))  # the recorded plan replays to the same result
         torch.cuda.synchronize()

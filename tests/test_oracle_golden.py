@@ -77,6 +77,22 @@ def test_nms_vectors():
             assert np.array_equal(o.numpy(), e), name
 
 
+def test_nms_multilabel_vectors():
+    """The validator's NMS (multi_label=True, ops.py:286-288) restated by the oracle against the REAL reference's rows (nms_ml.npz)."""
+    g = golden("nms_ml.npz")
+    names = sorted({k.split("__")[0] for k in g.files})
+    assert len(names) >= 8
+    for name in names:
+        pred = torch.from_numpy(g[f"{name}__pred"])
+        kw = ast.literal_eval(str(g[f"{name}__kw"]))
+        out, idx = O.non_max_suppression(pred, return_index=True, **kw)
+        exp = split_rows(g[f"{name}__out"], g[f"{name}__n"])
+        assert [len(o) for o in out] == [len(e) for e in exp], name
+        for o, e in zip(out, exp):
+            assert np.array_equal(o.numpy(), e), name
+        assert np.array_equal(np.concatenate([t.numpy() for t in idx]) if len(idx) else np.zeros(0), g[f"{name}__idx"]), name
+
+
 def test_nms_greedy_properties():
     """Brute-force properties of greedy NMS (the boundary the reference's own tests do not pin):
     kept boxes are pairwise IoU <= thr within a class; every dropped box overlaps an earlier kept one."""

@@ -650,10 +650,14 @@ def test_yolo_train_api_end_to_end(device, tmp_path):
     rows = list(csv.DictReader(open(tmp_path / "t" / "results.csv")))
     assert [r["epoch"] for r in rows] == ["1", "2"]
     assert {"time", "train/box_loss", "train/cls_loss", "train/dfl_loss", "lr/pg0", "lr/pg1", "lr/pg2"} <= set(rows[0])
+    # r04: validation inside the loop (trainer.py:427-442): the EMA weights through the validator's NMS every epoch -> metrics + best.pt
+    assert {"metrics/precision(B)", "metrics/recall(B)", "metrics/mAP50(B)", "metrics/mAP50-95(B)", "val/box_loss", "val/cls_loss", "val/dfl_loss"} <= set(rows[0])
+    assert all(float(r["val/cls_loss"]) > 0 for r in rows) and (tmp_path / "t" / "weights" / "best.pt").exists()
     assert all(float(r["train/cls_loss"]) > 0 for r in rows) and "train/box_loss" in out  # (2-pixel synthetic boxes at 64x64 rarely get a foreground anchor)
     ck = torch.load(tmp_path / "t" / "weights" / "last.pt", map_location="cpu", weights_only=False, pickle_module=__import__("drone_yolo_amd").nn.checkpoint._pickle_module())
     assert {"epoch", "best_fitness", "model", "ema", "updates", "optimizer", "train_args", "train_metrics", "train_results", "date", "version"} <= set(ck)
     assert ck["epoch"] == 1 and ck["model"] is None and ck["updates"] == 4 and len(ck["optimizer"]["param_groups"]) == 3
+    assert ck["best_fitness"] is not None and "fitness" in ck["train_metrics"] and "metrics/mAP50-95(B)" in ck["train_metrics"]
     assert next(ck["ema"].parameters()).dtype == torch.float16
     assert not torch.equal(yolo.model.model[0].conv.weight.detach().cpu(), w0.cpu())  # the live model trained
     # after train() the live model carries the EMA weights — what last.pt holds (fp16 there) and what the reference
@@ -1011,3 +1015,38 @@ def test_modules_in_train_mode_match_the_reference_modules(dtype, device):
     with pytest.raises(NotImplementedError):  # launch options of the eval path have no training form
         m = build("conv", M.Conv(16, 32, 3, 2))
         m(nhwc(quantize(t("conv_x"), dtype), dtype, device), residual=torch.zeros(1, device=device))
+
+
+def test_validator_scores_a_model_against_its_own_detections(device):
+    """engine/validator.py end to end on the device (model pass in eval mode, ``dy_nms`` with multi_label at conf 0.001, matching + AP on
+    the host): labels built from the model's OWN fp32 detections at conf 0.25 must come back as (nearly) perfect mAP50 — the labelled
+    boxes are exactly the model's highest-scored outputs, so every one is matched at IoU ~ 1 by a detection that outranks the clutter —
+    and shifting every label by half a box must collapse it.  Also: the validation loss equals the training criterion on the same maps."""
+    import drone_yolo_amd as D
+    from drone_yolo_amd.engine.trainer import TensorLoader
+    from drone_yolo_amd.engine.validator import DetectionValidator
+    from drone_yolo_amd.utils.parity import seeded_state_dict
+
+    model = D.DetectionModel("yolov8n-p2-repvgg.yaml", nc=10, verbose=False)
+    model.load_state_dict(seeded_state_dict(model.state_dict(), 5, cls_bias=-1.2))
+    model = model.to(device).eval()
+    n, s = 6, 128
+    img = torch.randint(0, 256, (n, 3, s, s), generator=torch.Generator().manual_seed(3), dtype=torch.uint8)
+    pred = D.engine.predictor.DetectionPredictor(model, dict(conf=0.25, iou=0.7, max_det=40, dtype="fp32", device=0))
+    res = pred(img.float() / 255.0)
+    bi, cls, bb = [], [], []
+    for i, r in enumerate(res):
+        b = r.boxes.data.cpu()
+        bi.append(torch.full((len(b),), float(i))), cls.append(b[:, 5:6])
+        xyxy = b[:, :4]
+        bb.append(torch.stack(((xyxy[:, 0] + xyxy[:, 2]) / 2 / s, (xyxy[:, 1] + xyxy[:, 3]) / 2 / s, (xyxy[:, 2] - xyxy[:, 0]) / s, (xyxy[:, 3] - xyxy[:, 1]) / s), 1))
+    data = dict(img=img, batch_idx=torch.cat(bi), cls=torch.cat(cls), bboxes=torch.cat(bb))
+    assert len(data["cls"]) >= 10
+    val = DetectionValidator(dict(iou=0.7, max_det=300))
+    out = val(model, TensorLoader(data, 4, 0, 1, shuffle=False), torch.device(device), torch.float32)
+    assert out["metrics/mAP50(B)"] >= 0.95 and out["metrics/mAP50-95(B)"] >= 0.9 and out["metrics/recall(B)"] >= 0.9, out
+    assert abs(out["fitness"] - (0.1 * out["metrics/mAP50(B)"] + 0.9 * out["metrics/mAP50-95(B)"])) < 1e-4
+    assert out["val/box_loss"] > 0 and out["val/cls_loss"] > 0 and out["val/dfl_loss"] > 0
+    moved = dict(data, bboxes=data["bboxes"] + torch.tensor([0.5, 0.5, 0.0, 0.0]) * data["bboxes"][:, 2:].repeat(1, 2))
+    out2 = DetectionValidator(dict(iou=0.7, max_det=300))(model, TensorLoader(moved, 4, 0, 1, shuffle=False), torch.device(device), torch.float32)
+    assert out2["metrics/mAP50-95(B)"] < 0.3 * out["metrics/mAP50-95(B)"], (out, out2)
