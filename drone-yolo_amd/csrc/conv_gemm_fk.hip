@@ -75,7 +75,11 @@ __device__ __forceinline__ void fk_store4(unsigned char* sp, const float (&v)[4]
   }
 }
 
-template <typename T, typename OT, int MFR, int NFR, int WM, int WN>
+// RES: the call has a residual (Bottleneck shortcut, block.py:348-350).  The first form read it per MFMA result lane — 8 (4) bytes of a
+// lane's own pixel row, one L1 request per lane — and ran the residual layers 15-20 % slower than the plain ones.  With RES the
+// transposing scratch holds fp32, and the store phase, where a lane owns a 16-byte chunk of a pixel row, loads the residual as the same
+// coalesced 16-byte chunk, adds in fp32 and rounds ONCE — the arithmetic of the reference expression x + cv2(cv1(x)).
+template <typename T, typename OT, int MFR, int NFR, int WM, int WN, bool RES = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs p) {
   constexpr bool MX = FkIsFp8<T>::v;
   constexpr int EPC = Elem<T>::EPC;
@@ -88,7 +92,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
   constexpr int PB = (PBT + NW - 1) / NW;          // ... per wave (the last ones may not exist: wave-uniform skip)
   static_assert(PA >= 1 && BM % (8 * NW) == 0, "every wave stages whole A pieces");
   constexpr int OES = (int)sizeof(OT);
-  constexpr int EP_PITCH = NFR * 16 * OES + 16;    // one pixel row of the wave tile + a 16-byte skew
+  static_assert(!RES || std::is_same<T, OT>::value, "the residual has the input's type; built for same-type outputs");
+  constexpr int SES = RES ? 4 : OES;               // scratch element: the output type, or fp32 in front of a residual add
+  constexpr int EP_PITCH = NFR * 16 * SES + 16;    // one pixel row of the wave tile + a 16-byte skew
   constexpr int CPP = NFR * OES;                   // 16-byte chunks per pixel row of the wave tile
   constexpr int NH = (MFR * 16 * EP_PITCH * NW <= 2 * STAGE) ? 1 : ((MFR * 8 * EP_PITCH * NW <= 2 * STAGE) ? 2 : 4);  // epilogue passes per wave tile
   constexpr int PXP = MFR * 16 / NH;               // pixels per wave and pass
@@ -296,29 +302,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
         }
-        if (rg != nullptr) {
-          const int m = m0 + ii * 16 + lr;
-          if (m < p.M && co < p.Cout) {
-            const T* rp = rg + (size_t)m * (size_t)p.ldres + (size_t)co;
-            if constexpr (MX) {
-              const int rv = *reinterpret_cast<const int*>(rp);  // four e4m3 quanta
-              v[0] += __builtin_amdgcn_cvt_f32_fp8(rv, 0) * p.res_scale;
-              v[1] += __builtin_amdgcn_cvt_f32_fp8(rv, 1) * p.res_scale;
-              v[2] += __builtin_amdgcn_cvt_f32_fp8(rv, 2) * p.res_scale;
-              v[3] += __builtin_amdgcn_cvt_f32_fp8(rv, 3) * p.res_scale;
-            } else {
-              typedef __attribute__((ext_vector_type(4))) T t4;
-              const t4 rv = *reinterpret_cast<const t4*>(rp);
+        if constexpr (RES) {
+          *reinterpret_cast<f32x4*>(escr + (ii * 16 + lr) * EP_PITCH + (j * 16 + lq * 4) * 4) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+          if constexpr (FkIsFp8<OT>::v) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += Elem<T>::to_f32(rv[e]);
-            }
+            for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
           }
+          fk_store4<OT>(escr + (ii * 16 + lr) * EP_PITCH + (j * 16 + lq * 4) * OES, v);
         }
-        if constexpr (FkIsFp8<OT>::v) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
-        }
-        fk_store4<OT>(escr + (ii * 16 + lr) * EP_PITCH + (j * 16 + lq * 4) * OES, v);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -330,7 +322,21 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
       const int px = idx / CPP, cc = idx - px * CPP;
       const int m = m0 + px;
       if (px < PXP && m < p.M && n0 + cc * OEPC < p.Cout) {
-        const u32x4 val = *reinterpret_cast<const u32x4*>(escr + px * EP_PITCH + cc * 16);
+        u32x4 val;
+        if constexpr (RES) {
+          float f[OEPC], r[OEPC];
+#pragma unroll
+          for (int e = 0; e < OEPC; e += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(escr + px * EP_PITCH + (cc * OEPC + e) * 4);
+            f[e] = t[0], f[e + 1] = t[1], f[e + 2] = t[2], f[e + 3] = t[3];
+          }
+          Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(rg + (size_t)m * (size_t)p.ldres + (size_t)(n0 + cc * OEPC)), r);
+#pragma unroll
+          for (int e = 0; e < OEPC; ++e) f[e] = (f[e] + r[e] * p.res_scale) * p.out_scale;
+          val = Chunk<OT>::pack(f);
+        } else {
+          val = *reinterpret_cast<const u32x4*>(escr + px * EP_PITCH + cc * 16);
+        }
         *reinterpret_cast<u32x4*>(yg + (size_t)m * (size_t)p.ldy + (size_t)(n0 + cc * OEPC)) = val;
       }
     }
@@ -349,6 +355,12 @@ static int launch_fk(const FkArgs& a, hipStream_t st, const char* name) {
   const int tilesM = (p.M + BM - 1) / BM;
   p.tilesN = (p.Cout + BN - 1) / BN;
   p.nblk = tilesM * p.tilesN;
+  if constexpr (std::is_same<T, OT>::value) {
+    if (p.res != nullptr) {
+      hipLaunchKernelGGL((conv_gemm_fk_kernel<T, OT, MFR, NFR, WM, WN, true>), dim3((unsigned)p.nblk), dim3(WM * WN * 64), 0, st, p);
+      return check_launch(name);
+    }
+  }
   hipLaunchKernelGGL((conv_gemm_fk_kernel<T, OT, MFR, NFR, WM, WN>), dim3((unsigned)p.nblk), dim3(WM * WN * 64), 0, st, p);
   return check_launch(name);
 }
@@ -392,7 +404,7 @@ int conv_gemm_fk_try(const dy_conv_desc* d, hipStream_t st) {
   if (d->up2x > 1 || (d->up2x && d->stride != 1)) return 1;
   if (d->x2 && (d->cin_split % bke || d->cin_split <= 0 || d->cin_split >= d->cin)) return 1;
   if (!aligned16(d->y) || (d->ld_y * oes) % 16 || (d->ld_x * es) % 16 || !aligned16(d->x)) return 1;
-  if (d->residual && ((d->ld_res * es) % 4 || (reinterpret_cast<uintptr_t>(d->residual) & 3))) return 1;
+  if (d->residual && ((d->ld_res * es) % 16 || !aligned16(d->residual) || ydt != d->dtype)) return 1;
   const int hb = d->up2x ? d->h / 2 : d->h, wb = d->up2x ? d->w_in / 2 : d->w_in;
   const long long lim = (1ll << 32) - (1ll << 24);
   const long long xb = (long long)d->batch * hb * wb * d->ld_x * es, x2b = d->x2 ? (long long)d->batch * d->h * d->w_in * d->ld_x2 * es : 0;

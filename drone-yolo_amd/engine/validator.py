@@ -59,6 +59,11 @@ class DetectionValidator:
                 bb = batch["bboxes"][sel].float()
                 tbox = (ops.xywh2xyxy(bb) * torch.tensor((w, h, w, h), dtype=torch.float32)).numpy() if len(cls) else np.zeros((0, 4), np.float32)
                 pn = pred.cpu().numpy()
+                # _prepare_batch / _prepare_pred (detect/val.py:108-124): labels and predictions go through ops.scale_boxes to the original
+                # image — for a tensor dataset that is gain 1, pad 0 and the clip to the image (ops.py:92-127, 335-354)
+                for arr in (pn, tbox):
+                    arr[:, [0, 2]] = arr[:, [0, 2]].clip(0, w)
+                    arr[:, [1, 3]] = arr[:, [1, 3]].clip(0, h)
                 if self.single_cls:
                     pn[:, 5] = 0
                 tp = np.zeros((len(pn), len(self.iouv)), dtype=bool)

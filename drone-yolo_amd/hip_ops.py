@@ -1195,10 +1195,14 @@ def conv_grouped_bwd(x: torch.Tensor, dz: torch.Tensor, weight: torch.Tensor, st
     return dw, dx
 
 
-def colsum(z: torch.Tensor) -> torch.Tensor:
-    """Per-channel sum over (N, H, W) of an NHWC view: the bias gradient of a plain convolution."""
+def colsum(z: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Per-channel sum over (N, H, W) of an NHWC view: the bias gradient of a plain convolution.  ``out``: a contiguous fp32 (c,) tensor
+    the sums are ADDED to (a trainer's gradient sink) instead of a fresh zeroed one."""
     zp, ld = view_params(z)
-    out = torch.zeros(z.shape[1], dtype=torch.float32, device=z.device)
+    if out is None:
+        out = torch.zeros(z.shape[1], dtype=torch.float32, device=z.device)
+    elif out.dtype != torch.float32 or out.numel() != z.shape[1] or not out.is_contiguous():
+        raise ValueError("colsum: out must be a contiguous fp32 (c,) tensor")
     _launch(lib().dy_colsum, (zp, out.data_ptr(), _rows(z), z.shape[1], ld, dy_dtype(z.dtype)), keep=(z, out))
     return out
 

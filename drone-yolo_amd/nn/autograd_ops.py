@@ -318,12 +318,14 @@ class HeadTail(torch.autograd.Function):
         H.conv2d(xb, H.PackedConv(wb, bb, 1, 0, 1, False, dtype, dev, for_out_f32=True), out=buf[:, :nb], out_f32=True)
         H.conv2d(xc, H.PackedConv(wc, bc, 1, 0, 1, False, dtype, dev, for_out_f32=True), out=buf[:, nb : nb + nc], out_f32=True)
         ctx.save_for_backward(xb, xc, wb, wc)
+        ctx.biases = (bb, bc)  # (only their gradient-sink slots are looked up in backward)
         ctx.dims = (nb, nc, ncp)
         return buf[:, : nb + nc]
 
-    @staticmethod
+    @_commits_sink
     def backward(ctx, dy):
         xb, xc, wb, wc = ctx.saved_tensors
+        bb, bc = ctx.biases
         nb, nc, ncp = ctx.dims
         dtype, dev = xb.dtype, xb.device
         n, _, h, w = xb.shape
@@ -331,9 +333,13 @@ class HeadTail(torch.autograd.Function):
         # of the backward pass (LAZY_SEED below), read on the device
         seed = LAZY_SEED.pop(dy.data_ptr(), None)  # by the address DetectionLossFn.backward handed over, before any re-layout
         dzb, dzc = H.head_grad_split(dy if dy.stride(1) == 1 else as_nhwc(dy), nb, nc, ncp, dtype, scale=seed)
-        dwb = H.conv_wgrad(xb, dzb, 1, 1, 0)
-        dwc = H.conv_wgrad(xc, dzc[:, :nc], 1, 1, 0)
-        dbb, dbc = H.colsum(dzb), H.colsum(dzc[:, :nc])
+        # r04: the 16 Detect-tail parameters go through the trainer's gradient sink like every other parameter (they were the last
+        # gradients handed back to autograd: AccumulateGrad nodes created in an eager step and met again under capture on another stream)
+        swb, sbb, swc, sbc = grad_sink(wb), grad_sink(bb), grad_sink(wc), grad_sink(bc)
+        dwb = H.conv_wgrad(xb, dzb, 1, 1, 0, out=None if swb is None else swb.view(nb, 1, 1, wb.shape[1]))
+        dwc = H.conv_wgrad(xc, dzc[:, :nc], 1, 1, 0, out=None if swc is None else swc.view(nc, 1, 1, wc.shape[1]))
+        dbb, dbc = H.colsum(dzb, out=sbb), H.colsum(dzc[:, :nc], out=sbc)
+        dwb, dwc, dbb, dbc = (None if swb is not None else dwb), (None if swc is not None else dwc), (None if sbb is not None else dbb), (None if sbc is not None else dbc)
         dxb = H.conv_dgrad(dzb, H.pack_dgrad(wb, 1, dtype, dev), 1)
         wcp = torch.zeros((ncp, wc.shape[1], 1, 1), device=dev, dtype=wc.dtype)
         wcp[:nc] = wc.detach()
