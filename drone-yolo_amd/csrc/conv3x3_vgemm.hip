@@ -15,8 +15,14 @@
 // MACs: 2.6x fewer DMA bytes per flop than the per-tap gather.
 //
 // Workgroup = 512 threads = 8 waves as 4 (M) x 2 (N); wave tile 64 pixels x 64 couts, weights as the MFMA A operand.
-// LDS: 2 halo stages x 48 KiB (384 slots: maps up to 62 wide; 56 KiB / 448 slots up to 94 wide), swizzled as in
-// conv_gemm_glds.hip, + 3 weight stages x 16 KiB = 144 / 160 KiB.
+// LDS: 2 halo stages x 48 KiB (384 slots: maps up to 62 wide; 56 KiB / 448 slots up to 94 wide) + 3 weight stages x 16 KiB = 144 /
+// 160 KiB.  Weight rows are swizzled as in conv_gemm_glds.hip (chunk ^ ((row >> 1) & 7): fragment bases are multiples of 16).  The
+// HALO is read at nine different shifts, so its swizzle has to be conflict-free at EVERY fragment base: chunk ^ (slot & 6) (r04).
+// A ds_read_b128 is served in groups of 16 lanes — rows lr in {0..3, 12..15} of lane quarter q and lr in {4..11} of quarter q ^ 1 —
+// and a row's bank half is slot & 1, so the 8 same-parity rows of a group must land on 8 different chunks: slot & 6 gives the 4
+// rows two apart 4 different values, and the rows EIGHT apart, which share it, always sit in different quarters (bit 0 of the chunk
+// differs).  With (slot >> 1) & 7, right for aligned bases only, every shifted read took 8 LDS cycles instead of 4
+// (SQ_LDS_BANK_CONFLICT = 23 % of the LDS cycles, profiles/r03_pmc_vgemm16_128x128_3x3_40.txt).
 // One continuous software pipeline across K-steps AND tiles (persistent grid): weights run two steps ahead, the halo one
 // chunk ahead, behind counted s_waitcnt vmcnt(N) and raw s_barriers; the only bubble is the epilogue.
 #include "common_hip.h"
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(512) void conv3x3_vgemm_kernel(const ConvArgs p, co
     for (int i = 0; i < PA; ++i) {
       const int s = (i * NW + wave) * 8 + prow;
       const int px = s < g.S ? real_px(vstart + s) : -1;
-      a_off[i] = px < 0 ? -1 : px * p.ldx + (((lane & 7) ^ ((s >> 1) & 7))) * EPC;
+      a_off[i] = px < 0 ? -1 : px * p.ldx + ((lane & 7) ^ (s & 6)) * EPC;  // halo swizzle: see the header (r04)
     }
   };
   auto issue_a = [&](int stage) {
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(512) void conv3x3_vgemm_kernel(const ConvArgs p, co
   u32x4 an[2][4];
   auto load_a = [&](int astage, int tapoff, u32x4 (&dst)[2][4]) {
     const int s = sl0 + tapoff;
-    const int swzA = (s >> 1) & 7;
+    const int swzA = s & 6;
     const unsigned char* sa = smA + astage * A_BYTES + s * 128;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(1024) void conv3x3_vgemm16_kernel(const ConvArgs p,
     for (int i = 0; i < PA; ++i) {
       const int s = (i * NW + wave) * 8 + prow;
       const int px = s < g.S ? real_px(vstart + s) : -1;
-      a_off[i] = px < 0 ? -1 : px * p.ldx + (((lane & 7) ^ ((s >> 1) & 7))) * EPC;
+      a_off[i] = px < 0 ? -1 : px * p.ldx + ((lane & 7) ^ (s & 6)) * EPC;  // halo swizzle: see the header (r04)
     }
   };
   auto issue_a = [&](int stage) {
@@ -440,7 +446,7 @@ __global__ __launch_bounds__(1024) void conv3x3_vgemm16_kernel(const ConvArgs p,
   const int sl0 = wm * 32 + lr;
   auto compute = [&](int astage, int tapoff, int bstage, int, int) {
     const int s = sl0 + tapoff;
-    const int swzA = (s >> 1) & 7, swzB = lr >> 1;
+    const int swzA = s & 6, swzB = lr >> 1;
     const unsigned char* sa = smA + astage * A_BYTES + s * 128;
     const unsigned char* sb = smB + bstage * B_BYTES + (wn * 64 + lr) * 128;
 #pragma unroll

@@ -52,6 +52,8 @@ struct FkArgs {
   unsigned xb, x2b, wb;  // bytes addressable from x / x2 / w (buffer descriptor ranges)
   float res_scale;        // fp8 residual: real value of one quantum (act_scale); 1 otherwise
   float out_scale;        // fp8 output: 1 / act_scale; 1 otherwise
+  FastDiv dCin;           // exact division by Cin (tap table)
+  int dbg;                // ablate build only (DYOLO_FK_DBG): 1 no MFMAs, 2 no LDS-DMA after the first step, 3 no LDS fragment reads, 4 no epilogue stores
 };
 
 template <typename T> struct FkIsFp8 { static constexpr bool v = std::is_same<T, fp8_t>::value; };
@@ -79,7 +81,14 @@ __device__ __forceinline__ void fk_store4(unsigned char* sp, const float (&v)[4]
 // lane's own pixel row, one L1 request per lane — and ran the residual layers 15-20 % slower than the plain ones.  With RES the
 // transposing scratch holds fp32, and the store phase, where a lane owns a 16-byte chunk of a pixel row, loads the residual as the same
 // coalesced 16-byte chunk, adds in fp32 and rounds ONCE — the arithmetic of the reference expression x + cv2(cv1(x)).
-template <typename T, typename OT, int MFR, int NFR, int WM, int WN, bool RES = false>
+// TABN: entries of the tap table (3x3 only).  The first version kept a per-lane (channel, kernel row, kernel column) state and advanced
+// it every K-step with adds, compares and selects: ~36 vector instructions per step for the two states, ~11 more per staged piece for
+// the padding test — the loop issued ~110 vector instructions beside 40 MFMAs and was bound by exactly that (the kernel did not care
+// about tile shapes or wave counts, and the ablate build, which adds a dozen instructions, ran at HALF the speed).  Now the
+// workgroup writes, once, one word per 16-byte K chunk into LDS — (byte offset of the chunk's tap and channel) << 4 | tap, tap 9 for
+// the zero-padded K tail —, every staged row carries a 9-bit mask of the taps that fall inside the image, and a piece's source
+// offset is (row base + table offset) | (mask bit - 1): an out-of-range offset wherever the tap is padding.
+template <typename T, typename OT, int MFR, int NFR, int WM, int WN, bool RES = false, int TABN = 768>
 __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs p) {
   constexpr bool MX = FkIsFp8<T>::v;
   constexpr int EPC = Elem<T>::EPC;
@@ -101,7 +110,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
   constexpr int MPP = MFR / NH;                    // pixel fragments per pass
   static_assert(MFR % NH == 0 && PXP * EP_PITCH * NW <= 2 * STAGE, "epilogue scratch must fit the stage memory");
 
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + TABN * 4];
+  unsigned* const tab = reinterpret_cast<unsigned*>(smem + 2 * STAGE);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -120,7 +130,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
 
   // ---- per-lane gather bookkeeping (constant over the K loop) ----
   const int prow = lane >> 3;
-  int a_hi0[PA], a_wi0[PA];
+  const int nsteps = p.Kpad / BKE;
+  bool a_ok[PA];
+  unsigned a_mask[PA];  // 3x3: bit t = tap t of this row reads inside the image
   unsigned av1[PA], av2[PA];
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
@@ -133,8 +145,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
     const int ho = rem / p.Wo;
     const int wo = rem - ho * p.Wo;
     const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-    a_hi0[i] = ok ? hi0 : -(1 << 28);  // never valid
-    a_wi0[i] = wi0;
+    a_ok[i] = ok;
+    // tap (r, q) is inside the image iff row hi0 + r and column wi0 + q are: three row bits x three column bits
+    unsigned rm = 0, cm = 0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      rm |= ((unsigned)(hi0 + t) < (unsigned)p.H) ? (1u << t) : 0u;
+      cm |= ((unsigned)(wi0 + t) < (unsigned)p.W) ? (1u << t) : 0u;
+    }
+    a_mask[i] = ok ? (((rm & 1u) ? cm : 0u) | ((rm & 2u) ? cm << 3 : 0u) | ((rm & 4u) ? cm << 6 : 0u)) : 0u;
     const int hb = p.up2x ? (hi0 >> 1) : hi0, wb_ = p.up2x ? (wi0 >> 1) : wi0;
     av1[i] = (unsigned)(((n * p.HB + hb) * p.WB + wb_) * p.ldx) * ES + pre1;
     av2[i] = (unsigned)(((n * p.H + hi0) * p.W + wi0) * p.ldx2) * ES + pre2;
@@ -147,15 +166,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
   }
   // chunk column of this lane in an even / odd piece: (lane & 7) ^ ((row >> 1) & 7), row = 8 piece + prow  ->  bit 2 = piece parity
   const int cc0 = (lane & 7) ^ (prow >> 1), cc1 = cc0 ^ 4;
-  // flat-K state of the NEXT step to issue, per parity: channel offset c inside tap (kr, kq)
-  int sc[2], skr[2], skq[2];
-#pragma unroll
-  for (int v = 0; v < 2; ++v) {
-    const int k0 = (v ? cc1 : cc0) * EPC;
-    const int tap = k0 / p.Cin;
-    sc[v] = k0 - tap * p.Cin;
-    skr[v] = tap / p.ks;
-    skq[v] = tap - skr[v] * p.ks;
+  unsigned ent[2] = {0u, 0u};  // table words of the NEXT step to issue, for the even / odd pieces
+  if (p.ks != 1) {
+    const int nf = nsteps * 8;
+    for (int f = tid; f < nf; f += NW * 64) {
+      const unsigned k = (unsigned)f * EPC;
+      const unsigned tap = fastdiv(k, p.dCin);
+      const unsigned c = k - tap * (unsigned)p.Cin;
+      const unsigned kr = (tap * 11u) >> 5, kq = tap - 3u * kr;
+      tab[f] = tap < 9u ? (((kr * (unsigned)p.W + kq) * (unsigned)p.ldx + c) * ES) << 4 | tap : 9u;
+    }
+    __syncthreads();
+    ent[0] = tab[cc0];
+    ent[1] = tab[cc1];
   }
   int kstep = 0;
 
@@ -172,7 +195,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
         const unsigned o = ((wave * PA + i) & 1) ? oo : oe;
-        const bool ok = a_hi0[i] >= 0 && o != kOob;
+        const bool ok = a_ok[i] && o != kOob;
         const unsigned off = ok ? (from_x ? av1[i] : av2[i]) + o : kOob;
         if (from_x)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(sa + (wave * PA + i) * 1024), 16, (int)off, 0, 0, 0);
@@ -180,33 +203,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
           __builtin_amdgcn_raw_ptr_buffer_load_lds(x2rs, (__attribute__((address_space(3))) void*)(sa + (wave * PA + i) * 1024), 16, (int)off, 0, 0, 0);
       }
     } else {
-      unsigned toff[2];
-      bool tok[2];
-#pragma unroll
-      for (int v = 0; v < 2; ++v) {
-        toff[v] = (unsigned)((skr[v] * p.W + skq[v]) * p.ldx + sc[v]) * ES;
-        tok[v] = skr[v] < p.ks;  // beyond the last tap: the zero-padded K tail
-      }
+      const unsigned toff[2] = {ent[0] >> 4, ent[1] >> 4}, tp[2] = {ent[0] & 15u, ent[1] & 15u};
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
         const int v = (wave * PA + i) & 1;
-        const bool ok = tok[v] && ((unsigned)(a_hi0[i] + skr[v]) < (unsigned)p.H) && ((unsigned)(a_wi0[i] + skq[v]) < (unsigned)p.W);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(sa + (wave * PA + i) * 1024), 16, (int)(ok ? av1[i] + toff[v] : kOob), 0, 0, 0);
+        const unsigned bit = __builtin_amdgcn_ubfe(a_mask[i], tp[v], 1u);
+        const unsigned off = (av1[i] + toff[v]) | (bit - 1u);  // padding / K tail: 0xffffffff, past the descriptor's range -> zeros
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(sa + (wave * PA + i) * 1024), 16, (int)off, 0, 0, 0);
       }
-      // advance both states by one K-step (Cin >= BKE / 2: at most two wrap-arounds)
-#pragma unroll
-      for (int v = 0; v < 2; ++v) {
-        sc[v] += BKE;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const bool wrap = sc[v] >= p.Cin;
-          sc[v] -= wrap ? p.Cin : 0;
-          skq[v] += wrap ? 1 : 0;
-          const bool wq = skq[v] >= p.ks;
-          skq[v] = wq ? 0 : skq[v];
-          skr[v] += wq ? 1 : 0;
-        }
-      }
+      const int nx = kstep + 1 < nsteps ? kstep + 1 : kstep;  // (the last prefetch is not used)
+      ent[0] = tab[nx * 8 + cc0];
+      ent[1] = tab[nx * 8 + cc1];
     }
     const unsigned soffw = (unsigned)(kstep * BKE) * ES;
 #pragma unroll
@@ -227,6 +234,25 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
   auto compute = [&](int stage) {
     const unsigned char* sa = smem + stage * STAGE + (wm * MFR * 16 + lr) * 128;
     const unsigned char* sb = smem + stage * STAGE + A_BYTES + (wn * NFR * 16 + lr) * 128;
+#ifdef DYOLO_ABLATE
+    if (p.dbg == 3) {  // no fragment reads: MFMAs on whatever the registers hold
+      sa = smem + (lr & 1) * 128;
+      sb = smem + (lr & 1) * 128 + 512;
+    }
+    if (p.dbg == 1) {  // no MFMAs: the reads only (kept alive through the accumulator)
+#pragma unroll
+      for (int j = 0; j < NFR; ++j) {
+        const u32x4 t = *reinterpret_cast<const u32x4*>(sb + j * 16 * 128 + ((lq ^ swz) * 16)), u = *reinterpret_cast<const u32x4*>(sb + j * 16 * 128 + (((4 + lq) ^ swz) * 16));
+        acc[j][0][0] += __uint_as_float(t[0] ^ u[1]);
+      }
+#pragma unroll
+      for (int i = 0; i < MFR; ++i) {
+        const u32x4 t = *reinterpret_cast<const u32x4*>(sa + i * 16 * 128 + ((lq ^ swz) * 16)), u = *reinterpret_cast<const u32x4*>(sa + i * 16 * 128 + (((4 + lq) ^ swz) * 16));
+        acc[0][i][1] += __uint_as_float(t[2] ^ u[3]);
+      }
+      return;
+    }
+#endif
     if constexpr (MX) {
       const int s0 = ((0 + lq) ^ swz) * 16, s1 = ((4 + lq) ^ swz) * 16;
       i32x8 a[MFR], b[NFR];
@@ -266,12 +292,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
   };
 
   // ---- main loop: one barrier per K-step, the next step's DMA runs under this step's MFMAs ----
-  const int nsteps = p.Kpad / BKE;
   issue(0);
   for (int s = 0; s < nsteps; ++s) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of step s has landed
     __syncthreads();                                   // publishes stage s & 1; everyone is done with the other one
+#ifdef DYOLO_ABLATE
+    if (s + 1 < nsteps && p.dbg != 2) issue((s + 1) & 1);
+#else
     if (s + 1 < nsteps) issue((s + 1) & 1);
+#endif
     compute(s & 1);
   }
   __syncthreads();  // stage memory becomes the per-wave transpose scratch
@@ -337,6 +366,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
         } else {
           val = *reinterpret_cast<const u32x4*>(escr + px * EP_PITCH + cc * 16);
         }
+#ifdef DYOLO_ABLATE
+        if (p.dbg == 4 && val[0] != 0x7fc07fc1u) continue;
+#endif
         *reinterpret_cast<u32x4*>(yg + (size_t)m * (size_t)p.ldy + (size_t)(n0 + cc * OEPC)) = val;
       }
     }
@@ -348,7 +380,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
   }
 }
 
-template <typename T, typename OT, int MFR, int NFR, int WM, int WN>
+template <typename T, typename OT, int MFR, int NFR, int WM, int WN, int TABN>
 static int launch_fk(const FkArgs& a, hipStream_t st, const char* name) {
   FkArgs p = a;
   constexpr int BM = WM * MFR * 16, BN = WN * NFR * 16;
@@ -357,11 +389,11 @@ static int launch_fk(const FkArgs& a, hipStream_t st, const char* name) {
   p.nblk = tilesM * p.tilesN;
   if constexpr (std::is_same<T, OT>::value) {
     if (p.res != nullptr) {
-      hipLaunchKernelGGL((conv_gemm_fk_kernel<T, OT, MFR, NFR, WM, WN, true>), dim3((unsigned)p.nblk), dim3(WM * WN * 64), 0, st, p);
+      hipLaunchKernelGGL((conv_gemm_fk_kernel<T, OT, MFR, NFR, WM, WN, true, TABN>), dim3((unsigned)p.nblk), dim3(WM * WN * 64), 0, st, p);
       return check_launch(name);
     }
   }
-  hipLaunchKernelGGL((conv_gemm_fk_kernel<T, OT, MFR, NFR, WM, WN>), dim3((unsigned)p.nblk), dim3(WM * WN * 64), 0, st, p);
+  hipLaunchKernelGGL((conv_gemm_fk_kernel<T, OT, MFR, NFR, WM, WN, false, TABN>), dim3((unsigned)p.nblk), dim3(WM * WN * 64), 0, st, p);
   return check_launch(name);
 }
 
@@ -369,6 +401,9 @@ static int launch_fk(const FkArgs& a, hipStream_t st, const char* name) {
 // (tools/fk_ab.sh, r04): 256-pixel tiles — 256 x 160 as sixteen waves of 32 x 80 (LDS-read bound in fp8: 14 ds_read_b128 per 10 MFMAs)
 // 3-12 % slower, 256 x 320 as sixteen waves of 64 x 80 (128-register cap: spills) 2x slower; two 128-pixel workgroups per CU that
 // cover for each other's barriers beat one big one; eight waves of 32 x 80 on the 128 x 160 tile, two waves of 64 x 80 on 128 x 80: +-2 %.
+// The tap table of a 3x3 layer (one word per 16-byte K chunk) has to fit the tile's LDS: 768 words beside the 128 x 160 / 128 / 64
+// tiles (K <= 6144 16-bit / 12288 fp8 elements), 128 beside 128 x 80 (53,760 B: the LDS is handed out in 1,280-byte granules, and a
+// 256-word table made the workgroup 43 of them — two per CU instead of three: -9 % on the 80 -> 80 layers); returns 1 when it does not.
 template <typename T, typename OT>
 static int launch_fk_tiles(const FkArgs& a, hipStream_t st) {
   static const int force = dy_ablate("DYOLO_FK_BN");
@@ -380,11 +415,14 @@ static int launch_fk_tiles(const FkArgs& a, hipStream_t st) {
     if (w < bw) bw = w, best = c;
   }
   if (force) best = force;
+  const int nf = a.ks == 1 ? 0 : a.Kpad / (8 * Elem<T>::EPC) * 8;  // tap-table words
+  if (nf > 768) return 1;
+  if (best == 80 && nf > 128) best = 160;
   switch (best) {
-    case 160: return launch_fk<T, OT, 4, 5, 2, 2>(a, st, "conv_gemm_fk_kernel<128,160>");
-    case 128: return launch_fk<T, OT, 4, 4, 2, 2>(a, st, "conv_gemm_fk_kernel<128,128>");
-    case 80: return launch_fk<T, OT, 2, 5, 4, 1>(a, st, "conv_gemm_fk_kernel<128,80>");
-    default: return launch_fk<T, OT, 2, 4, 4, 1>(a, st, "conv_gemm_fk_kernel<128,64>");
+    case 160: return launch_fk<T, OT, 4, 5, 2, 2, 768>(a, st, "conv_gemm_fk_kernel<128,160>");
+    case 128: return launch_fk<T, OT, 4, 4, 2, 2, 768>(a, st, "conv_gemm_fk_kernel<128,128>");
+    case 80: return launch_fk<T, OT, 2, 5, 4, 1, 128>(a, st, "conv_gemm_fk_kernel<128,80>");
+    default: return launch_fk<T, OT, 2, 4, 4, 1, 768>(a, st, "conv_gemm_fk_kernel<128,64>");
   }
 }
 
@@ -423,6 +461,9 @@ int conv_gemm_fk_try(const dy_conv_desc* d, hipStream_t st) {
   a.act = d->act;
   a.cout_pad = d->cout_pad;
   a.xb = (unsigned)xb, a.x2b = (unsigned)(d->x2 ? x2b : xb), a.wb = (unsigned)wbytes;
+  a.dCin = make_fastdiv((unsigned)d->cin);
+  if (d->ksize == 3 && ((long long)(2 * d->w_in + 2) * d->ld_x + d->cin) * es >= (1ll << 28)) return 1;  // table words hold a 28-bit byte offset
+  a.dbg = dy_ablate("DYOLO_FK_DBG");
   a.res_scale = in8 ? d->act_scale : 1.f;
   a.out_scale = out8 ? 1.f / d->act_scale : 1.f;
   if (in8) return out8 ? launch_fk_tiles<fp8_t, fp8_t>(a, st) : launch_fk_tiles<fp8_t, f16_t>(a, st);

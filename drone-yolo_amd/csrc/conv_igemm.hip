@@ -480,7 +480,7 @@ int32_t conv2d_entry(const dy_conv_desc* d, dy_stream_t stream) {
 
   // cout tiles of 80 / 160 (the x scale: 160, 320, 800 ... outputs) beat the 64-cout persistent tiles of the tap-aligned kernel:
   // a layer whose Cout is no multiple of 128 but fills 160-wide tiles exactly goes to the flat-K kernel first
-  const bool fk_first = d->cout % 128 != 0 && d->cout % 80 == 0 && (d->dtype == DY_BF16 || d->dtype == DY_F16) && !d->out_f32 && !d->up2x;
+  const bool fk_first = d->cout % 128 != 0 && d->cout % 80 == 0 && (d->dtype == DY_BF16 || d->dtype == DY_F16) && !d->out_f32 && d->up2x != 2;
   if (fk_first) {
     const int rf = conv_gemm_fk_try(d, st);
     if (rf <= 0) return rf;

@@ -416,10 +416,9 @@ class PackedConv:
         kstep = 8 * elems_per_chunk(dtype)
         deep3x3 = halo is None and k == 3 and stride == 1 and self.cin % kstep == 0 and cout % 64 == 0 and \
             self.cin >= 128 and cout >= 128
-        # r04: ... unless cout is no multiple of 128 on a 16-bit type (scale x: 320 -> 320): neither the virtual-flat GEMM (cout % 128) nor
-        # the 256-wide LDS-DMA tiles apply, the 64-cout persistent tiles ran it at 536 TFLOP/s, the halo kernel at 857 (tools/fk_bench.sh)
-        if deep3x3 and cout % 128 != 0 and dtype in (torch.bfloat16, torch.float16) and self.cin * cout <= 320 * 320:
-            deep3x3 = False
+        # (r04: deep layers whose cout is no multiple of 128 — scale x: 320 -> 320 — take the flat-K kernel's 160-wide tiles behind the same
+        # layout (csrc/conv_igemm.hip: fk_first): 19.09 -> 18.68 ms per x1536 pass against the halo kernel, 536 -> 860 TFLOP/s against the
+        # 64-cout persistent tiles of the tap-aligned kernel)
         # r04: 3x3 layers whose channel counts are not whole 64-channel K-steps / 64-cout tiles (the n / m / x scales: 80, 160, 320 ...)
         # run on the flat-K LDS-DMA kernel behind DY_WLAYOUT_ROWS (conv_gemm_fk.hip) instead of the halo kernel's 32-channel chunks
         flat3x3 = FLAT_K_3X3[0] and halo is None and k == 3 and pad == 1 and groups == 1 and dtype in (torch.bfloat16, torch.float16) and \
