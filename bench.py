@@ -565,7 +565,7 @@ def main():
         tconv = sum(times.values())
         peak = MFMA_PEAK_TFLOPS[a.dtype]
         traffic, tsrc = None, None  # HBM bytes of the conv launches of one pass, from the committed PMC summary of this command (same batch / dtype only)
-        for rnd in ("r03", "r02"):
+        for rnd in ("r04", "r03", "r02"):
             tfile = os.path.join(ROOT, "profiles", f"{rnd}_traffic_b{a.batch}.json")
             if traffic is None and os.path.exists(tfile) and a.imgsz == 640 and "yolov8s-p2-repvgg" in a.model:
                 tj = json.load(open(tfile))

@@ -210,7 +210,32 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hhead_kernel(const HheadArgs p
   // tail, part 2, DEFERRED to the start of the next item (after that item's DMA has been issued, before its MFMAs): the global
   // stores then have a whole item of matrix work behind them before the item's closing s_waitcnt vmcnt(0), instead of being waited
   // for right after they were issued (first version: the fused kernels cost as much as conv + separate tail kernel)
+  // class branch: the candidate append of a tile is FINISHED one tile later (r04).  The counter atomic returns the wave's slot range;
+  // the first form used it at once — every wave stood still for the round trip (1-2 us of an 11 us tile, in front of the item's MFMAs):
+  // the class branch ran 17 % slower than the box branch for 1/6 of its 1x1 work.  Now the atomic is issued at the end of tail_out and
+  // its value read at the start of the next one (or after the last tile): it returns under a whole item of matrix work.
+  int pv_base = 0, pv_n = 0, pv_n0 = 0, pv_total = 0;
+  unsigned long long pv_mk0 = 0ull, pv_mk1 = 0ull;
+  float pv_best[2] = {0.f, 0.f};
+  int pv_bj[2] = {0, 0}, pv_a[2] = {0, 0};
+  auto flush_keys = [&]() {
+    if (pv_total != 0) {
+      const int base = __shfl(pv_base, 0);
+      const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const unsigned long long mk = j ? pv_mk1 : pv_mk0;
+        if ((mk >> lane) & 1ull) {
+          const int pos = base + (j ? pv_n0 : 0) + __popcll(mk & below);
+          p.keys[(size_t)pv_n * p.P + pos] = ((unsigned long long)(~__float_as_uint(pv_best[j])) << 32) | (unsigned long long)(unsigned)pv_a[j];
+          p.cls[(size_t)pv_n * p.A + pv_a[j]] = (unsigned short)pv_bj[j];
+        }
+      }
+      pv_total = 0;
+    }
+  };
   auto tail_out = [&](int tile) {
+    if constexpr (KIND == 2) flush_keys();
     const int tx = tile % p.tilesX;
     const int r_ = tile / p.tilesX;
     const int ty = r_ % p.tilesY, n = r_ / p.tilesY;
@@ -294,18 +319,10 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hhead_kernel(const HheadArgs p
         const unsigned long long mk0 = __ballot(passv[0]), mk1 = __ballot(passv[1]);
         const int n0 = __popcll(mk0), total = n0 + __popcll(mk1);
         if (total != 0) {
-          int base = 0;
-          if (lane == 0) base = atomicAdd(p.counts + n, total);
-          base = __shfl(base, 0);
-          const unsigned long long below = (1ull << lane) - 1ull;
+          if (lane == 0) pv_base = atomicAdd(p.counts + n, total);  // (value used by flush_keys, one tile later)
+          pv_n = n, pv_n0 = n0, pv_total = total, pv_mk0 = mk0, pv_mk1 = mk1;
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            if (passv[j]) {
-              const int pos = base + (j ? n0 : 0) + __popcll((j ? mk1 : mk0) & below);
-              p.keys[(size_t)n * p.P + pos] = ((unsigned long long)(~__float_as_uint(bestv[j])) << 32) | (unsigned long long)(unsigned)av[j];
-              p.cls[(size_t)n * p.A + av[j]] = (unsigned short)bjv[j];
-            }
-          }
+          for (int j = 0; j < 2; ++j) pv_best[j] = bestv[j], pv_bj[j] = bjv[j], pv_a[j] = av[j];
         }
       }
     }
@@ -337,6 +354,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hhead_kernel(const HheadArgs p
     }
   }
   if (pending >= 0) tail_out(pending);
+  if constexpr (KIND == 2) flush_keys();
 }
 
 template <typename T>

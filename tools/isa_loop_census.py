@@ -1,36 +1,40 @@
-"""Instruction-class census of the innermost loop of one kernel in a hipcc -save-temps .s file.
-usage: python tools/isa_loop_census.py FILE.s KERNEL_NAME_SUBSTRING"""
+"""Instruction-class census per basic block of a kernel in a hipcc -save-temps .s file: every block that holds MFMAs, with its mix.
+usage: python tools/isa_loop_census.py FILE.s KERNEL_NAME_SUBSTRING [min_mfma]"""
 import collections
 import re
 import sys
 
-s = open(sys.argv[1]).read()
-names = [l.split(":")[0] for l in s.splitlines() if re.match(r"^_Z\w+:", l) and sys.argv[2] in l]
-for name in names[:3]:
-    i = s.index(name + ":")
-    j = s.index(".Lfunc_end", i)
-    body = s[i:j].splitlines()
-    hdr = [k for k, l in enumerate(body) if "Loop Header" in l]
-    if not hdr:
-        print(name, "no loop")
-        continue
-    for st in hdr[:3]:
-        lab = body[st].split(":")[0]
-        ends = [k for k, l in enumerate(body) if lab in l and "s_cbranch" in l and k > st]
-        if not ends:
+CLASSES = (("v_mfma", "mfma"), ("ds_read", "ds_read"), ("ds_write", "ds_write"), ("ds_", "ds_other"), ("buffer_load", "vmem_ld"), ("global_load", "vmem_ld"),
+           ("buffer_store", "vmem_st"), ("global_store", "vmem_st"), ("global_atomic", "atomic"), ("v_exp", "trans"), ("v_rcp", "trans"), ("v_accvgpr", "acc_mov"),
+           ("v_", "valu"), ("s_nop", "s_nop"), ("s_waitcnt", "s_waitcnt"), ("s_barrier", "s_barrier"), ("s_cbranch", "branch"), ("s_branch", "branch"), ("s_", "salu"))
+
+lines = open(sys.argv[1]).read().splitlines()
+min_mfma = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+starts = [k for k, l in enumerate(lines) if re.match(r"^_Z\w+:", l) and sys.argv[2] in l]
+for idx in starts[:4]:
+    end = next(k for k in range(idx, len(lines)) if lines[k].startswith(".Lfunc_end"))
+    print(lines[idx].split(":")[0][:140])
+    blocks, cur, name = [], collections.Counter(), "entry"
+    for l in lines[idx + 1:end]:
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            blocks.append((name, cur))
+            cur, name = collections.Counter(), m.group(1) + (" LOOP" if "Loop Header" in l else "")
             continue
-        loop = body[st:max(ends) + 1]
-        cnt = collections.Counter()
-        for l in loop:
-            l = l.strip()
-            if not l or l.startswith(";") or l.startswith("."):
-                continue
-            op = l.split()[0]
-            for pre, key in (("v_mfma", "mfma"), ("ds_read", "ds_read"), ("ds_write", "ds_write"), ("buffer_load", "buffer_load"), ("global_load", "global_load"), ("global_store", "global_store"),
-                             ("buffer_store", "buffer_store"), ("v_", "valu"), ("s_nop", "s_nop"), ("s_waitcnt", "s_waitcnt"), ("s_barrier", "s_barrier"), ("s_cbranch", "branch"), ("s_branch", "branch"), ("s_", "salu")):
-                if op.startswith(pre):
-                    cnt[key] += 1
-                    break
-            else:
-                cnt[op] += 1
-        print(f"{name[:110]}  loop@{st} ({len(loop)} lines): {dict(cnt)}")
+        t = l.strip()
+        if not t or t.startswith(";") or t.startswith("."):
+            continue
+        op = t.split()[0]
+        for pre, key in CLASSES:
+            if op.startswith(pre):
+                cur[key] += 1
+                break
+        else:
+            cur["other"] += 1
+    blocks.append((name, cur))
+    tot = collections.Counter()
+    for n, c in blocks:
+        tot.update(c)
+        if c["mfma"] >= min_mfma:
+            print(f"   {n:<18s} {dict(c)}")
+    print(f"   whole kernel: {dict(tot)}")

@@ -13,7 +13,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sta
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --batch $B --steps 2 --warmup 1 --streams 1 --bare --no-graph > $O/bench_fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --batch $B --steps 2 --warmup 1 --streams 1 --bare --no-graph > $O/bench_write.log 2>&1
 mkdir -p $O/pmc && cp -r $O/fetch $O/pmc/ && cp -r $O/write $O/pmc/
-python3 tools/traffic_summary.py $O/pmc $B 9 > $O/traffic.json
+python3 tools/traffic_summary.py $O/pmc $B 9 ${TAG//[!0-9]/} > $O/traffic.json
 python3 bench.py --batch $B --layers $O/layers_b$B.txt --bare > $O/bench_layers.log 2>&1
 find $O -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 # raw counter csvs are large; keep only the summaries
