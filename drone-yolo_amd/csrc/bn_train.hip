@@ -14,7 +14,8 @@
 
 namespace dy {
 
-constexpr int kBnMaxSlabs = 1024;  // workgroups of a reduction pass (dy_bn_workspace_bytes reserves one partial each)
+constexpr int kBnMaxSlabs = kStatSlots;
+constexpr int kBnMaxC = 2048;  // widest layer one workgroup row covers: 256 threads x one 16-byte chunk of 16-bit elements  // workgroups of a reduction pass (dy_bn_workspace_bytes reserves one partial each)
 
 struct BnArgs {
   const void* z;
@@ -36,6 +37,7 @@ struct BnArgs {
   double* acc;  // [2][c]
   int partial_slabs;  // forward: > 0 = that many slab partials are already in the workspace (a convolution epilogue's)
   int nch, R, rows_per_block;
+  double invn;  // 1 / rows (host side: a double division per thread is ~40 quarter-rate instructions)
 };
 
 __device__ __forceinline__ float silu_grad(float u) {  // d/du u*sigmoid(u)
@@ -44,7 +46,7 @@ __device__ __forceinline__ float silu_grad(float u) {  // d/du u*sigmoid(u)
 }
 
 // MODE 0: sum z, sum z^2.   MODE 1: sum du, sum du*xhat with du = dy * act'(u), u = gamma*xhat + beta.
-template <typename T, int MODE>
+template <typename T, int MODE, int UNR>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const BnArgs p) {
   constexpr int E = Elem<T>::EPC;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
@@ -88,7 +90,6 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const BnArgs p) {
       }
     };
     // UNR rows in flight per thread: with one load per iteration the pass ran at 1.2 TB/s (latency bound)
-    constexpr int UNR = MODE == 0 ? 8 : 4;
     long long r = r0 + rr;
     for (; r + (long long)(UNR - 1) * p.R < r1; r += (long long)UNR * p.R) {
       u32x4 zr[UNR], dr[UNR];
@@ -140,49 +141,55 @@ __global__ __launch_bounds__(256) void bn_sum_partials_kernel(const BnArgs p, in
   }
 }
 
-// mean / rstd from the double sums, running statistics update (unbiased variance, torch semantics)
-__global__ void bn_finalize_kernel(const BnArgs p) {
-  const int cc = blockIdx.x * 256 + threadIdx.x;
-  if (cc >= p.c) return;
-  const double n = (double)p.rows;
-  const double m = p.acc[cc] / n;
-  double var = p.acc[p.c + cc] / n - m * m;
-  if (var < 0.0) var = 0.0;
-  p.mean[cc] = (float)m;
-  p.rstd[cc] = (float)(1.0 / sqrt(var + (double)p.eps));
-  if (p.running_mean) {
-    const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
-    p.running_mean[cc] = (1.f - p.momentum) * p.running_mean[cc] + p.momentum * (float)m;
-    p.running_var[cc] = (1.f - p.momentum) * p.running_var[cc] + p.momentum * (float)unb;
-  }
-}
-
 // y = act(gamma * (z - mean) * rstd + beta (+ addend)).  Threads keep their channel chunk (tid % nch) and walk rows, so the
-// per-channel constants are loaded once into registers.
-template <typename T>
+// per-channel constants are loaded once into registers.  r04: the constants come straight from the double sums (mean, biased variance,
+// rstd = 1 / sqrt(var + eps) in fp32 as torch's batch_norm computes invstd), and workgroup 0 leaves mean / rstd for the backward pass
+// and updates the running statistics (unbiased variance, torch semantics) -- until r04 a launch of its own (bn_finalize_kernel: 74
+// launches of ~5 us per training step).  UNR rows are in flight per thread.
+template <typename T, int UNR>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs p) {
   constexpr int E = Elem<T>::EPC;
   const int tid = threadIdx.x;
   const int ch = tid % p.nch, rr = tid / p.nch;
+  // one thread per channel computes the constants (in every thread the double-precision prologue cost more VALU time than the pass:
+  // 8 waves per SIMD x ~4,000 issue cycles each), the workgroup shares them through LDS
+  __shared__ float s_sc[kBnMaxC], s_sh[kBnMaxC];
+  {
+    const double n = (double)p.rows, invn = p.invn;
+    for (int cc = tid; cc < p.c; cc += 256) {
+      const double m = p.acc[cc] * invn;
+      double var = p.acc[p.c + cc] * invn - m * m;
+      if (var < 0.0) var = 0.0;
+      const float mean = (float)m, rstd = 1.0f / sqrtf((float)var + p.eps);
+      const float scv = p.gamma[cc] * rstd;
+      s_sc[cc] = scv;
+      s_sh[cc] = p.beta[cc] - mean * scv;
+      if (blockIdx.x == 0) {
+        p.mean[cc] = mean, p.rstd[cc] = rstd;
+        if (p.running_mean) {
+          const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+          p.running_mean[cc] = (1.f - p.momentum) * p.running_mean[cc] + p.momentum * mean;
+          p.running_var[cc] = (1.f - p.momentum) * p.running_var[cc] + p.momentum * (float)unb;
+        }
+      }
+    }
+  }
+  __syncthreads();
   if (rr >= p.R) return;
   float sc[E], sh[E];
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const int cc = ch * E + e;
-    sc[e] = p.gamma[cc] * p.rstd[cc];
-    sh[e] = p.beta[cc] - p.mean[cc] * sc[e];
-  }
+  for (int e = 0; e < E; ++e) sc[e] = s_sc[ch * E + e], sh[e] = s_sh[ch * E + e];
   const T* zb = reinterpret_cast<const T*>(p.z) + ch * E;
   const T* ab = reinterpret_cast<const T*>(p.addend) + ch * E;
   T* yb = reinterpret_cast<T*>(p.y) + ch * E;
-  for (long long r = (long long)blockIdx.x * p.R + rr; r < p.rows; r += (long long)gridDim.x * p.R) {
+  auto one = [&](long long r, const u32x4 zraw, const u32x4 araw) {
     float zf[E], o[E];
-    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(zb + r * p.ld_z), zf);
+    Chunk<T>::unpack(zraw, zf);
 #pragma unroll
     for (int e = 0; e < E; ++e) o[e] = zf[e] * sc[e] + sh[e];
     if (p.addend) {
       float af[E];
-      Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(ab + r * p.ld_add), af);
+      Chunk<T>::unpack(araw, af);
 #pragma unroll
       for (int e = 0; e < E; ++e) o[e] += af[e];
     }
@@ -191,11 +198,25 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs p) {
       for (int e = 0; e < E; ++e) o[e] = silu_f32(o[e]);
     }
     *reinterpret_cast<u32x4*>(yb + r * p.ld_y) = Chunk<T>::pack(o);
+  };
+  const long long G = (long long)gridDim.x * p.R;
+  long long r = (long long)blockIdx.x * p.R + rr;
+  for (; r + (UNR - 1) * G < p.rows; r += UNR * G) {
+    u32x4 zr[UNR], ar[UNR];
+#pragma unroll
+    for (int k = 0; k < UNR; ++k) {
+      zr[k] = *reinterpret_cast<const u32x4*>(zb + (r + k * G) * p.ld_z);
+      ar[k] = p.addend ? *reinterpret_cast<const u32x4*>(ab + (r + k * G) * p.ld_add) : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int k = 0; k < UNR; ++k) one(r + k * G, zr[k], ar[k]);
   }
+  for (; r < p.rows; r += G)
+    one(r, *reinterpret_cast<const u32x4*>(zb + r * p.ld_z), p.addend ? *reinterpret_cast<const u32x4*>(ab + r * p.ld_add) : u32x4{0u, 0u, 0u, 0u});
 }
 
-// dz = gamma * rstd * (du - mean(du) - xhat * mean(du * xhat));  dgamma = sum du*xhat, dbeta = sum du
-template <typename T>
+// dz = gamma * rstd * (du - mean(du) - xhat * mean(du * xhat));  dgamma = sum du*xhat, dbeta = sum du.  UNR rows in flight per thread.
+template <typename T, int UNR>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs p) {
   constexpr int E = Elem<T>::EPC;
   const int tid = threadIdx.x;
@@ -207,7 +228,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs p) {
   }
   const int ch = tid % p.nch, rr = tid / p.nch;
   if (rr >= p.R) return;
-  const double invn = 1.0 / (double)p.rows;
+  const double invn = p.invn;
   float mu[E], rs[E], ga[E], be[E], gr[E], mdu[E], mdx[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -219,10 +240,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs p) {
   const T* zb = reinterpret_cast<const T*>(p.z) + ch * E;
   const T* db = reinterpret_cast<const T*>(p.dy) + ch * E;
   T* ob = reinterpret_cast<T*>(p.dz) + ch * E;
-  for (long long r = (long long)blockIdx.x * p.R + rr; r < p.rows; r += (long long)gridDim.x * p.R) {
+  auto one = [&](long long r, const u32x4 zraw, const u32x4 draw) {
     float zf[E], df[E], o[E];
-    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(zb + r * p.ld_z), zf);
-    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(db + r * p.ld_dy), df);
+    Chunk<T>::unpack(zraw, zf);
+    Chunk<T>::unpack(draw, df);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const float xh = (zf[e] - mu[e]) * rs[e];
@@ -231,7 +252,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs p) {
       o[e] = gr[e] * (du - mdu[e] - xh * mdx[e]);
     }
     *reinterpret_cast<u32x4*>(ob + r * p.ld_dz) = Chunk<T>::pack(o);
+  };
+  const long long G = (long long)gridDim.x * p.R;
+  long long r = (long long)blockIdx.x * p.R + rr;
+  for (; r + (UNR - 1) * G < p.rows; r += UNR * G) {
+    u32x4 zr[UNR], dr[UNR];
+#pragma unroll
+    for (int k = 0; k < UNR; ++k) {
+      zr[k] = *reinterpret_cast<const u32x4*>(zb + (r + k * G) * p.ld_z);
+      dr[k] = *reinterpret_cast<const u32x4*>(db + (r + k * G) * p.ld_dy);
+    }
+#pragma unroll
+    for (int k = 0; k < UNR; ++k) one(r + k * G, zr[k], dr[k]);
   }
+  for (; r < p.rows; r += G) one(r, *reinterpret_cast<const u32x4*>(zb + r * p.ld_z), *reinterpret_cast<const u32x4*>(db + r * p.ld_dy));
 }
 
 // y = silu(u)  /  du = dy * silu'(u)   (RepVGG: the activation after the sum of two BN branches)
@@ -282,6 +316,7 @@ static int bn_prepare(const dy_bn_desc* d, BnArgs* a, const char* who, bool bwd)
   a->partial_slabs = bwd ? 0 : d->partial_slabs;
   DY_REQUIRE(a->partial_slabs >= 0 && a->partial_slabs <= kBnMaxSlabs, DY_ERR_INVALID_ARG, "%s: partial_slabs out of range", who);
   a->nch = d->c / epc;
+  a->invn = 1.0 / (double)d->rows;
   int R = 256 / a->nch;
   if (R < 1) R = 1;
   a->R = R;
@@ -293,16 +328,28 @@ static int bn_prepare(const dy_bn_desc* d, BnArgs* a, const char* who, bool bwd)
   return 0;
 }
 
+// rows per pass of an apply grid = blocks * R; at most `cap` workgroups (the grid-stride loop takes the rest).  Measured per kernel over
+// the eight BatchNorm shapes of the B = 64 training step (tools/bn_prof.sh, buffers rotating through 1 GB): 1 / 2 / 4 rows in flight and
+// 1024 / 2048 / 4096 workgroups all land within 5 % of each other (apply 20.2-21.4 us, backward apply 30.0-31.8 us on average): both
+// passes sit at 4.3-4.7 TB/s of the box's 5.4 TB/s copy rate, the backward one co-limited by its two quarter-rate transcendentals per
+// element.  What did matter (49 -> 21 us): the statistics prologue in ONE thread per channel instead of every thread.
+static unsigned apply_blocks(const BnArgs& a, int unr, int cap) {
+  const long long nb = (a.rows + (long long)a.R * unr - 1) / ((long long)a.R * unr);
+  return (unsigned)(nb < cap ? (nb < 1 ? 1 : nb) : cap);
+}
+
 template <typename T>
 static int bn_fwd_t(const BnArgs& a, hipStream_t st) {
   const unsigned blocks = (unsigned)((a.rows + a.rows_per_block - 1) / a.rows_per_block);
   const size_t smem = (size_t)2 * a.R * a.c * 4;
-  if (a.partial_slabs <= 0) hipLaunchKernelGGL((bn_reduce_kernel<T, 0>), dim3(blocks), dim3(256), smem, st, a);
+  if (a.partial_slabs <= 0) hipLaunchKernelGGL((bn_reduce_kernel<T, 0, 8>), dim3(blocks), dim3(256), smem, st, a);
   hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((unsigned)((2 * a.c + 31) / 32), kBnSumY), dim3(256), 0, st, a, a.partial_slabs > 0 ? a.partial_slabs : (int)blocks);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((a.c + 255) / 256)), dim3(256), 0, st, a);
-  const long long nb = (a.rows + a.R - 1) / a.R;
-  const unsigned ab = (unsigned)(nb < 4096 ? nb : 4096);
-  hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ab), dim3(256), 0, st, a);
+  const int unr = dy_ablate("DYOLO_BN_UNR") ? dy_ablate("DYOLO_BN_UNR") : 2;
+  const int cap = dy_ablate("DYOLO_BN_GRID") ? dy_ablate("DYOLO_BN_GRID") : 2048;
+  const unsigned ab = apply_blocks(a, unr, cap);
+  if (unr == 1) hipLaunchKernelGGL((bn_apply_kernel<T, 1>), dim3(ab), dim3(256), 0, st, a);
+  else if (unr == 2) hipLaunchKernelGGL((bn_apply_kernel<T, 2>), dim3(ab), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((bn_apply_kernel<T, 4>), dim3(ab), dim3(256), 0, st, a);
   return check_launch("dy_bn_train_fwd");
 }
 
@@ -310,11 +357,15 @@ template <typename T>
 static int bn_bwd_t(const BnArgs& a, hipStream_t st) {
   const unsigned blocks = (unsigned)((a.rows + a.rows_per_block - 1) / a.rows_per_block);
   const size_t smem = (size_t)2 * a.R * a.c * 4;
-  hipLaunchKernelGGL((bn_reduce_kernel<T, 1>), dim3(blocks), dim3(256), smem, st, a);
+  if (dy_ablate("DYOLO_BN_RUNR") == 8) hipLaunchKernelGGL((bn_reduce_kernel<T, 1, 8>), dim3(blocks), dim3(256), smem, st, a);
+  else hipLaunchKernelGGL((bn_reduce_kernel<T, 1, 4>), dim3(blocks), dim3(256), smem, st, a);
   hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((unsigned)((2 * a.c + 31) / 32), kBnSumY), dim3(256), 0, st, a, (int)blocks);
-  const long long nb = (a.rows + a.R - 1) / a.R;
-  const unsigned ab = (unsigned)(nb < 4096 ? nb : 4096);
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ab), dim3(256), 0, st, a);
+  const int unr = dy_ablate("DYOLO_BN_BUNR") ? dy_ablate("DYOLO_BN_BUNR") : 2;
+  const int cap = dy_ablate("DYOLO_BN_GRID") ? dy_ablate("DYOLO_BN_GRID") : 2048;
+  const unsigned ab = apply_blocks(a, unr, cap);
+  if (unr == 1) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1>), dim3(ab), dim3(256), 0, st, a);
+  else if (unr == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 2>), dim3(ab), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 4>), dim3(ab), dim3(256), 0, st, a);
   return check_launch("dy_bn_train_bwd");
 }
 

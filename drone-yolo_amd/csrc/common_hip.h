@@ -28,6 +28,7 @@ int check_launch(const char* what);
 void zero_async(void* p, size_t bytes, hipStream_t stream);
 void note_stats(int written);  // dy_conv_stats_written(): set by a convolution launch that fills dy_conv_desc.bn_stats
 }  // namespace dy
+constexpr int kStatSlots = 1024;  // partial-sum slots of a BatchNorm workspace (bn_train.hip: kBnMaxSlabs; dy_bn_workspace_bytes)
 
 namespace DY_NS {
 #ifdef DYOLO_L2E_BUILD

@@ -43,6 +43,7 @@ struct Conv3Args {
   unsigned x_bytes, w_bytes, y_bytes, r_bytes;  // extents of the x / y / residual views and of the packed weights (buffer descriptors)
   int dbg;  // ablation switches (DYOLO_DBG env): 1 skip global loads after the first item, 2 skip MFMAs,
             // 4 skip epilogue, 8 skip LDS staging writes, 16 force the streaming (non-WS) variant
+  double* stats;  // optional: a dy_bn_train_fwd workspace (dy_conv_desc.bn_stats; see STATS below)
 };
 
 constexpr int kHaloPixPitch = 80;  // bytes per halo pixel in LDS (64 data + 16 pad)
@@ -51,9 +52,13 @@ constexpr int kHaloPixPitch = 80;  // bytes per halo pixel in LDS (64 data + 16 
 // tile is deferred into the first item of the NEXT tile and interleaved in source order with that item's MFMAs (one
 // accumulator fragment's SiLU + scratch write after each tap), so its VALU / LDS / store work is issued in the shadow of
 // the matrix instructions instead of stalling all eight barrier-locked waves between tiles (64->64 @80x80: 151 -> 135 us).
-template <typename T, int S, int MF, int NF, bool OUTF32, bool WS, int NCH = 0>
+// STATS (r04; training forward in front of a train-mode BatchNorm, Conv3Args.stats; WS without PIPE only): a weight-stationary block
+// stays on one n-tile, so a lane keeps sum / sum of squares of its NF x 4 channels over ALL its tiles; the pixel lanes meet in a
+// shuffle tree, the eight waves in LDS, and block b writes its BN channels of slot b / tilesN of the dy_bn_train_fwd workspace.
+template <typename T, int S, int MF, int NF, bool OUTF32, bool WS, int NCH = 0, bool STATS = false>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
   constexpr bool PIPE = NCH > 0;
+  static_assert(!STATS || (WS && !PIPE && !OUTF32 && sizeof(T) == 2), "STATS: weight-stationary, 16-bit outputs, plain epilogue");
   constexpr int NT = 512;
   constexpr int EPC = Elem<T>::EPC;
   constexpr int KCE = 4 * EPC;             // channels per chunk (one MFMA k-group)
@@ -236,6 +241,15 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
   // ---- epilogue from registers: lane holds couts (lq*4 .. +3) of pixel lr for every (i, j) ------------
   OutT* __restrict__ yg = reinterpret_cast<OutT*>(p.y);
   const T* __restrict__ rg = reinterpret_cast<const T*>(p.res);
+  float st_sum[STATS ? NF : 1][4], st_sq[STATS ? NF : 1][4];
+  if constexpr (STATS) {
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) st_sum[j][e] = 0.f, st_sq[j][e] = 0.f;
+    if (blockIdx.x == 0)  // the totals bn_sum_partials_kernel adds the slots into
+      for (int i = tid; i < 2 * p.Cout; i += NT) p.stats[i] = 0.0;
+  }
   auto epilogue = [&](const TileIt& t, const f32x4 (&acc)[MF][NF], bool valid) {
     if constexpr (!PIPE) mfma_epilogue_fence<T>();
     const int xx = t.tx * TW + lr;
@@ -296,6 +310,15 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f32(v[e]);
           *reinterpret_cast<u32x2*>(sp) = __builtin_bit_cast(u32x2, o);
+          if constexpr (STATS) {
+            if (rowok[i]) {  // (channels beyond Cout carry zero weights and a zero bias: they add nothing, and are not written out below)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float f = Elem<T>::to_f32(o[e]);  // what BatchNorm will read back
+                st_sum[j][e] += f, st_sq[j][e] += f * f;
+              }
+            }
+          }
         }
       }
     }
@@ -488,6 +511,36 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const Conv3Args p) {
     tile_end();
     __syncthreads();
   }
+  if constexpr (STATS) {
+    float* sred = reinterpret_cast<float*>(dyn_smem);  // [8 waves][2][BN]
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) st_sum[j][e] += __shfl_xor(st_sum[j][e], m, 64), st_sq[j][e] += __shfl_xor(st_sq[j][e], m, 64);
+      }
+    __syncthreads();  // the weights at the head of the LDS are not read any more
+    if (lr == 0) {
+#pragma unroll
+      for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int cc = j * 16 + lq * 4 + e;
+          sred[(wave * 2 + 0) * BN + cc] = st_sum[j][e];
+          sred[(wave * 2 + 1) * BN + cc] = st_sq[j][e];
+        }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, cc = tid - which * BN;
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += sred[(k * 2 + which) * BN + cc];
+      const int co = ((int)blockIdx.x % p.tilesN) * BN + cc;
+      if (co < p.Cout) p.stats[(size_t)(1 + (int)blockIdx.x / p.tilesN) * 2 * p.Cout + which * p.Cout + co] = (double)t;
+    }
+  }
 }
 
 template <typename T, int S, int MF, int NF>
@@ -547,6 +600,19 @@ static int launch_halo(const Conv3Args& a, int batch, hipStream_t st) {
       return check_launch("conv3x3_halo_kernel");
     }
   }
+#ifndef DYOLO_L2E_BUILD  // (training convolutions carry no activation: they never come through the scaled-domain build)
+  if constexpr (sizeof(T) == 2 && !OUTF32) {
+    // every block on one n-tile (grid a multiple of tilesN), every block with at least one tile, one slot per block row
+    if (p.stats && ws && !p.res && !p.dbg && grid % p.tilesN == 0 && grid <= p.nTiles && grid / p.tilesN <= kStatSlots) {
+      auto kern = conv3x3_halo_kernel<T, S, MF, NF, OUTF32, true, 0, true>;
+      static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
+      (void)once;
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, st, p);
+      note_stats(grid / p.tilesN);
+      return check_launch("conv3x3_halo_kernel");
+    }
+  }
+#endif
   if (ws) {
     auto kern = conv3x3_halo_kernel<T, S, MF, NF, OUTF32, true>;
     static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
@@ -620,6 +686,7 @@ int conv3x3_halo_dispatch(const dy_conv_desc* d, hipStream_t st) {
   a.ldy = d->ld_y;
   a.ldres = d->ld_res;
   a.act = d->act;
+  a.stats = (d->out_f32 || d->y_dtype1) ? nullptr : d->bn_stats;
   a.nChunks = (d->cin + 4 * epc - 1) / (4 * epc);
   a.x_bytes = (unsigned)((long long)d->batch * d->h * d->w_in * d->ld_x * es);
   {

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_hreg_kernel(const HregArgs p) 
 constexpr int kH2TH = 4, kH2TW = 16, kH2HH = 9, kH2Pitch = 40, kH2PlaneB = 24;
 constexpr int kH2Stage = 24 * 1024;  // 9 x 40 slots x 64 B = 23,040 B, padded to 24 wave-instructions (6 per wave)
 
-template <typename T, int NCH>
+template <typename T, int NCH, bool STATS = false>  // STATS: as in the stride-1 kernel (r04)
 __global__ __launch_bounds__(256, 2) void conv3x3_hreg_s2_kernel(const HregArgs p) {
   constexpr int EPC = Elem<T>::EPC;  // 8
   __shared__ __attribute__((aligned(1024))) unsigned char smem[kHrStages * kH2Stage];
@@ -341,6 +341,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_hreg_s2_kernel(const HregArgs 
   const int nt = logical % p.tilesN;
   const int sb = logical / p.tilesN, Gs = G / p.tilesN;
   const int myTiles = sb < p.nSpatial ? (p.nSpatial - sb + Gs - 1) / Gs : 0;
+  if constexpr (STATS) {
+    if (blockIdx.x == 0)  // the totals the BatchNorm's partial-sum launch adds into
+      for (int i = tid; i < 2 * p.Cout; i += 256) p.stats[i] = 0.0;
+    if (myTiles <= 0 && tid < 128) {  // a slot is summed whether its workgroup had tiles or not
+      const int co = nt * 64 + (tid & 63);
+      if (co < p.Cout) p.stats[(size_t)(1 + sb) * 2 * p.Cout + (tid >> 6) * p.Cout + co] = 0.0;
+    }
+  }
   if (myTiles <= 0) return;
   const int nItems = myTiles * NCH;
 
@@ -452,6 +460,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_hreg_s2_kernel(const HregArgs 
 #pragma unroll
     for (int o = 0; o < kH2TH; o += 2) lane_out[o / 2] = (unsigned)(((o + (lq & 1)) * Wo + lr) * p.ldy + co16) * (unsigned)sizeof(T);
   }
+  float st_sum[4] = {0.f, 0.f, 0.f, 0.f}, st_sq[4] = {0.f, 0.f, 0.f, 0.f};  // STATS: this lane's four channels, all its tiles
   auto epilogue = [&](int tile) {
     const int tx = tile % p.tilesX;
     const int r = tile / p.tilesX;
@@ -471,6 +480,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_hreg_s2_kernel(const HregArgs 
 #pragma unroll
       for (int e = 0; e < 4; ++e) ov[e] = Elem<T>::from_f32(v[e]);
       pk[o] = __builtin_bit_cast(u32x2, ov);
+      if constexpr (STATS) {
+        if (whole || (y0 + o < Ho && x0 + lr < Wo)) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float f = Elem<T>::to_f32(ov[e]);  // what BatchNorm will read back
+            st_sum[e] += f, st_sq[e] += f * f;
+          }
+        }
+      }
       acc[o] = bias4;
     }
 #pragma unroll
@@ -505,6 +523,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_hreg_s2_kernel(const HregArgs 
       }
       __builtin_amdgcn_s_barrier();
       stage = stage + 1 == kHrStages ? 0 : stage + 1;
+    }
+  }
+  if constexpr (STATS) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a = st_sum[e], b = st_sq[e];
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) a += __shfl_xor(a, m, 64), b += __shfl_xor(b, m, 64);  // over the 16 pixel lanes of a quarter
+      const int co = nt * 64 + wave * 16 + lq * 4 + e;
+      if (lr == 0 && co < p.Cout) {
+        double* slot = p.stats + (size_t)(1 + sb) * 2 * p.Cout;
+        slot[co] = (double)a, slot[p.Cout + co] = (double)b;
+      }
     }
   }
 }
@@ -543,6 +574,13 @@ static int launch_hreg_s2(const HregArgs& a, hipStream_t st) {
   if (nwork < grid) grid = (int)nwork;
   const int q = 8 * p.tilesN;
   grid = (grid + q - 1) / q * q;
+#ifndef DYOLO_L2E_BUILD
+  if (p.stats) {
+    hipLaunchKernelGGL((conv3x3_hreg_s2_kernel<T, 2, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    note_stats(grid / p.tilesN);  // slots written: one per spatial block (at most 512 + 8 * tilesN - 1 workgroups)
+    return check_launch("conv3x3_hreg_s2_kernel");
+  }
+#endif
   hipLaunchKernelGGL((conv3x3_hreg_s2_kernel<T, 2>), dim3((unsigned)grid), dim3(256), 0, st, p);
   return check_launch("conv3x3_hreg_s2_kernel");
 }
@@ -564,6 +602,7 @@ int conv3x3_hreg_try(const dy_conv_desc* d, hipStream_t st) {
     a.tilesN = d->cout / 64;
     a.nSpatial = d->batch * a.tilesY * a.tilesX;
     a.x_bytes = (unsigned)xb2, a.y_bytes = (unsigned)yb2, a.r_bytes = 0;
+    a.stats = d->y_dtype1 ? nullptr : d->bn_stats;
     return d->dtype == DY_BF16 ? launch_hreg_s2<bf16_t>(a, st) : launch_hreg_s2<f16_t>(a, st);
   }
   if (d->stride != 1) return 1;

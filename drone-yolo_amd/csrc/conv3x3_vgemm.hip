@@ -335,6 +335,9 @@ __global__ __launch_bounds__(512) void conv3x3_vgemm_kernel(const ConvArgs p, co
 // ---- 16-wave variant: the same tile and staging with wave tiles of 32 pixels x 64 couts, four waves per SIMD (<= 128
 // registers each).  The counters of the 8-wave kernel show no saturated unit and 39 % of the wave cycles waiting; more
 // waves hide more of that at the price of 0.75 instead of 0.5 LDS reads per MFMA.
+// (r04: a BatchNorm-statistics epilogue as in conv_gemm_glds.hip was measured here and dropped: its 32 accumulators do not fit beside
+// the tile at the 128-register cap of a 1024-thread workgroup -- 34 spills, 40 -> 64 us on 128 -> 128 @40x40 at B = 64, more than the
+// reduction pass over those 26 MB outputs costs.)
 template <typename T, int PA, int BST>
 __global__ __launch_bounds__(1024) void conv3x3_vgemm16_kernel(const ConvArgs p, const VGeom g) {
   constexpr int EPC = Elem<T>::EPC;
@@ -605,8 +608,8 @@ static int launch_vgemm(const ConvArgs& a, hipStream_t st) {
   } else if (var != 8 && sizeof(T) == 2) {
     // sixteen waves of 32 x 64 hide more of the per-step waits than eight of 64 x 64: 3-5 % faster on every shape in an
     // alternating A/B (tools/ab_conv.sh; 128->128 @40x40 160 -> 151 us, 256->256 @20x20 145 -> 138 us)
-    hipLaunchKernelGGL((conv3x3_vgemm16_kernel<T, 3, 3>), gr, dim3(1024), 0, st, p, g);
     name = "conv3x3_vgemm16_kernel";
+    hipLaunchKernelGGL((conv3x3_vgemm16_kernel<T, 3, 3>), gr, dim3(1024), 0, st, p, g);
   } else {
     hipLaunchKernelGGL((conv3x3_vgemm_kernel<T, 6, 3, false>), gr, bl, 0, st, p, g);
   }

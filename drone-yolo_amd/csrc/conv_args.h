@@ -32,7 +32,13 @@ struct ConvArgs {
   FastDiv dWB, dHW;
   const float* wscale;  // DY_FP8: per-output-channel dequantisation multiplier (act_scale * weight scale), else nullptr
   float act_scale;      // DY_FP8: real value of one activation quantum (x, residual, y); 1 otherwise
+  // optional (training forward in front of a train-mode BatchNorm, dy_conv_desc.bn_stats): a dy_bn_train_fwd workspace; a kernel with
+  // a statistics epilogue stores per-channel sum / sum of squares of its STORED outputs in slot 1 + i of its i-th row block, zeroes
+  // the totals (slot 0) and reports the slot count through note_stats(); the others ignore it
+  double* stats;
+  int stats_atomic;  // conv_gemm_glds.hip: more row blocks than slots -- block i ADDS into slot 1 + i % kStatSlots (the host zeroed them)
 };
+
 
 // conv_gemm_glds.hip: LDS-DMA staged 128 x {64,128} tile.  Returns 1 when the shape is not one it is built for
 // (the caller then runs the generic kernel), else the launch status.

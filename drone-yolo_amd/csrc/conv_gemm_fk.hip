@@ -54,6 +54,8 @@ struct FkArgs {
   float out_scale;        // fp8 output: 1 / act_scale; 1 otherwise
   FastDiv dCin;           // exact division by Cin (tap table)
   int dbg;                // ablate build only (DYOLO_FK_DBG): 1 no MFMAs, 2 no LDS-DMA after the first step, 3 no LDS fragment reads, 4 no epilogue stores
+  double* stats;          // optional (dy_conv_desc.bn_stats, STATS kernels): a dy_bn_train_fwd workspace, row block i fills (or, stats_atomic, adds into) slot 1 + i
+  int stats_atomic;       // more row blocks than slots: block i ADDS into slot 1 + i % kStatSlots (the host zeroed them)
 };
 
 template <typename T> struct FkIsFp8 { static constexpr bool v = std::is_same<T, fp8_t>::value; };
@@ -88,9 +90,12 @@ __device__ __forceinline__ void fk_store4(unsigned char* sp, const float (&v)[4]
 // workgroup writes, once, one word per 16-byte K chunk into LDS — (byte offset of the chunk's tap and channel) << 4 | tap, tap 9 for
 // the zero-padded K tail —, every staged row carries a 9-bit mask of the taps that fall inside the image, and a piece's source
 // offset is (row base + table offset) | (mask bit - 1): an out-of-range offset wherever the tap is padding.
-template <typename T, typename OT, int MFR, int NFR, int WM, int WN, bool RES = false, int TABN = 768>
+// STATS (r04; training forward in front of a train-mode BatchNorm): per-channel sum / sum of squares of the STORED outputs of the tile,
+// as in conv_gemm_glds.hip.
+template <typename T, typename OT, int MFR, int NFR, int WM, int WN, bool RES = false, int TABN = 768, bool STATS = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs p) {
   constexpr bool MX = FkIsFp8<T>::v;
+  static_assert(!STATS || (!RES && !MX && sizeof(OT) == 2), "STATS: 16-bit storage, no residual");
   constexpr int EPC = Elem<T>::EPC;
   constexpr int NW = WM * WN;
   constexpr int BM = WM * MFR * 16, BN = WN * NFR * 16;
@@ -311,6 +316,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
   const T* __restrict__ rg = reinterpret_cast<const T*>(p.res);
   const int n0 = tileN * BN + wn * NFR * 16;
   constexpr int OEPC = 16 / OES;  // output elements per 16-byte chunk
+  float st_sum[STATS ? NFR : 1][4], st_sq[STATS ? NFR : 1][4];
+  if constexpr (STATS) {
+#pragma unroll
+    for (int j = 0; j < NFR; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) st_sum[j][e] = 0.f, st_sq[j][e] = 0.f;
+    if (blockIdx.x == 0)  // the totals bn_sum_partials_kernel adds the slots into
+      for (int i = tid; i < 2 * p.Cout; i += NW * 64) p.stats[i] = 0.0;
+  }
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
     const int m0 = tileM * BM + wm * MFR * 16 + h * PXP;
@@ -339,6 +353,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
             for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
           }
           fk_store4<OT>(escr + (ii * 16 + lr) * EP_PITCH + (j * 16 + lq * 4) * OES, v);
+          if constexpr (STATS) {
+            if (m0 + ii * 16 + lr < p.M) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float f = Elem<OT>::to_f32(Elem<OT>::from_f32(v[e]));  // what BatchNorm will read back
+                st_sum[j][e] += f, st_sq[j][e] += f * f;
+              }
+            }
+          }
         }
       }
     }
@@ -378,6 +401,40 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   }
+  if constexpr (STATS) {
+    float* sred = reinterpret_cast<float*>(smem);  // [WM][2][BN]
+#pragma unroll
+    for (int j = 0; j < NFR; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) st_sum[j][e] += __shfl_xor(st_sum[j][e], m, 64), st_sq[j][e] += __shfl_xor(st_sq[j][e], m, 64);
+      }
+    __syncthreads();  // every wave is done with its transpose scratch
+    if (lr == 0) {
+#pragma unroll
+      for (int j = 0; j < NFR; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int cc = wn * NFR * 16 + j * 16 + lq * 4 + e;
+          sred[(wm * 2 + 0) * BN + cc] = st_sum[j][e];
+          sred[(wm * 2 + 1) * BN + cc] = st_sq[j][e];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * BN; i += NW * 64) {
+      const int which = i / BN, cc = i - which * BN;
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < WM; ++k) t += sred[(k * 2 + which) * BN + cc];
+      const int co = tileN * BN + cc;
+      if (co < p.Cout) {
+        double* dst = p.stats + (size_t)(1 + (p.stats_atomic ? tileM % kStatSlots : tileM)) * 2 * p.Cout + which * p.Cout + co;
+        if (p.stats_atomic) unsafeAtomicAdd(dst, (double)t);  // (global_atomic_add_f64; atomicAdd compiles to a compare-and-swap loop)
+        else *dst = (double)t;
+      }
+    }
+  }
 }
 
 template <typename T, typename OT, int MFR, int NFR, int WM, int WN, int TABN>
@@ -392,6 +449,17 @@ static int launch_fk(const FkArgs& a, hipStream_t st, const char* name) {
       hipLaunchKernelGGL((conv_gemm_fk_kernel<T, OT, MFR, NFR, WM, WN, true, TABN>), dim3((unsigned)p.nblk), dim3(WM * WN * 64), 0, st, p);
       return check_launch(name);
     }
+#ifndef DYOLO_L2E_BUILD  // (training convolutions carry no activation: they never come through the scaled-domain build)
+    if constexpr (sizeof(T) == 2) {
+      if (p.stats != nullptr) {
+        p.stats_atomic = tilesM > kStatSlots ? 1 : 0;  // (32 -> 64 1x1 stride 2 @320 at B = 64: 12,800 row blocks)
+        if (p.stats_atomic) zero_async(p.stats, (size_t)(1 + kStatSlots) * 2 * p.Cout * sizeof(double), st);
+        hipLaunchKernelGGL((conv_gemm_fk_kernel<T, OT, MFR, NFR, WM, WN, false, TABN, true>), dim3((unsigned)p.nblk), dim3(WM * WN * 64), 0, st, p);
+        note_stats(p.stats_atomic ? kStatSlots : tilesM);
+        return check_launch(name);
+      }
+    }
+#endif
   }
   hipLaunchKernelGGL((conv_gemm_fk_kernel<T, OT, MFR, NFR, WM, WN, false, TABN>), dim3((unsigned)p.nblk), dim3(WM * WN * 64), 0, st, p);
   return check_launch(name);
@@ -464,6 +532,7 @@ int conv_gemm_fk_try(const dy_conv_desc* d, hipStream_t st) {
   a.dCin = make_fastdiv((unsigned)d->cin);
   if (d->ksize == 3 && ((long long)(2 * d->w_in + 2) * d->ld_x + d->cin) * es >= (1ll << 28)) return 1;  // table words hold a 28-bit byte offset
   a.dbg = dy_ablate("DYOLO_FK_DBG");
+  a.stats = d->y_dtype1 ? nullptr : d->bn_stats;
   a.res_scale = in8 ? d->act_scale : 1.f;
   a.out_scale = out8 ? 1.f / d->act_scale : 1.f;
   if (in8) return out8 ? launch_fk_tiles<fp8_t, fp8_t>(a, st) : launch_fk_tiles<fp8_t, f16_t>(a, st);

@@ -29,7 +29,11 @@ __device__ __attribute__((aligned(256))) const unsigned int g_zero_page[64] = {0
 // BM x BN tile, WM x 2 waves (wave tile 64 x BN/2), STAGES LDS stages.  STAGES == 2: plain barrier per K-step, one step of
 // DMA in flight (2 workgroups per CU cover for each other).  STAGES == 3: two steps in flight behind a counted
 // s_waitcnt vmcnt(N) and a raw s_barrier (a __syncthreads() would drain the DMA), one 8-wave workgroup per CU.
-template <typename T, int BM, int BN, int STAGES, int WN = 2>
+// STATS (r04; training forward, the convolution in front of a train-mode BatchNorm): per-channel sum / sum of squares of the STORED
+// outputs of this tile go to slot tileM of the dy_bn_train_fwd workspace (ConvArgs.stats), so the BatchNorm needs no reduction pass
+// over z (conv3x3_hreg.hip / conv1x1_stream.hip do the same): a lane keeps its four channels of each fragment over the tile's rows,
+// the 16 pixel lanes of a quarter meet in a shuffle tree, the BM/64 wave rows in LDS.
+template <typename T, int BM, int BN, int STAGES, int WN = 2, bool STATS = false>
 __global__ __launch_bounds__(BM * WN) void conv_gemm_glds_kernel(const ConvArgs p) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr int NW = BM / 64 * WN;      // waves: BM/64 along M x WN along N (WN = 4: 64 x BN/4 wave tiles, twice the waves per SIMD)
@@ -288,6 +292,16 @@ __global__ __launch_bounds__(BM * WN) void conv_gemm_glds_kernel(const ConvArgs 
     const unsigned xo = rem - yo * (unsigned)p.WB;
     return (int)((n * (unsigned)p.H + 2u * yo + (unsigned)cpy) * (unsigned)p.W + 2u * xo + (unsigned)cpx);
   };
+  float st_sum[STATS ? NFR : 1][4], st_sq[STATS ? NFR : 1][4];
+  if constexpr (STATS) {
+    static_assert(!STATS || sizeof(T) == 2, "STATS: 16-bit outputs");
+#pragma unroll
+    for (int j = 0; j < NFR; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) st_sum[j][e] = 0.f, st_sq[j][e] = 0.f;
+    if (blockIdx.x == 0)  // the totals bn_sum_partials_kernel adds the slots into
+      for (int i = tid; i < 2 * p.Cout; i += BM * WN) p.stats[i] = 0.0;
+  }
 #pragma unroll
   for (int g = 0; g < NFR / EG; ++g) {
 #pragma unroll
@@ -321,6 +335,15 @@ __global__ __launch_bounds__(BM * WN) void conv_gemm_glds_kernel(const ConvArgs 
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f32(v[e]);
             *reinterpret_cast<u32x2*>(sp) = __builtin_bit_cast(u32x2, o);
+            if constexpr (STATS) {
+              if (m0 + i * 16 + lr < p.M) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float f = Elem<T>::to_f32(o[e]);  // what BatchNorm will read back
+                  st_sum[j][e] += f, st_sq[j][e] += f * f;
+                }
+              }
+            }
           }
         }
       }
@@ -340,6 +363,41 @@ __global__ __launch_bounds__(BM * WN) void conv_gemm_glds_kernel(const ConvArgs 
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+  if constexpr (STATS) {
+    constexpr int WM = BM / 64;
+    float* sred = reinterpret_cast<float*>(smem);  // [WM][2][BN]
+#pragma unroll
+    for (int j = 0; j < NFR; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) st_sum[j][e] += __shfl_xor(st_sum[j][e], m, 64), st_sq[j][e] += __shfl_xor(st_sq[j][e], m, 64);
+      }
+    __syncthreads();  // every wave is done with its transpose scratch
+    if (lr == 0) {
+#pragma unroll
+      for (int j = 0; j < NFR; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int cc = wn * (BN / WN) + j * 16 + lq * 4 + e;
+          sred[(wm * 2 + 0) * BN + cc] = st_sum[j][e];
+          sred[(wm * 2 + 1) * BN + cc] = st_sq[j][e];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * BN; i += BM * WN) {
+      const int which = i / BN, cc = i - which * BN;
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < WM; ++k) t += sred[(k * 2 + which) * BN + cc];
+      const int co = tileN * BN + cc;
+      if (co < p.Cout) {
+        double* dst = p.stats + (size_t)(1 + (p.stats_atomic ? tileM % kStatSlots : tileM)) * 2 * p.Cout + which * p.Cout + co;
+        if (p.stats_atomic) unsafeAtomicAdd(dst, (double)t);  // (global_atomic_add_f64; atomicAdd compiles to a compare-and-swap loop)
+        else *dst = (double)t;
+      }
     }
   }
 }
@@ -568,6 +626,21 @@ static int launch_glds_persist(const ConvArgs& a, hipStream_t st) {
 template <typename T, int BM, int BN, int STAGES, int WN = 2>
 static int launch_glds(const ConvArgs& a, hipStream_t st) {
   ConvArgs p = a;
+#ifndef DYOLO_L2E_BUILD  // (training convolutions carry no activation: they never come through the scaled-domain build)
+  if constexpr (sizeof(T) == 2 && BM * WN <= 1024 && !(BM == 256 && BN == 128)) {
+    if (p.stats && !p.dil_cls && !p.res) {
+      const int tilesM = (p.M + BM - 1) / BM;
+      p.tilesN = (p.Cout + BN - 1) / BN;
+      p.nblk = tilesM * p.tilesN;
+      p.stats_atomic = tilesM > kStatSlots ? 1 : 0;  // (64 -> 128 1x1 stride 2 @160 at B = 64: 3,200 row blocks)
+      if (p.stats_atomic) zero_async(p.stats, (size_t)(1 + kStatSlots) * 2 * p.Cout * sizeof(double), st);
+      auto kern = conv_gemm_glds_kernel<T, BM, BN, STAGES, WN, true>;
+      hipLaunchKernelGGL(kern, dim3((unsigned)p.nblk), dim3(BM * WN), 0, st, p);
+      note_stats(p.stats_atomic ? kStatSlots : tilesM);
+      return check_launch("conv_gemm_glds_kernel<stats>");
+    }
+  }
+#endif
   int tilesM = (p.M + BM - 1) / BM;
   if (p.dil_cls) {  // one tile = one parity class of the output (conv_args.h)
     p.tilesPerClass = (p.Mq + BM - 1) / BM;
@@ -586,7 +659,7 @@ static int launch_glds_dtype(const ConvArgs& a, hipStream_t st) {
   static const int big = dy_ablate("DYOLO_GLDS_BIG");  // 1: 256x128 three-stage, 2: never persistent, 3: always persistent
   // short K (<= 9 steps, the 64-channel stride-2 layers on 160x160 maps: thousands of tiles) measured faster one tile per
   // workgroup; everything else gains 3-14 % from the persistent walk with the next tile's first K-step prefetched
-  const bool persist = big != 2 && !a.dil_cls && a.Cout % 64 == 0 && (big == 3 || a.Kpad > 9 * 8 * (16 / (int)sizeof(T)));  // (the parity-class tiling lives in the plain kernel)
+  const bool persist = big != 2 && !a.dil_cls && !a.stats && a.Cout % 64 == 0 && (big == 3 || a.Kpad > 9 * 8 * (16 / (int)sizeof(T)));  // (the parity-class tiling lives in the plain kernel)
   // 256 x 256 tiles (one workgroup per CU; sixteen waves of 64 x 64 = four per SIMD measured 5-14 % faster than eight of 64 x 128:
   // the kernels are wait-bound, not LDS-bound) halve the gathered-operand bytes per flop: 4-19 % faster on
   // the wide 1x1 layers and the 256-cout stride-2 layers at throughput batch sizes (512->256 @40x40: 241 -> 204 us); slower on

@@ -412,6 +412,7 @@ int32_t conv2d_entry(const dy_conv_desc* d, dy_stream_t stream) {
   a.HoWo = ho * wo;
   a.act = d->act;
   a.up2x = d->up2x;  // 0 plain, 1 nearest-upsampled source, 2 zero-dilated source (stride-2 transposed conv)
+  a.stats = (d->out_f32 || d->y_dtype1) ? nullptr : d->bn_stats;  // (kernels without a statistics epilogue ignore it: dy_conv_stats_written() stays 0)
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
   if (d->dtype == DY_FP8) {

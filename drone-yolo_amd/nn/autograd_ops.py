@@ -32,6 +32,7 @@ def as_nhwc(t: torch.Tensor) -> torch.Tensor:
 
 
 CONV_STATS = [os.environ.get("DYOLO_CONV_STATS", "1") != "0"]  # BatchNorm statistics from convolution epilogues (conv_bn_fwd)
+STATS_LOG = [None]  # tools/train_stats_census.py: a list here collects (weight shape, stride, input shape, kernel, slots) of every conv_bn_fwd
 
 
 def conv_bn_fwd(x, weight, gamma, beta, bn, stride, pad, act, out=None, stem_u8=None):
@@ -47,6 +48,8 @@ def conv_bn_fwd(x, weight, gamma, beta, bn, stride, pad, act, out=None, stem_u8=
         pc = H.PackedConv(weight, H.zero_bias(weight.shape[0], dev), stride, pad, 1, False, dtype, dev, cin_pad=cin_pad)
         z = H.conv2d(x, pc, bn_stats=st if CONV_STATS[0] else None)
         slabs = H.conv_stats_written() if CONV_STATS[0] else 0
+        if STATS_LOG[0] is not None:
+            STATS_LOG[0].append((tuple(weight.shape), stride, tuple(x.shape), H.last_kernel_name(), slabs))
     y = H.bn_train_fwd(z, gamma, beta, st, act, eps=bn.eps, momentum=bn.momentum, running_mean=bn.running_mean, running_var=bn.running_var, out=out,
                        partial_slabs=slabs)
     return z, st, y
@@ -262,12 +265,20 @@ class RepVGGTrain(torch.autograd.Function):
     def forward(ctx, x, w3, g3, b3, w1, g1, b1, bn3, bn1, stride):
         dtype, dev = x.dtype, x.device
         zero = lambda w: H.zero_bias(w.shape[0], dev)  # noqa: E731
-        z3 = H.conv2d(x, H.PackedConv(w3, zero(w3), stride, 1, 1, False, dtype, dev))
-        z1 = H.conv2d(x, H.PackedConv(w1, zero(w1), stride, 0, 1, False, dtype, dev, halo=False))
         s3, s1 = H.BnState(w3.shape[0], dev), H.BnState(w1.shape[0], dev)
-        u3 = H.bn_train_fwd(z3, g3, b3, s3, False, eps=bn3.eps, momentum=bn3.momentum, running_mean=bn3.running_mean, running_var=bn3.running_var)
+        st = CONV_STATS[0]  # batch statistics from the convolutions' epilogues where the launched kernel has one (conv_bn_fwd)
+        z3 = H.conv2d(x, H.PackedConv(w3, zero(w3), stride, 1, 1, False, dtype, dev), bn_stats=s3 if st else None)
+        n3 = H.conv_stats_written() if st else 0
+        if STATS_LOG[0] is not None:
+            STATS_LOG[0].append((tuple(w3.shape), stride, tuple(x.shape), H.last_kernel_name(), n3))
+        z1 = H.conv2d(x, H.PackedConv(w1, zero(w1), stride, 0, 1, False, dtype, dev, halo=False), bn_stats=s1 if st else None)
+        n1 = H.conv_stats_written() if st else 0
+        if STATS_LOG[0] is not None:
+            STATS_LOG[0].append((tuple(w1.shape), stride, tuple(x.shape), H.last_kernel_name(), n1))
+        u3 = H.bn_train_fwd(z3, g3, b3, s3, False, eps=bn3.eps, momentum=bn3.momentum, running_mean=bn3.running_mean, running_var=bn3.running_var,
+                            partial_slabs=n3)
         u = H.bn_train_fwd(z1, g1, b1, s1, False, eps=bn1.eps, momentum=bn1.momentum, running_mean=bn1.running_mean, running_var=bn1.running_var,
-                           addend=u3)
+                           addend=u3, partial_slabs=n1)
         y = H.silu_fwd(u)
         ctx.save_for_backward(x, z3, z1, u, w3, g3, b3, w1, g1, b1)
         ctx.s3, ctx.s1, ctx.stride = s3, s1, stride
