@@ -260,6 +260,7 @@ class PackCache:
         self.table = None         # (device table, n_jobs, total_blocks, job order)
         self.dirty = False
         self.gen = 0
+        self._retired = []  # superseded job tables (see _build)
 
     def lookup(self, job):
         e = self.jobs.get(job)
@@ -286,6 +287,10 @@ class PackCache:
         host = torch.empty(nbytes, dtype=torch.uint8)
         blocks = C.c_int32(0)
         check(L.dy_pack_conv_weights_table(arr, n, dy_dtype(self.dtype), host.data_ptr(), nbytes, C.byref(blocks)), "dy_pack_conv_weights_table")
+        if self.table is not None:
+            # a captured step graph has the old table's device address baked into its dy_pack_conv_weights_batched node: a table that
+            # was ever launched stays allocated for the life of the cache (a few KB each; rebuilt only when a new layer shape appears)
+            self._retired.append(self.table[0])
         self.table = (host.to(self.device), n, int(blocks.value), order)
         self.dirty = False
 
@@ -661,7 +666,7 @@ def stem_conv_u8(img: torch.Tensor, weight: torch.Tensor, dtype: torch.dtype, di
     cout, cin = weight.shape[0], weight.shape[1]
     if img.dtype != torch.uint8 or not img.is_contiguous() or img.shape[1] != cin or tuple(weight.shape[2:]) != (3, 3) or cout % 16 or cout > 80:
         raise ValueError("stem_conv_u8: contiguous uint8 (N, cin, H, W) image, (cout % 16 == 0, cin, 3, 3) weights")
-    key = (weight.data_ptr(), dtype, str(img.device))
+    key = (weight.data_ptr(), cout, cin, dtype, str(img.device))  # (an address may be handed to another model's stem of another width later)
     ent = _STEM_TRAIN_W.get(key)
     if ent is None:
         ent = _STEM_TRAIN_W[key] = (torch.zeros((cout, 32), dtype=dtype, device=img.device), zero_bias(cout, img.device))
@@ -1162,6 +1167,7 @@ def conv_wgrad(x: torch.Tensor, dz: torch.Tensor, ksize: int, stride: int, pad: 
 
 
 _WGRAD_WS: dict = {}
+_WGRAD_WS_RETIRED: list = []
 
 
 def _wgrad_workspace(device, need: int) -> torch.Tensor:
@@ -1170,6 +1176,8 @@ def _wgrad_workspace(device, need: int) -> torch.Tensor:
     key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     ws = _WGRAD_WS.get(key)
     if ws is None or ws.numel() < need:
+        if ws is not None:
+            _WGRAD_WS_RETIRED.append(ws)  # a captured step graph may still replay launches that write the smaller buffer: it stays allocated
         ws = _WGRAD_WS[key] = torch.empty(max(need, 48 << 20), dtype=torch.uint8, device=device)
     return ws
 
