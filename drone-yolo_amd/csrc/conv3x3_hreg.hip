@@ -63,7 +63,7 @@ constexpr int kHrStages = 3;
 // the 2 x Cout totals from ~770 workgroups serialise: +0.7 ms per step, measured) -- instead of a separate pass that reads the whole
 // map again (dy_bn_train_fwd's reduction: 1.4 of 10 ms of BatchNorm per step at B = 64).
 template <typename T, int NCH, bool RES, bool STATS = false>
-__global__ __launch_bounds__(256, 3) void conv3x3_hreg_kernel(const HregArgs p) {
+__global__ __launch_bounds__(256, NCH <= 2 ? 3 : 2) void conv3x3_hreg_kernel(const HregArgs p) {
   constexpr int EPC = Elem<T>::EPC;  // 8
   __shared__ __attribute__((aligned(1024))) unsigned char smem[kHrStages * kHrStage];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -544,7 +544,9 @@ template <typename T>
 static int launch_hreg(const HregArgs& a, hipStream_t st) {
   HregArgs p = a;
   const int nch = p.Cin / 32;
-  int grid = 256 * 3;  // three 256-thread workgroups per CU (48 KB of LDS and <= 168 VGPRs each)
+  // three 256-thread workgroups per CU (48 KB of LDS and <= 168 VGPRs each); r04, 128 input channels (four chunks: 144 weight registers):
+  // two per CU with up to 256 registers
+  int grid = 256 * (nch <= 2 ? 3 : 2);
   const long long nwork = (long long)p.nSpatial * p.tilesN;
   if (nwork < grid) grid = (int)nwork;
   const int q = 8 * p.tilesN;
@@ -552,16 +554,19 @@ static int launch_hreg(const HregArgs& a, hipStream_t st) {
   const bool res = p.res != nullptr;
   if (p.stats) {  // conv3x3_hreg_try admits it without a residual only
     if (nch == 1) hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 1, false, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 2, false, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    else if (nch == 2) hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 2, false, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 4, false, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
     note_stats(grid / p.tilesN);  // slots written: one per spatial block
     return check_launch("conv3x3_hreg_kernel");
   }
   if (nch == 1) {
     if (res) hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 1, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 1, false>), dim3((unsigned)grid), dim3(256), 0, st, p);
-  } else {
+  } else if (nch == 2) {
     if (res) hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 2, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 2, false>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  } else {
+    hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 4, false>), dim3((unsigned)grid), dim3(256), 0, st, p);  // (no residual: conv3x3_hreg_try)
   }
   return check_launch("conv3x3_hreg_kernel");
 }
@@ -610,7 +615,7 @@ int conv3x3_hreg_try(const dy_conv_desc* d, hipStream_t st) {
   // @20 29 -> 18, 64->128 @80 285 -> 268; cin 32 (one chunk per tile: an epilogue every item) 205-250 -> 227-252: no gain, stays on
   // the halo kernel; with a Bottleneck residual (halo -> this kernel): 8-byte gathers 210 -> 237 @80, 16-byte pieces per row pair 187 -> 203:
   // stays there too
-  if (d->cin != 64 || d->cout % 64 != 0 || d->cout > 256 || d->residual) return 1;
+  if ((d->cin != 64 && d->cin != 128) || d->cout % 64 != 0 || d->cout > 256 || d->residual) return 1;
   if (d->ho != d->h || d->wo != d->w_in) return 1;
   const long long xb = (long long)d->batch * d->h * d->w_in * d->ld_x * 2, yb = (long long)d->batch * d->ho * d->wo * d->ld_y * 2;
   const long long rb = d->residual ? (long long)d->batch * d->ho * d->wo * d->ld_res * 2 : 0;

@@ -310,6 +310,7 @@ class PackCache:
 
 
 _PACK_CACHE = {"active": None}
+HREG_128 = [os.environ.get("DYOLO_HREG_128", "1") != "0"]  # see PackedConv: 128-channel 3x3 layers on the register-weight kernel (0: the virtual-flat GEMM, for A/B runs)
 FLAT_K_3X3 = [os.environ.get("DYOLO_FLAT_K_3X3", "1") != "0"]  # see PackedConv: odd-width 3x3 layers on the flat-K kernel (0: the halo kernel, for A/B runs)
 
 
@@ -419,8 +420,12 @@ class PackedConv:
         # deep 3x3 layers (small maps, weight sets far beyond LDS) run faster as a flat-M implicit GEMM on the LDS-DMA
         # big-tile kernel behind DY_WLAYOUT_ROWS (conv_gemm_glds.hip): measured at batch 128, 256->256 @20x20 90 vs 162 us
         kstep = 8 * elems_per_chunk(dtype)
+        # r04: 128 input channels fit the register-weight kernel too (four 32-channel chunks: 144 weight registers, two workgroups per CU):
+        # 128->128 @40x40 149 -> 136 us, @80x80 543 -> 437 us (1,100 TFLOP/s) at B = 256 against the virtual-flat GEMM
+        hreg128 = HREG_128[0] and halo is None and k == 3 and stride == 1 and pad == 1 and groups == 1 and dtype in (torch.bfloat16, torch.float16) and \
+            self.cin == 128 and cout % 64 == 0 and cout <= 256
         deep3x3 = halo is None and k == 3 and stride == 1 and self.cin % kstep == 0 and cout % 64 == 0 and \
-            self.cin >= 128 and cout >= 128
+            self.cin >= 128 and cout >= 128 and not hreg128
         # (r04: deep layers whose cout is no multiple of 128 — scale x: 320 -> 320 — take the flat-K kernel's 160-wide tiles behind the same
         # layout (csrc/conv_igemm.hip: fk_first): 19.09 -> 18.68 ms per x1536 pass against the halo kernel, 536 -> 860 TFLOP/s against the
         # 64-cout persistent tiles of the tap-aligned kernel)
@@ -515,6 +520,9 @@ class PackedConv:
             return self.rows()
         if self.stride == 2 and self.cin == 64 and self.cout > 32:
             if residual or out_f32 or ld_y % 8 or y_ptr % 16 or x_bytes >= (1 << 31) or y_bytes >= (1 << 32) - 64 or self.dtype == torch.float32:
+                return self.rows()
+        if self.stride == 1 and self.cin == 128:  # packed for conv3x3_hreg's four-chunk form: what it declines runs on the virtual-flat GEMM
+            if residual or out_f32 or ld_y % 8 or y_ptr % 16 or x_bytes >= (1 << 31) or y_bytes >= (1 << 32) - 64:
                 return self.rows()
         return self
 

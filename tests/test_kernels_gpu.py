@@ -71,6 +71,10 @@ CONV_CASES = [
     (64, 128, 3, 2, 3, 33, 31, True, "hreg s2 64->128 odd dims"),
     (64, 64, 3, 2, 1, 8, 8, False, "hreg s2 tiny no act"),
     (64, 64, 3, 2, 2, 160, 160, True, "hreg s2 many tiles"),
+    (128, 128, 3, 1, 2, 40, 40, True, "hreg 128->128 (four chunks in registers)"),
+    (128, 64, 3, 1, 3, 33, 31, True, "hreg 128->64 odd dims"),
+    (128, 256, 3, 1, 1, 8, 16, False, "hreg 128->256 tiny no act"),
+    (128, 128, 3, 1, 24, 80, 80, True, "hreg 128->128 many tiles per block"),
 ]
 
 
@@ -129,6 +133,35 @@ def test_halo_layout_pack_falls_back_to_rows_for_calls_its_kernels_refuse(how, d
     y2 = H.conv2d(nhwc(quantize(torch.randn(b, cin, h, w, generator=g), dtype), dtype, device), pc)  # the plain call still takes the fast kernel
     torch.cuda.synchronize()
     assert H.last_kernel_name().startswith("conv3x3_hreg_s2") and tuple(y2.shape) == (b, cout, h // 2, w // 2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("how", ["plain", "residual", "out_f32", "unaligned_out"])
+def test_128_channel_3x3_runs_on_the_register_weight_kernel_or_its_rows_twin(how, dtype, device):
+    """r04: a 16-bit 3x3 stride-1 layer with 128 input channels is packed for conv3x3_hreg's four-chunk form (DY_WLAYOUT_HALO3X3).  The
+    plain call runs there; what that kernel declines (residual, fp32 output, an output pitch without 16-byte rows) runs on the pack's
+    DY_WLAYOUT_ROWS twin (the virtual-flat GEMM / LDS-DMA GEMM).  Every call against the fp32 CPU convolution."""
+    g = torch.Generator().manual_seed(zlib.crc32(("h128" + how).encode()) % 1000)
+    b, cin, cout, h, w = 2, 128, 128, 24, 20
+    wt = quantize(torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5, dtype)
+    bias = torch.randn(cout, generator=g) * 0.2
+    pc = H.PackedConv(wt, bias, 1, 1, 1, True, dtype, device)
+    assert pc.layout == H._lib.DY_WLAYOUT_HALO3X3
+    x = quantize(torch.randn(b, cin, h, w, generator=g), dtype)
+    ref = F.silu(F.conv2d(x, wt, bias, 1, 1))
+    kw = {}
+    if how == "residual":
+        r = quantize(torch.randn(ref.shape, generator=g), dtype)
+        ref, kw = ref + r, {"residual": nhwc(r, dtype, device)}
+    elif how == "out_f32":
+        kw = {"out_f32": True}
+    elif how == "unaligned_out":
+        kw = {"out": nhwc(torch.zeros(ref.shape), dtype, device, ld=cout + 4)}
+    y = H.conv2d(nhwc(x, dtype, device), pc, **kw)
+    torch.cuda.synchronize()
+    name = H.last_kernel_name()
+    assert name.startswith("conv3x3_hreg") if how == "plain" else not name.startswith("conv3x3_h"), name
+    check_close(back(y), ref, dtype, f"hreg128 {how}", extra=2.0 if how == "residual" else 1.0)
 
 
 FK_CASES = [
@@ -205,7 +238,7 @@ GLDS_CASES = [
 ]
 
 
-L2E_CASES = [(64, 64, 3, 1, 2, 40, 36, "hreg / halo 3x3"), (32, 64, 3, 2, 2, 40, 40, "halo s2"), (128, 128, 3, 1, 2, 20, 20, "vgemm"), (256, 256, 1, 1, 2, 40, 40, "glds 1x1"),
+L2E_CASES = [(64, 64, 3, 1, 2, 40, 36, "hreg / halo 3x3"), (32, 64, 3, 2, 2, 40, 40, "halo s2"), (256, 256, 3, 1, 2, 20, 20, "vgemm"), (128, 128, 3, 1, 2, 20, 20, "hreg 128"), (256, 256, 1, 1, 2, 40, 40, "glds 1x1"),
              (192, 128, 1, 1, 2, 40, 40, "stream 1x1"), (16, 24, 3, 1, 1, 12, 12, "generic"), (128, 256, 3, 2, 2, 20, 20, "glds s2")]
 
 
