@@ -614,7 +614,9 @@ int conv3x3_hreg_try(const dy_conv_desc* d, hipStream_t st) {
   // measured (B = 256, alternating A/B against conv3x3_halo, tools/bench_conv.py): 64->64 @160 650 -> 598 us, @80 150 -> 141, @40 55 -> 42,
   // @20 29 -> 18, 64->128 @80 285 -> 268; cin 32 (one chunk per tile: an epilogue every item) 205-250 -> 227-252: no gain, stays on
   // the halo kernel; with a Bottleneck residual (halo -> this kernel): 8-byte gathers 210 -> 237 @80, 16-byte pieces per row pair 187 -> 203:
-  // stays there too
+  // stays there too (r04, measured again in the model at B = 256 with the residual form at two workgroups per CU, no spills, and the loads
+  // requested a whole item earlier: 64->64 @80 178 -> 230 us, 128->128 @40 177 -> 240 us -- a wave's residual read is 64 16-byte pieces of 32
+  // pixel rows, and every in-order vmcnt wait behind it pays for that; the latency was not the cost)
   if ((d->cin != 64 && d->cin != 128) || d->cout % 64 != 0 || d->cout > 256 || d->residual) return 1;
   if (d->ho != d->h || d->wo != d->w_in) return 1;
   const long long xb = (long long)d->batch * d->h * d->w_in * d->ld_x * 2, yb = (long long)d->batch * d->ho * d->wo * d->ld_y * 2;
