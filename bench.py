@@ -627,11 +627,13 @@ def main():
                                                                 "note": f"headline: {ns} batches in flight"}]
     train = None
     if world == 1 and not a.bare and not a.no_train and a.imgsz == 640 and "yolov8s-p2-repvgg" in a.model:
-        # SURVEY §8(d) config 3 in the driver's record: 10 graphed training steps at B = 64 (bf16 storage), after the inference state is gone
+        # SURVEY §8(d) config 3 in the driver's record: 30 graphed training steps at B = 64 (bf16 storage), after the inference state is gone
+        # (r04: 10 steps after 4 warm-up steps read 29.5 ms on one box and 34.1 on the next -- 0.3 s is too short a window beside the
+        # allocator's and the graph's first replays; `python bench.py --mode train` always timed 30)
         del preds, xs, cfs, pred, x, cf
         torch.cuda.empty_cache()
-        dt_t, enq_t, loss_t, tr = train_steps(a.model, 64, "bf16", 10, 4, rank, world, dev)
-        train = train_record(a, dt_t, enq_t, loss_t, tr, 64, world, 10, 4, "bf16")
+        dt_t, enq_t, loss_t, tr = train_steps(a.model, 64, "bf16", 30, 6, rank, world, dev)
+        train = train_record(a, dt_t, enq_t, loss_t, tr, 64, world, 30, 6, "bf16")
         del tr
         torch.cuda.empty_cache()
     cpu = None
