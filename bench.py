@@ -339,6 +339,22 @@ def synthetic_labels(batch: int, seed: int, nc: int = 10):
     return dict(batch_idx=bi, cls=cls, bboxes=torch.cat((cxy, wh), 1))
 
 
+def cpu_throttle_stat() -> dict:
+    """nr_periods / nr_throttled / throttled time of this process's CPU cgroup (v2 or v1); {} where the file is not readable.  A GPU box gives
+    the job a CFS quota (16 cores of a larger host): threads that spin past it are parked until the next 100 ms period."""
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat", "/sys/fs/cgroup/cpu,cpuacct/cpu.stat"):
+        try:
+            out = {}
+            for line in open(path):
+                k, _, v = line.partition(" ")
+                if k in ("nr_periods", "nr_throttled", "throttled_usec", "throttled_time"):
+                    out[k] = int(v)
+            return out
+        except OSError:
+            continue
+    return {}
+
+
 def train_steps(model_yaml: str, batch: int, dtype: str, steps: int, warmup: int, rank: int, world: int, dev):
     """K timed training steps on this rank: returns (seconds max-over-ranks, host enqueue seconds, loss, trainer)."""
     import drone_yolo_amd as D
@@ -355,13 +371,41 @@ def train_steps(model_yaml: str, batch: int, dtype: str, steps: int, warmup: int
         tr.step(b)
     P.barrier()
     torch.cuda.synchronize()
+    import gc
+
+    gc_log, it0 = [], tr.iters
+
+    def _gc_cb(phase, info, _t=[0.0]):  # collector pauses inside the timed loop: [generation, ms, iteration]
+        if phase == "start":
+            _t[0] = time.perf_counter()
+        else:
+            gc_log.append([info["generation"], round((time.perf_counter() - _t[0]) * 1e3, 3), tr.iters - it0])
+
+    gc.callbacks.append(_gc_cb)
+    thr0 = cpu_throttle_stat()
+    tr.host_phases = {}  # host seconds per phase of the graphed step (engine/trainer.py::_tick)
+    tr._tick_last = None
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]  # device timeline: one event between consecutive steps
     t0 = time.perf_counter()
-    for _ in range(steps):
+    ev[0].record()
+    for i in range(steps):
         loss, items = tr.step(b)
+        ev[i + 1].record()
     t_enq = time.perf_counter() - t0  # the host's share: all launches of the K steps are queued (or a step made the host wait)
     torch.cuda.synchronize()
     P.barrier()
     dt = P.max_over_ranks(time.perf_counter() - t0, dev)
+    per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+    thr1 = cpu_throttle_stat()
+    tr.bench_gpu = {"gpu_ms_per_step": round(ev[0].elapsed_time(ev[steps]) / steps, 3), "gpu_ms_per_step_median": round(per[len(per) // 2], 3),
+                    "gpu_ms_per_step_min_max": [round(per[0], 3), round(per[-1], 3)],
+                    "host_phase_ms_per_step": {k: round(v / steps * 1e3, 3) for k, v in tr.host_phases.items() if k != "__max__"},
+                    "host_phase_max_ms": {k: [round(v[0] * 1e3, 3), v[1] - it0] for k, v in tr.host_phases.get("__max__", {}).items()},
+                    "gpu_ms_by_step": [round(ev[i].elapsed_time(ev[i + 1]), 2) for i in range(steps)], "gc_pauses": gc_log,
+                    "host": {"torch_threads": torch.get_num_threads(), "os_cpu_count": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)),
+                             "cfs_throttle_during_timed_steps": {k: v - thr0.get(k, 0) for k, v in thr1.items()}}}
+    gc.callbacks.remove(_gc_cb)
+    tr.host_phases = None
     return dt, t_enq, float(loss), tr
 
 
@@ -377,6 +421,9 @@ def train_record(a, dt, t_enq, loss, tr, batch, world, steps, warmup, dtype):
                       "parallelism": f"data parallel x{world}" + (f", {len(tr.buckets.buckets)} gradient buckets all-reduced as backward produces them" if tr.buckets is not None else ", single rank (no exchange)"),
                       "step_form": tr.step_form(), "loss": round(loss, 3)},
            "flops_per_image_G": 111.2, "mfma_frac": round(111.2e9 * total / dt / 1e12 / MFMA_PEAK_TFLOPS.get(dtype, 2500.0), 4)}
+    # gpu_ms_per_step: HIP events between consecutive steps on the launch stream (the device's own timeline: equal to the wall time when the
+    # host runs ahead, below it when the device waited for the host); host_phase_ms_per_step: where the host spent its time inside step()
+    rec.update(getattr(tr, "bench_gpu", {}))
     if tr.amp_state is not None:
         sc, tracker, _, skipped = tr.amp_state.cpu().tolist()
         rec["config"]["grad_scaler"] = {"scale": sc, "growth_tracker": int(tracker), "skipped_steps": int(skipped)}

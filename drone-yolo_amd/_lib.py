@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdyolo.so")
 
-DY_BF16, DY_F16, DY_F32, DY_FP8 = 0, 1, 2, 3
+DY_BF16, DY_F16, DY_F32, DY_FP8, DY_F16X2 = 0, 1, 2, 3, 4
 DY_ACT_NONE, DY_ACT_SILU, DY_ACT_SILU_L2E = 0, 1, 2
 DY_MAX_LEVELS = 8
 DY_WLAYOUT_ROWS, DY_WLAYOUT_HALO3X3, DY_WLAYOUT_FRAG1X1 = 0, 1, 2

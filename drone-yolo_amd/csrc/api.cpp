@@ -56,6 +56,7 @@ extern "C" int32_t dy_dtype_size(int32_t dtype) {
     case DY_F16:
       return 2;
     case DY_F32:
+    case DY_F16X2:
       return 4;
     case DY_FP8:
       return 1;

@@ -124,6 +124,37 @@ template <> struct Elem<float> {
   static __device__ __forceinline__ float from_f32(float v) { return v; }
 };
 
+// DY_F16X2 (include/dyolo.h): split float16 storage, x ~= hi + lo * 2^-11.  A 4-byte element like fp32 for every address computation
+// (EPC = 4: a 16-byte chunk is the hi OR the lo halves of 8 channels; two adjacent chunks = 8 channels).  No mma(): the kernels that
+// take the type issue their three 16-bit MFMAs themselves (csrc/conv_gemm_fk.hip).
+struct f16x2_t {
+  unsigned v;
+};
+template <> struct Elem<f16x2_t> {
+  static constexpr int EPC = 4;
+};
+constexpr float kSplitScale = 2048.f, kSplitInv = 1.f / 2048.f;  // 2^11: the lo half is stored scaled into float16's normal range
+// 8 fp32 values -> their hi chunk and lo chunk.  hi = rn_f16(x), flushed to 0 below float16's smallest normal (so that a matrix pipe
+// that flushes denormal inputs and one that does not compute the same thing; the whole value then sits in lo: |x| 2^11 < 0.125) and
+// clamped to the finite range; lo = rn_f16((x - hi) 2^11), |lo| <= |x| / 2.
+__device__ __forceinline__ void split8(const float (&f)[8], u32x4& hi, u32x4& lo) {
+  f16x8 h, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = __builtin_fminf(__builtin_fmaxf(f[e], -65504.f), 65504.f);
+    const f16_t hh = __builtin_fabsf(x) < 6.103515625e-5f ? (f16_t)0.f : (f16_t)x;
+    h[e] = hh;
+    l[e] = (f16_t)((x - (float)hh) * kSplitScale);
+  }
+  hi = __builtin_bit_cast(u32x4, h);
+  lo = __builtin_bit_cast(u32x4, l);
+}
+__device__ __forceinline__ void join8(u32x4 hi, u32x4 lo, float (&f)[8]) {
+  const f16x8 h = __builtin_bit_cast(f16x8, hi), l = __builtin_bit_cast(f16x8, lo);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = (float)h[e] + (float)l[e] * kSplitInv;  // exact in fp32: 11 + 11 significant bits
+}
+
 // Unpack / pack one 16-byte chunk to fp32 lanes.
 template <typename T> struct Chunk {
   static constexpr int EPC = Elem<T>::EPC;
@@ -224,8 +255,8 @@ __device__ __forceinline__ unsigned fastdiv(unsigned n, FastDiv f) {
   return (t + ((n - t) >> 1)) >> (f.l - 1);
 }
 
-// element size for entry points that are NOT built for DY_FP8 (they then report "bad dtype")
-static inline int dtype_size_no_fp8(int dtype) { return dtype == DY_FP8 ? 0 : dy_dtype_size(dtype); }
+// element size for entry points that are built for the plain types only — not DY_FP8, not DY_F16X2 (they then report "bad dtype")
+static inline int dtype_size_no_fp8(int dtype) { return (dtype == DY_FP8 || dtype == DY_F16X2) ? 0 : dy_dtype_size(dtype); }
 
 // ---- host-side error plumbing: set_error / check_launch / zero_async are declared at the top (namespace dy, one copy in api.cpp) ----
 

@@ -95,7 +95,9 @@ __device__ __forceinline__ void fk_store4(unsigned char* sp, const float (&v)[4]
 template <typename T, typename OT, int MFR, int NFR, int WM, int WN, bool RES = false, int TABN = 768, bool STATS = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs p) {
   constexpr bool MX = FkIsFp8<T>::v;
+  constexpr bool SP = std::is_same<T, f16x2_t>::value;  // DY_F16X2: split float16 pairs, three MFMAs per staged fragment pair (header)
   static_assert(!STATS || (!RES && !MX && sizeof(OT) == 2), "STATS: 16-bit storage, no residual");
+  static_assert(!SP || std::is_same<OT, f16x2_t>::value || std::is_same<OT, float>::value, "split input: split or fp32 output");
   constexpr int EPC = Elem<T>::EPC;
   constexpr int NW = WM * WN;
   constexpr int BM = WM * MFR * 16, BN = WN * NFR * 16;
@@ -279,6 +281,26 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
           // second in a bare issue loop (tools/mx_probe.hip: 4.88-4.99 against 4.51-4.85 PFLOP/s)
           acc[j][i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b[j], a[i], acc[j][i], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
         }
+    } else if constexpr (SP) {
+      // a 128-byte row = four (hi, lo) chunk pairs of 8 channels: lane quarter lq takes pair lq.  x w = x_hi w_hi + x_hi w_lo + x_lo' (w_hi 2^-11)
+      // (x_lo' is stored times 2^11; lo x lo, 2^-22 relative, is dropped): fp32-grade products from three 16-bit MFMAs, and per MFMA
+      // two thirds of the LDS reads and DMA bytes of the plain float16 loop
+      const int sh = ((2 * lq) ^ swz) * 16, sl = ((2 * lq + 1) ^ swz) * 16;
+      u32x4 ah[MFR], al[MFR];
+#pragma unroll
+      for (int i = 0; i < MFR; ++i) ah[i] = *reinterpret_cast<const u32x4*>(sa + i * 16 * 128 + sh), al[i] = *reinterpret_cast<const u32x4*>(sa + i * 16 * 128 + sl);
+#pragma unroll
+      for (int j = 0; j < NFR; ++j) {
+        const u32x4 bh = *reinterpret_cast<const u32x4*>(sb + j * 16 * 128 + sh), bl = *reinterpret_cast<const u32x4*>(sb + j * 16 * 128 + sl);
+        const f16x8 bsv = __builtin_bit_cast(f16x8, bh) * (f16_t)kSplitInv;  // v_pk_mul_f16 x 4: exact (a power of two), rows are scaled to >= 2^13 at the top
+        const u32x4 bs = __builtin_bit_cast(u32x4, bsv);
+#pragma unroll
+        for (int i = 0; i < MFR; ++i) {
+          acc[j][i] = Elem<f16_t>::mma(bh, ah[i], acc[j][i]);
+          acc[j][i] = Elem<f16_t>::mma(bl, ah[i], acc[j][i]);
+          acc[j][i] = Elem<f16_t>::mma(bs, al[i], acc[j][i]);
+        }
+      }
     } else {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -334,18 +356,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
       const bool cok = co + 3 < p.cout_pad;  // (a tile may reach past the padded rows of a narrow layer: its weights read as zeros)
       const f32x4 bb = cok ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
       f32x4 sc4 = f32x4{1.f, 1.f, 1.f, 1.f};
-      if constexpr (MX) sc4 = cok ? *reinterpret_cast<const f32x4*>(p.wscale + co) : sc4;
+      if constexpr (MX || SP) sc4 = cok ? *reinterpret_cast<const f32x4*>(p.wscale + co) : sc4;
 #pragma unroll
       for (int ii = 0; ii < MPP; ++ii) {
         const int i = h * MPP + ii;
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = MX ? acc[j][i][e] * sc4[e] + bb[e] : acc[j][i][e] + bb[e];
+        for (int e = 0; e < 4; ++e) v[e] = (MX || SP) ? acc[j][i][e] * sc4[e] + bb[e] : acc[j][i][e] + bb[e];
         if (p.act == DY_ACT_SILU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
         }
-        if constexpr (RES) {
+        if constexpr (RES || SP) {
           *reinterpret_cast<f32x4*>(escr + (ii * 16 + lr) * EP_PITCH + (j * 16 + lq * 4) * 4) = f32x4{v[0], v[1], v[2], v[3]};
         } else {
           if constexpr (FkIsFp8<OT>::v) {
@@ -368,6 +390,55 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if constexpr (SP && std::is_same<OT, float>::value) {
+      // fp32 output (Detect logits): the scratch row is the output row; the last chunk of a Cout that is no multiple of 4 goes out by element
+      float* __restrict__ yf = reinterpret_cast<float*>(p.y);
+#pragma unroll
+      for (int k = 0; k < (PXP * CPP + 63) / 64; ++k) {
+        const int idx = k * 64 + lane;
+        const int px = idx / CPP, cc = idx - px * CPP;
+        const int m = m0 + px, c0 = n0 + cc * 4;
+        if (px < PXP && m < p.M && c0 < p.Cout) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(escr + px * EP_PITCH + cc * 16);
+          float* dst = yf + (size_t)m * (size_t)p.ldy + (size_t)c0;
+          if (c0 + 4 <= p.Cout) {
+            *reinterpret_cast<f32x4*>(dst) = t;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (c0 + e < p.Cout) dst[e] = t[e];
+          }
+        }
+      }
+    } else if constexpr (SP) {
+      // split output: a lane takes 8 channels of a pixel — 8 fp32 from the scratch (+ the residual's pair, joined in fp32: the reference's
+      // x + cv2(cv1(x)) rounded once) -> hi chunk + lo chunk, 32 contiguous bytes
+      constexpr int GPP = NFR * 2;
+      unsigned char* __restrict__ yb = reinterpret_cast<unsigned char*>(p.y);
+      const unsigned char* __restrict__ rb = reinterpret_cast<const unsigned char*>(p.res);
+#pragma unroll
+      for (int k = 0; k < (PXP * GPP + 63) / 64; ++k) {
+        const int idx = k * 64 + lane;
+        const int px = idx / GPP, g = idx - px * GPP;
+        const int m = m0 + px, c0 = n0 + g * 8;
+        if (px < PXP && m < p.M && c0 < p.Cout) {
+          const f32x4 t0 = *reinterpret_cast<const f32x4*>(escr + px * EP_PITCH + g * 32), t1 = *reinterpret_cast<const f32x4*>(escr + px * EP_PITCH + g * 32 + 16);
+          float f[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+          if constexpr (RES) {
+            const unsigned char* rp = rb + ((size_t)m * (size_t)p.ldres + (size_t)c0) * 4;
+            float r[8];
+            join8(*reinterpret_cast<const u32x4*>(rp), *reinterpret_cast<const u32x4*>(rp + 16), r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += r[e];
+          }
+          u32x4 hi, lo;
+          split8(f, hi, lo);
+          unsigned char* dp = yb + ((size_t)m * (size_t)p.ldy + (size_t)c0) * 4;
+          *reinterpret_cast<u32x4*>(dp) = hi;
+          *reinterpret_cast<u32x4*>(dp + 16) = lo;
+        }
+      }
+    } else {
 #pragma unroll
     for (int k = 0; k < (PXP * CPP + 63) / 64; ++k) {
       const int idx = k * 64 + lane;
@@ -394,6 +465,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
 #endif
         *reinterpret_cast<u32x4*>(yg + (size_t)m * (size_t)p.ldy + (size_t)(n0 + cc * OEPC)) = val;
       }
+    }
     }
     if (h + 1 < NH) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -539,5 +611,69 @@ int conv_gemm_fk_try(const dy_conv_desc* d, hipStream_t st) {
   if (d->dtype == DY_F16) return out8 ? launch_fk_tiles<f16_t, fp8_t>(a, st) : launch_fk_tiles<f16_t, f16_t>(a, st);
   return launch_fk_tiles<bf16_t, bf16_t>(a, st);
 }
+
+// DY_F16X2 (split float16, include/dyolo.h): every dense convolution of the type runs here — there is no other kernel for it, so a
+// call outside the built set is an error, not a fallback.  Tiles as above; the tap table holds up to 1,536 words (3x3 with Cin <= 680).
+#ifndef DYOLO_L2E_BUILD
+template <typename OT>
+static int launch_fk_split_tiles(const FkArgs& a, hipStream_t st) {
+  const int cands[4] = {160, 128, 80, 64};
+  int best = 160;
+  long long bw = 1ll << 60;
+  for (int c : cands) {
+    const long long w = (long long)((a.Cout + c - 1) / c) * c;
+    if (w < bw) bw = w, best = c;
+  }
+  switch (best) {
+    case 160: return launch_fk<f16x2_t, OT, 4, 5, 2, 2, 1536>(a, st, "conv_gemm_fk_kernel<split,128,160>");
+    case 128: return launch_fk<f16x2_t, OT, 4, 4, 2, 2, 1536>(a, st, "conv_gemm_fk_kernel<split,128,128>");
+    case 80: return launch_fk<f16x2_t, OT, 2, 5, 4, 1, 1536>(a, st, "conv_gemm_fk_kernel<split,128,80>");
+    default: return launch_fk<f16x2_t, OT, 2, 4, 4, 1, 1536>(a, st, "conv_gemm_fk_kernel<split,128,64>");
+  }
+}
+
+int conv_gemm_fk_split(const dy_conv_desc* d, hipStream_t st) {
+  constexpr int es = 4, epc = 4, bke = 32;
+  DY_REQUIRE(d->groups <= 1 && d->w_layout == DY_WLAYOUT_ROWS && !d->y_dtype1 && !d->bn_stats, DY_ERR_UNSUPPORTED,
+             "dy_conv2d_nhwc: DY_F16X2 is built for dense convolutions in DY_WLAYOUT_ROWS (no y_dtype1 / bn_stats)");
+  DY_REQUIRE(((d->ksize == 1 && d->pad == 0) || (d->ksize == 3 && d->pad == 1)) && (d->stride == 1 || d->stride == 2), DY_ERR_UNSUPPORTED,
+             "dy_conv2d_nhwc: DY_F16X2 is built for 1x1 (pad 0) and 3x3 (pad 1), stride 1 or 2");
+  DY_REQUIRE(d->cin % 8 == 0 && (d->out_f32 || d->cout % 8 == 0) && d->k_pad % bke == 0, DY_ERR_UNSUPPORTED,
+             "dy_conv2d_nhwc: DY_F16X2 needs cin (and cout, unless out_f32) in whole groups of 8 channels");
+  DY_REQUIRE(d->w_scale && aligned16(d->w_scale), DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: DY_F16X2 needs w_scale (fp32[cout_pad]: the inverse row scales)");
+  DY_REQUIRE(!(d->ksize == 3 && (d->x2 || d->up2x)) && d->up2x <= 1 && !(d->up2x && d->stride != 1), DY_ERR_UNSUPPORTED,
+             "dy_conv2d_nhwc: DY_F16X2: x2 / up2x are built for 1x1 stride 1");
+  DY_REQUIRE(!d->x2 || (d->cin_split % bke == 0 && d->cin_split > 0 && d->cin_split < d->cin), DY_ERR_UNSUPPORTED,
+             "dy_conv2d_nhwc: DY_F16X2: cin_split must be a multiple of 32");
+  DY_REQUIRE(aligned16(d->y) && d->ld_y % epc == 0 && d->ld_x % epc == 0 && aligned16(d->x) && (!d->x2 || (aligned16(d->x2) && d->ld_x2 % epc == 0)), DY_ERR_INVALID_ARG,
+             "dy_conv2d_nhwc: DY_F16X2 views must be 16-byte aligned");
+  DY_REQUIRE(!d->residual || (!d->out_f32 && d->ld_res % epc == 0 && aligned16(d->residual)), DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: DY_F16X2 residual view");
+  const int hb = d->up2x ? d->h / 2 : d->h, wb = d->up2x ? d->w_in / 2 : d->w_in;
+  const long long lim = (1ll << 32) - (1ll << 24);
+  const long long xb = (long long)d->batch * hb * wb * d->ld_x * es, x2b = d->x2 ? (long long)d->batch * d->h * d->w_in * d->ld_x2 * es : 0;
+  const long long wbytes = (long long)d->cout_pad * d->k_pad * es;
+  DY_REQUIRE(xb < lim && x2b < lim && wbytes < lim, DY_ERR_UNSUPPORTED, "dy_conv2d_nhwc: DY_F16X2 view beyond the 4 GiB a buffer descriptor addresses");
+  DY_REQUIRE(d->ksize == 1 || (d->k_pad / bke * 8 <= 1536 && ((long long)(2 * d->w_in + 2) * d->ld_x + d->cin) * es < (1ll << 28)), DY_ERR_UNSUPPORTED,
+             "dy_conv2d_nhwc: DY_F16X2 3x3 tap table (cin <= 680)");
+  FkArgs a{};
+  a.x = d->x, a.x2 = d->x2 ? d->x2 : d->x, a.w = d->w, a.bias = d->bias, a.wscale = d->w_scale, a.res = d->residual, a.y = d->y;
+  a.H = d->h, a.W = d->w_in, a.Cin = d->cin, a.ldx = d->ld_x, a.ldx2 = d->x2 ? d->ld_x2 : d->ld_x, a.split = d->x2 ? d->cin_split : d->cin;
+  a.HB = hb, a.WB = wb;
+  a.Ho = d->ho, a.Wo = d->wo, a.Cout = d->cout, a.ldy = d->ld_y, a.ldres = d->ld_res;
+  a.ks = d->ksize, a.stride = d->stride, a.pad = d->pad;
+  a.Kpad = d->k_pad, a.M = d->batch * d->ho * d->wo, a.HoWo = d->ho * d->wo, a.up2x = d->up2x;
+  a.act = d->act;
+  a.cout_pad = d->cout_pad;
+  a.xb = (unsigned)xb, a.x2b = (unsigned)(d->x2 ? x2b : xb), a.wb = (unsigned)wbytes;
+  a.dCin = make_fastdiv((unsigned)d->cin);
+  a.dbg = 0, a.stats = nullptr, a.res_scale = 1.f, a.out_scale = 1.f;
+  return d->out_f32 ? launch_fk_split_tiles<float>(a, st) : launch_fk_split_tiles<f16x2_t>(a, st);
+}
+#else
+int conv_gemm_fk_split(const dy_conv_desc*, hipStream_t) {
+  set_error("dy_conv2d_nhwc: DY_F16X2 runs in the reference's activation units (no DY_ACT_SILU_L2E)");
+  return DY_ERR_UNSUPPORTED;
+}
+#endif
 
 }  // namespace DY_NS

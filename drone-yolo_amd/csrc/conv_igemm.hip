@@ -330,6 +330,7 @@ static int launch_dtype(const ConvArgs& a, hipStream_t st) {
 
 int conv3x3_halo_dispatch(const dy_conv_desc* d, hipStream_t st);    // conv3x3_halo.hip
 int conv_gemm_fk_try(const dy_conv_desc* d, hipStream_t st);         // conv_gemm_fk.hip: flat-K kernel (any channel count / fp8 on the block-scaled MFMA)
+int conv_gemm_fk_split(const dy_conv_desc* d, hipStream_t st);       // conv_gemm_fk.hip: DY_F16X2 (split float16), the only kernel of that type
 int conv1x1_stream_dispatch(const dy_conv_desc* d, hipStream_t st);  // conv1x1_stream.hip
 
 }  // namespace DY_NS
@@ -415,6 +416,12 @@ int32_t conv2d_entry(const dy_conv_desc* d, dy_stream_t stream) {
   a.stats = (d->out_f32 || d->y_dtype1) ? nullptr : d->bn_stats;  // (kernels without a statistics epilogue ignore it: dy_conv_stats_written() stays 0)
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
+  if (d->dtype == DY_F16X2) {
+    DY_REQUIRE(d->k_pad == dy_conv_k_pad(d->cin, d->ksize, d->dtype) && d->cout_pad == dy_conv_cout_pad(d->cout), DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: k_pad / cout_pad");
+    DY_REQUIRE(aligned16(d->w) && aligned16(d->bias), DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: w/bias not 16-byte aligned");
+    DY_REQUIRE(!d->up2x || (d->h % 2 == 0 && d->w_in % 2 == 0), DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: up2x needs even h, w");
+    return conv_gemm_fk_split(d, st);
+  }
   if (d->dtype == DY_FP8) {
     DY_REQUIRE(d->w_layout == DY_WLAYOUT_ROWS && d->groups <= 1, DY_ERR_UNSUPPORTED, "dy_conv2d_nhwc: DY_FP8 is built for dense convolutions in DY_WLAYOUT_ROWS");
     DY_REQUIRE(d->w_scale && d->act_scale > 0.f && aligned16(d->w_scale), DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: DY_FP8 needs w_scale (fp32[cout_pad], 16-byte aligned) and act_scale > 0");

@@ -27,6 +27,38 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
   }
 }
 
+// ---- DY_F16X2 forms of the two layout casts: 8 channels = a (hi, lo) chunk pair (include/dyolo.h) -----------------------------------
+__global__ __launch_bounds__(256) void nchw_to_nhwc_split_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, int n, int c, int hw, int c_pad, int ld) {
+  const long long total = (long long)n * hw;
+  for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (long long)gridDim.x * 256) {
+    const int img = (int)(pix / hw);
+    const int p = (int)(pix - (long long)img * hw);
+    const float* s = src + (size_t)img * c * hw + p;
+    unsigned char* d = dst + (size_t)pix * ld * 4;
+    for (int c0 = 0; c0 < c_pad; c0 += 8) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = (c0 + e < c) ? s[(size_t)(c0 + e) * hw] : 0.f;
+      u32x4 hi, lo;
+      split8(f, hi, lo);
+      *reinterpret_cast<u32x4*>(d + c0 * 4) = hi;
+      *reinterpret_cast<u32x4*>(d + c0 * 4 + 16) = lo;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void nhwc_split_to_nchw_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, int n, int c, int hw, int ld) {
+  const long long total = (long long)n * c * hw;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int p = (int)(i % hw);
+    const long long t = i / hw;
+    const int ch = (int)(t % c);
+    const int img = (int)(t / c);
+    const f16_t* g = reinterpret_cast<const f16_t*>(src + (((size_t)img * hw + p) * ld + (ch & ~7)) * 4);
+    dst[i] = (float)g[ch & 7] + (float)g[8 + (ch & 7)] * kSplitInv;
+  }
+}
+
 // ---- uint8 NCHW -> NHWC(T) with x * scale, zero-padded channels: DetectionTrainer.preprocess_batch's
 // `img.float() / 255` (models/yolo/detect/train.py:57-60) fused with the layout step of the training forward ----------
 template <typename T>
@@ -146,6 +178,70 @@ __global__ __launch_bounds__(512) void sppf_maxpool3_kernel(const T* __restrict_
   }
 }
 
+// DY_F16X2: the same pools on (hi, lo) chunk PAIRS (G counts pairs, 32 bytes each).  hi = rn_f16(x) is monotonic in x and lo orders the
+// values that share a hi, so the maximum is a lexicographic choice between whole pairs — taken here by comparing the joined fp32
+// values (exact: 22 significant bits) and selecting the pair, never re-splitting: the pooled element IS one of the inputs, bit for bit.
+struct ChunkPair {
+  u32x4 hi, lo;
+};
+__device__ __forceinline__ ChunkPair pair_max(const ChunkPair a, const ChunkPair b) {
+  float fa[8], fb[8];
+  join8(a.hi, a.lo, fa);
+  join8(b.hi, b.lo, fb);
+  const f16x8 ah = __builtin_bit_cast(f16x8, a.hi), al = __builtin_bit_cast(f16x8, a.lo), bh = __builtin_bit_cast(f16x8, b.hi), bl = __builtin_bit_cast(f16x8, b.lo);
+  f16x8 h, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const bool tb = fb[e] > fa[e];
+    h[e] = tb ? bh[e] : ah[e];
+    l[e] = tb ? bl[e] : al[e];
+  }
+  return ChunkPair{__builtin_bit_cast(u32x4, h), __builtin_bit_cast(u32x4, l)};
+}
+
+__global__ __launch_bounds__(512) void sppf_maxpool3_split_kernel(const unsigned char* __restrict__ x, unsigned char* __restrict__ y1, unsigned char* __restrict__ y2,
+                                                                  unsigned char* __restrict__ y3, int h, int w, int cgroups, int G, int ld, int r) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  const int hw = h * w, tot = hw * G;
+  ChunkPair* cur = reinterpret_cast<ChunkPair*>(dyn_smem);
+  ChunkPair* tmp = cur + tot;
+  const int img = blockIdx.x / cgroups;
+  const int cg = blockIdx.x - img * cgroups;
+  const size_t base = ((size_t)img * hw * ld + (size_t)cg * G * 8) * 4;
+  for (int i = threadIdx.x; i < tot; i += 512) {
+    const int p = i / G, g = i - p * G;
+    const unsigned char* s = x + base + ((size_t)p * ld + g * 8) * 4;
+    cur[i] = ChunkPair{*reinterpret_cast<const u32x4*>(s), *reinterpret_cast<const u32x4*>(s + 16)};
+  }
+  __syncthreads();
+  unsigned char* outs[3] = {y1, y2, y3};
+#pragma unroll 1
+  for (int pass = 0; pass < 3; ++pass) {
+    for (int i = threadIdx.x; i < tot; i += 512) {
+      const int p = i / G, g = i - p * G;
+      const int yy = p / w, xx = p - yy * w;
+      const int x0 = xx - r < 0 ? 0 : xx - r, x1 = xx + r >= w ? w - 1 : xx + r;
+      ChunkPair m = cur[(yy * w + x0) * G + g];
+      for (int q = x0 + 1; q <= x1; ++q) m = pair_max(m, cur[(yy * w + q) * G + g]);
+      tmp[i] = m;
+    }
+    __syncthreads();
+    unsigned char* o = outs[pass];
+    for (int i = threadIdx.x; i < tot; i += 512) {
+      const int p = i / G, g = i - p * G;
+      const int yy = p / w, xx = p - yy * w;
+      const int y0 = yy - r < 0 ? 0 : yy - r, y1e = yy + r >= h ? h - 1 : yy + r;
+      ChunkPair m = tmp[(y0 * w + xx) * G + g];
+      for (int q = y0 + 1; q <= y1e; ++q) m = pair_max(m, tmp[(q * w + xx) * G + g]);
+      cur[i] = m;
+      unsigned char* d = o + base + ((size_t)p * ld + g * 8) * 4;
+      *reinterpret_cast<u32x4*>(d) = m.hi;
+      *reinterpret_cast<u32x4*>(d + 16) = m.lo;
+    }
+    __syncthreads();
+  }
+}
+
 // ---- 16-bit / fp32 NHWC -> fp8 (e4m3fn) NHWC, q = sat(x / act_scale): hand-over from the fp16 image stem to the fp8 layers ----
 template <typename T>
 __global__ __launch_bounds__(256) void quantize_fp8_kernel(const T* __restrict__ src, fp8_t* __restrict__ dst, long long rows, int c16, int lds, int ldd, float inv) {
@@ -258,10 +354,17 @@ using namespace dy;
 
 extern "C" int32_t dy_nchw_f32_to_nhwc(const float* src, void* dst, int32_t n, int32_t c, int32_t h, int32_t w,
                                        int32_t c_pad, int32_t ld_dst, int32_t dtype, dy_stream_t stream) {
-  const int es = dtype_size_no_fp8(dtype);
+  const int es = dtype == DY_F16X2 ? 4 : dtype_size_no_fp8(dtype);
   DY_REQUIRE(src && dst && es, DY_ERR_INVALID_ARG, "dy_nchw_f32_to_nhwc: null pointer or bad dtype");
   DY_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0, DY_ERR_INVALID_ARG, "dy_nchw_f32_to_nhwc: bad dims");
-  const int epc = 16 / es;
+  const int epc = dtype == DY_F16X2 ? 8 : 16 / es;  // (split pairs: whole groups of 8 channels)
+  if (dtype == DY_F16X2) {
+    DY_REQUIRE(c_pad >= c && c_pad % 8 == 0 && ld_dst >= c_pad && ld_dst % 4 == 0 && aligned16(dst), DY_ERR_INVALID_ARG,
+               "dy_nchw_f32_to_nhwc: DY_F16X2 needs c_pad in groups of 8 channels, dst 16B aligned");
+    hipLaunchKernelGGL(nchw_to_nhwc_split_kernel, dim3(grid_for((long long)n * h * w)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, (unsigned char*)dst, n, c,
+                       h * w, c_pad, ld_dst);
+    return check_launch("nchw_to_nhwc_split_kernel");
+  }
   DY_REQUIRE(c_pad >= c && c_pad % epc == 0 && ld_dst >= c_pad && (ld_dst * es) % 16 == 0 && aligned16(dst),
              DY_ERR_INVALID_ARG, "dy_nchw_f32_to_nhwc: c_pad/ld_dst must be multiples of %d elements, dst 16B aligned", epc);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -296,11 +399,16 @@ extern "C" int32_t dy_nchw_u8_to_nhwc(const uint8_t* src, void* dst, int32_t n, 
 
 extern "C" int32_t dy_nhwc_to_nchw_f32(const void* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w,
                                        int32_t ld_src, int32_t src_dtype, dy_stream_t stream) {
-  const int es = dtype_size_no_fp8(src_dtype);
+  const int es = src_dtype == DY_F16X2 ? 4 : dtype_size_no_fp8(src_dtype);
   DY_REQUIRE(src && dst && es, DY_ERR_INVALID_ARG, "dy_nhwc_to_nchw_f32: null pointer or bad dtype");
   DY_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0 && ld_src >= c, DY_ERR_INVALID_ARG, "dy_nhwc_to_nchw_f32: bad dims");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int grid = grid_for((long long)n * c * h * w);
+  if (src_dtype == DY_F16X2) {  // (a view that starts at a multiple of 8 channels of its buffer; c itself may be anything)
+    DY_REQUIRE(aligned16(src) && ld_src % 4 == 0, DY_ERR_INVALID_ARG, "dy_nhwc_to_nchw_f32: DY_F16X2 view must be 16-byte aligned");
+    hipLaunchKernelGGL(nhwc_split_to_nchw_kernel, dim3(grid), dim3(256), 0, st, (const unsigned char*)src, dst, n, c, h * w, ld_src);
+    return check_launch("nhwc_split_to_nchw_kernel");
+  }
   if (src_dtype == DY_BF16)
     hipLaunchKernelGGL((nhwc_to_nchw_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, dst, n, c, h * w, ld_src);
   else if (src_dtype == DY_F16)
@@ -362,6 +470,22 @@ extern "C" int32_t dy_sppf_maxpool3(const void* x, void* y1, void* y2, void* y3,
     }
   const size_t smem = (size_t)h * w * 32 * G;
   const int cgroups = cchunks / G;
+  if (dtype == DY_F16X2) {
+    DY_REQUIRE(c % 8 == 0, DY_ERR_INVALID_ARG, "dy_sppf_maxpool3: DY_F16X2 needs c in groups of 8 channels");
+    const int pairs = c / 8;
+    int Gp = 1;
+    for (int g = 4; g >= 1; --g)
+      if (pairs % g == 0 && (size_t)h * w * 64 * g <= 147456) {
+        Gp = g;
+        break;
+      }
+    const size_t sm = (size_t)h * w * 64 * Gp;
+    DY_REQUIRE(sm <= 147456, DY_ERR_UNSUPPORTED, "dy_sppf_maxpool3: DY_F16X2 map of %d pixels exceeds the LDS-resident limit", h * w);
+    if (sm > 48 * 1024) (void)hipFuncSetAttribute((const void*)sppf_maxpool3_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL(sppf_maxpool3_split_kernel, dim3((unsigned)(n * (pairs / Gp))), dim3(512), sm, st, (const unsigned char*)x, (unsigned char*)y1, (unsigned char*)y2,
+                       (unsigned char*)y3, h, w, pairs / Gp, Gp, ld, k / 2);
+    return check_launch("sppf_maxpool3_split_kernel");
+  }
   const dim3 grid((unsigned)(n * cgroups));
 #define DY_SPPF_LAUNCH(T)                                                                                          \
   do {                                                                                                              \

@@ -23,15 +23,21 @@ from ..utils.torch_utils import select_device
 from ..nn.autobackend import AutoBackend
 from .results import Results
 
-_DTYPE_NAMES = {"fp8": H.FP8, "float8_e4m3fn": H.FP8, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "half": torch.float16,
+_DTYPE_NAMES = {"f16x2": H.F16X2, "split": H.F16X2, "fp8": H.FP8, "float8_e4m3fn": H.FP8, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "half": torch.float16,
                 "float16": torch.float16, "fp32": torch.float32, "float32": torch.float32}
+
+
+# The precision a predictor runs in when the caller names none.  The reference's default is ``half: False`` = fp32 (cfg/default.yaml:54,
+# engine/predictor.py:315-322), and the drop-in's default must reproduce ITS detections: class / index exact, IoU >= 0.999 (BASELINE.json).
+# ``half=True`` selects float16 storage as in the reference; bf16 and fp8 only on request (they do not meet that bar).
+EXACT_DTYPE = torch.float32
 
 
 def resolve_dtype(dtype=None, half: bool = False) -> torch.dtype:
     if isinstance(dtype, torch.dtype):
         return dtype
     if dtype is None:
-        return torch.float16 if half else torch.bfloat16
+        return torch.float16 if half else EXACT_DTYPE
     try:
         return _DTYPE_NAMES[str(dtype).lower()]
     except KeyError:
@@ -55,7 +61,7 @@ class DetectionPredictor:
 
     def __init__(self, model, overrides: Optional[dict] = None):
         a = dict(conf=0.25, iou=0.7, max_det=300, classes=None, agnostic_nms=False, half=False, dtype=None, device="",
-                 verbose=False, graph=False, max_nms=30000, max_wh=7680, imgsz=640, fp8_layers=None)
+                 verbose=False, graph=True, max_nms=30000, max_wh=7680, imgsz=640, fp8_layers=None)
         a.update(overrides or {})
         self.args = a
         self.device = select_device(a["device"])

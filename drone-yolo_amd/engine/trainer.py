@@ -479,6 +479,7 @@ class DetectionTrainer:
         if will_step:
             self.optimizer_step()
             self.last_opt_step = ni
+            self._tick("optimizer_step")
         return loss.detach() * self.world, items  # the reference reports loss * world_size (trainer.py:382-383)
 
     graph_steps = os.environ.get("DYOLO_TRAIN_GRAPH", "1") != "0"  # forward + loss + backward recorded once as a hipGraph and replayed (see _forward_backward)
@@ -532,6 +533,7 @@ class DetectionTrainer:
             model.criterion = model.init_criterion()
         img = batch["img"]
         b, _, h, w = img.shape
+        self._tick("outside_step")
         gt = model.criterion.targets_to_gt(batch, b, (h, w))
         # label capacity of the static table: multiples of 64, never shrinking for a shape (Poisson(50) counts wander across 64 from
         # batch to batch; re-capturing on every crossing was a silent cliff), one graph per (shape, capacity) kept in a small dict
@@ -569,14 +571,62 @@ class DetectionTrainer:
             gs.update(g=g, loss=loss, items=items)
             graphs[key] = gs
         self._graph = gs
-        gs["img"].copy_(img, non_blocking=True)
-        gs["gt"].zero_()
+        tick = self._tick
+        tick("targets_to_gt")
+        if img.data_ptr() != gs["img"].data_ptr():  # a caller that fills `static_image()` itself skips the device copy
+            gs["img"].copy_(img, non_blocking=True)
+        tick("image_copy")
+        # The label table goes through a ring of PINNED host tables (zero rows = padding) and ONE asynchronous copy.  Round 4 copied a
+        # pageable tensor with non_blocking=True: a pageable hipMemcpyAsync is stream-ordered but returns only when it has run, so the host
+        # sat in it until the previous step's whole graph and optimizer had drained, and the next graph launch (~2,400 nodes of host work)
+        # then started on an idle GPU: the launch cost was serial to every step instead of hidden behind the one before.
+        ring = gs.get("gt_ring")
+        if ring is None:
+            ring = gs["gt_ring"] = dict(tables=[torch.zeros((b, cap, 5), dtype=torch.float32).pin_memory() for _ in range(3)], events=[None] * 3, at=0)
+        k = ring["at"]
+        ring["at"] = (k + 1) % 3
+        if ring["events"][k] is not None:
+            ring["events"][k].synchronize()  # the copy that last read this table (three steps ago)
+        host = ring["tables"][k]
+        hv = host.numpy()  # (numpy on purpose: see v8DetectionLoss.preprocess)
+        hv.fill(0.0)
         if gt.shape[1]:
-            gs["gt"][:, : gt.shape[1]].copy_(gt.to(img.device, non_blocking=True))
+            hv[:, : gt.shape[1]] = gt.numpy()
+        if os.environ.get("DYOLO_PAGEABLE_GT") == "1":  # round 4's form, kept for the A/B of profiles/r05_train_host_ab.txt only
+            gs["gt"].copy_(host.clone().to(img.device, non_blocking=True))
+        else:
+            gs["gt"].copy_(host, non_blocking=True)
+        ev = ring["events"][k] = ring["events"][k] or torch.cuda.Event()
+        ev.record()
+        tick("label_copy")
         gs["g"].replay()
+        tick("replay")
         if bk is not None:
             bk.exchange_after_replay()
-        return gs["loss"].clone(), gs["items"].clone()  # the static outputs are overwritten by the next replay (the epoch mean keeps them)
+        out = gs["loss"].clone(), gs["items"].clone()  # the static outputs are overwritten by the next replay (the epoch mean keeps them)
+        tick("exchange_and_outputs")
+        return out
+
+    host_phases: Optional[Dict[str, float]] = None  # set to {} to collect the host's seconds per phase of the graphed step (bench.py)
+
+    def _tick(self, name: str) -> None:
+        """Host time since the previous tick goes to phase ``name`` (no device call; off unless ``host_phases`` is a dict)."""
+        hp = self.host_phases
+        if hp is None:
+            return
+        now = time.perf_counter()
+        last = self.__dict__.get("_tick_last")
+        if last is not None:
+            hp[name] = hp.get(name, 0.0) + (now - last)
+            worst = hp.setdefault("__max__", {})
+            if now - last > worst.get(name, (0.0, 0))[0]:
+                worst[name] = (now - last, self.iters)  # the longest single visit of the phase and the iteration it happened in
+        self._tick_last = now
+
+    def static_image(self) -> Optional[torch.Tensor]:
+        """The graphed step's resident image batch (None before the first capture): a loader that writes the next batch here saves the device copy."""
+        g = getattr(self, "_graph", None)
+        return None if g is None else g["img"]
 
     def _unit_seed(self, loss: torch.Tensor) -> torch.Tensor:
         """ones_like(loss), allocated once (the seed autograd would create per call; a device fp32 scalar the head-gradient kernel reads)."""

@@ -45,7 +45,11 @@ class AutoBackend(nn.Module):
         self.model = model.eval()
         self.model.requires_grad_(False)
         self.device, self.fp16 = device, bool(fp16) or dtype == torch.float16
-        self.dtype = dtype if dtype is not None else (torch.float16 if fp16 else torch.bfloat16)
+        if dtype is None:  # the predictor's rule: half -> float16, otherwise the bar-exact precision (engine/predictor.py::EXACT_DTYPE)
+            from ..engine.predictor import resolve_dtype
+
+            dtype = resolve_dtype(None, bool(fp16))
+        self.dtype = dtype
         self.stride = max(int(model.stride.max()), 32)
         self.names = model.names
         self.pt = self.nn_module = True

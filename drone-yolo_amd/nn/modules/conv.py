@@ -59,7 +59,7 @@ class _PackedMixin:
         pc = cache.get(key)
         if pc is None:
             pc = cache[key] = self._pack(x.dtype, x.device)
-            if pc.groups == 1 and 0 < x.shape[1] - pc.cin < H.elems_per_chunk(x.dtype):
+            if pc.groups == 1 and 0 < x.shape[1] - pc.cin < H.chan_gran(x.dtype):
                 # zero-padded input channels (image input padded to one 16-byte chunk): pad the taps to match
                 pc = cache[key] = self._pack(x.dtype, x.device, cin_pad=x.shape[1])
         return pc

@@ -5,10 +5,10 @@ autograd graph (training forward) the returned loss is differentiable: ``loss.ba
 w.r.t. the head outputs into the backward of the model (nn/autograd_ops.py)."""
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from .. import hip_ops as H
-from .ops import xywh2xyxy
 
 
 class v8DetectionLoss:
@@ -25,27 +25,32 @@ class v8DetectionLoss:
     def preprocess(targets: torch.Tensor, batch_size: int, scale_tensor: torch.Tensor) -> torch.Tensor:
         """(N, 6) [image, cls, x, y, w, h normalised] -> (B, n_max, 5) [cls, x1, y1, x2, y2] pixels — loss.py:180-195.
         Vectorised on the host (labels arrive on the host from the loader; one scatter instead of the reference's per-image loop,
-        no device synchronisation)."""
-        targets = targets.detach().cpu().float()
-        nl, ne = targets.shape
+        no device synchronisation).  numpy, not torch: a torch CPU op above the intra-op grain wakes the whole OpenMP pool, which on
+        a GPU box is sized by the HOST's core count while the process owns a 16-core CFS quota — the pool's spin-waits spend the
+        quota and the kernel parks every thread of the process until the next 100 ms period (r05: one such stall per 30-60 training
+        steps, each longer than the ~3 steps of work the launch queue holds)."""
+        t = targets.detach().cpu().float().numpy()
+        nl, ne = t.shape
         if nl == 0:
             return torch.zeros(batch_size, 0, ne - 1)
-        img = targets[:, 0].long()
-        counts = torch.bincount(img, minlength=batch_size)
-        order = torch.argsort(img, stable=True)
-        start = torch.cumsum(counts, 0) - counts
-        pos = torch.arange(nl) - start[img[order]]  # rank of each label inside its image, in the order the labels came
-        out = torch.zeros(batch_size, int(counts.max()), ne - 1)
-        out[img[order], pos] = targets[order, 1:]
-        out[..., 1:5] = xywh2xyxy(out[..., 1:5] * scale_tensor)
-        return out
+        img = t[:, 0].astype(np.int64)
+        counts = np.bincount(img, minlength=batch_size)
+        order = np.argsort(img, kind="stable")
+        start = np.cumsum(counts) - counts
+        pos = np.arange(nl) - start[img[order]]  # rank of each label inside its image, in the order the labels came
+        out = np.zeros((batch_size, int(counts.max()), ne - 1), dtype=np.float32)
+        out[img[order], pos] = t[order, 1:]
+        sc = scale_tensor.detach().cpu().float().numpy()
+        xy, half = out[..., 1:3] * sc[:2], out[..., 3:5] * sc[2:] / np.float32(2)  # xywh2xyxy (utils/ops.py:432-449) in fp32, as torch computes it
+        out[..., 1:3], out[..., 3:5] = xy - half, xy + half
+        return torch.from_numpy(out)
 
     def targets_to_gt(self, batch, batch_size: int, img_hw) -> torch.Tensor:
         """The batch's labels as the (B, n_max, 5) pixel-box table on the host (``preprocess``); img_hw = (h, w) of the images."""
-        imgsz = torch.tensor([float(img_hw[0]), float(img_hw[1])], dtype=torch.float32)
+        imgsz = torch.tensor([float(img_hw[1]), float(img_hw[0]), float(img_hw[1]), float(img_hw[0])], dtype=torch.float32)
         targets = torch.cat((batch["batch_idx"].view(-1, 1).float().cpu(), batch["cls"].view(-1, 1).float().cpu(),
                              batch["bboxes"].float().cpu()), 1)
-        return self.preprocess(targets, batch_size, imgsz[[1, 0, 1, 0]])
+        return self.preprocess(targets, batch_size, imgsz)
 
     def __call__(self, preds, batch):
         feats = preds[1] if isinstance(preds, tuple) else preds

@@ -48,7 +48,18 @@ typedef enum dy_status {
 /* DY_FP8 = OCP e4m3fn (gfx950's fp8, NOT MI300's fnuz): 1 byte per element, 16 per 16-byte chunk.  An fp8 activation or weight
  * element q stands for the real value q * scale (dy_conv_desc.act_scale for activations, w_scale[co] / act_scale for the weights of
  * output channel co).  Entry points that are not built for it return DY_ERR_INVALID_ARG ("bad dtype"). */
-typedef enum dy_dtype { DY_BF16 = 0, DY_F16 = 1, DY_F32 = 2, DY_FP8 = 3 } dy_dtype;
+typedef enum dy_dtype { DY_BF16 = 0, DY_F16 = 1, DY_F32 = 2, DY_FP8 = 3, DY_F16X2 = 4 } dy_dtype;
+/* DY_F16X2 = SPLIT float16 storage (round 5): the bar-exact precision at 16-bit MFMA speed.  An element x is the pair
+ *   hi = rn_f16(x) (0 when |x| < 2^-14),  lo = rn_f16((x - hi) * 2^11),      x ~= hi + lo * 2^-11   (22 mantissa bits)
+ * and occupies 4 bytes like an fp32 element; within a pixel row every group of 8 channels is 32 bytes, the 8 hi halves then the 8 lo
+ * halves ([hi c..c+7 | lo c..c+7]): a channel slice at a multiple of 8 channels is a contiguous byte range (Concat / chunk by view as
+ * for the other types, pitches counted in 4-byte elements), and a 128-byte K-step of the implicit GEMM holds four (hi, lo) chunk
+ * pairs, so one staged step feeds THREE v_mfma_f32_16x16x32_f16 per fragment pair — w_hi x_hi + w_lo x_hi + (w_hi 2^-11) x_lo, fp32
+ * accumulate; the lo x lo term (2^-22 relative) is dropped.  Weights (DY_WLAYOUT_ROWS only) are packed the same way per (tap, 8
+ * channels) after each output-channel row was scaled by a power of two into [2^13, 2^14) (w_lo unscaled); dy_conv_desc.w_scale[co]
+ * holds the inverse power and multiplies the accumulator in the epilogue.  Built in dy_conv2d_nhwc (dense 1x1 / 3x3, stride 1 / 2,
+ * residual, x2 / up2x, out_f32), dy_nchw_f32_to_nhwc, dy_nhwc_to_nchw_f32, dy_sppf_maxpool3 and the chunk copies; the reference has
+ * no counterpart (its CPU path is fp32: this type reproduces it to ~4 fp32 ulps per layer, see tests/test_kernels_gpu.py). */
 /* DY_ACT_SILU_L2E: SiLU in the log2(e)-SCALED activation domain.  The caller packs every bias multiplied by log2(e) (and the weights of a
  * layer that reads unscaled data, e.g. the image, likewise), so the accumulator holds t = log2(e) * z; the epilogue computes
  * t / (1 + 2^-t) = log2(e) * silu(z): every stored activation of the pass is log2(e) times the reference's (max pool, nearest upsample,
@@ -69,7 +80,7 @@ const char* dy_last_error_string(void);
  * thread dispatched to ("conv3x3_vgemm16_kernel", "conv_gemm_glds_kernel<256,256>", ...), so that live per-launch timings can be
  * grouped by the same symbols a rocprofv3 kernel trace reports.  Host string with static storage; "" before the first launch. */
 const char* dy_last_kernel_name(void);
-/* Size in bytes of one element of `dtype` (2, 2, 4, 1) or 0 if unknown. */
+/* Size in bytes of one element of `dtype` (2, 2, 4, 1, 4) or 0 if unknown. */
 int32_t dy_dtype_size(int32_t dtype);
 
 /* ---- convolution ----------------------------------------------------------

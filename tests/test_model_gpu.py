@@ -160,10 +160,8 @@ def test_end_to_end_against_reference_vectors(tag, dtype, device):
         # two-sided: detections the reference does not keep ("extra") are bounded like the ones it keeps and we lose ("missed").
         # A detection whose score sits within the storage type's score error of `conf` is decided by rounding (the v8n320 case keeps 14 boxes,
         # ALL scored 0.2500 .. 0.2557): such flips are not counted; everything else is, up to `allowed` (NMS near-ties).
-        # (r04: bf16 floor 0.998 -> 0.997.  Moving the 128-channel 3x3 layers to the register-weight kernel changed their summation order;
-        # the s640 fixture's worst bf16 box moved from 0.9981 to 0.9979 while fp16 and fp32 did not move -- bf16's own rounding, 0.9968 on
-        # s640bench since round 3, is what this floor tracks.  The fp16 floor, the headline's, is unchanged.)
-        tol, iou_floor = (0.03, 0.997) if dtype == torch.bfloat16 else (0.01, 0.9995)
+        # (r05: the bf16 floor is 0.998 again; bf16 inference packs of 128-channel layers run the kernel they ran when the floor was set.)
+        tol, iou_floor = (0.03, 0.998) if dtype == torch.bfloat16 else (0.01, 0.9995)
         margin = 2e-3 if dtype == torch.bfloat16 else 5e-4
         for i in range(len(counts)):
             n_ref = max(len(exp_idx[i]), 1)
@@ -398,6 +396,10 @@ def test_config5_fp8_trunk_against_reference_rows(tag, device):
         _report(f"config5 fp8 {tag}", {"dtype": "fp8_e4m3fn trunk, float16 Detect tail", "box_rms_px": box_rms, "cls_max_err": cls_err, "fp8_conv_launches": n8,
                                        "conv_launches": nconv, **par, **pred.fp8_calibration})
         assert bool(torch.isfinite(cf.pred).all()) and n8 >= 0.7 * nconv
-        assert par["match_rate"] >= 0.50 and par["iou_mean"] >= 0.975 and par["iou_min"] >= 0.90 and box_rms <= 1.5 and cls_err <= 0.1, (par, box_rms, cls_err)
+        # min-IoU floor: 0.93 as set in round 3 on s640bench (measured 0.957 in r03 and r04).  x1536 is ONE image with 176 matched boxes: r03's
+        # plan (everything e4m3, Detect too) had its worst box at 0.955, r04's plan (float16 Detect tails behind an e4m3 trunk) at 0.921 --
+        # another plan, not the same arithmetic on a new kernel -- and is held to 0.90 (DESIGN §12 lists both measurements)
+        iou_floor = 0.93 if tag == "s640bench" else 0.90
+        assert par["match_rate"] >= 0.50 and par["iou_mean"] >= 0.975 and par["iou_min"] >= iou_floor and box_rms <= 1.5 and cls_err <= 0.1, (par, box_rms, cls_err)
     finally:
         H.set_fp8_act_scale(1.0)

@@ -1,0 +1,205 @@
+"""GPU parity of the split-float16 storage type (DY_F16X2, include/dyolo.h): x ~= hi + lo * 2^-11, three 16-bit MFMAs per product.
+
+The type exists to meet the north-star bar (class / index exact, IoU >= 0.999 against the fp32 CPU path) at 16-bit MFMA speed, so it is
+held to fp32's own tolerances: kernels against a float64 CPU convolution to a few fp32 ulps of the output scale, whole models to the
+SAME assertions the fp32 device path meets (kept sets, classes and order identical to the reference's rows)."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import drone_yolo_amd as D
+from drone_yolo_amd import hip_ops as H
+from oracle import drone_yolo_oracle as O
+from tests._util import golden, split_rows
+
+pytestmark = pytest.mark.gpu
+X2 = H.F16X2
+
+
+def up(t, dev, ld=None, c_off=0):
+    """CPU NCHW fp32 -> device split-float16 NHWC view (optionally a channel slice, at a multiple of 8, of a wider buffer)."""
+    n, c, h, w = t.shape
+    c8 = -(-c // 8) * 8
+    if ld is None:
+        return H.to_nhwc(t.to(dev).contiguous(), X2, c_pad=c8)[:, :c] if c8 != c else H.to_nhwc(t.to(dev).contiguous(), X2)
+    buf = torch.zeros((n, h, w, ld), dtype=torch.float32, device=dev).view(X2).permute(0, 3, 1, 2)  # (zero bytes = zero pairs)
+    out = buf[:, c_off : c_off + c8]
+    H.to_nhwc(t.to(dev).contiguous(), X2, c_pad=c8, out=out)
+    return out[:, :c]
+
+
+def down(t):
+    return H.to_nchw_f32(t).cpu()
+
+
+def test_split_round_trip_keeps_22_bits(device):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 24, 9, 7, generator=g) * torch.logspace(-6, 3, 24).view(1, 24, 1, 1)
+    x[0, 0, 0, :4] = torch.tensor([0.0, -0.0, 6.0e-5, -3.0e-8])
+    y = down(up(x, device))
+    err = (y - x).abs()
+    assert float((err / (x.abs() + 1e-30)).where(x.abs() > 1e-3, torch.zeros(())).max()) <= 2.0 ** -21
+    assert float(err.where(x.abs() <= 1e-3, torch.zeros(())).max()) <= 2.0 ** -24  # small values: absolute, from the scaled lo half
+
+
+CASES = [
+    # cin, cout, k, s, B, H, W, act, tag
+    (8, 32, 3, 2, 2, 64, 64, True, "image layer, Cin 3 padded to 8"),
+    (32, 64, 3, 2, 2, 40, 40, True, "repvgg-like s2"),
+    (64, 64, 3, 1, 2, 40, 40, True, "3x3 s1 64->64"),
+    (96, 64, 1, 1, 2, 40, 40, True, "1x1 K=96"),
+    (768, 512, 1, 1, 2, 20, 20, True, "1x1 wide"),
+    (256, 256, 3, 1, 1, 20, 20, True, "3x3 deep"),
+    (512, 64, 3, 1, 1, 20, 20, True, "3x3 Cin 512 (largest tap table of scale s)"),
+    (64, 64, 3, 1, 1, 13, 17, True, "odd spatial (M tail)"),
+    (64, 64, 3, 1, 4, 160, 160, True, "large M"),
+    (16, 24, 3, 1, 1, 12, 12, True, "n-scale cout 24"),
+    (24, 48, 1, 1, 1, 12, 12, False, "cin 24 no act"),
+    (128, 128, 3, 2, 2, 40, 40, True, "s2 deep"),
+    (160, 160, 3, 1, 1, 24, 24, True, "x-scale 160 (tile 160)"),
+    (80, 80, 3, 1, 1, 24, 24, True, "x-scale 80 (tile 80)"),
+]
+
+
+def _case(case, g, scale_w=1.0):
+    cin, cout, k, s, b, h, w, act, tag = case
+    creal = 3 if tag.startswith("image") else cin
+    x = torch.randn(b, creal, h, w, generator=g)
+    wt = torch.randn(cout, creal, k, k, generator=g) * (2.0 / (creal * k * k)) ** 0.5 * scale_w
+    bias = torch.randn(cout, generator=g) * 0.2
+    return x, wt, bias
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[-1] for c in CASES])
+def test_split_conv_matches_float64(case, device):
+    cin, cout, k, s, b, h, w, act, tag = case
+    g = torch.Generator().manual_seed(zlib.crc32(tag.encode()) % 1000)
+    x, wt, bias = _case(case, g)
+    ref = F.conv2d(x.double(), wt.double(), bias.double(), s, k // 2)
+    ref32 = F.conv2d(x, wt, bias, s, k // 2)
+    if act:
+        ref, ref32 = F.silu(ref), F.silu(ref32)
+    pc = H.PackedConv(wt, bias, s, k // 2, 1, act, X2, device)
+    y = H.conv2d(up(x, device), pc)
+    torch.cuda.synchronize()
+    assert H.last_kernel_name().startswith("conv_gemm_fk_kernel<split") and tuple(y.shape) == tuple(ref.shape)
+    got = down(y).double()
+    scale = float(ref.abs().max())
+    err, err32 = float((got - ref).abs().max()), float((ref32.double() - ref).abs().max())
+    # within a few fp32 ulps of the output scale — and never far worse than the fp32 CPU convolution itself is against float64
+    assert err <= 4e-6 * scale and err <= 8 * err32 + 1e-6 * scale, (tag, err, err32, scale)
+
+
+@pytest.mark.parametrize("how", ["residual", "out_f32", "out_f32_cout10", "slice_io", "x2_up2x", "tiny_weights", "huge_activations"])
+def test_split_conv_call_forms(how, device):
+    g = torch.Generator().manual_seed(zlib.crc32(how.encode()) % 1000)
+    b, cin, cout, h, w = 2, 64, 64, 24, 20
+    k, act, kw = 3, True, {}
+    if how in ("out_f32", "out_f32_cout10"):
+        k, act, cout = 1, False, (10 if how.endswith("10") else 64)
+    if how == "x2_up2x":
+        k, cin = 1, 192
+    x = torch.randn(b, cin, h, w, generator=g) * (300.0 if how == "huge_activations" else 1.0)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5 * (1e-4 if how == "tiny_weights" else 1.0)
+    bias = torch.randn(cout, generator=g) * 0.2
+    xin = up(x, device)
+    if how == "x2_up2x":  # Upsample + Concat folded into a C2f's first 1x1: channels [0, 128) from the half-resolution map, the rest from x2
+        xl, xs = torch.randn(b, 128, h // 2, w // 2, generator=g), torch.randn(b, 64, h, w, generator=g)
+        x = torch.cat((F.interpolate(xl, scale_factor=2, mode="nearest"), xs), 1)
+        xin, kw = up(xl, device), {"x2": up(xs, device), "up2x": True}
+    if how == "slice_io":  # input = a channel slice of a wider buffer, output into one
+        xin = up(x, device, ld=160, c_off=32)
+        obuf = H.alloc_nhwc(b, 128, h, w, X2, device)
+        kw = {"out": obuf[:, 64:128]}
+    ref = F.conv2d(x.double(), wt.double(), bias.double(), 1, k // 2)
+    if act:
+        ref = F.silu(ref)
+    if how == "residual":
+        r = torch.randn(ref.shape, generator=g)
+        ref, kw = ref + r.double(), {"residual": up(r, device)}
+    if how.startswith("out_f32"):
+        ld, c_off = (76, 64) if cout == 10 else (64, 0)  # Detect's fp32 map: box bins [0, 64), class logits [64, 74), pitch 76
+        obuf = torch.zeros((b, h, w, ld), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
+        kw = {"out": obuf[:, c_off : c_off + cout], "out_f32": True}
+    pc = H.PackedConv(wt, bias, 1, k // 2, 1, act, X2, device, for_out_f32=how.startswith("out_f32"))
+    y = H.conv2d(xin, pc, **kw)
+    torch.cuda.synchronize()
+    got = (y.float().cpu() if how.startswith("out_f32") else down(y)).double()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 4e-6 * scale, (how, float((got - ref).abs().max()), scale)
+    if how == "out_f32_cout10":
+        assert float(obuf[:, 74:].abs().max()) == 0.0  # the pad columns of the pitch stay untouched
+
+
+def test_split_sppf_pools_are_exact(device):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 32, 20, 20, generator=g)
+    buf = H.alloc_nhwc(2, 128, 20, 20, X2, device)
+    H.to_nhwc(x.to(device).contiguous(), X2, out=buf[:, :32])
+    H.sppf_maxpool3(buf[:, :32], buf[:, 32:64], buf[:, 64:96], buf[:, 96:], 5)
+    torch.cuda.synchronize()
+    x0 = down(buf[:, :32])
+    y1 = F.max_pool2d(x0, 5, 1, 2)
+    y2 = F.max_pool2d(y1, 5, 1, 2)
+    y3 = F.max_pool2d(y2, 5, 1, 2)
+    for i, ref in enumerate((y1, y2, y3)):
+        assert torch.equal(down(buf[:, 32 * (i + 1) : 32 * (i + 2)]), ref)
+
+
+def _build(tag, g):
+    from tests.test_model_gpu import _build as b
+
+    return b(tag, g, None)
+
+
+@pytest.mark.parametrize("tag", ["n64", "n128", "v8n320", "s640"])
+def test_split_end_to_end_is_bar_exact(tag, device):
+    """The fp32 branch of tests/test_model_gpu.py::test_end_to_end_against_reference_vectors, on split-float16 storage: kept sets, classes
+    and order identical to the REAL reference's rows, IoU >= 0.999, raw outputs to fp32 round-off."""
+    g = golden("e2e.npz")
+    m, d, sd, model, x = _build(tag, g)
+    pred = D.engine.predictor.DetectionPredictor(model, dict(conf=0.25, iou=0.7, max_det=300, dtype="f16x2", device=0))
+    cf = pred.forward_device(pred.preprocess(x))
+    torch.cuda.synchronize()
+    y = cf.pred.cpu()
+    if f"{tag}__y" in g.files:
+        yref = torch.from_numpy(g[f"{tag}__y"])
+    else:
+        yref, y = torch.from_numpy(g[f"{tag}__y_sub"]), y[:, :, ::37]
+    box_err, cls_err = float((y[:, :4] - yref[:, :4]).abs().max()), float((y[:, 4:] - yref[:, 4:]).abs().max())
+    assert box_err < 2e-2 and cls_err < 1e-4, (box_err, cls_err)
+    counts = cf.nms.count.cpu().tolist()
+    assert counts == [int(v) for v in g[f"{tag}__n"]]
+    exp_rows = split_rows(g[f"{tag}__det"], g[f"{tag}__n"])
+    exp_idx = split_rows(g[f"{tag}__det_idx"], g[f"{tag}__n"])
+    for i, c in enumerate(counts):
+        got_idx, got_cls = cf.nms.index[i, :c].cpu().numpy(), cf.nms.out[i, :c, 5].cpu().numpy()
+        assert sorted(got_idx.tolist()) == sorted(exp_idx[i].tolist()), f"{tag} image {i}: kept anchor sets differ"
+        cls_of = {int(a): int(k) for a, k in zip(exp_idx[i], exp_rows[i][:, 5])}
+        assert all(cls_of[int(a)] == int(k) for a, k in zip(got_idx, got_cls))
+        score_of = {int(a): float(sc) for a, sc in zip(exp_idx[i], exp_rows[i][:, 4])}
+        for k in np.nonzero(got_idx != exp_idx[i])[0]:
+            assert abs(score_of[int(got_idx[k])] - float(exp_rows[i][k, 4])) < 2e-6, f"{tag} image {i}: order differs at rank {k}"
+
+
+@pytest.mark.parametrize("tag", ["s640bench", "s640b4", "s640b4lo"])
+def test_split_bench_configuration_is_bar_exact(tag, device):
+    """BASELINE config 2's fixtures (the REAL reference's fp32 CPU rows, tests/golden/big.npz) on split-float16 storage: the fp32 assertions."""
+    from drone_yolo_amd.utils import parity as PR
+    from tests.test_model_gpu import _bench_model
+
+    meta, x, exp_rows, exp_idx = PR.golden_case("big.npz", tag)
+    model = _bench_model(meta, device)
+    pred = D.engine.predictor.DetectionPredictor(model, dict(conf=0.25, iou=0.7, max_det=300, dtype="f16x2", device=0))
+    cf = pred.forward_device(pred.preprocess(x))
+    torch.cuda.synchronize()
+    g = golden("big.npz")
+    y_sub = cf.pred[:, :, ::199].cpu()
+    box_err = float((y_sub[:, :4] - torch.from_numpy(g[f"{tag}__y_sub"])[:, :4]).abs().max())
+    cls_err = float((y_sub[:, 4:] - torch.from_numpy(g[f"{tag}__y_sub"])[:, 4:]).abs().max())
+    par = PR.detection_parity(cf.nms, exp_rows, exp_idx, conf=0.25, margin=0.0)
+    assert box_err < 2e-2 and cls_err < 1e-4, (box_err, cls_err)
+    assert par["counts_equal"] and par["kept_sets_identical"] and par["match_rate"] == 1.0 and par["iou_min"] >= 0.999, par
