@@ -36,8 +36,9 @@ if ROOT not in sys.path:
 # uses runs at the bf16 rate (same guide), the line still prices against 5000 as BASELINE config 5 asks
 # fp8 = the block-scaled v_mfma_f32_16x16x128_f8f6f4 (csrc/conv_gemm_fk.hip); fp8-mixed prices against the 16-bit peak: three quarters
 # of its FLOPs run in float16 (the P2 path), the rest on the fp8 MFMA
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "fp8": 5000.0, "fp8-mixed": 2500.0}
-ELEM_BYTES = {"bf16": 2, "fp16": 2, "fp32": 4, "fp8": 1, "fp8-mixed": 2}
+# f16x2 (split float16, DY_F16X2): three 16-bit MFMAs per product, so the roof for ALGORITHMIC flops is a third of the 16-bit peak
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "fp8": 5000.0, "fp8-mixed": 2500.0, "f16x2": 2500.0 / 3}
+ELEM_BYTES = {"bf16": 2, "fp16": 2, "fp32": 4, "fp8": 1, "fp8-mixed": 2, "f16x2": 4}
 HBM_PEAK_GBS = 8000.0
 
 
@@ -132,7 +133,7 @@ def conv_work(plan):
         d = args[0]._obj
         m = d.batch * d.ho * d.wo
         k = d.ksize * d.ksize * (d.cin // max(d.groups, 1))
-        es = {_lib.DY_F32: 4, _lib.DY_FP8: 1}.get(d.dtype, 2)
+        es = {_lib.DY_F32: 4, _lib.DY_FP8: 1, _lib.DY_F16X2: 4}.get(d.dtype, 2)
         flops = 2.0 * m * d.cout * k
         hin, win = (d.h // 2, d.w_in // 2) if d.up2x else (d.h, d.w_in)
         in_elems = d.batch * (hin * win * (d.cin_split if d.x2 else d.cin) + (d.h * d.w_in * (d.cin - d.cin_split) if d.x2 else 0))
@@ -480,7 +481,8 @@ def batch_sweep(model, dtype, device_index, batches=(1, 8, 64), steps: int = 20)
     from drone_yolo_amd.engine.predictor import DetectionPredictor
 
     out = []
-    for b, dt_name in [(b, dtype) for b in batches] + [(64, "fp32"), (256, "fp32")]:
+    exact = [(64, "fp32"), (256, "fp32"), (64, "f16x2"), (256, "f16x2")]
+    for b, dt_name in [(b, dtype) for b in batches] + [e for e in exact if e[1] != dtype]:
         p = DetectionPredictor(model, dict(conf=0.25, iou=0.7, max_det=300, dtype=dt_name, device=device_index, graph=True))
         x = torch.rand(b, 3, 640, 640, generator=torch.Generator().manual_seed(2000 + b)).to(torch.device("cuda", device_index))
         cf = p.forward_device(x)
@@ -501,7 +503,8 @@ def batch_sweep(model, dtype, device_index, batches=(1, 8, 64), steps: int = 20)
             gates = batch_sweep.__dict__.setdefault("_gates", {})
             g = gates.get(dt_name) or gates.setdefault(dt_name, parity_gate(dt_name, device_index))
             row["parity"] = {k: g[k] for k in ("match_rate", "missed", "extra", "iou_min", "counts_equal", "kept_sets_identical")}
-            row["note"] = "bar-exact precision (class / index identical to the reference, IoU >= 0.999)"
+            row["note"] = ("bar-exact precision (class / index identical to the reference, IoU >= 0.999)" if dt_name == "fp32" else
+                           "split float16 (DY_F16X2: hi + lo 2^-11 pairs, three 16-bit MFMAs per product): the drop-in API's default precision")
         out.append(row)
     return out
 
@@ -513,7 +516,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps first (default 10 infer / 5 train)")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 256 for infer, SURVEY §8d config 2; 64 for train, config 3)")
     ap.add_argument("--imgsz", type=int, default=640, help="square input size (BASELINE config 5: --model yolov8x-p2-repvgg.yaml --imgsz 1536 --dtype fp8 --batch 8)")
-    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32", "fp8", "fp8-mixed"],
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32", "f16x2", "fp8", "fp8-mixed"],
                     help="storage dtype.  infer: fp16 by default - the fastest precision that meets the IoU >= 0.999 bar (BASELINE config 2 names bf16, which "
                          "misses it: see `parity`); train: bf16 by default (SURVEY config 3: AMP bf16; fp16 runs under the device-side GradScaler)")
     ap.add_argument("--model", default="yolov8s-p2-repvgg.yaml")
@@ -700,6 +703,8 @@ def main():
                                               "headline runs the 16-bit format that meets it; same MFMA rate, same bytes)",
                                       "bf16": "bf16 storage / fp32 accumulate (BASELINE config 2's dtype; misses the IoU >= 0.999 bar, see parity)",
                                       "fp32": "fp32 storage (bar-exact)",
+                                      "f16x2": "split float16 storage (DY_F16X2: every value a float16 pair hi + lo 2^-11, three 16-bit MFMAs per product, fp32 "
+                                               "accumulate; bar-exact: the precision YOLO.predict runs by default)",
                                       "fp8": "fp8 e4m3fn storage of the whole trunk on the block-scaled fp8 MFMA / fp32 accumulate, Detect branch tails float16 (BASELINE config 5, "
                                              "throughput plan: does not meet the deployable parity gate, see parity)",
                                       "fp8-mixed": "float16 storage with the layers off the P2 path (19..27) in fp8 e4m3fn on the block-scaled fp8 MFMA (BASELINE config 5, the plan "

@@ -617,6 +617,27 @@ int conv_gemm_fk_try(const dy_conv_desc* d, hipStream_t st) {
 #ifndef DYOLO_L2E_BUILD
 template <typename OT>
 static int launch_fk_split_tiles(const FkArgs& a, hipStream_t st) {
+#ifdef DYOLO_ABLATE
+  if constexpr (std::is_same<OT, f16x2_t>::value) {  // tile study (tools/split_tiles.py): MFR, NFR, WM, WN, table words
+    const char* v = getenv("DYOLO_SPLIT_CFG");
+    switch (v ? atoi(v) : 0) {
+      case 1: return launch_fk<f16x2_t, OT, 2, 4, 4, 1, 256>(a, st, "split<128,64> 4w 32x64 t256");
+      case 2: return launch_fk<f16x2_t, OT, 4, 4, 2, 1, 256>(a, st, "split<128,64> 2w 64x64 t256");
+      case 3: return launch_fk<f16x2_t, OT, 4, 4, 4, 1, 256>(a, st, "split<256,64> 4w 64x64 t256");
+      case 4: return launch_fk<f16x2_t, OT, 2, 4, 8, 1, 256>(a, st, "split<256,64> 8w 32x64 t256");
+      case 5: return launch_fk<f16x2_t, OT, 2, 2, 4, 1, 256>(a, st, "split<128,32> 4w 32x32 t256");
+      case 6: return launch_fk<f16x2_t, OT, 4, 2, 4, 1, 256>(a, st, "split<256,32> 4w 64x32 t256");
+      case 7: return launch_fk<f16x2_t, OT, 2, 2, 8, 1, 256>(a, st, "split<256,32> 8w 32x32 t256");
+      case 8: return launch_fk<f16x2_t, OT, 4, 4, 2, 2, 640>(a, st, "split<128,128> 4w 64x64 t640");
+      case 9: return launch_fk<f16x2_t, OT, 4, 4, 4, 2, 640>(a, st, "split<256,128> 8w 64x64 t640");
+      case 10: return launch_fk<f16x2_t, OT, 2, 4, 4, 2, 640>(a, st, "split<128,128> 8w 32x64 t640");
+      case 11: return launch_fk<f16x2_t, OT, 4, 2, 2, 4, 640>(a, st, "split<128,128> 8w 64x32 t640");
+      case 12: return launch_fk<f16x2_t, OT, 4, 4, 1, 1, 256>(a, st, "split<64,64> 1w 64x64 t256");
+      case 13: return launch_fk<f16x2_t, OT, 4, 2, 2, 1, 256>(a, st, "split<128,32> 2w 64x32 t256");
+      default: break;
+    }
+  }
+#endif
   const int cands[4] = {160, 128, 80, 64};
   int best = 160;
   long long bw = 1ll << 60;

@@ -185,6 +185,149 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const StemArgs p) {
   }
 }
 
+// DY_F16X2 (split float16, include/dyolo.h) form of the same kernel: the gathered taps are split into (hi, lo) on the fly — the image
+// itself is an fp32 operand of the reference's first convolution, so it gets the same 22 bits as every later activation — and each
+// (pixel fragment, cout fragment) takes the three 16-bit MFMAs w_hi x_hi + w_lo x_hi + (w_hi 2^-11) x_lo.  p.w = [cout_pad16][32] hi
+// halves, then as many lo halves, then fp32[cout_pad16] inverse row scales (the rows were scaled into [2^13, 2^14) when packed); the
+// output leaves as [hi x 8 | lo x 8] groups.  Replaces the layout cast + flat-K launch the type's first version ran: 3.0 -> ~1 ms at B = 256.
+#ifndef DYOLO_L2E_BUILD
+template <int NF>
+__global__ __launch_bounds__(256) void conv_stem_split_kernel(const StemArgs p) {
+  constexpr int MF = 4;
+  constexpr int BN = NF * 16;
+  constexpr int EP_PITCH = BN * 4 + 16;
+  constexpr int EP_BYTES = MF * 16 * EP_PITCH;
+  constexpr int PLANE = kStemPH * kStemPitch;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  float* patch = reinterpret_cast<float*>(dyn_smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane >> 4, lr = lane & 15;
+  unsigned char* escr = dyn_smem + ((p.Cin * PLANE * 4 + 15) / 16) * 16 + wave * EP_BYTES;
+
+  int t = blockIdx.x;
+  const int tx = t % p.tilesX;
+  t /= p.tilesX;
+  const int ty = t % p.tilesY;
+  const int n = t / p.tilesY;
+  const int y0 = ty * kStemTH, x0 = tx * kStemTW;
+  const int gy0 = 2 * y0 - 1, gx0 = 2 * x0 - 1;
+  if (p.vec4) {
+    constexpr int V = kStemPitch / 4;
+    for (int i = tid; i < p.Cin * kStemPH * V; i += 256) {
+      const int row = i / V, j = i - row * V;
+      const int c = row / kStemPH, py = row - c * kStemPH;
+      const int gy = gy0 + py, gx = gx0 - kStemShift + 4 * j;
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(n * p.Cin + c) * p.H + gy) * p.W + gx);
+      *reinterpret_cast<f32x4*>(patch + c * PLANE + py * kStemPitch + 4 * j) = v;
+    }
+  } else {
+    for (int i = tid; i < p.Cin * kStemPH * kStemPW; i += 256) {
+      const int c = i / (kStemPH * kStemPW);
+      const int r2 = i - c * (kStemPH * kStemPW);
+      const int py = r2 / kStemPW, px = r2 - py * kStemPW;
+      const int gy = gy0 + py, gx = gx0 + px;
+      float v = 0.f;
+      if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) v = p.x[((size_t)(n * p.Cin + c) * p.H + gy) * p.W + gx];
+      patch[c * PLANE + py * kStemPitch + px + kStemShift] = v;
+    }
+  }
+  const int cp16 = (p.Cout + 15) / 16 * 16;
+  const f16_t* wh = reinterpret_cast<const f16_t*>(p.w);
+  const f16_t* wl = wh + (size_t)cp16 * 32;
+  const float* wsc = reinterpret_cast<const float*>(wl + (size_t)cp16 * 32);
+  u32x4 fh[NF], fl[NF], fs[NF];
+#pragma unroll
+  for (int j = 0; j < NF; ++j) {
+    fh[j] = *reinterpret_cast<const u32x4*>(wh + (size_t)(j * 16 + lr) * 32 + lq * 8);
+    fl[j] = *reinterpret_cast<const u32x4*>(wl + (size_t)(j * 16 + lr) * 32 + lq * 8);
+    const f16x8 sv = __builtin_bit_cast(f16x8, fh[j]) * (f16_t)kSplitInv;
+    fs[j] = __builtin_bit_cast(u32x4, sv);
+  }
+  int koff[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = lq * 8 + e;
+    const int c = k / 9, r = (k - c * 9) / 3, q = k - c * 9 - r * 3;
+    koff[e] = (k < p.Cin * 9) ? c * PLANE + r * kStemPitch + q : -1;
+  }
+  __syncthreads();
+
+  f32x4 acc[MF][NF];
+#pragma unroll
+  for (int j = 0; j < NF; ++j)
+#pragma unroll
+    for (int i = 0; i < MF; ++i) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < MF; ++i) {
+    const int row = wave * 2 + (i >> 1), col = (i & 1) * 16 + lr;
+    const float* org = patch + (2 * row) * kStemPitch + 2 * col + kStemShift;
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = koff[e] >= 0 ? org[koff[e]] : 0.f;
+    u32x4 ah, al;
+    split8(f, ah, al);
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+      acc[i][j] = Elem<f16_t>::mma(fh[j], ah, acc[i][j]);
+      acc[i][j] = Elem<f16_t>::mma(fl[j], ah, acc[i][j]);
+      acc[i][j] = Elem<f16_t>::mma(fs[j], al, acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NF; ++j) {
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + j * 16 + lq * 4), sc = *reinterpret_cast<const f32x4*>(wsc + j * 16 + lq * 4);
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * sc[e] + bb[e];
+      if (p.act == DY_ACT_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
+      }
+      *reinterpret_cast<f32x4*>(escr + (i * 16 + lr) * EP_PITCH + (j * 16 + lq * 4) * 4) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  constexpr int GPR = BN / 8;  // groups of 8 channels per pixel
+  unsigned char* __restrict__ yb = reinterpret_cast<unsigned char*>(p.y);
+#pragma unroll
+  for (int k = 0; k < (MF * 16 * GPR + 63) / 64; ++k) {
+    const int idx = k * 64 + lane;
+    const int pixl = idx / GPR, g = idx - pixl * GPR;
+    const int i = pixl >> 4;
+    const int yy = y0 + wave * 2 + (i >> 1), xx = x0 + (i & 1) * 16 + (pixl & 15);
+    if (pixl < MF * 16 && yy < p.Ho && xx < p.Wo && g * 8 < p.Cout) {
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(escr + pixl * EP_PITCH + g * 32), t1 = *reinterpret_cast<const f32x4*>(escr + pixl * EP_PITCH + g * 32 + 16);
+      const float f[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+      u32x4 hi, lo;
+      split8(f, hi, lo);
+      unsigned char* dp = yb + (((size_t)(n * p.Ho + yy) * p.Wo + xx) * (size_t)p.ldy + (size_t)g * 8) * 4;
+      *reinterpret_cast<u32x4*>(dp) = hi;
+      *reinterpret_cast<u32x4*>(dp + 16) = lo;
+    }
+  }
+}
+
+template <int NF>
+static int launch_stem_split(const StemArgs& a, hipStream_t st) {
+  StemArgs p = a;
+  p.tilesX = (p.Wo + kStemTW - 1) / kStemTW;
+  p.tilesY = (p.Ho + kStemTH - 1) / kStemTH;
+  p.vec4 = (p.W % 4 == 0 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
+  const int smem = ((p.Cin * kStemPH * kStemPitch * 4 + 15) / 16) * 16 + 4 * 4 * 16 * (NF * 16 * 4 + 16);
+  auto kern = conv_stem_split_kernel<NF>;
+  static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)once;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.N * p.tilesY * p.tilesX)), dim3(256), smem, st, p);
+  return check_launch("conv_stem_split_kernel");
+}
+#endif
+
 template <typename T, int NF, bool U8 = false>
 static int launch_stem(const StemArgs& a, hipStream_t st) {
   StemArgs p = a;
@@ -263,7 +406,7 @@ extern "C" int32_t dy_stem_conv3x3s2_nchw_u8(const uint8_t* x, float divisor, co
 namespace DY_NS {
 int32_t stem_entry(const float* x, const void* w, const float* bias, void* y, int32_t n, int32_t cin, int32_t h, int32_t w_in, int32_t cout, int32_t ld_y, int32_t act,
                    int32_t dtype, dy_stream_t stream) {
-  const int es = dtype_size_no_fp8(dtype);
+  const int es = dtype == DY_F16X2 ? 4 : dtype_size_no_fp8(dtype);
   DY_REQUIRE(x && w && bias && y && es, DY_ERR_INVALID_ARG, "dy_stem_conv3x3s2_nchw: null pointer or bad dtype");
   DY_REQUIRE(n > 0 && h > 0 && w_in > 0 && cout > 0 && cin >= 1 && cin * 9 <= 32, DY_ERR_INVALID_ARG,
              "dy_stem_conv3x3s2_nchw: needs 1 <= cin <= 3 (K = 9*cin <= 32)");
@@ -284,6 +427,20 @@ int32_t stem_entry(const float* x, const void* w, const float* bias, void* y, in
   a.ldy = ld_y;
   a.act = act;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == DY_F16X2) {
+#ifndef DYOLO_L2E_BUILD
+    DY_REQUIRE(cout % 8 == 0 && cout <= 64, DY_ERR_UNSUPPORTED, "dy_stem_conv3x3s2_nchw: DY_F16X2 is built for cout a multiple of 8 up to 64");
+    switch ((cout + 15) / 16) {
+      case 1: return launch_stem_split<1>(a, st);
+      case 2: return launch_stem_split<2>(a, st);
+      case 3: return launch_stem_split<3>(a, st);
+      default: return launch_stem_split<4>(a, st);
+    }
+#else
+    set_error("dy_stem_conv3x3s2_nchw: DY_F16X2 runs in the reference's activation units");
+    return DY_ERR_UNSUPPORTED;
+#endif
+  }
   switch (dtype) {
     case DY_BF16: return launch_stem_dtype<bf16_t>(a, st);
     case DY_F16: return launch_stem_dtype<f16_t>(a, st);

@@ -344,7 +344,10 @@ class DetectionTrainer:
     ``train()`` for the whole loop (model from ``overrides['model']``, data from ``overrides['data']``)."""
 
     def __init__(self, model: Optional[nn.Module] = None, overrides: Optional[dict] = None, iterations_hint: int = 0):
-        self.args = a = get_cfg(overrides or {})
+        self.args = get_cfg(overrides or {})
+        self._resume_ckpt = None
+        self.check_resume(overrides or {})  # may replace self.args by the checkpoint's (trainer.py:105)
+        a = self.args
         data = a.get("data")
         if isinstance(data, (str, Path)) and not (str(data).startswith("synthetic") or str(data).endswith(".pt")):
             load_dataset(data, 0, 0, 0)  # raises NotImplementedError naming what is built, before any device work
@@ -362,11 +365,116 @@ class DetectionTrainer:
         self.epochs = int(a["epochs"])
         self.start_epoch, self.epoch = 0, 0
         self.loss_names = ("box_loss", "cls_loss", "dfl_loss")
+        from ..utils.torch_utils import EarlyStopping
+
+        self.stopper, self.stop = EarlyStopping(patience=a.get("patience", 100)), False  # trainer.py:314
         self.flat = None
         self.tloss = None
         self.train_loader = None
         if model is not None:
             self._setup_model_state()
+
+    # ---- resume ----------------------------------------------------------------------------------------------------------
+    def check_resume(self, overrides: dict) -> None:
+        """trainer.py:697-729: ``resume`` = True (with ``model`` = .../last.pt) or the path of a last.pt.  The checkpoint's ``train_args``
+        become the arguments, ``model`` / ``resume`` point at the file, and imgsz / batch / device may be overridden (less memory, another
+        GPU).  A tensor dataset handed over as a dict is not in the file: ``data`` from the overrides is kept when the checkpoint has none."""
+        resume = self.args.get("resume")
+        if resume:
+            try:
+                cand = resume if isinstance(resume, (str, Path)) and Path(str(resume)).exists() else self.args.get("model")
+                last = Path(str(cand))
+                if not (last.suffix == ".pt" and last.exists()):
+                    raise FileNotFoundError(str(cand))
+                from ..nn.checkpoint import read_checkpoint_dict
+
+                ckpt = read_checkpoint_dict(str(last))
+                ck_args = {k: v for k, v in dict(ckpt.get("train_args") or {}).items() if k in self.args}  # (keys this path knows)
+                if isinstance(overrides.get("data"), dict) or not ck_args.get("data"):
+                    ck_args["data"] = overrides.get("data", self.args.get("data"))
+                self.args = get_cfg(ck_args)
+                self.args["model"] = self.args["resume"] = str(last)
+                for k in ("imgsz", "batch", "device"):
+                    if k in overrides:
+                        self.args[k] = overrides[k]
+                self._resume_ckpt = ckpt
+                resume = True
+            except Exception as e:
+                raise FileNotFoundError("Resume checkpoint not found. Please pass a valid checkpoint to resume from, i.e. "
+                                        "YOLO('path/to/last.pt').train(resume=True)") from e
+        self.resume = bool(resume)
+
+    def resume_training(self, ckpt: Optional[dict]) -> None:
+        """trainer.py:731-754: optimizer state, EMA weights + ``updates``, ``best_fitness`` and the next epoch from a last.pt.  A file written
+        by this trainer also carries ``dyolo_state`` — the fp32 live weights, BatchNorm buffers, EMA and optimizer moments, the GradScaler
+        state and the step counters — and then the run continues as if it had never stopped; a file written by the reference has the fp16
+        EMA graph and fp16 optimizer state only, and resumes as the reference does (the live weights restart from the EMA, tasks.py:906)."""
+        if ckpt is None or not self.resume:
+            return
+        best_fitness = 0.0
+        start_epoch = int(ckpt.get("epoch", -1)) + 1
+        exact = ckpt.get("dyolo_state")
+        dev = self.device
+        if ckpt.get("optimizer") is not None:
+            self.load_optimizer_state_dict(ckpt["optimizer"])
+            best_fitness = ckpt.get("best_fitness")
+        if ckpt.get("ema") is not None:
+            sd = {k: v.float() for k, v in ckpt["ema"].state_dict().items() if v.is_floating_point()}
+            for k, (off, c) in self.flat.offsets.items():
+                self.ema.P[off : off + c].copy_(sd[k].reshape(-1))
+            off = 0
+            for k, b in self.model.named_buffers():
+                if b.is_floating_point():
+                    c = b.numel()
+                    self.ema.B[off : off + c].copy_(sd[k].reshape(-1))
+                    off += c
+            self.ema.updates = int(ckpt.get("updates") or 0)
+        if isinstance(exact, dict) and exact.get("P") is not None and exact["P"].numel() == self.flat.P.numel():
+            self.flat.P.copy_(exact["P"].to(dev))
+            self.flat.B.copy_(exact["B"].to(dev))
+            self.ema.P.copy_(exact["ema_P"].to(dev))
+            self.ema.B.copy_(exact["ema_B"].to(dev))
+            self.buf1.copy_(exact["buf1"].to(dev))
+            if self.buf2 is not None and exact.get("buf2") is not None:
+                self.buf2.copy_(exact["buf2"].to(dev))
+            if self.amp_state is not None and exact.get("amp_state") is not None:
+                self.amp_state.copy_(exact["amp_state"].to(dev))
+            if exact.get("G") is not None:
+                self.flat.G.copy_(exact["G"].to(dev))
+            self.opt_steps, self.last_opt_step = int(exact["opt_steps"]), int(exact["last_opt_step"])
+            self._resumed_exact = True
+        assert start_epoch > 0, (f"{self.args['model']} training to {self.epochs} epochs is finished, nothing to resume.\n"
+                                 f"Start a new training without resuming, i.e. YOLO('{self.args['model']}').train()")
+        LOGGER.info(f"Resuming training {self.args['model']} from epoch {start_epoch + 1} to {self.epochs} total epochs")
+        if self.epochs < start_epoch:
+            LOGGER.info(f"the model has been trained for {ckpt['epoch']} epochs. Fine-tuning for {self.epochs} more epochs.")
+            self.epochs += int(ckpt["epoch"])  # finetune additional epochs
+            self.sched.epochs = self.epochs
+        self.best_fitness = best_fitness
+        self.start_epoch = start_epoch
+
+    def load_optimizer_state_dict(self, sd: dict) -> None:
+        """``torch.optim``'s state-dict layout (what ``optimizer_state_dict`` writes, fp16 in the file: torch_utils.py:619-632) back into the
+        flat moment buffers; entries follow the reference's parameter enumeration (biases, decay weights, norm weights)."""
+        g0, g1, g2 = param_group_names(self.model, include_frozen=True)
+        order = list(g2) + list(g0) + list(g1)
+        state = sd.get("state", {})
+        ran = None
+        for i, k in enumerate(order):
+            st = state.get(i, state.get(str(i)))
+            if st is None or k not in self.flat.offsets:
+                continue
+            off, c = self.flat.offsets[k]
+            if self.opt_name == "SGD":
+                if st.get("momentum_buffer") is not None:
+                    self.buf1[off : off + c].copy_(st["momentum_buffer"].reshape(-1).float())
+            else:
+                self.buf1[off : off + c].copy_(st["exp_avg"].reshape(-1).float())
+                self.buf2[off : off + c].copy_(st["exp_avg_sq"].reshape(-1).float())
+                ran = int(float(st["step"])) if "step" in st else ran
+        if state:
+            # SGD's first step seeds the momentum buffer with the gradient (first-step flag = opt_steps == 1): any restored state is past it
+            self.opt_steps = ran if ran is not None else max(self.opt_steps, 1)
 
     # ---- setup -----------------------------------------------------------------------------------------------------------
     def _device_list(self) -> List[int]:
@@ -722,9 +830,17 @@ class DetectionTrainer:
                 # carries its split as data["val"] (same layout); without one the training tensors are evaluated
                 from .validator import DetectionValidator
 
-                vd = data.get("val") if isinstance(data.get("val"), dict) else data
-                self.val_loader = TensorLoader({k: vd[k] for k in ("img", "batch_idx", "cls", "bboxes")}, per_rank * 2, 0, 1, shuffle=False)
-                self.validator = DetectionValidator(a)
+                # the reference needs a real val split (check_det_dataset).  Without one there is nothing to validate ON: the
+                # metrics/* and val/* columns and best.pt stay out rather than being computed on the training tensors under a validation
+                # label; `val: "train"` asks for exactly that evaluation by name (smoke runs, the self-consistency test of the validator)
+                vd = data.get("val") if isinstance(data.get("val"), dict) else (data if a.get("val") == "train" else None)
+                if vd is None:
+                    LOGGER.info("val: the dataset has no 'val' split -- validation skipped (fitness = -loss decides best.pt)")
+                else:
+                    self.val_loader = TensorLoader({k: vd[k] for k in ("img", "batch_idx", "cls", "bboxes")}, per_rank * 2, 0, 1, shuffle=False)
+                    self.validator = DetectionValidator(a)
+        self.resume_training(self._resume_ckpt)  # trainer.py:315 (after the optimizer exists)
+        self._resume_ckpt = None
 
     def _do_train(self, world: int = 1):
         if world > 1:
@@ -733,9 +849,11 @@ class DetectionTrainer:
         self._setup_train(world)
         nb = len(self.train_loader)
         nw = self.warmup_iters(nb)
-        self.last_opt_step = -1
-        self.flat.G.zero_()
-        t_start = time.time()
+        if not getattr(self, "_resumed_exact", False):
+            self.last_opt_step = -1
+            self.flat.G.zero_()
+        t_start = self.train_time_start = time.time()
+        self.stop = False
         LOGGER.info(f"Image sizes {self.args['imgsz']} train\\nLogging results to {self.save_dir}\\nStarting training for {self.epochs} epochs...") if self.rank == 0 else None
         epoch = self.start_epoch
         while True:
@@ -749,24 +867,71 @@ class DetectionTrainer:
                 batch = self.preprocess_batch(batch)
                 self.loss, self.loss_items = self.train_batch(batch, ni, epoch, nb)
                 self.tloss = (self.tloss * i + self.loss_items) / (i + 1) if self.tloss is not None else self.loss_items
+                if self.args.get("time"):  # timed stopping (trainer.py:396-404): rank 0's clock decides for every rank
+                    self.stop = P.broadcast_flag((time.time() - t_start) > float(self.args["time"]) * 3600, self.device)
+                    if self.stop:
+                        break
             final_epoch = epoch + 1 >= self.epochs
             if self.rank == 0:
                 self.lr = {f"lr/pg{ir}": x for ir, x in enumerate((self.cur_lrs[2], self.cur_lrs[0], self.cur_lrs[1]))}  # reference group order
-                if self.validator is not None and (self.args.get("val", True) or final_epoch):  # trainer.py:430-432
+                if self.validator is not None and (self.args.get("val", True) or final_epoch or self.stopper.possible_stop or self.stop):  # trainer.py:430-432
                     self.metrics, self.fitness = self.validate()
+                elif self.validator is None:
+                    self.fitness = -float(self.loss)  # (validate()'s own rule when there are no metrics, trainer.py:611-612)
+                    if not self.best_fitness or self.best_fitness < self.fitness:
+                        self.best_fitness = self.fitness
                 self.save_metrics({"time": time.time() - t_start, **self.label_loss_items(self.tloss), **self.metrics, **self.lr})
+                self.stop |= self.stopper(epoch + 1, self.fitness) or final_epoch  # trainer.py:435
+                if self.args.get("time"):
+                    self.stop |= (time.time() - t_start) > float(self.args["time"]) * 3600
                 if self.args.get("save", True) or final_epoch:
                     self.save_model()
                 LOGGER.info(f"{epoch + 1}/{self.epochs}  " + "  ".join(f"{k} {float(v):.4g}" for k, v in self.label_loss_items(self.tloss).items()))
-            if final_epoch:
+            # trainer.py:457-463: rank 0's decision reaches every rank (all of them must leave the loop in the same epoch) — one int32 over RCCL
+            self.stop = P.broadcast_flag(bool(self.stop) or final_epoch, self.device)
+            if self.stop:
                 break
             epoch += 1
         torch.cuda.synchronize(self.device)
         if self.rank == 0:
             LOGGER.info(f"{epoch - self.start_epoch + 1} epochs completed in {(time.time() - t_start) / 3600:.3f} hours.")
+            self.final_eval()
         if world > 1 and torch.distributed.is_initialized():
             torch.distributed.barrier()
         return {**self.label_loss_items(self.tloss), "save_dir": str(self.save_dir)}
+
+    def final_eval(self) -> None:
+        """trainer.py:681-695: the optimizer (and this trainer's exact-resume state) stripped from last.pt and best.pt; best.pt takes
+        last.pt's ``train_results``, is validated once more and its metrics become the run's."""
+        from ..utils.torch_utils import strip_optimizer
+
+        ckpt = {}
+        for f in (self.last, self.best):
+            if not f.exists():
+                continue
+            if f is self.last:
+                ckpt = strip_optimizer(f)
+            else:
+                k = "train_results"
+                best = strip_optimizer(f, updates={k: ckpt[k]} if k in ckpt else None)
+                if self.validator is not None and best.get("model") is not None:
+                    LOGGER.info(f"Validating {f}...")
+                    sd = {k2: v.float() for k2, v in best["model"].state_dict().items() if v.is_floating_point()}
+                    keep = (self.ema.P.clone(), self.ema.B.clone())
+                    try:  # validate() evaluates the EMA buffers: lend them best.pt's weights for the pass
+                        for k2, (off, c) in self.flat.offsets.items():
+                            self.ema.P[off : off + c].copy_(sd[k2].reshape(-1))
+                        off = 0
+                        for k2, b in self.model.named_buffers():
+                            if b.is_floating_point():
+                                self.ema.B[off : off + b.numel()].copy_(sd[k2].reshape(-1))
+                                off += b.numel()
+                        bf = self.best_fitness
+                        self.metrics, _ = self.validate()
+                        self.best_fitness = bf
+                    finally:
+                        self.ema.P.copy_(keep[0])
+                        self.ema.B.copy_(keep[1])
 
     def validate(self):
         """trainer.py:605-615 + validator.py:109-221 (training branch): the EMA weights evaluated on the validation tensors; fitness =
@@ -852,10 +1017,16 @@ class DetectionTrainer:
         from ..nn.checkpoint import save_reference_checkpoint
 
         args = {k: v for k, v in self.args.items() if not isinstance(v, dict)}  # (a tensor dataset passed as a dict does not belong in the file)
+        # what the reference's keys cannot carry (they hold the EMA graph and the optimizer moments in fp16, and no live weights at all:
+        # its resume restarts from the EMA): the fp32 state of the run, so that `resume` continues where this epoch ended.  Plain tensors
+        # under a key of their own — the reference's loader ignores it, strip_optimizer drops it
+        exact = {"P": self.flat.P.cpu(), "B": self.flat.B.cpu(), "ema_P": self.ema.P.cpu(), "ema_B": self.ema.B.cpu(), "buf1": self.buf1.cpu(),
+                 "buf2": self.buf2.cpu() if self.buf2 is not None else None, "amp_state": self.amp_state.cpu() if self.amp_state is not None else None,
+                 "G": self.flat.G.cpu() if self.accumulate > 1 else None, "opt_steps": self.opt_steps, "last_opt_step": self.last_opt_step, "iters": self.iters}
         save_reference_checkpoint(self.last, self.model, self.ema.state_dict(self.model), extra={
             "epoch": self.epoch, "best_fitness": self.best_fitness, "updates": self.ema.updates, "optimizer": self.optimizer_state_dict(),
             "train_args": args, "train_metrics": {**self.metrics, "fitness": self.fitness},
-            "train_results": self.read_results_csv(), "date": datetime.now().isoformat()})
+            "train_results": self.read_results_csv(), "date": datetime.now().isoformat(), "dyolo_state": exact})
         if self.best_fitness is not None and self.best_fitness == self.fitness:  # trainer.py:541-542
             import shutil
 

@@ -38,10 +38,17 @@ class DetectionValidator:
         nc = model.yaml["nc"]
         stats = dict(tp=[], conf=[], pred_cls=[], target_cls=[])
         loss = torch.zeros(3, device=device)
-        nb = 0
         if getattr(model, "criterion", None) is None:
             model.criterion = model.init_criterion()
         det = model.model[-1]
+        fuse_tail = getattr(det, "fuse_tail", False)
+        try:
+            return self._evaluate(model, loader, device, dtype, nc, stats, loss, det)
+        finally:
+            det.fuse_tail = fuse_tail  # (a predictor that shares the model keeps its fused tail: ADVICE r4)
+
+    def _evaluate(self, model, loader, device, dtype, nc, stats, loss, det) -> Dict[str, float]:
+        nb = 0
         for batch in loader:
             nb += 1
             img = batch["img"].to(device)
@@ -52,11 +59,11 @@ class DetectionValidator:
                 y, feats = model._predict_once(x.contiguous(), image_dtype=dtype)
                 loss += model.criterion(feats, batch)[1]  # validator.py:186-187: loss items of the same pass
                 preds = ops.non_max_suppression(y, self.conf, self.iou, nc=nc, multi_label=True, agnostic=self.agnostic, max_det=self.max_det)
-            bi = batch["batch_idx"].long()
+            bi = batch["batch_idx"].long().cpu()
             for si, pred in enumerate(preds):  # detect/val.py:126-174
                 sel = bi == si
-                cls = batch["cls"][sel].view(-1).cpu().numpy()
-                bb = batch["bboxes"][sel].float()
+                cls = batch["cls"].cpu()[sel].view(-1).numpy()
+                bb = batch["bboxes"].cpu()[sel].float()  # (a dataset held on the device: the scaling below is host arithmetic)
                 tbox = (ops.xywh2xyxy(bb) * torch.tensor((w, h, w, h), dtype=torch.float32)).numpy() if len(cls) else np.zeros((0, 4), np.float32)
                 pn = pred.cpu().numpy()
                 # _prepare_batch / _prepare_pred (detect/val.py:108-124): labels and predictions go through ops.scale_boxes to the original

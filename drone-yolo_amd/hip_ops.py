@@ -686,6 +686,18 @@ class PackedStem:
         wp[:cout, : cin * 9] = weight.detach().to(torch.float32).cpu().reshape(cout, cin * 9)
         bp = torch.zeros((cp,), dtype=torch.float32)
         bp[:cout] = bias.detach().to(torch.float32).cpu()
+        if dtype == F16X2:  # [hi rows | lo rows | inverse row scales] in one buffer (include/dyolo.h); the split rules of PackedConv
+            if cout % 8 or cout > 64:
+                raise ValueError("PackedStem: split-float16 storage needs cout a multiple of 8 up to 64")
+            sc = torch.exp2(13.0 - torch.floor(torch.log2(wp.abs().amax(1).clamp_min(1e-30))))
+            ws = wp * sc[:, None]
+            hi = torch.where(ws.abs() < 2.0 ** -14, torch.zeros_like(ws), ws).to(torch.float16)
+            lo = (ws - hi.to(torch.float32)).to(torch.float16)
+            inv = (1.0 / sc).to(torch.float32)
+            raw = torch.cat((hi.reshape(-1).view(torch.uint8), lo.reshape(-1).view(torch.uint8), inv.view(torch.uint8)))
+            self.w = raw.contiguous().to(device)
+            self.b = bp.contiguous().to(device)
+            return
         self.w = wp.to(dtype).contiguous().to(device)
         self.b = bp.contiguous().to(device)
 
@@ -698,7 +710,7 @@ def stem_conv(src: torch.Tensor, ps: PackedStem, out: Optional[torch.Tensor] = N
     n, c, h, w = src.shape
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     if out is None:
-        e = elems_per_chunk(ps.dtype)
+        e = chan_gran(ps.dtype)
         out = alloc_nhwc(n, ps.cout, ho, wo, ps.dtype, src.device, ld=-(-ps.cout // e) * e)
     op, ld = view_params(out)
     args = (src.data_ptr(), ps.w.data_ptr(), ps.b.data_ptr(), op, n, c, h, w, ps.cout, ld, ps.act, dy_dtype(ps.dtype))

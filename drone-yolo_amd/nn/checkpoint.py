@@ -112,6 +112,16 @@ def read_reference_checkpoint(path: str) -> Tuple[dict, Dict[str, torch.Tensor],
     return dict(yaml_d), sd, meta
 
 
+def read_checkpoint_dict(path: str) -> Dict[str, Any]:
+    """The whole checkpoint dictionary as written by ``BaseTrainer.save_model`` (``ema`` = the module graph restored as THIS package's
+    classes, ``optimizer`` = torch.optim's state-dict layout, ``epoch``, ``best_fitness``, ``updates``, ``train_args`` ...) through the
+    restricted unpickler: what ``resume_training`` and ``strip_optimizer`` work on (engine/trainer.py:731-754, utils/torch_utils.py:553-616)."""
+    ckpt = torch.load(str(path), map_location="cpu", pickle_module=_pickle_module(), weights_only=False)
+    if not isinstance(ckpt, dict):
+        raise TypeError(f"{path}: checkpoint is not a Python dictionary")
+    return ckpt
+
+
 def load_reference_checkpoint(path: str, verbose: bool = False):
     """A ``DetectionModel`` of this package carrying the checkpoint's architecture and weights."""
     from .tasks import DetectionModel
@@ -219,7 +229,8 @@ def save_reference_checkpoint(path, model: nn.Module, state_dict: Dict[str, torc
     """Write ``path`` with the keys of ``BaseTrainer.save_model`` (engine/trainer.py:514-545): ``model`` None, ``ema`` the module
     graph in fp16 — pickled under the reference's class paths, so the reference's own ``torch.load`` / ``attempt_load_one_weight``
     (nn/tasks.py:786-926) restore it as ITS classes — optimizer state in fp16 (torch_utils.py:553-566), train_args as a dict."""
-    ck = {"epoch": -1, "best_fitness": None, "model": None, "ema": reference_module_graph(model, state_dict), "updates": 0, "optimizer": None,
+    ck = {"epoch": -1, "best_fitness": None, "model": None, "ema": reference_module_graph(model, state_dict) if model is not None else None, "updates": 0,
+          "optimizer": None,
           "train_args": {}, "train_metrics": {}, "train_results": {}, "date": None, "version": "8.3.0", "license": "AGPL-3.0 (https://ultralytics.com/license)",
           "docs": "https://docs.ultralytics.com"}
     ck.update(extra or {})

@@ -215,7 +215,8 @@ class BaseModel(nn.Module):
         stem_image = None
         if image_dtype is not None:
             first = self.model[0]
-            if isinstance(first, Conv) and first.is_stem() and 0 not in self._place and getattr(self, "fuse_stem", True) and image_dtype != H.F16X2:
+            if isinstance(first, Conv) and first.is_stem() and 0 not in self._place and getattr(self, "fuse_stem", True) and \
+                    (image_dtype != H.F16X2 or (first.conv.out_channels % 8 == 0 and first.conv.out_channels <= 64)):
                 stem_image = x
                 n, _, h, w = x.shape
                 x = torch.empty((n, 0, h, w), dtype=image_dtype, device=x.device)  # shape/dtype carrier only

@@ -96,6 +96,17 @@ def sum_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
+def broadcast_flag(flag: bool, device=None, src: int = 0) -> bool:
+    """Rank ``src``'s boolean on every rank — the reference's per-epoch ``dist.broadcast_object_list([self.stop], 0)`` (trainer.py:401,
+    460): all ranks must leave the loop together.  One int32 device tensor over RCCL (a CPU tensor over gloo) instead of a pickled list."""
+    if not dist.is_initialized():
+        return bool(flag)
+    dev = device if (device is not None and dist.get_backend() == "nccl") else "cpu"
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    dist.broadcast(t, src)
+    return bool(int(t.item()))
+
+
 def allreduce_gradients(flat_grad: torch.Tensor) -> torch.Tensor:
     """In-place SUM all-reduce of the flat gradient buffer over all ranks (reference: loss *= world_size, trainer.py:382-383,
     then DistributedDataParallel's gradient mean — the product is the plain sum).  One bucket: for Drone-YOLO-s 43 MB fp32,

@@ -63,3 +63,77 @@ def init_seeds(seed=0, deterministic=False) -> None:
     torch.manual_seed(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)
+
+
+def strip_optimizer(f="best.pt", s: str = "", updates: dict = None) -> dict:
+    """Finalise a training checkpoint — reference torch_utils.py:553-616: ``model`` := the EMA module graph in fp16 with frozen
+    parameters, ``optimizer`` / ``best_fitness`` / ``ema`` / ``updates`` := None, ``epoch`` := -1, ``train_args`` merged over the defaults,
+    fresh ``date`` / ``version`` metadata, ``updates`` overlaid last; written back to ``s or f`` under the reference's class paths (so the
+    reference's own ``torch.load`` restores its classes).  This package's exact-resume state (``dyolo_state``, engine/trainer.py) is
+    dropped with the optimizer.  Returns the combined dict ({} for a file that is no checkpoint, with a warning, as the reference)."""
+    from datetime import datetime
+
+    from ..nn import checkpoint as CK
+    from . import LOGGER
+
+    try:
+        x = CK.read_checkpoint_dict(str(f))
+        assert "model" in x, "'model' missing from checkpoint"
+    except Exception as e:  # noqa: BLE001 (the reference skips anything it cannot read)
+        LOGGER.warning(f"WARNING Skipping {f}, not a valid checkpoint: {e}")
+        return {}
+    metadata = {"date": datetime.now().isoformat(), "version": "8.3.0", "license": "AGPL-3.0 License (https://ultralytics.com/license)",
+                "docs": "https://docs.ultralytics.com"}
+    if x.get("ema"):
+        x["model"] = x["ema"]  # replace model with EMA
+    model = x["model"]
+    if not isinstance(model, nn.Module):
+        LOGGER.warning(f"WARNING Skipping {f}: no module graph under 'ema' / 'model'")
+        return {}
+    if hasattr(model, "args") and not isinstance(model.args, dict):
+        model.args = dict(getattr(model.args, "__dict__", {}))  # (IterableSimpleNamespace -> dict)
+    if hasattr(model, "criterion"):
+        model.criterion = None  # strip loss criterion
+    model.half()
+    for p in model.parameters():
+        p.requires_grad = False
+    from ..engine.trainer import get_cfg
+
+    args = {**get_cfg({}), **{k: v for k, v in dict(x.get("train_args") or {}).items()}}
+    for k in ("optimizer", "best_fitness", "ema", "updates"):
+        x[k] = None
+    x.pop("dyolo_state", None)
+    x["epoch"] = -1
+    x["train_args"] = args
+    combined = {**metadata, **x, **(updates or {})}
+    with CK._reference_class_paths():
+        torch.save(combined, str(s or f))
+    mb = os.path.getsize(str(s or f)) / 1e6
+    LOGGER.info(f"Optimizer stripped from {f},{f' saved as {s},' if s else ''} {mb:.1f}MB")
+    return combined
+
+
+class EarlyStopping:
+    """Stop when ``patience`` epochs have passed without a fitness improvement — reference torch_utils.py:733-776."""
+
+    def __init__(self, patience=50):
+        self.best_fitness = 0.0  # i.e. mAP
+        self.best_epoch = 0
+        self.patience = patience or float("inf")  # epochs to wait after fitness stops improving to stop
+        self.possible_stop = False  # possible stop may occur next epoch
+
+    def __call__(self, epoch, fitness) -> bool:
+        if fitness is None:  # val=False
+            return False
+        if fitness > self.best_fitness or self.best_fitness == 0:  # allow for early zero-fitness stage of training
+            self.best_epoch = epoch
+            self.best_fitness = fitness
+        delta = epoch - self.best_epoch  # epochs without improvement
+        self.possible_stop = delta >= (self.patience - 1)
+        stop = delta >= self.patience
+        if stop:
+            from . import LOGGER
+
+            LOGGER.info(f"EarlyStopping: Training stopped early as no improvement observed in last {self.patience} epochs. "
+                        f"Best results observed at epoch {self.best_epoch}, best model saved as best.pt.")
+        return stop

@@ -258,7 +258,9 @@ int32_t dy_c2f_fused(const dy_c2f_desc* d, dy_stream_t stream);
  * yolov8-p2-repvgg.yaml layer 0), so the image is never materialised in NHWC.
  * x: fp32 NCHW (n, cin, h, w) contiguous.  w: [ceil(cout/16)*16][32] of `dtype`, row co = the folded taps in
  * k = c*9 + r*3 + q order (i.e. OIHW flattened), zero padded to 32; bias fp32[ceil(cout/16)*16].
- * y: NHWC view (n, (h-1)/2+1, (w-1)/2+1, cout) of `dtype`, pitch ld_y.  cout <= 80. */
+ * y: NHWC view (n, (h-1)/2+1, (w-1)/2+1, cout) of `dtype`, pitch ld_y.  cout <= 80.
+ * DY_F16X2 (round 5): w = [cout_pad16][32] float16 hi halves, then as many lo halves, then fp32[cout_pad16] inverse row scales in ONE buffer
+ * (rows scaled by a power of two into [2^13, 2^14) before the split, as for dy_conv2d_nhwc); the image is split on the fly; cout % 8 == 0, <= 64. */
 int32_t dy_stem_conv3x3s2_nchw(const float* x, const void* w, const float* bias, void* y, int32_t n, int32_t cin,
                                int32_t h, int32_t w_in, int32_t cout, int32_t ld_y, int32_t act, int32_t dtype,
                                dy_stream_t stream);

@@ -145,10 +145,16 @@ def test_128_channel_3x3_runs_on_the_register_weight_kernel_or_its_rows_twin(how
     b, cin, cout, h, w = 2, 128, 128, 24, 20
     wt = quantize(torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5, dtype)
     bias = torch.randn(cout, generator=g) * 0.2
-    pc = H.PackedConv(wt, bias, 1, 1, 1, True, dtype, device)
+    # r05: bf16 packs WITH an activation (inference) stay on the virtual-flat GEMM (hip_ops.PackedConv: the four-chunk summation order cost the
+    # s640 fixture's worst bf16 box its 0.998 IoU floor); the raw convolutions of a training step (no activation) and float16 keep the kernel
+    act = dtype == torch.float16
+    pc = H.PackedConv(wt, bias, 1, 1, 1, act, dtype, device)
     assert pc.layout == H._lib.DY_WLAYOUT_HALO3X3
+    if dtype == torch.bfloat16:
+        assert H.PackedConv(wt, bias, 1, 1, 1, True, dtype, device).layout == H._lib.DY_WLAYOUT_ROWS
     x = quantize(torch.randn(b, cin, h, w, generator=g), dtype)
-    ref = F.silu(F.conv2d(x, wt, bias, 1, 1))
+    ref = F.conv2d(x, wt, bias, 1, 1)
+    ref = F.silu(ref) if act else ref
     kw = {}
     if how == "residual":
         r = quantize(torch.randn(ref.shape, generator=g), dtype)

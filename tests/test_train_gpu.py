@@ -649,8 +649,18 @@ def test_yolo_train_api_end_to_end(device, tmp_path):
     x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(1))
     before = yolo.predict(x, device=0, conf=0.001, dtype="fp32")
     # nbs = batch: the reference accumulates gradients up to nbs (64) images per optimizer step (trainer.py:254); 8 here -> every batch steps
-    out = yolo.train(data="synthetic:16", epochs=2, imgsz=64, batch=8, nbs=8, device=0, dtype="fp32", optimizer="SGD", lr0=0.01, warmup_epochs=0.0,
-                     project=str(tmp_path), name="t")
+    from drone_yolo_amd.engine.trainer import DetectionTrainer
+
+    class KeepsLast(DetectionTrainer):  # final_eval strips the optimizer from last.pt (trainer.py:681-695): keep what the last epoch wrote beside it
+        def final_eval(self):
+            import shutil
+
+            shutil.copyfile(self.last, self.wdir / "last_epoch.pt")
+            super().final_eval()
+
+    # val="train": the synthetic set has no val split; the metrics of this run are asked for, by name, on the training tensors
+    out = yolo.train(trainer=KeepsLast, data="synthetic:16", epochs=2, imgsz=64, batch=8, nbs=8, device=0, dtype="fp32", optimizer="SGD", lr0=0.01, warmup_epochs=0.0,
+                     project=str(tmp_path), name="t", val="train")
     rows = list(csv.DictReader(open(tmp_path / "t" / "results.csv")))
     assert [r["epoch"] for r in rows] == ["1", "2"]
     assert {"time", "train/box_loss", "train/cls_loss", "train/dfl_loss", "lr/pg0", "lr/pg1", "lr/pg2"} <= set(rows[0])
@@ -658,7 +668,15 @@ def test_yolo_train_api_end_to_end(device, tmp_path):
     assert {"metrics/precision(B)", "metrics/recall(B)", "metrics/mAP50(B)", "metrics/mAP50-95(B)", "val/box_loss", "val/cls_loss", "val/dfl_loss"} <= set(rows[0])
     assert all(float(r["val/cls_loss"]) > 0 for r in rows) and (tmp_path / "t" / "weights" / "best.pt").exists()
     assert all(float(r["train/cls_loss"]) > 0 for r in rows) and "train/box_loss" in out  # (2-pixel synthetic boxes at 64x64 rarely get a foreground anchor)
-    ck = torch.load(tmp_path / "t" / "weights" / "last.pt", map_location="cpu", weights_only=False, pickle_module=__import__("drone_yolo_amd").nn.checkpoint._pickle_module())
+    from drone_yolo_amd.nn.checkpoint import read_checkpoint_dict
+
+    # after train() last.pt / best.pt are the STRIPPED files, as the reference leaves them (strip_optimizer, torch_utils.py:553-616)
+    for name in ("last.pt", "best.pt"):
+        st = read_checkpoint_dict(str(tmp_path / "t" / "weights" / name))
+        assert st["epoch"] == -1 and st["optimizer"] is None and st["ema"] is None and st["updates"] is None and st["best_fitness"] is None and "dyolo_state" not in st
+        assert isinstance(st["model"], torch.nn.Module) and next(st["model"].parameters()).dtype == torch.float16 and not any(p.requires_grad for p in st["model"].parameters())
+        assert st["train_args"]["epochs"] == 2 and len(st["train_results"]["epoch"]) == 2
+    ck = read_checkpoint_dict(str(tmp_path / "t" / "weights" / "last_epoch.pt"))
     assert {"epoch", "best_fitness", "model", "ema", "updates", "optimizer", "train_args", "train_metrics", "train_results", "date", "version"} <= set(ck)
     assert ck["epoch"] == 1 and ck["model"] is None and ck["updates"] == 4 and len(ck["optimizer"]["param_groups"]) == 3
     assert ck["best_fitness"] is not None and "fitness" in ck["train_metrics"] and "metrics/mAP50-95(B)" in ck["train_metrics"]
@@ -680,6 +698,55 @@ def test_yolo_train_api_end_to_end(device, tmp_path):
     again = D.YOLO(str(tmp_path / "t" / "weights" / "last.pt")).predict(x, device=0, conf=0.001, dtype="fp32")
     assert len(again) == 2 and again[0].boxes.data.shape[1] == 6
     assert len(before) == 2
+
+
+def test_resume_continues_a_killed_run_and_equals_the_straight_one(device, tmp_path):
+    """VERDICT r4 item 6 (reference trainer.py:697-754): a three-epoch run killed after its second epoch and resumed from last.pt
+    against the same three epochs run straight.  last.pt carries the reference's keys plus this trainer's fp32 state (``dyolo_state``),
+    so the resumed run continues where the epoch ended: live weights, EMA (+ updates), momentum buffers, best_fitness and the epoch
+    counter — equal to fp32 round-off of the kernels' atomics.  Also: the stripped last.pt of a finished run refuses to resume."""
+    import drone_yolo_amd as D
+    from drone_yolo_amd.engine.trainer import DetectionTrainer, synthetic_dataset
+
+    data = synthetic_dataset(16, 64, seed=1003, nc=10)
+    common = dict(model="yolov8n-p2-repvgg.yaml", nc=10, epochs=3, imgsz=64, batch=8, nbs=8, device=0, dtype="fp32", optimizer="SGD", lr0=0.01, warmup_epochs=1.0,
+                  project=str(tmp_path))
+
+    class Killed(Exception):
+        pass
+
+    class DiesAfterEpoch2(DetectionTrainer):
+        def save_model(self):
+            super().save_model()
+            if self.epoch == 1:
+                raise Killed
+
+    straight = DetectionTrainer(overrides=dict(common, data=data, name="straight"))
+    straight.train()
+    victim = DiesAfterEpoch2(overrides=dict(common, data=data, name="victim"))
+    with pytest.raises(Killed):
+        victim.train()
+    last = tmp_path / "victim" / "weights" / "last.pt"
+    del victim
+    resumed = DetectionTrainer(overrides=dict(resume=str(last), data=data))
+    assert resumed.args["epochs"] == 3 and resumed.args["name"] == "victim" and resumed.args["model"] == str(last)
+    resumed.train()
+    assert resumed.start_epoch == 2 and resumed.epoch == 2 and resumed.ema.updates == straight.ema.updates == 6 and resumed.opt_steps == straight.opt_steps == 6
+    for what, a, b in (("weights", resumed.flat.P, straight.flat.P), ("EMA", resumed.ema.P, straight.ema.P), ("momentum", resumed.buf1, straight.buf1),
+                       ("BatchNorm buffers", resumed.flat.B, straight.flat.B)):
+        err = float((a - b).abs().max())
+        assert err <= 2e-3 * float(b.abs().max()), (what, err, float(b.abs().max()))
+    rows = resumed.read_results_csv()
+    assert rows["epoch"] == [1.0, 2.0, 3.0]  # the resumed run appended its epoch to the victim's results.csv
+    # a finished run's last.pt is stripped (epoch -1): nothing to resume (trainer.py:744-747)
+    with pytest.raises(AssertionError, match="nothing to resume"):
+        DetectionTrainer(overrides=dict(resume=str(tmp_path / "straight" / "weights" / "last.pt"), data=data)).train()
+    # and YOLO('last.pt').train(resume=True) is the same door (engine/model.py:744-817)
+    victim2 = DiesAfterEpoch2(overrides=dict(common, data=data, name="victim2"))
+    with pytest.raises(Killed):
+        victim2.train()
+    out = D.YOLO(str(tmp_path / "victim2" / "weights" / "last.pt")).train(resume=True, data=data)
+    assert "train/box_loss" in out
 
 
 def test_two_rank_training_rehearsal_on_one_gpu(device, tmp_path):
