@@ -430,7 +430,7 @@ def train_record(a, dt, t_enq, loss, tr, batch, world, steps, warmup, dtype):
         rec["config"]["grad_scaler"] = {"scale": sc, "growth_tracker": int(tracker), "skipped_steps": int(skipped)}
     if tr.buckets is not None:
         rec["config"]["exchange"] = {"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(), "buckets": len(tr.buckets.buckets),
-                                     "event_path_verified": tr.buckets.event_path_verified}
+                                     "graphs_per_step": len(tr._graph["graphs"]) if getattr(tr, "_graph", None) else 0}
     return rec
 
 
@@ -509,6 +509,80 @@ def batch_sweep(model, dtype, device_index, batches=(1, 8, 64), steps: int = 20)
     return out
 
 
+def predict_api_record(model_yaml: str, sd, device_index: int, batch: int = 256, iters: int = 5):
+    """what the PUBLIC API delivers — ``YOLO(yaml).predict(x)`` end to end on a resident batch, `Results` objects included
+    (preprocess, hipGraph replay, the host read of the kept counts, one clone per image): with no precision argument (the bar-exact default)
+    and with ``half=True`` (float16, the headline's storage type).  Reference: engine/model.py:501-560, engine/predictor.py:230-300."""
+    import drone_yolo_amd as D
+
+    dev = torch.device("cuda", device_index)
+    yolo = D.YOLO(model_yaml)
+    m = D.DetectionModel(model_yaml, nc=10, verbose=False)
+    m.load_state_dict(sd)
+    yolo.model = m
+    x = torch.rand(batch, 3, 640, 640, generator=torch.Generator().manual_seed(3000)).to(dev)
+    rows = []
+    for kw in ({}, {"half": True}):
+        res = yolo.predict(x, device=device_index, **kw)  # records the pass and captures the graph
+        res = yolo.predict(x, device=device_index, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            res = yolo.predict(x, device=device_index, **kw)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+        sp = res[0].speed
+        rows.append({"call": "YOLO(yaml).predict(x)" if not kw else "YOLO(yaml).predict(x, half=True)", "dtype": str(yolo.predictor.dtype).replace("torch.", "")
+                     .replace("complex32", "f16x2 (split float16, carried as complex32)"), "hipgraph": bool(yolo.predictor.args["graph"]), "batch": batch,
+                     "ms_per_call": round(dt * 1e3, 3), "img_s": round(batch / dt, 1), "detections": int(sum(len(r) for r in res)),
+                     "per_image_ms": {k: round(v, 4) for k, v in sp.items()}})
+        yolo.predictor = None
+        torch.cuda.empty_cache()
+    return rows
+
+
+def other_scales_record(device_index: int, batch: int = 256, steps: int = 10):
+    """the small scale and the -sf YAML (DWConv on the generic grouped kernel) at the headline's batch, float16, hipGraph
+    replay on one stream, with the conv-family roofline of each (live per-launch timing as for the headline)."""
+    import drone_yolo_amd as D
+    from drone_yolo_amd.engine.predictor import DetectionPredictor
+
+    dev = torch.device("cuda", device_index)
+    out = []
+    for yaml_name in ("yolov8n-p2-repvgg.yaml", "yolov8n-p2-repvgg-sf.yaml"):
+        model = D.DetectionModel(yaml_name, nc=10, verbose=False)
+        model.load_state_dict(synthetic_state_dict(model, seed=0))
+        p = DetectionPredictor(model, dict(conf=0.25, iou=0.7, max_det=300, dtype="fp16", device=device_index, graph=True))
+        x = torch.rand(batch, 3, 640, 640, generator=torch.Generator().manual_seed(4000)).to(dev)
+        cf = p.forward_device(x)
+        x = cf.static_in
+        for _ in range(2):
+            p.forward_device(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            p.forward_device(x)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        work, times, knames = time_convs(cf.plan, iters=3)
+        flops, tconv = sum(w[1] for w in work), sum(times.values())
+        by = {}
+        for w in work:
+            e = by.setdefault((knames.get(w[0]) or "?").split("<")[0], [0, 0.0, 0.0])
+            e[0] += 1
+            e[1] += times[w[0]] * 1e6
+            e[2] += w[1] / 1e9
+        top = sorted(by.items(), key=lambda kv: -kv[1][1])[:4]
+        out.append({"model": yaml_name, "dtype": "fp16", "batch": batch, "ms_per_pass": round(dt * 1e3, 3), "img_s": round(batch / dt, 1),
+                    "kept_per_image": round(float(cf.nms.count.float().mean()), 1), "gflop_per_image": round(flops / batch / 1e9, 3),
+                    "roofline": {"bound": "mfma", "achieved": round(flops / tconv / 1e12, 2), "peak": MFMA_PEAK_TFLOPS["fp16"], "unit": "TFLOP/s",
+                                 "frac": round(flops / tconv / 1e12 / MFMA_PEAK_TFLOPS["fp16"], 4), "conv_ms_per_pass": round(tconv * 1e3, 3),
+                                 "top_kernels": {k: {"launches": v[0], "us": round(v[1], 1), "TFLOPs": round(v[2] / v[1] * 1e3, 1) if v[1] else None} for k, v in top}}})
+        del p, cf
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -523,14 +597,15 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="replay the launch plan from Python instead of a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the B = 1 / 8 / 64 batch sweep")
-    ap.add_argument("--no-train", action="store_true", help="skip the training sub-record (10 steps of SURVEY config 3 at B = 64)")
+    ap.add_argument("--no-train", action="store_true", help="skip the training sub-record (30 steps of SURVEY config 3 at B = 64)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the public-API rows (YOLO.predict) and the other-scales rows of the default line")
     ap.add_argument("--bare", action="store_true", help="profiling runs: no parity gate, breakdown, batch sweep or CPU baseline (only the passes of the timed workload)")
     ap.add_argument("--layers", default="", help="write a per-conv-launch timing table to this file")
     ap.add_argument("--streams", type=int, default=2, help="independent batches in flight on separate HIP streams (2 measured best: 1 -> 14.5k, 2 -> 15.1k, 3 -> 14.9k img/s)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"], help="infer = the headline metric (default); train = SURVEY §8(d) config 3")
     a = ap.parse_args()
     if a.bare:
-        a.no_sweep = a.no_cpu_baseline = True
+        a.no_sweep = a.no_cpu_baseline = a.no_extra = True
     if a.batch is None:
         a.batch = 64 if a.mode == "train" else int(os.environ.get("DYOLO_BENCH_BATCH", 256))
     if a.dtype is None:
@@ -626,6 +701,7 @@ def main():
                 "achieved": round(flops / tconv / 1e12, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(flops / tconv / 1e12 / peak, 4), "traffic": traffic,
                 "traffic_unit": f"GB of HBM traffic per pass (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, {tsrc})",
+                "traffic_source": "the COMMITTED counter summary of this command (PMC passes cannot run inside the timed process); not measured in this run",
                 "launches": len(work), "flops_per_image": round(flops / a.batch / 1e9, 3), "conv_ms_per_step": round(tconv * 1e3, 3),
                 "hbm_algorithmic_GB": round(nbytes / 1e9, 4), "hbm_achieved_GBs": round(nbytes / tconv / 1e9, 1), "hbm_peak_GBs": HBM_PEAK_GBS,
                 "hbm_frac": round(nbytes / tconv / 1e9 / HBM_PEAK_GBS, 4)}
@@ -675,6 +751,13 @@ def main():
         if world == 1 and not a.no_sweep and a.imgsz == 640:
             sweep = batch_sweep(model, a.dtype, local_rank) + [{"batch": a.batch, "dtype": a.dtype, "ms_per_pass": round(dt / a.steps * 1e3, 3), "img_s": round(a.batch * a.steps / dt, 1),
                                                                 "note": f"headline: {ns} batches in flight"}]
+    api = scales = None
+    if rank == 0 and world == 1 and not a.no_extra and a.imgsz == 640 and "yolov8s-p2-repvgg" in a.model:
+        del preds, xs, cfs, pred, x, cf
+        preds = xs = cfs = pred = x = cf = None
+        torch.cuda.empty_cache()
+        api = predict_api_record(a.model, sd, local_rank, batch=a.batch)
+        scales = other_scales_record(local_rank, batch=a.batch)
     train = None
     if world == 1 and not a.bare and not a.no_train and a.imgsz == 640 and "yolov8s-p2-repvgg" in a.model:
         # SURVEY §8(d) config 3 in the driver's record: 30 graphed training steps at B = 64 (bf16 storage), after the inference state is gone
@@ -712,7 +795,7 @@ def main():
                        "parallelism": f"batch-split x{world}, no collective", "hipgraph": not a.no_graph, "streams": ns,
                        "conf": 0.25, "iou": 0.7, "max_det": 300, "candidates_frac": round(cand, 4), "kept_per_image": round(kept, 1)},
             "ranks_seen": ranks_seen, "collective": collective, "parity": parity, "breakdown": breakdown, "batch_sweep": sweep,
-            "roofline": roof, "tiled": tiled, "train": train, "cpu_baseline": cpu}))
+            "roofline": roof, "tiled": tiled, "predict_api": api, "other_scales": scales, "train": train, "cpu_baseline": cpu}))
 
 
 if __name__ == "__main__":

@@ -638,6 +638,12 @@ static int launch_fk_split_tiles(const FkArgs& a, hipStream_t st) {
     }
   }
 #endif
+  // Tile rule (tools/split_tiles.py on the layer shapes of scale s at B = 256, r05): the kernel is bound by LDS traffic and latency, not
+  // by the matrix pipe, and MORE waves beat bigger wave tiles — 128 x 128 as eight waves of 32 x 64 ran 1.35-1.6x the four 64 x 64 waves
+  // of the 16-bit kernel's shape, Cout <= 32 (the stride-4 C2f's Bottlenecks) wants a 256-pixel tile of eight 32 x 32 waves (1.9x the
+  // half-empty 64-wide tile), and the tap table is sized by need (256 / 640 / 1536 words): 6 KB of table beside a 128 x 64 tile cost
+  // the third workgroup of a CU (-15 %).  The x scale's 160 / 80 wide tiles keep the 16-bit kernel's shapes.
+  const int words = a.ks == 1 ? 0 : a.Kpad / 32 * 8;
   const int cands[4] = {160, 128, 80, 64};
   int best = 160;
   long long bw = 1ll << 60;
@@ -645,12 +651,19 @@ static int launch_fk_split_tiles(const FkArgs& a, hipStream_t st) {
     const long long w = (long long)((a.Cout + c - 1) / c) * c;
     if (w < bw) bw = w, best = c;
   }
+  if (a.Cout <= 32) best = 32;
+#define DY_SPLIT_TAB(MFR, NFR, WM, WN, NAME)                                                   \
+  return words <= 256 ? launch_fk<f16x2_t, OT, MFR, NFR, WM, WN, 256>(a, st, NAME)              \
+         : words <= 640 ? launch_fk<f16x2_t, OT, MFR, NFR, WM, WN, 640>(a, st, NAME)            \
+                        : launch_fk<f16x2_t, OT, MFR, NFR, WM, WN, 1536>(a, st, NAME)
   switch (best) {
     case 160: return launch_fk<f16x2_t, OT, 4, 5, 2, 2, 1536>(a, st, "conv_gemm_fk_kernel<split,128,160>");
-    case 128: return launch_fk<f16x2_t, OT, 4, 4, 2, 2, 1536>(a, st, "conv_gemm_fk_kernel<split,128,128>");
     case 80: return launch_fk<f16x2_t, OT, 2, 5, 4, 1, 1536>(a, st, "conv_gemm_fk_kernel<split,128,80>");
-    default: return launch_fk<f16x2_t, OT, 2, 4, 4, 1, 1536>(a, st, "conv_gemm_fk_kernel<split,128,64>");
+    case 128: DY_SPLIT_TAB(2, 4, 4, 2, "conv_gemm_fk_kernel<split,128,128>");
+    case 32: DY_SPLIT_TAB(2, 2, 8, 1, "conv_gemm_fk_kernel<split,256,32>");
+    default: DY_SPLIT_TAB(2, 4, 4, 1, "conv_gemm_fk_kernel<split,128,64>");
   }
+#undef DY_SPLIT_TAB
 }
 
 int conv_gemm_fk_split(const dy_conv_desc* d, hipStream_t st) {

@@ -168,3 +168,39 @@ extern "C" int32_t dy_rows_to_pred(const float* rows, const int32_t* counts, con
                      max_det, nc);
   return dy::check_launch("dy_rows_to_pred");
 }
+
+// ---- multi_scale of DetectionTrainer.preprocess_batch (models/yolo/detect/train.py:60-73) -------------------------------------------
+// batch["img"].float() / 255 followed by nn.functional.interpolate(imgs, size=ns, mode="bilinear", align_corners=False), one pass over a
+// uint8 NCHW batch: source coordinate (d + 0.5) * (in / out) - 0.5 clamped at 0, neighbours i and min(i + 1, in - 1), the four taps
+// divided by 255 first (the reference scales before it resizes) and blended horizontally then vertically in fp32 as torch's CPU kernel does.
+namespace dy {
+__global__ __launch_bounds__(256) void resize_bilinear_u8_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int planes, int h, int w, int ho, int wo,
+                                                                 float sy, float sx) {
+  const long long total = (long long)planes * ho * wo;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % wo);
+    long long t = i / wo;
+    const int y = (int)(t % ho);
+    const int pl = (int)(t / ho);
+    float fy = __fsub_rn(__fmul_rn((float)y + 0.5f, sy), 0.5f), fx = __fsub_rn(__fmul_rn((float)x + 0.5f, sx), 0.5f);
+    fy = fy < 0.f ? 0.f : fy, fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const uint8_t* s = src + (size_t)pl * h * w;
+    const float v00 = (float)s[(size_t)y0 * w + x0] / 255.0f, v01 = (float)s[(size_t)y0 * w + x1] / 255.0f;
+    const float v10 = (float)s[(size_t)y1 * w + x0] / 255.0f, v11 = (float)s[(size_t)y1 * w + x1] / 255.0f;
+    dst[i] = __fadd_rn(__fmul_rn(hy, __fadd_rn(__fmul_rn(hx, v00), __fmul_rn(lx, v01))), __fmul_rn(ly, __fadd_rn(__fmul_rn(hx, v10), __fmul_rn(lx, v11))));
+  }
+}
+}  // namespace dy
+
+extern "C" int32_t dy_resize_bilinear_u8_nchw_f32(const uint8_t* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t ho, int32_t wo, dy_stream_t stream) {
+  DY_REQUIRE(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && ho > 0 && wo > 0, DY_ERR_INVALID_ARG, "dy_resize_bilinear_u8_nchw_f32: bad arguments");
+  const long long total = (long long)n * c * ho * wo;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(dy::resize_bilinear_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, n * c, h, w, ho, wo,
+                     (float)h / (float)ho, (float)w / (float)wo);
+  return dy::check_launch("dy_resize_bilinear_u8_nchw_f32");
+}

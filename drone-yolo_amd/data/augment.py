@@ -39,6 +39,16 @@ class LetterBox:
         left, right = (int(round(dw - 0.1)) if self.center else 0), int(round(dw + 0.1))
         return new_unpad[0], new_unpad[1], top, bottom, left, right
 
+    def into(self, frame: torch.Tensor, out: torch.Tensor, swap_rb: bool = True) -> None:
+        """ONE device uint8 (H, W, 3) frame -> ``out``, a (1, 3, Hn, Wn) fp32 slice of a batch tensor whose size is this LetterBox's output
+        for the frame: the per-image form ``pre_transform`` uses for sources of different shapes (engine/predictor.py:147-163, auto = False:
+        every image letterboxed to the full ``new_shape``)."""
+        h0, w0, _ = frame.shape
+        nw, nh, top, bottom, left, right = self.geometry((h0, w0))
+        if tuple(out.shape) != (1, 3, nh + top + bottom, nw + left + right) or not out.is_contiguous():
+            raise ValueError(f"LetterBox.into: out must be a contiguous (1, 3, {nh + top + bottom}, {nw + left + right}) slice")
+        H.letterbox(frame[None], nw, nh, top, left, nh + top + bottom, nw + left + right, swap_rb, out=out)
+
     def __call__(self, frames: torch.Tensor, swap_rb: bool = True) -> torch.Tensor:
         """frames: device uint8 (N, H, W, 3) -> fp32 (N, 3, Hn, Wn) in [0, 1], letterboxed."""
         H.require_device(frames, "frames")

@@ -30,14 +30,34 @@ _DTYPE_NAMES = {"f16x2": H.F16X2, "split": H.F16X2, "fp8": H.FP8, "float8_e4m3fn
 # The precision a predictor runs in when the caller names none.  The reference's default is ``half: False`` = fp32 (cfg/default.yaml:54,
 # engine/predictor.py:315-322), and the drop-in's default must reproduce ITS detections: class / index exact, IoU >= 0.999 (BASELINE.json).
 # ``half=True`` selects float16 storage as in the reference; bf16 and fp8 only on request (they do not meet that bar).
-EXACT_DTYPE = torch.float32
+# Two precisions meet it: fp32 storage on the fp32 MFMA (1/16 of the 16-bit rate) and split float16 (hip_ops.F16X2: every value a float16
+# pair hi + lo 2^-11, three 16-bit MFMAs per product — kept sets identical to the reference's on every fixture, at ~2x the fp32 path's
+# throughput).  The default is the split type wherever its kernels cover the model (dense convolutions on whole groups of 8 channels),
+# fp32 otherwise (the DWConv of the -sf YAML).
+EXACT_DTYPE = H.F16X2
 
 
-def resolve_dtype(dtype=None, half: bool = False) -> torch.dtype:
+def split_supported(model) -> bool:
+    """Whether every convolution of ``model`` is one the split-float16 kernels take (dense, channel counts in whole groups of 8 — the image
+    layer's input and the class logits excepted)."""
+    import torch.nn as nn
+
+    convs = [m for k, m in model.named_modules() if isinstance(m, nn.Conv2d) and ".dfl" not in k]  # (DFL's fixed 16 -> 1 conv lives inside the decode kernel)
+    for c in convs:
+        if c.groups != 1 or c.kernel_size not in ((1, 1), (3, 3)) or c.stride[0] not in (1, 2):
+            return False
+        if (c.in_channels % 8 and c.in_channels > 3) or (c.out_channels % 8 and c.bias is None):  # (plain biased 1x1 = Detect's fp32 outputs)
+            return False
+    return bool(convs)
+
+
+def resolve_dtype(dtype=None, half: bool = False, model=None) -> torch.dtype:
     if isinstance(dtype, torch.dtype):
         return dtype
     if dtype is None:
-        return torch.float16 if half else EXACT_DTYPE
+        if half:
+            return torch.float16
+        return EXACT_DTYPE if (model is None or split_supported(model)) else torch.float32
     try:
         return _DTYPE_NAMES[str(dtype).lower()]
     except KeyError:
@@ -68,7 +88,7 @@ class DetectionPredictor:
         # dtype="fp8-mixed" (BASELINE config 5): float16 storage with the internals of the C2f blocks the error budget allows in
         # e4m3 (BaseModel.fp8_plan_off_p2, or the blocks given as overrides["fp8_layers"]); dtype="fp8": the whole trunk in e4m3, Detect tail float16
         self.mixed8 = isinstance(a["dtype"], str) and a["dtype"].lower().replace("_", "-") == "fp8-mixed"
-        self.dtype = torch.float16 if self.mixed8 else resolve_dtype(a["dtype"], a["half"])
+        self.dtype = torch.float16 if self.mixed8 else resolve_dtype(a["dtype"], a["half"], model)
         # setup_model (predictor.py:300-323): AutoBackend moves the graph to the device, fuses, picks the precision and freezes it
         self.backend = AutoBackend(model, device=self.device, fp16=bool(a["half"]), dtype=self.dtype, fuse=False, verbose=bool(a["verbose"]))
         self.model = self.backend.model
@@ -95,7 +115,19 @@ class DetectionPredictor:
             if not isinstance(im, torch.Tensor):
                 frames = [im] if type(im).__name__ == "ndarray" and im.ndim == 3 else list(im)
                 if len({f.shape for f in frames}) != 1:
-                    raise NotImplementedError("image sources of different shapes in one batch are not built (one LetterBox geometry per launch)")
+                    # sources of different shapes (pre_transform, predictor.py:147-163: same_shapes False -> auto False): every image is
+                    # letterboxed on its own to the full imgsz x imgsz and the batch stacked; boxes map back per image (r05)
+                    lb = LetterBox(self.args.get("imgsz", 640), auto=False, stride=int(self.model.stride.max()))
+                    size = lb.new_shape
+                    out = torch.empty((len(frames), 3, size[0], size[1]), dtype=torch.float32, device=self.device)
+                    info = []
+                    for i, f in enumerate(frames):
+                        if f.ndim != 3 or f.shape[2] != 3 or f.dtype != np.uint8:
+                            raise ValueError("image sources must be uint8 HWC BGR frames")
+                        lb.into(torch.from_numpy(np.ascontiguousarray(f)).to(self.device), out[i : i + 1], swap_rb=True)
+                        info.append((f.shape[0], f.shape[1], size[0], size[1]))
+                    self.letterbox_info = info
+                    return out
                 im = torch.from_numpy(np.ascontiguousarray(np.stack(frames)))
             frames = im.to(self.device).contiguous()
             lb = LetterBox(self.args.get("imgsz", 640), auto=True, stride=int(self.model.stride.max()))
@@ -135,8 +167,8 @@ class DetectionPredictor:
             plan8 = frozenset(a["fp8_layers"]) if a.get("fp8_layers") is not None else self.model.fp8_plan_off_p2()
             self.fp8_calibration["fp8_layers"] = sorted(plan8)
         n, _, h, w = im.shape
-        params = torch.tensor([self._box_params(h, w)] * n, dtype=torch.float32, device=self.device)
-        cf.box_params, cf.box_key = params, self._box_params(h, w)
+        params = torch.tensor(self._box_params(h, w, n), dtype=torch.float32, device=self.device)
+        cf.box_params, cf.box_key = params, self._box_params(h, w, n)
         det = self.model.model[-1]
         holder = {}
 
@@ -164,14 +196,16 @@ class DetectionPredictor:
         cf.plan.keep.append(params)
         return cf
 
-    def _box_params(self, h: int, w: int):
-        """(gain, pad_x, pad_y, clip_w, clip_h) of ops.scale_boxes (utils/ops.py:92-127) for the current source."""
+    def _box_params(self, h: int, w: int, n: int):
+        """Per image (gain, pad_x, pad_y, clip_w, clip_h) of ops.scale_boxes (utils/ops.py:92-127) for the current source: n rows."""
         info = getattr(self, "letterbox_info", None)
         if info is None:
-            return [1.0, 0.0, 0.0, float(w), float(h)]
-        h0, w0, hn, wn = info
-        gain = min(hn / h0, wn / w0)
-        return [gain, float(round((wn - w0 * gain) / 2 - 0.1)), float(round((hn - h0 * gain) / 2 - 0.1)), float(w0), float(h0)]
+            return [[1.0, 0.0, 0.0, float(w), float(h)]] * n
+        rows = []
+        for h0, w0, hn, wn in (info if isinstance(info, list) else [info] * n):
+            gain = min(hn / h0, wn / w0)
+            rows.append([gain, float(round((wn - w0 * gain) / 2 - 0.1)), float(round((hn - h0 * gain) / 2 - 0.1)), float(w0), float(h0)])
+        return rows
 
     def forward_device(self, im: torch.Tensor) -> CompiledForward:
         """Run one batch; outputs stay on the device in the returned object's ``nms`` buffers."""
@@ -184,9 +218,9 @@ class DetectionPredictor:
             self._compiled.pop(key)
             cf = None
         if cf is not None:  # the recorded dy_scale_boxes launch reads this device tensor: refresh it when the source geometry changed
-            bp = self._box_params(im.shape[2], im.shape[3])
+            bp = self._box_params(im.shape[2], im.shape[3], im.shape[0])
             if bp != cf.box_key:
-                cf.box_params.copy_(torch.tensor([bp] * im.shape[0], dtype=torch.float32))
+                cf.box_params.copy_(torch.tensor(bp, dtype=torch.float32))
                 cf.box_key = bp
         if cf is None:
             cf = self._compiled[key] = self._record(im)  # recording also executes the launches
@@ -223,10 +257,11 @@ class DetectionPredictor:
         counts = cf.nms.count.tolist()  # the pass's only device->host synchronisation
         names = self.model.names
         out = []
+        info = getattr(self, "letterbox_info", None)
         for i, k in enumerate(counts):
-            info = getattr(self, "letterbox_info", None)
+            one = (info[i] if isinstance(info, list) else info) if info else None
             out.append(Results(im[i], paths[i] if paths else f"image{i}.jpg", names, boxes=cf.nms.out[i, :k].clone(),
-                               orig_shape=(info[0], info[1]) if info else im.shape[2:]))
+                               orig_shape=(one[0], one[1]) if one else im.shape[2:]))
         return out
 
     def __call__(self, source, stream: bool = False):

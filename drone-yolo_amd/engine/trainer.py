@@ -296,48 +296,6 @@ class OptimSchedule:
             self.cur_momentum = float(np.interp(ni, xi, [a["warmup_momentum"], a["momentum"]]))
 
 
-_EXT_EVENTS: Dict[str, bool] = {}
-
-
-def external_events_work(device) -> bool:
-    """Does an EXTERNAL event recorded inside a hipGraph order a second stream on this runtime?  Probed once per device with a
-    small graph: a chain of kernels ends in a write of ``x``, the event is recorded behind it, and a side stream that waits for the
-    event copies ``x`` — a wait that did nothing would copy the stale value while the chain still runs.  Three replays, three values."""
-    key = str(device)
-    if key in _EXT_EVENTS:
-        return _EXT_EVENTS[key]
-    ok = False
-    try:
-        ev = torch.cuda.Event(external=True)
-        side = torch.cuda.Stream(device=device)
-        a = torch.rand(32 * 1024 * 1024, device=device)  # 128 MB: every pass below is ~60 us of plain element-wise work (no library calls inside a capture)
-        src = torch.zeros(1, device=device)
-        x = torch.zeros(1, device=device)
-        y = torch.zeros(1, device=device)
-        torch.cuda.synchronize(device)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for _ in range(40):  # a few ms of work in front of the write
-                a.mul_(0.999).add_(1e-3)
-            x.copy_(src + a[0] * 0.0)
-            ev.record()
-            for _ in range(8):
-                a.mul_(0.999).add_(1e-3)
-        ok = True
-        for val in (3.0, 7.0, 11.0):
-            src.fill_(val)
-            g.replay()
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                y.copy_(x)
-            torch.cuda.synchronize(device)
-            ok = ok and float(y) == val
-    except Exception:
-        ok = False
-    _EXT_EVENTS[key] = ok
-    return ok
-
-
 # ---- trainer -------------------------------------------------------------------------------------------------------------
 class DetectionTrainer:
     """``DetectionTrainer(model, overrides)`` for tensor batches (``step``) or ``DetectionTrainer(overrides=...)`` +
@@ -493,6 +451,7 @@ class DetectionTrainer:
         if os.environ.get("DYOLO_FORCE_DEVICE"):  # N-rank rehearsal on one GPU (gloo)
             index = int(os.environ["DYOLO_FORCE_DEVICE"])
         self.device = torch.device("cuda", index)
+        torch.manual_seed(int(a.get("seed", 0)))  # trainer.py:121 init_seeds, BEFORE the model is built: two runs of one process start from the same weights
         if self.model is None:
             from ..nn.tasks import DetectionModel
 
@@ -503,7 +462,6 @@ class DetectionTrainer:
                 self.model, _ = load_reference_checkpoint(src)
             else:
                 self.model = DetectionModel(src, nc=a.get("nc") or None, verbose=False)
-        torch.manual_seed(int(a.get("seed", 0)))  # trainer.py:121 init_seeds: replicas start identical
         self.model = self.model.to(self.device).train()
         for k, v in self.model.named_parameters():  # _setup_train's freeze block (trainer.py:238-254): '.dfl' stays frozen, the rest trains
             v.requires_grad_(".dfl" not in k and v.dtype.is_floating_point)  # (a predictor may have frozen the graph before)
@@ -602,12 +560,11 @@ class DetectionTrainer:
         and replayed: the images and the label table are copied into static buffers, the parameter gradients accumulate into
         the flat gradient buffer exactly as in the eager backward.  Nothing in it depends on a host value that changes between
         steps; the optimizer step (learning rate, momentum, EMA decay, first-step flag) stays outside.
-        Several ranks (reference: DistributedDataParallel, trainer.py:274, whose bucket all-reduces overlap backward): the same ONE
-        graph; inside it every gradient bucket's sink flush is followed by an EXTERNAL event record (a graph node), and after the
-        replay is launched the bucket all-reduces are issued on a second stream, each behind its bucket's event — bucket k's ring
-        runs under the backward kernels of buckets k+1.. — so the host still enqueues ~10 calls per step instead of ~2,400."""
+        Several ranks (reference: DistributedDataParallel, trainer.py:274, whose bucket all-reduces overlap backward): the capture is cut
+        behind every gradient bucket's sink flush (``_capture_cut``): K graphs, bucket k's all-reduce issued between the launches of graph k
+        and graph k + 1 — the ring runs under the backward kernels that follow, and the host still enqueues ~10 calls per step."""
         use = (self.graph_steps and self.iters >= 2 and batch["img"].is_cuda and self.model.training
-               and (self.buckets is None or self.grad_sink))
+               and (self.buckets is None or self.grad_sink) and not self.args.get("multi_scale"))  # (multi_scale: ~40 input shapes, a graph pool each: eager)
         from ..nn.autograd_ops import lazy_head_seed, sink_armed
 
         bk = self.buckets
@@ -659,24 +616,28 @@ class DetectionTrainer:
             gs["img"].copy_(img)
             armed = bk.armed if bk is not None else False
             if bk is not None:
-                # external events inside the graph are OPT-IN (DYOLO_DDP_OVERLAP=1): this image's ROCm refuses them ("External events are
-                # disallowed in rocm"), so the shipped form issues the bucket all-reduces after the graph; where a runtime takes them the
-                # timing probe below and the first-replay check in exchange_after_replay guard the path
-                if bk.events is None and os.environ.get("DYOLO_DDP_OVERLAP", "0") == "1" and external_events_work(img.device):
-                    bk.make_events()
-                self._graph_events = bk.events is not None
                 bk.arm(armed, capturing=True)
-            torch.cuda.synchronize(img.device)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g), H.batched_weight_packing(packs):
+
+            def body():
                 if packs is not None:
                     packs.pack_all()
                 with sink_armed():
                     loss, items = model.criterion.from_gt(model.forward_train(gs["img"]), gs["gt"])
                 backward(loss)
+                gs.update(loss=loss, items=items)
+
+            torch.cuda.synchronize(img.device)
+            cut = bk is not None and os.environ.get("DYOLO_DDP_GRAPH_CUT", "1") != "0"
+            if not cut:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g), H.batched_weight_packing(packs):
+                    body()
+                gs.update(graphs=[g], ends=[len(bk.buckets) if bk is not None else 0])
+            else:
+                gs.update(graphs=[], ends=[])
+                self._capture_cut(gs, bk, packs, body)
             if bk is not None:
                 bk.arm(armed)
-            gs.update(g=g, loss=loss, items=items)
             graphs[key] = gs
         self._graph = gs
         tick = self._tick
@@ -707,13 +668,61 @@ class DetectionTrainer:
         ev = ring["events"][k] = ring["events"][k] or torch.cuda.Event()
         ev.record()
         tick("label_copy")
-        gs["g"].replay()
-        tick("replay")
         if bk is not None:
-            bk.exchange_after_replay()
+            bk.begin_replay()
+        for g, end in zip(gs["graphs"], gs["ends"]):
+            g.replay()
+            if bk is not None:
+                bk.exchange_upto(end)  # the all-reduces of the buckets this graph flushed: they run under the graphs launched next
+        tick("replay")
         out = gs["loss"].clone(), gs["items"].clone()  # the static outputs are overwritten by the next replay (the epoch mean keeps them)
         tick("exchange_and_outputs")
         return out
+
+    def _capture_cut(self, gs: dict, bk, packs, body) -> None:
+        """Several ranks (reference: DistributedDataParallel overlaps its bucket all-reduces with backward, trainer.py:274): the step is
+        captured as K hipGraphs CUT behind each gradient bucket's sink flush — ``GradBuckets.cut`` ends the running capture and begins the
+        next graph in the same memory pool — so that a replayed step is: launch graph 0, issue bucket 0's all-reduce, launch graph 1, ...
+        RCCL's stream waits for what the compute stream held when the all-reduce was issued (graph k), and the ring runs under the backward
+        kernels of graphs k + 1 ..: the eager form's overlap at a handful of host calls per step.  (r03 / r04 wanted ONE graph with an
+        external event per bucket; this ROCm refuses external events.)  The cut happens inside ``loss.backward()``, i.e. on autograd's
+        device thread, hence relaxed capture mode: begin and end of one capture may then sit on different threads."""
+        import gc
+
+        from .. import hip_ops as H
+
+        dev = gs["img"].device
+        gc.collect()
+        torch.cuda.empty_cache()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        state = {"pool": torch.cuda.graph_pool_handle(), "open": None}  # ONE memory pool: what graph k allocates, graph k + 1 reads
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin(pool=state["pool"], capture_error_mode="relaxed")
+            state["open"] = g
+
+        def end(upto: int):
+            g, state["open"] = state["open"], None
+            g.capture_end()
+            gs["graphs"].append(g)
+            gs["ends"].append(upto)
+
+        def cut(bi: int):  # called by GradBuckets right behind bucket bi's flush (autograd's thread)
+            end(bi + 1)
+            begin()
+
+        with torch.cuda.stream(side), H.batched_weight_packing(packs):
+            begin()
+            bk.cut = cut
+            try:
+                body()
+            finally:
+                bk.cut = None
+                if state["open"] is not None:
+                    end(len(bk.buckets))
+        torch.cuda.current_stream(dev).wait_stream(side)
 
     host_phases: Optional[Dict[str, float]] = None  # set to {} to collect the host's seconds per phase of the graphed step (bench.py)
 
@@ -744,14 +753,16 @@ class DetectionTrainer:
         return u
 
     def step_form(self) -> str:
-        """How a step is issued (for the bench line): eager launches, one hipGraph, or one hipGraph with the bucket exchange behind it."""
-        graphed = getattr(self, "_graph", None) is not None
+        """How a step is issued (for the bench line): eager launches, one hipGraph, or hipGraphs cut at the gradient-bucket boundaries."""
+        gs = getattr(self, "_graph", None)
         if self.buckets is None:
-            return "forward + loss + backward replayed as ONE hipGraph, gradients through the sink (one flush)" if graphed else "eager launches"
-        if graphed:
-            return ("forward + loss + backward replayed as ONE hipGraph; per-bucket sink flush + external event inside the graph, bucket all-reduces "
-                    "issued behind those events (overlap with the remaining backward)" if getattr(self, "_graph_events", False) else
-                    "forward + loss + backward replayed as ONE hipGraph with a per-bucket sink flush; the bucket all-reduces are issued AFTER the graph "
+            return "forward + loss + backward replayed as ONE hipGraph, gradients through the sink (one flush)" if gs is not None else "eager launches"
+        if gs is not None:
+            k = len(gs["graphs"])
+            if k > 1:
+                return (f"forward + loss + backward replayed as {k} hipGraphs cut behind each gradient bucket's sink flush; bucket k's all-reduce is issued "
+                        f"between the launches of graph k and graph k + 1 (overlaps the remaining backward)")
+            return ("forward + loss + backward replayed as ONE hipGraph with a per-bucket sink flush; the bucket all-reduces are issued AFTER the graph "
                     "(no overlap with backward)")
         return "eager launches, bucket all-reduces issued from backward as each bucket's last gradient lands (overlap with the remaining backward)"
 
@@ -954,8 +965,26 @@ class DetectionTrainer:
         return metrics, fitness
 
     def preprocess_batch(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        """detect/train.py:57-74: images to the device (the /255 and the layout change ride in the first kernel)."""
+        """detect/train.py:57-74: images to the device (the /255 and the layout change ride in the first kernel); ``multi_scale``: the
+        batch resized to a random multiple of the stride in [0.5, 1.5] x imgsz — same draw (``random.randrange``), same size rule, the
+        resize itself = interpolate(img / 255, bilinear, align_corners=False) as one kernel on the uint8 batch."""
         batch["img"] = batch["img"].to(self.device, non_blocking=True)
+        if self.args.get("multi_scale"):
+            import random
+
+            from .. import hip_ops as H
+
+            imgs = batch["img"]
+            stride = max(int(self.model.stride.max()), 32)
+            imgsz = int(self.args["imgsz"])
+            sz = random.randrange(int(imgsz * 0.5), int(imgsz * 1.5 + stride)) // stride * stride
+            sf = sz / max(imgs.shape[2:])
+            if sf != 1:
+                ns = [math.ceil(x * sf / stride) * stride for x in imgs.shape[2:]]
+                if imgs.dtype != torch.uint8:
+                    raise NotImplementedError("multi_scale resizes the loader's uint8 batches (dy_resize_bilinear_u8_nchw_f32); float batches are not built")
+                imgs = H.resize_bilinear_u8(imgs.contiguous(), ns)
+            batch["img"] = imgs
         return batch
 
     def label_loss_items(self, loss_items=None, prefix: str = "train") -> Dict[str, float]:

@@ -1408,6 +1408,19 @@ def letterbox(frames: torch.Tensor, new_w: int, new_h: int, top: int, left: int,
     return out
 
 
+def resize_bilinear_u8(img: torch.Tensor, size) -> torch.Tensor:
+    """uint8 NCHW batch -> fp32 NCHW of ``size`` = interpolate(img.float() / 255, size, mode="bilinear", align_corners=False): the
+    ``multi_scale`` branch of preprocess_batch (models/yolo/detect/train.py:60-73) in one kernel."""
+    require_device(img, "image batch")
+    if img.dtype != torch.uint8 or img.dim() != 4 or not img.is_contiguous():
+        raise ValueError("resize_bilinear_u8 expects a contiguous uint8 (N, C, H, W) device tensor")
+    n, c, h, w = img.shape
+    ho, wo = int(size[0]), int(size[1])
+    out = torch.empty((n, c, ho, wo), dtype=torch.float32, device=img.device)
+    _launch(lib().dy_resize_bilinear_u8_nchw_f32, (img.data_ptr(), out.data_ptr(), n, c, h, w, ho, wo), keep=(img, out))
+    return out
+
+
 # ---- fused C2f block ------------------------------------------------------------------------------------------------------
 
 

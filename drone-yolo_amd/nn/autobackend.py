@@ -48,7 +48,7 @@ class AutoBackend(nn.Module):
         if dtype is None:  # the predictor's rule: half -> float16, otherwise the bar-exact precision (engine/predictor.py::EXACT_DTYPE)
             from ..engine.predictor import resolve_dtype
 
-            dtype = resolve_dtype(None, bool(fp16))
+            dtype = resolve_dtype(None, bool(fp16), model)
         self.dtype = dtype
         self.stride = max(int(model.stride.max()), 32)
         self.names = model.names

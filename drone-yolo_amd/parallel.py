@@ -131,7 +131,9 @@ class GradBuckets:
     a bucket has landed, the bucket's slices are SUM-all-reduced asynchronously (RCCL runs on its own stream behind an event
     on the compute stream, so it waits for the kernels that wrote those gradients and overlaps the rest of backward).
     Buckets are issued strictly in order on every rank (collectives must match across ranks); ``finish()`` issues whatever
-    backward did not complete and waits for all of them.  xGMI is point-to-point: a ring all-reduce moves 2(N-1)/N of the bytes
+    backward did not complete and waits for all of them.  When the trainer replays the step from hipGraphs the capture is cut behind
+    every bucket's flush (``cut``): K graphs, bucket k's all-reduce issued between the launches of graph k and graph k + 1, so the ring
+    runs under the backward kernels of the later graphs exactly as in the eager form.  xGMI is point-to-point: a ring all-reduce moves 2(N-1)/N of the bytes
     over each link, so a few ~10 MB buckets keep the links busy without paying the per-collective latency 238 times.
     Reference: DistributedDataParallel's bucketed all-reduce behind ``trainer.py:274``; loss * world_size (trainer.py:382-383)
     followed by DDP's mean is the plain SUM used here."""
@@ -179,11 +181,8 @@ class GradBuckets:
         self.issued_during_backward = 0
         # sink mode (FlatState.enable_sink): gradients land in the sink, a bucket is flushed into G when its last one is in the stream
         self.sink_entries: Optional[List[torch.Tensor]] = None
-        self.capturing = False  # inside a hipGraph capture: a ready bucket is flushed and marked by an event, exchanged after the replay
-        self.events: Optional[list] = None
-        self.comm_stream = None
-        self._events_checked = False
-        self.event_path_verified: Optional[bool] = None
+        self.capturing = False  # inside a hipGraph capture: a ready bucket is flushed, and the capture is CUT behind the flush (``cut``)
+        self.cut = None  # callable(bucket index), set by the trainer while it captures: ends the running capture and begins the next graph
         self._noted: dict = {}
         self._seen: set = set()
         self._done: set = set()
@@ -249,10 +248,7 @@ class GradBuckets:
 
             H.join_side_stream()  # the bucket's weight-gradient kernels run on a second stream (hip_ops.conv_wgrad_into)
             H.grad_sink_flush_(self.sink_entries[bi], self.flat.G, self.flat.S)
-        if self.capturing:
-            if self.events is not None:
-                self.events[bi].record()  # external event: an event-record node of the graph, waited on by the comm stream per replay
-        elif self.armed:
+        if not self.capturing and self.armed:
             self._issue(bi)
             self.issued_during_backward += 1
 
@@ -262,9 +258,13 @@ class GradBuckets:
         if not self.pending:
             return
         self.pending[bi] -= 1
+        last = None
         while self.next < len(self.buckets) and self.pending[self.next] <= 0:  # in order, identically on every rank
             self._bucket_ready(self.next)
+            last = self.next
             self.next += 1
+        if last is not None and self.capturing and self.cut is not None and last < len(self.buckets) - 1:
+            self.cut(last)  # the graph captured so far ends with bucket `last`'s flush; what follows belongs to the next graph
 
     def end_backward(self) -> None:
         """After ``loss.backward()``: buckets whose parameters received no gradient this step (or whose count did not run down) are
@@ -274,42 +274,22 @@ class GradBuckets:
             self._bucket_ready(self.next)
             self.next += 1
 
-    def make_events(self) -> bool:
-        """One EXTERNAL event per bucket (torch.cuda.Event(external=True): recorded inside a capture it becomes an event-record node
-        instead of a captured cross-stream dependency) and the stream the exchange is issued on.  False when this HIP runtime does
-        not take such events (then the exchange simply follows the whole graph)."""
-        try:
-            self.events = [torch.cuda.Event(external=True) for _ in self.buckets]
-            self.comm_stream = torch.cuda.Stream(device=self.flat.G.device)
-            return True
-        except Exception:
-            self.events, self.comm_stream = None, None
-            return False
-
-    def exchange_after_replay(self) -> None:
-        """The step's graph (forward + loss + backward, per-bucket flush + event) has been launched on the current stream: issue
-        every bucket's all-reduce behind ITS event on the comm stream, so the ring of bucket k runs under the backward kernels of the
-        buckets after it.  Without events the all-reduces follow the whole graph on the current stream."""
-        self.next = len(self.buckets)  # the graph flushed every bucket; nothing is left for end_backward / finish to issue
+    def exchange_upto(self, upto: int) -> None:
+        """The graphed step: the graphs that end with the flushes of buckets < ``upto`` have been launched on the current stream — issue the
+        all-reduces of the buckets not exchanged yet, in order.  An asynchronous RCCL all-reduce waits for what the current stream holds NOW
+        (ProcessGroupNCCL records an event there) and runs on its own stream, i.e. under the graphs launched after this call."""
         if not self.armed:
+            self._exchanged = upto
             return
+        for bi in range(getattr(self, "_exchanged", 0), upto):
+            self._issue(bi)
+        self._exchanged = upto
+
+    def begin_replay(self) -> None:
+        """Before the first graph of a step is launched: the graphs flush every bucket themselves, nothing is left for end_backward."""
+        self.next = len(self.buckets)
         self.works = []
-        check = None
-        if self.events is not None and not self._events_checked:
-            # first armed replay on the event path: the same exchange once more the plain way (a copy of G taken behind the WHOLE graph,
-            # all-reduced on the current stream); finish() compares.  An event wait that ordered nothing would let a ring read G before
-            # its bucket's flush — silently wrong gradients — so a mismatch turns the event path off for good and keeps the plain result.
-            check = self._event_check = self.flat.G.clone()
-            for bi in range(len(self.buckets)):
-                for lo, hi in self.buckets[bi]["ranges"]:
-                    self._all_reduce(check[lo:hi])
-        for bi in range(len(self.buckets)):
-            if self.events is None:
-                self._issue(bi)
-                continue
-            self.comm_stream.wait_event(self.events[bi])
-            with torch.cuda.stream(self.comm_stream):
-                self._issue(bi)
+        self._exchanged = 0
 
     def finish(self) -> None:
         if not self.exchange:
@@ -317,25 +297,11 @@ class GradBuckets:
         if not self.armed:  # a step without an armed backward (should not happen): one plain all-reduce
             dist.all_reduce(self.flat.G, op=dist.ReduceOp.SUM)
             return
-        self.end_backward()  # (a no-op after the trainer's own end_backward / exchange_after_replay)
+        self.end_backward()  # (a no-op after the trainer's own end_backward / the graphed step's exchange)
         for w in self.works:
             if w is not None:
                 w.wait()
-        if self.comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.works, self.armed = [], False
-        check = self.__dict__.pop("_event_check", None)
-        if check is not None:
-            self._events_checked = True
-            same = bool(torch.allclose(check, self.flat.G, rtol=1e-5, atol=1e-10))  # (one host read, on the first armed replay only; a missed flush is off by whole gradients)
-            if not same:
-                import logging
-
-                logging.getLogger("drone_yolo_amd").error("GradBuckets: the event-ordered bucket exchange disagrees with the exchange behind the whole graph; "
-                                                          "external events do not order streams on this runtime -> exchange after the graph from now on")
-                self.flat.G.copy_(check)
-                self.events = None
-            self.event_path_verified = same
 
 
 def gather_detections(rows: torch.Tensor, counts: torch.Tensor) -> Optional[List[Tuple[torch.Tensor, torch.Tensor]]]:

