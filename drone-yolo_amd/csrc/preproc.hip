@@ -182,7 +182,9 @@ __global__ __launch_bounds__(256) void resize_bilinear_u8_kernel(const uint8_t* 
     long long t = i / wo;
     const int y = (int)(t % ho);
     const int pl = (int)(t / ho);
-    float fy = __fsub_rn(__fmul_rn((float)y + 0.5f, sy), 0.5f), fx = __fsub_rn(__fmul_rn((float)x + 0.5f, sx), 0.5f);
+    // (one rounding, as torch's own kernels compute scale * (dst + 0.5) - 0.5: the host build contracts it into an fma, and a coordinate
+    // that differs in its last bit moves the blend weight by 6e-5 at 640 pixels)
+    float fy = __fmaf_rn((float)y + 0.5f, sy, -0.5f), fx = __fmaf_rn((float)x + 0.5f, sx, -0.5f);
     fy = fy < 0.f ? 0.f : fy, fx = fx < 0.f ? 0.f : fx;
     const int y0 = (int)fy, x0 = (int)fx;
     const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);

@@ -36,7 +36,7 @@ def test_loss_matches_oracle(bs, hw, seed, n_mean, device):
     torch.cuda.synchronize()
     out, owner = out.cpu(), owner.cpu().long()
     assert torch.allclose(out[:3], items, rtol=2e-4, atol=1e-5), (out, items)
-    assert abs(float(out[3]) - float(total)) <= 2e-4 * abs(float(total)) + 1e-5
+    assert abs(float(out[3]) - float(total.detach())) <= 2e-4 * abs(float(total.detach())) + 1e-5
     # assignment: positive-target anchors identical, same ground-truth box
     pos = asg["target_scores"].sum(-1) > 0
     fg_dev = owner >= 0
@@ -88,7 +88,7 @@ def test_loss_gradient_matches_autograd(bs, hw, seed, n_mean, device):
     total.backward()
     out, _, grads = H.detection_loss(_dev_feats([f.detach() for f in feats], device), _gt(labels, bs, hw), STRIDES, 10, want_grad=True)
     torch.cuda.synchronize()
-    assert abs(float(out[3]) - float(total)) <= 2e-4 * abs(float(total))
+    assert abs(float(out[3]) - float(total.detach())) <= 2e-4 * abs(float(total.detach()))
     for f, gd in zip(feats, grads):
         ref = f.grad
         err = float((gd.cpu() - ref).abs().max())

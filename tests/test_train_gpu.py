@@ -616,7 +616,7 @@ def test_config3_full_size_step_properties(device):
         torch.cuda.synchronize()
         model.load_state_dict(sd0, strict=False)  # every variant starts from the same BatchNorm buffers
         grads = {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters() if p.grad is not None}
-        return float(loss), items.cpu().clone(), grads
+        return float(loss.detach()), items.cpu().clone(), grads
 
     def gnorm(g):
         return float(torch.sqrt(sum((v.double() ** 2).sum() for v in g.values())))
