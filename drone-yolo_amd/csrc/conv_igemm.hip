@@ -306,6 +306,81 @@ __global__ __launch_bounds__(256) void conv_grouped_kernel(const ConvArgs p, int
   }
 }
 
+// The DWConv layers of the -sf YAML are Conv(c1, c2, 3, 2, g = gcd(c1, c2)) with c2 = c1 / 2 (yolov8-p2-repvgg-sf.yaml:32,38,44): every output
+// channel reads CPG = 2 input channels (1 or 4 at other widths).  The kernel above walks them one output element per thread with 2-byte
+// loads (r05 bench: three launches, 2.1 ms of a 15 ms pass at 1.6 TFLOP/s).  Here a thread owns ONE 16-byte chunk of output channels of a
+// pixel: per tap it loads the CPG input chunks those channels read (contiguous), the weights of the workgroup's channel range sit in LDS as
+// [tap][cin-in-group][cout] so that a lane's operands are unit-stride; fp32 accumulate, bias + SiLU, one 16-byte store: HBM-bound work at HBM speed.
+template <typename T, int CPG>
+__global__ __launch_bounds__(256) void conv_smallgroup_kernel(const ConvArgs p) {
+  constexpr int EPC = Elem<T>::EPC;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  float* wl = reinterpret_cast<float*>(dyn_smem);  // [ks*ks][CPG][Cout]
+  const int taps = p.ks * p.ks;
+  const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+  for (int i = threadIdx.x; i < taps * CPG * p.Cout; i += 256) {
+    const int co = i % p.Cout, t2 = i / p.Cout;
+    const int ci = t2 % CPG, tap = t2 / CPG;
+    wl[i] = Elem<T>::to_f32(wg[(size_t)co * (size_t)(taps * CPG) + tap * CPG + ci]);
+  }
+  __syncthreads();
+  const int cch = p.Cout / EPC;  // output chunks per pixel
+  const long long total = (long long)p.M * cch;
+  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+  T* __restrict__ yg = reinterpret_cast<T*>(p.y);
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int cc = (int)(idx % cch);
+    const int m = (int)(idx / cch);
+    const int n = m / p.HoWo;
+    const int rem = m - n * p.HoWo;
+    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    const int co0 = cc * EPC;
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = p.bias[co0 + e];
+    for (int r = 0; r < p.ks; ++r) {
+      const int hi = ho * p.stride - p.pad + r;
+      if ((unsigned)hi >= (unsigned)p.H) continue;
+      for (int q = 0; q < p.ks; ++q) {
+        const int wi = wo * p.stride - p.pad + q;
+        if ((unsigned)wi >= (unsigned)p.W) continue;
+        const T* xp = xg + (size_t)((n * p.H + hi) * p.W + wi) * (size_t)p.ldx + (size_t)co0 * CPG;  // input channels co * CPG .. of this chunk: CPG chunks
+        const float* wt = wl + (size_t)((r * p.ks + q) * CPG) * p.Cout + co0;
+        float xin[CPG * EPC];
+#pragma unroll
+        for (int k = 0; k < CPG; ++k) {
+          float f[EPC];
+          Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(xp + k * EPC), f);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) xin[k * EPC + e] = f[e];
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+#pragma unroll
+          for (int ci = 0; ci < CPG; ++ci) acc[e] += xin[e * CPG + ci] * wt[(size_t)ci * p.Cout + e];
+      }
+    }
+    if (p.act == DY_ACT_SILU) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) acc[e] = silu_f32(acc[e]);
+    }
+    *reinterpret_cast<u32x4*>(yg + (size_t)m * (size_t)p.ldy + co0) = Chunk<T>::pack(acc);
+  }
+}
+
+template <typename T>
+static int launch_smallgroup(const ConvArgs& a, int cpg, hipStream_t st) {
+  const long long total = (long long)a.M * (a.Cout / Elem<T>::EPC);
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  const size_t smem = (size_t)a.ks * a.ks * cpg * a.Cout * 4;
+  switch (cpg) {
+    case 1: hipLaunchKernelGGL((conv_smallgroup_kernel<T, 1>), dim3(blocks), dim3(256), smem, st, a); break;
+    case 2: hipLaunchKernelGGL((conv_smallgroup_kernel<T, 2>), dim3(blocks), dim3(256), smem, st, a); break;
+    default: hipLaunchKernelGGL((conv_smallgroup_kernel<T, 4>), dim3(blocks), dim3(256), smem, st, a); break;
+  }
+  return check_launch("conv_smallgroup_kernel");
+}
+
 template <typename T, int BM, int BN, bool OUTF32>
 static int launch_tile(const ConvArgs& a, hipStream_t st) {
   ConvArgs p = a;
@@ -442,6 +517,17 @@ int32_t conv2d_entry(const dy_conv_desc* d, dy_stream_t stream) {
                "dy_conv2d_nhwc: groups %d does not divide cin/cout", d->groups);
     DY_REQUIRE(!d->out_f32 && !d->up2x && !d->x2, DY_ERR_UNSUPPORTED, "dy_conv2d_nhwc: grouped conv option unsupported");
     DY_REQUIRE(d->ld_x >= d->cin, DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: bad ld_x");
+    {
+      // one output channel per group, 1 / 2 / 4 input channels each, whole 16-byte chunks everywhere, weights of the layer within 48 KB of LDS
+      const int cpg = d->cin / d->groups;
+      const int epc_g = 16 / es;
+      if (d->cout == d->groups && (cpg == 1 || cpg == 2 || cpg == 4) && !d->residual && d->cout % epc_g == 0 && (d->ld_x * es) % 16 == 0 && (d->ld_y * es) % 16 == 0 &&
+          aligned16(d->x) && aligned16(d->y) && (size_t)d->ksize * d->ksize * cpg * d->cout * 4 <= 48 * 1024 && (d->dtype == DY_BF16 || d->dtype == DY_F16 || d->dtype == DY_F32)) {
+        if (d->dtype == DY_BF16) return launch_smallgroup<bf16_t>(a, cpg, st);
+        if (d->dtype == DY_F16) return launch_smallgroup<f16_t>(a, cpg, st);
+        return launch_smallgroup<float>(a, cpg, st);
+      }
+    }
     const long long total = (long long)a.M * a.Cout;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (d->dtype == DY_BF16)

@@ -932,6 +932,21 @@ def detect_branch_fused(x: torch.Tensor, pc3: "PackedConv", w1: torch.Tensor, b1
 
 def pack_frag1x1(weight: torch.Tensor, bias: torch.Tensor, dtype: torch.dtype, device) -> Tuple[torch.Tensor, torch.Tensor]:
     """(cout, cin[,1,1]) weights + bias in DY_WLAYOUT_FRAG1X1 order (include/dyolo.h), whatever kernel PackedConv would pick."""
+    if dtype == F16X2:
+        # split float16 (dy_detect_head_decode with DY_F16X2): the float16 fragment image of the hi halves, then of the lo halves (rows scaled by
+        # a power of two into [2^13, 2^14) first, hi flushed to 0 below float16's smallest normal: PackedConv's rule); bias followed by the
+        # inverse row scales
+        w2 = weight.detach().to(torch.float32).cpu().reshape(weight.shape[0], -1)
+        sc = torch.exp2(13.0 - torch.floor(torch.log2(w2.abs().amax(1).clamp_min(1e-30))))
+        ws = w2 * sc[:, None]
+        hi = torch.where(ws.abs() < 2.0 ** -14, torch.zeros_like(ws), ws).to(torch.float16)
+        lo = (ws - hi.to(torch.float32)).to(torch.float16)
+        zb = torch.zeros(weight.shape[0])
+        wh, bp = pack_frag1x1(hi.to(torch.float32), bias, torch.float16, "cpu")
+        wl, _ = pack_frag1x1(lo.to(torch.float32), zb, torch.float16, "cpu")
+        sp = torch.ones_like(bp)
+        sp[: weight.shape[0]] = 1.0 / sc
+        return torch.cat((wh, wl)).contiguous().to(device), torch.cat((bp, sp)).contiguous().to(device)
     e = elems_per_chunk(dtype)
     w2 = weight.detach().to(torch.float32).cpu().reshape(weight.shape[0], -1)
     cout, cin = w2.shape

@@ -443,6 +443,29 @@ def test_grouped_conv(dtype, device):
     y = H.conv2d(nhwc(x, dtype, device), pc)
     torch.cuda.synchronize()
     check_close(back(y), F.silu(F.conv2d(x, wt, bias, 2, 1, 1, 16)), dtype, "DWConv g=16")
+    assert H.last_kernel_name() == "conv_smallgroup_kernel"  # r05: the -sf YAML's DWConv shape (2 input channels per output channel) has its own kernel
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("case", [(16, 8, 3, 2, 2, 40, 36), (64, 64, 3, 1, 1, 13, 17), (128, 32, 3, 2, 2, 24, 20), (24, 12, 3, 2, 1, 9, 11), (32, 16, 1, 1, 1, 8, 8)],
+                         ids=["-sf layer 19 (n): 16->8 s2", "depthwise 64 s1", "cpg 4", "cout 12: generic kernel", "1x1 grouped"])
+def test_small_group_conv_shapes(case, dtype, device):
+    """DWConv(c1, c2, k, s) = Conv with g = gcd(c1, c2) (reference conv.py:102-107): one output channel per group with 1 / 2 / 4 input channels
+    runs on conv_smallgroup_kernel where the layer is whole 16-byte chunks, anything else on the generic grouped kernel — all against F.conv2d."""
+    import math
+
+    c1, c2, k, s, b, h, w = case
+    g = torch.Generator().manual_seed(c1 * 7 + c2)
+    groups = math.gcd(c1, c2)
+    x = quantize(torch.randn(b, c1, h, w, generator=g), dtype)
+    wt = quantize(torch.randn(c2, c1 // groups, k, k, generator=g) * 0.3, dtype)
+    bias = torch.randn(c2, generator=g) * 0.1
+    pc = H.PackedConv(wt, bias, s, k // 2, groups, True, dtype, device)
+    y = H.conv2d(nhwc(x, dtype, device), pc)
+    torch.cuda.synchronize()
+    check_close(back(y), F.silu(F.conv2d(x, wt, bias, s, k // 2, 1, groups)), dtype, f"grouped {case}")
+    fast = c2 == groups and (c1 // groups) in (1, 2, 4) and c2 % H.elems_per_chunk(dtype) == 0
+    assert (H.last_kernel_name() == "conv_smallgroup_kernel") == fast, H.last_kernel_name()
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])

@@ -203,6 +203,8 @@ def test_split_bench_configuration_is_bar_exact(tag, device):
     par = PR.detection_parity(cf.nms, exp_rows, exp_idx, conf=0.25, margin=0.0)
     assert box_err < 2e-2 and cls_err < 1e-4, (box_err, cls_err)
     assert par["counts_equal"] and par["kept_sets_identical"] and par["match_rate"] == 1.0 and par["iou_min"] >= 0.999, par
+    names = [fn.__name__ for fn, _, _ in cf.plan.ops]
+    assert "dy_detect_head_decode" in names and "dy_stem_conv3x3s2_nchw" in names  # the type's fused Detect tail (1x1 x 2 + decode + filter) and image stem ran
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 64, 64, 32), (1, 3, 50, 70, 16), (3, 3, 640, 640, 32), (1, 1, 32, 36, 64)], ids=["64x64", "odd 50x70 cout 16", "640x640", "cin 1 cout 64"])
