@@ -790,7 +790,7 @@ def main():
                                                "accumulate; bar-exact: the precision YOLO.predict runs by default)",
                                       "fp8": "fp8 e4m3fn storage of the whole trunk on the block-scaled fp8 MFMA / fp32 accumulate, Detect branch tails float16 (BASELINE config 5, "
                                              "throughput plan: does not meet the deployable parity gate, see parity)",
-                                      "fp8-mixed": "float16 storage with the layers off the P2 path (19..27) in fp8 e4m3fn on the block-scaled fp8 MFMA (BASELINE config 5, the plan "
+                                      "fp8-mixed": "float16 storage with the INTERNALS of the C2f blocks off the P2 path (layers 21, 24, 27) in fp8 e4m3fn on the block-scaled fp8 MFMA (BASELINE config 5, the plan "
                                                    "that meets match >= 0.90 / IoU >= 0.98)"}[a.dtype], "batch_per_gpu": a.batch, "global_batch": a.batch * world,
                        "parallelism": f"batch-split x{world}, no collective", "hipgraph": not a.no_graph, "streams": ns,
                        "conf": 0.25, "iou": 0.7, "max_det": 300, "candidates_frac": round(cand, 4), "kept_per_image": round(kept, 1)},

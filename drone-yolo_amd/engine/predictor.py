@@ -48,6 +48,8 @@ def split_supported(model) -> bool:
             return False
         if (c.in_channels % 8 and c.in_channels > 3) or (c.out_channels % 8 and c.bias is None):  # (plain biased 1x1 = Detect's fp32 outputs)
             return False
+        if c.kernel_size == (3, 3) and c.in_channels > 680:  # the 3x3 tap table of csrc/conv_gemm_fk.hip (1,536 words)
+            return False
     return bool(convs)
 
 

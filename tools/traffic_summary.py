@@ -2,6 +2,7 @@
 gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md, HBM); units are KiB."""
 import csv, glob, json, sys, collections
 root, batch, passes_per_run = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+DT = sys.argv[5] if len(sys.argv) > 5 and sys.argv[5] else "fp16"
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 sym = collections.defaultdict(lambda: collections.defaultdict(float))  # per kernel symbol (first 70 characters)
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
@@ -11,7 +12,7 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         acc[fam][r["Counter_Name"]] += float(r["Counter_Value"])
         sym[r["Kernel_Name"][:70]][r["Counter_Name"]] += float(r["Counter_Value"])
         sym[r["Kernel_Name"][:70]]["n_" + r["Counter_Name"]] += 1
-out = {"round": int(sys.argv[4]) if len(sys.argv) > 4 else 4, "dtype": "fp16", "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --streams 1 --bare --no-graph  (fp16, the default dtype)",
+out = {"round": int(sys.argv[4]) if len(sys.argv) > 4 else 4, "dtype": DT, "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --streams 1 --bare --no-graph" + ("" if DT == "fp16" else " --dtype " + DT),
        "correction": "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); counters are KiB; "
                      "%d passes profiled (1 record + 1 warm-up + 2 steps + 5 event-timing passes of the conv launches)" % passes_per_run,
        "batch": batch, "families": {}}
