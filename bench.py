@@ -583,6 +583,17 @@ def other_scales_record(device_index: int, batch: int = 256, steps: int = 10):
     return out
 
 
+def bar_exact_row(sweep):
+    """The north-star bar (class / index identical to the reference's fp32 CPU path, IoU >= 0.999) next to the headline: the fastest batch-sweep row whose
+    parity gate reports identical kept sets (split float16 — the precision `YOLO.predict` runs by default — or fp32 storage), one stream, B = the headline's."""
+    rows = [r for r in (sweep or []) if (r.get("parity") or {}).get("kept_sets_identical")]
+    if not rows:
+        return None
+    r = max(rows, key=lambda q: q["img_s"])
+    return {"dtype": r["dtype"], "batch": r["batch"], "img_s": r["img_s"], "ms_per_pass": r["ms_per_pass"], "parity": r["parity"],
+            "note": "hipGraph replay on one stream; the headline's fp16 storage is 3x faster and flips 0.1-0.4 % of the detections near the confidence threshold (`parity`)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -690,7 +701,7 @@ def main():
         tconv = sum(times.values())
         peak = MFMA_PEAK_TFLOPS[a.dtype]
         traffic, tsrc = None, None  # HBM bytes of the conv launches of one pass, from the committed PMC summary of this command (same batch / dtype only)
-        for rnd in ("r04", "r03", "r02"):
+        for rnd in ("r05", "r04", "r03", "r02"):
             tfile = os.path.join(ROOT, "profiles", f"{rnd}_traffic_b{a.batch}.json")
             if traffic is None and os.path.exists(tfile) and a.imgsz == 640 and "yolov8s-p2-repvgg" in a.model:
                 tj = json.load(open(tfile))
@@ -794,7 +805,7 @@ def main():
                                                    "that meets match >= 0.90 / IoU >= 0.98)"}[a.dtype], "batch_per_gpu": a.batch, "global_batch": a.batch * world,
                        "parallelism": f"batch-split x{world}, no collective", "hipgraph": not a.no_graph, "streams": ns,
                        "conf": 0.25, "iou": 0.7, "max_det": 300, "candidates_frac": round(cand, 4), "kept_per_image": round(kept, 1)},
-            "ranks_seen": ranks_seen, "collective": collective, "parity": parity, "breakdown": breakdown, "batch_sweep": sweep,
+            "bar_exact": bar_exact_row(sweep), "ranks_seen": ranks_seen, "collective": collective, "parity": parity, "breakdown": breakdown, "batch_sweep": sweep,
             "roofline": roof, "tiled": tiled, "predict_api": api, "other_scales": scales, "train": train, "cpu_baseline": cpu}))
 
 

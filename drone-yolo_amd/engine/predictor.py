@@ -81,6 +81,8 @@ class CompiledForward:
 class DetectionPredictor:
     """Device-resident predictor (reference predictor.py:64-323, detect/predict.py:8-73)."""
 
+    max_compiled = 8  # recorded (batch, H, W) passes kept alive (each holds activations, NMS buffers and a graph: a video's ragged last batch must not pile up)
+
     def __init__(self, model, overrides: Optional[dict] = None):
         a = dict(conf=0.25, iou=0.7, max_det=300, classes=None, agnostic_nms=False, half=False, dtype=None, device="",
                  verbose=False, graph=True, max_nms=30000, max_wh=7680, imgsz=640, fp8_layers=None)
@@ -225,6 +227,8 @@ class DetectionPredictor:
                 cf.box_params.copy_(torch.tensor(bp, dtype=torch.float32))
                 cf.box_key = bp
         if cf is None:
+            while len(self._compiled) >= self.max_compiled:  # a recorded pass owns its buffers and its hipGraph: keep the most recent shapes only
+                self._compiled.pop(next(iter(self._compiled)))
             cf = self._compiled[key] = self._record(im)  # recording also executes the launches
             cf.weights_sig = self.model.weights_signature()  # after recording: packing may itself touch caches
             if self.args["graph"]:

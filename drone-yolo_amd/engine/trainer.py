@@ -53,7 +53,38 @@ def get_cfg(overrides: Optional[dict] = None) -> dict:
     if unknown:
         raise KeyError(f"unknown training argument(s) {sorted(unknown)}")
     cfg.update(overrides or {})
+    check_cfg(cfg)
     return cfg
+
+
+# argument classes of the reference's check_cfg (ultralytics/cfg/__init__.py:147-236, 324-395), for the keys this path reads
+CFG_FLOAT_KEYS = frozenset({"warmup_epochs", "box", "cls", "dfl", "time", "batch"})  # int or float
+CFG_FRACTION_KEYS = frozenset({"lr0", "lrf", "momentum", "weight_decay", "warmup_momentum", "warmup_bias_lr", "conf", "iou"})  # 0.0 <= v <= 1.0
+CFG_INT_KEYS = frozenset({"epochs", "patience", "seed", "max_det", "nbs"})
+CFG_BOOL_KEYS = frozenset({"save", "verbose", "single_cls", "half", "agnostic_nms", "stream", "amp", "multi_scale"})
+
+
+def check_cfg(cfg: dict, hard: bool = True) -> None:
+    """Type and range checks of the arguments, as the reference's ``check_cfg`` (cfg/__init__.py:324-395): None is an unset optional; a float key takes int or
+    float, a fraction key additionally 0 <= v <= 1, an int key an int, a bool key a bool.  ``hard`` raises; otherwise the value is converted in place."""
+    for k, v in cfg.items():
+        if v is None:
+            continue
+        if k in CFG_FLOAT_KEYS or k in CFG_FRACTION_KEYS:
+            if isinstance(v, bool) or not isinstance(v, (int, float)):
+                if hard:
+                    raise TypeError(f"'{k}={v}' is of invalid type {type(v).__name__}. Valid '{k}' types are int (i.e. '{k}=0') or float (i.e. '{k}=0.5')")
+                cfg[k] = v = float(v)
+            if k in CFG_FRACTION_KEYS and not (0.0 <= v <= 1.0):
+                raise ValueError(f"'{k}={v}' is an invalid value. Valid '{k}' values are between 0.0 and 1.0.")
+        elif k in CFG_INT_KEYS and (isinstance(v, bool) or not isinstance(v, int)):
+            if hard:
+                raise TypeError(f"'{k}={v}' is of invalid type {type(v).__name__}. '{k}' must be an int (i.e. '{k}=8')")
+            cfg[k] = int(v)
+        elif k in CFG_BOOL_KEYS and not isinstance(v, bool):
+            if hard:
+                raise TypeError(f"'{k}={v}' is of invalid type {type(v).__name__}. '{k}' must be a bool (i.e. '{k}=True' or '{k}=False')")
+            cfg[k] = bool(v)
 
 
 def param_group_names(model: nn.Module, include_frozen: bool = False) -> Tuple[List[str], List[str], List[str]]:

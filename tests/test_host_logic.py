@@ -360,3 +360,20 @@ def test_validation_metrics_match_the_reference_functions():
     m.process(g["tp"], g["conf"], g["pred_cls"], g["target_cls"])
     assert np.allclose(m.mean_results(), g["mean_results"], atol=1e-12) and abs(m.fitness - float(g["fitness"])) < 1e-12
     assert set(m.results_dict) == {"metrics/precision(B)", "metrics/recall(B)", "metrics/mAP50(B)", "metrics/mAP50-95(B)", "fitness"}
+
+
+def test_check_cfg_types_and_ranges():
+    """engine/trainer.py::check_cfg against the rules of the reference's check_cfg (cfg/__init__.py:324-395): float / fraction / int / bool keys, None = unset."""
+    from drone_yolo_amd.engine.trainer import check_cfg, get_cfg
+
+    cfg = get_cfg(dict(epochs=3, lr0=0.01, batch=16, time=None, save=True))
+    assert cfg["epochs"] == 3 and cfg["patience"] == 100 and cfg["resume"] is False
+    for bad, exc in ((dict(momentum=1.2), ValueError), (dict(epochs=2.5), TypeError), (dict(save="true"), TypeError), (dict(lr0="0.1"), TypeError), (dict(conf=-0.1), ValueError),
+                     (dict(warmup_epochs="3"), TypeError), (dict(nbs=True), TypeError)):
+        with pytest.raises(exc):
+            get_cfg(bad)
+    soft = dict(epochs=2.0, save=1, lr0="0.1", time=None)
+    check_cfg(soft, hard=False)
+    assert soft == dict(epochs=2, save=True, lr0=0.1, time=None) and isinstance(soft["epochs"], int)
+    with pytest.raises(KeyError):
+        get_cfg(dict(not_an_argument=1))
