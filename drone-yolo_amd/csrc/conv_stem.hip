@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const StemArgs p) {
   const int lq = lane >> 4, lr = lane & 15;
   unsigned char* escr = dyn_smem + ((p.Cin * PLANE * 4 + 15) / 16) * 16 + wave * EP_BYTES;
 
-  int t = blockIdx.x;
+  int t = (int)xcd_remap(blockIdx.x, gridDim.x);  // neighbouring tiles behind one L2: the halo lines they share are fetched once (r05)
   const int tx = t % p.tilesX;
   t /= p.tilesX;
   const int ty = t % p.tilesY;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void conv_stem_split_kernel(const StemArgs p) 
   const int lq = lane >> 4, lr = lane & 15;
   unsigned char* escr = dyn_smem + ((p.Cin * PLANE * 4 + 15) / 16) * 16 + wave * EP_BYTES;
 
-  int t = blockIdx.x;
+  int t = (int)xcd_remap(blockIdx.x, gridDim.x);  // neighbouring tiles behind one L2: the halo lines they share are fetched once (r05)
   const int tx = t % p.tilesX;
   t /= p.tilesX;
   const int ty = t % p.tilesY;

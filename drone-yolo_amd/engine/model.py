@@ -83,6 +83,12 @@ class Model(nn.Module):
             self._pred_args = args
         return self.predictor(source, stream=stream)
 
+    def profile(self, source, **kwargs) -> list:
+        """Per-layer device time of one pass over ``source`` (reference ``predict(profile=True)`` -> ``_profile_one_layer``, nn/tasks.py:171-191):
+        [{layer, type, launches, ms, kernels}], see ``DetectionPredictor.profile_layers``."""
+        self.predict(source, **kwargs)
+        return self.predictor.profile_layers(self.predictor.preprocess(source))
+
     def train(self, trainer=None, **kwargs):
         """Reference engine/model.py:744-817: build the trainer from the model + overrides, train, then continue with the
         trained weights.  ``data``: a tensor dataset (.pt / dict) or "synthetic[:N]" (engine/trainer.py::load_dataset);

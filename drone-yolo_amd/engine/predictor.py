@@ -255,6 +255,36 @@ class DetectionPredictor:
             cf.plan.replay(torch.cuda.current_stream().cuda_stream)
         cf.graph = g
 
+    def profile_layers(self, im: torch.Tensor, iters: int = 3) -> List[dict]:
+        """Per-layer device time of the recorded pass for ``im``'s shape — the reference's ``_profile_one_layer`` (nn/tasks.py:171-191: time per layer
+        of ``_predict_once(profile=True)``), measured the way this path runs: the plan's launches replayed one by one with HIP events on the
+        launch stream and summed by the model layer that issued them (layers folded into a consumer's gather — Upsample, Concat — launch nothing
+        and do not appear; NMS and the box rescale come last as 'postprocess').  Returns [{layer, type, launches, ms, kernels}]."""
+        cf = self.forward_device(im)
+        L, stream = H.lib(), torch.cuda.current_stream().cuda_stream
+        tot, names = {}, {}
+        for _ in range(iters):
+            evs = []
+            for i, (fn, args, _) in enumerate(cf.plan.ops):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                fn(*args, stream)
+                e.record()
+                evs.append((i, s, e))
+                names[i] = (L.dy_last_kernel_name() or b"").decode() or fn.__name__
+            torch.cuda.synchronize(self.device)
+            for i, s, e in evs:
+                tot[i] = tot.get(i, 0.0) + s.elapsed_time(e)
+        rows: Dict = {}
+        for i in range(len(cf.plan.ops)):
+            tag = cf.plan.tags[i] if i < len(cf.plan.tags) and cf.plan.tags[i] is not None else (10 ** 6, "postprocess (NMS, box rescale; an input layout cast where layer 0 has no fused image kernel)")
+            r = rows.setdefault(tag, {"layer": tag[0] if tag[0] < 10 ** 6 else None, "type": tag[1], "launches": 0, "ms": 0.0, "kernels": []})
+            r["launches"] += 1
+            r["ms"] += tot[i] / iters
+            if names[i] not in r["kernels"]:
+                r["kernels"].append(names[i])
+        return [dict(r, ms=round(r["ms"], 4)) for _, r in sorted(rows.items(), key=lambda kv: kv[0][0])]
+
     def static_input(self, shape) -> Optional[torch.Tensor]:
         cf = self._compiled.get((tuple(shape), self.dtype))
         return None if cf is None else cf.static_in
@@ -264,9 +294,10 @@ class DetectionPredictor:
         names = self.model.names
         out = []
         info = getattr(self, "letterbox_info", None)
+        rows = cf.nms.out.clone()  # ONE copy of the padded (N, max_det, 6) rows: the next pass overwrites the buffer, the Results keep views of this one
         for i, k in enumerate(counts):
             one = (info[i] if isinstance(info, list) else info) if info else None
-            out.append(Results(im[i], paths[i] if paths else f"image{i}.jpg", names, boxes=cf.nms.out[i, :k].clone(),
+            out.append(Results(im[i], paths[i] if paths else f"image{i}.jpg", names, boxes=rows[i, :k],
                                orig_shape=(one[0], one[1]) if one else im.shape[2:]))
         return out
 

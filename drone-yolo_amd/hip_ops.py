@@ -124,6 +124,7 @@ class LaunchPlan:
 
     def __init__(self):
         self.ops: List[Tuple[object, tuple, bool]] = []  # (cfunc, args-without-stream, by_desc)
+        self.tags: List[object] = []  # per op: the model layer that issued it (``layer_tag``; None outside a layer) — per-layer profiling
         self.keep: List[object] = []  # tensors / descriptors that must outlive the plan
         self.input_slot: Optional[Tuple[int, int]] = None  # (op index, arg index) of the user input pointer
         self.outputs = None
@@ -146,6 +147,21 @@ class LaunchPlan:
 
 
 _recording: Optional[LaunchPlan] = None
+_LAYER_TAG = [None]  # (index, type name) of the model layer whose forward is running (set by nn/tasks.py::_predict_layers)
+
+
+class layer_tag:
+    """Launches issued inside are attributed to model layer ``tag`` in a recording plan (``LaunchPlan.tags``)."""
+
+    def __init__(self, tag):
+        self.tag = tag
+
+    def __enter__(self):
+        self.prev, _LAYER_TAG[0] = _LAYER_TAG[0], self.tag
+
+    def __exit__(self, *exc):
+        _LAYER_TAG[0] = self.prev
+        return False
 
 
 class record:
@@ -178,6 +194,7 @@ def _launch(fn, args: tuple, keep: Sequence[object] = (), record: bool = True) -
         check(rc, fn.__name__)
     if _recording is not None and record:
         _recording.ops.append((fn, args, False))
+        _recording.tags.append(_LAYER_TAG[0])
         _recording.keep.extend(keep)
 
 

@@ -264,16 +264,19 @@ class BaseModel(nn.Module):
                 pk2 = self._stem2_pack(stem_image, image_dtype, consumers0=self._consumers0)
                 if pk2 is not None:  # layers 0 + 1 in one kernel: the half-resolution map never reaches HBM
                     y.append(None)
-                    fused_stem2 = H.stem2_fused(stem_image, pk2, mark_input=True)
+                    with H.layer_tag((0, "Conv + RepVGGBlock (layers 0 + 1, fused)")):
+                        fused_stem2 = H.stem2_fused(stem_image, pk2, mark_input=True)
                     continue
-                if image_dtype == H.FP8:  # the 3-channel image layer runs in fp16 (K = 27), its output is quantised once
-                    out = H.quantize_fp8(m.forward_stem(stem_image, torch.float16, mark_input=True), out=kw.get("out"))
-                else:
-                    out = m.forward_stem(stem_image, image_dtype, mark_input=True, **kw)
+                with H.layer_tag((0, type(m).__name__)):
+                    if image_dtype == H.FP8:  # the 3-channel image layer runs in fp16 (K = 27), its output is quantised once
+                        out = H.quantize_fp8(m.forward_stem(stem_image, torch.float16, mark_input=True), out=kw.get("out"))
+                    else:
+                        out = m.forward_stem(stem_image, image_dtype, mark_input=True, **kw)
             elif i == 1 and fused_stem2 is not None:
                 out = fused_stem2
             else:
-                out = m(xin, **kw)
+                with H.layer_tag((i, type(m).__name__)):
+                    out = m(xin, **kw)
             y.append(out)
         return y[-1]
 

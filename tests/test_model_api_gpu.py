@@ -308,3 +308,16 @@ def test_image_sources_of_different_shapes_are_letterboxed_per_image(device):
         got = res[i].boxes.data.cpu()
         assert got.shape == exp.shape and len(exp) > 0, (i, got.shape, exp.shape)
         assert torch.equal(got[:, 5], exp[:, 5]) and torch.allclose(got[:, :5], exp[:, :5], atol=2e-2, rtol=1e-4), i
+
+
+def test_yolo_profile_reports_every_launching_layer(device):
+    """``YOLO.profile(x)`` (reference predict(profile=True) -> _profile_one_layer, nn/tasks.py:171-191): per-layer device time of the recorded pass; the rows
+    cover every launch of the plan, name the layers that launch (folded Upsample / Concat do not) and end with the postprocess row."""
+    yolo = D.YOLO("yolov8n-p2-repvgg.yaml")
+    x = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(2))
+    rows = yolo.profile(x, device=0, conf=0.001)
+    cf = next(iter(yolo.predictor._compiled.values()))
+    assert sum(r["launches"] for r in rows) == len(cf.plan.ops) and all(r["ms"] > 0 for r in rows)
+    types = [r["type"] for r in rows]
+    assert types[-1].startswith("postprocess") and "Detect" in types and "SPPF" in types and "C2f" in types and "Upsample" not in types
+    assert [r["layer"] for r in rows[:-1]] == sorted(r["layer"] for r in rows[:-1])
