@@ -112,3 +112,30 @@ def test_new_entry_points_validate_without_gpu():
     assert h.dy_stem2_fused_supported(3, 48, 96, 640, 640, L.DY_BF16) == 0 and h.dy_stem2_fused_supported(3, 32, 64, 640, 640, L.DY_F32) == 0
     assert h.dy_bn_workspace_bytes(64) == (1 + 1024) * 2 * 64 * 8 and h.dy_bn_workspace_bytes(0) == -1
     assert h.dy_detection_loss_workspace_bytes(2, 340, 7, 10) > 0 and h.dy_detection_loss_workspace_bytes(0, 340, 7, 10) == -1
+
+
+def test_split_float16_type_validates_without_gpu():
+    """DY_F16X2 (round 5): size / padding rules and the descriptor checks of the entry points built for it, before any HIP call."""
+    import drone_yolo_amd._lib as L
+
+    h = L.lib()
+    assert L.DY_F16X2 == 4 and h.dy_dtype_size(L.DY_F16X2) == 4
+    # a K-step is 32 channels (four hi / lo chunk pairs of a 128-byte row): 3x3 x 64 -> 576, 3x3 x 8 (the padded image) -> 96, 1x1 x 96 -> 96
+    assert h.dy_conv_k_pad(64, 3, L.DY_F16X2) == 576 and h.dy_conv_k_pad(8, 3, L.DY_F16X2) == 96 and h.dy_conv_k_pad(96, 1, L.DY_F16X2) == 96
+    assert h.dy_detect_head_decode_supported(64, 64, 10, 16, L.DY_F16X2) == 1 and h.dy_detect_head_decode_supported(64, 80, 10, 16, L.DY_F16X2) == 0
+    assert h.dy_detect_head_decode_supported(128, 64, 10, 16, L.DY_F16X2) == 0
+    assert h.dy_c2f_fused_supported(64, 0, 32, 64, 1, L.DY_F16X2) == 0 and h.dy_stem2_fused_supported(3, 32, 64, 640, 640, L.DY_F16X2) == 0  # fused 16-bit kernels: not for the type
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    d = L.ConvDesc()
+    d.x = d.w = d.bias = d.y = p
+    d.batch, d.h, d.w_in, d.cin, d.ld_x, d.ho, d.wo, d.cout, d.ld_y = 1, 8, 8, 64, 64, 8, 8, 64, 64
+    d.ksize, d.stride, d.pad, d.groups, d.dtype, d.k_pad, d.cout_pad = 3, 1, 1, 1, L.DY_F16X2, 576, 64
+    assert h.dy_conv2d_nhwc(ctypes.byref(d), None) == -1 and b"w_scale" in h.dy_last_error_string()  # the inverse row scales are part of the type
+    d.groups = 2
+    assert h.dy_conv2d_nhwc(ctypes.byref(d), None) == -2 and b"dense" in h.dy_last_error_string()  # DY_ERR_UNSUPPORTED: grouped convolutions are not built for it
+    d.groups, d.cin, d.k_pad = 1, 12, 128
+    assert h.dy_conv2d_nhwc(ctypes.byref(d), None) in (-1, -2)  # channels not in whole groups of 8
+    assert h.dy_resize_bilinear_u8_nchw_f32(None, None, 1, 3, 8, 8, 16, 16, None) == -1
+    assert h.dy_nchw_f32_to_nhwc(p, p, 1, 3, 8, 8, 4, 4, L.DY_F16X2, None) == -1  # c_pad must be whole groups of 8 channels
+    assert h.dy_sppf_maxpool3(p, p, p, p, 1, 8, 8, 12, 12, 5, L.DY_F16X2, None) == -1
