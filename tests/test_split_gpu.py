@@ -221,3 +221,33 @@ def test_split_stem_matches_float64(shape, device):
     assert H.last_kernel_name() == "conv_stem_split_kernel" and tuple(y.shape) == tuple(ref.shape)
     err = float((down(y).double() - ref).abs().max())
     assert err <= 4e-6 * float(ref.abs().max()), err
+
+
+def test_split_full_size_properties(device):
+    """Drone-YOLO-s 640x640 on split-float16 storage, size-independent properties at a real batch (no oracle at this size): images are independent (a batch
+    equals its images run one by one, bit for bit), a permuted batch gives permuted outputs, the hipGraph replay equals the recorded pass, and the NMS
+    output invariants hold (counts <= max_det, scores sorted and above conf, boxes inside the image, kept anchors unique)."""
+    g = golden("e2e.npz")
+    m, d, sd, model, _ = _build("s640", g)
+    pred = D.engine.predictor.DetectionPredictor(model, dict(conf=0.25, iou=0.7, dtype="f16x2", device=0, graph=True))
+    x = torch.rand(8, 3, 640, 640, generator=torch.Generator().manual_seed(5)).to(device)
+    cf = pred.forward_device(x)
+    torch.cuda.synchronize()
+    out, cnt, idx, y = cf.nms.out.clone(), cf.nms.count.clone(), cf.nms.index.clone(), cf.pred.clone()
+    cf2 = pred.forward_device(x.clone())  # the captured graph, another input buffer with the same contents
+    torch.cuda.synchronize()
+    assert cf2 is cf and cf.graph is not None and torch.equal(cf.pred, y) and torch.equal(cf.nms.out, out) and torch.equal(cf.nms.count, cnt)
+    perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4], device=device)
+    cf = pred.forward_device(x[perm].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(cf.pred, y[perm]) and torch.equal(cf.nms.out, out[perm]) and torch.equal(cf.nms.count, cnt[perm])
+    single = pred.forward_device(x[2:3].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(single.pred[0], y[2]) and torch.equal(single.nms.out[0], out[2])
+    for i in range(8):
+        c = int(cnt[i])
+        assert 0 < c <= 300
+        sc = out[i, :c, 4]
+        assert bool((sc[:-1] >= sc[1:]).all()) and float(sc.min()) > 0.25
+        assert float(out[i, :c, :4].min()) >= 0 and float(out[i, :c, :4].max()) <= 640
+        assert len(set(idx[i, :c].tolist())) == c
