@@ -113,3 +113,71 @@ class Results:
         r = Results(self._orig_img, self.path, self.names, None, self.speed, self.orig_shape)
         r.boxes = self.boxes.cpu() if self.boxes is not None else None
         return r
+
+    def numpy(self):
+        r = Results(self._orig_img, self.path, self.names, None, self.speed, self.orig_shape)
+        r.boxes = self.boxes.numpy() if self.boxes is not None else None
+        return r
+
+    def to(self, *args, **kwargs):
+        r = Results(self._orig_img, self.path, self.names, None, self.speed, self.orig_shape)
+        r.boxes = self.boxes.to(*args, **kwargs) if self.boxes is not None else None
+        return r
+
+    def __getitem__(self, idx):
+        r = Results(self._orig_img, self.path, self.names, None, self.speed, self.orig_shape)
+        r.boxes = self.boxes[idx] if self.boxes is not None else None
+        return r
+
+    # ---- text forms of a detection result (reference results.py:633-666 verbose, :668-757 save_txt, :759-823 summary, :906-940 to_json) ----
+    def verbose(self) -> str:
+        """'2 persons, 1 car, ' — detections per class in ascending class order; '(no detections), ' for none."""
+        if len(self) == 0:
+            return "(no detections), "
+        cls = torch.as_tensor(self.boxes.cls).cpu()
+        out = ""
+        for c in cls.unique():
+            n = int((cls == c).sum())
+            out += f"{n} {self.names[int(c)]}{'s' * (n > 1)}, "
+        return out
+
+    def summary(self, normalize: bool = False, decimals: int = 5) -> list:
+        """One dict per detection: name, class, confidence, box {x1, y1, x2, y2} (divided by the image size with ``normalize``)."""
+        if self.boxes is None:
+            return []
+        h, w = self.orig_shape if normalize else (1, 1)
+        rows = torch.as_tensor(self.boxes.data).cpu().tolist()
+        out = []
+        for r in rows:
+            k = int(r[-1])
+            d = {"name": self.names[k], "class": k, "confidence": round(r[-2], decimals),
+                 "box": {"x1": round(r[0] / w, decimals), "y1": round(r[1] / h, decimals), "x2": round(r[2] / w, decimals), "y2": round(r[3] / h, decimals)}}
+            if self.boxes.is_track:
+                d["track_id"] = int(r[-3])
+            out.append(d)
+        return out
+
+    def to_json(self, normalize: bool = False, decimals: int = 5) -> str:
+        import json
+
+        return json.dumps(self.summary(normalize=normalize, decimals=decimals), indent=2)
+
+    tojson = to_json
+
+    def save_txt(self, txt_file, save_conf: bool = False) -> str:
+        """Append one line per detection, `class x_center y_center width height [confidence]` with the box normalised to the image (the label format)."""
+        from pathlib import Path
+
+        lines = []
+        if self.boxes is not None and len(self.boxes):
+            xywhn = torch.as_tensor(self.boxes.xywhn).cpu().tolist()
+            conf = torch.as_tensor(self.boxes.conf).cpu().tolist()
+            cls = torch.as_tensor(self.boxes.cls).cpu().tolist()
+            for b, s, c in zip(xywhn, conf, cls):
+                vals = (int(c), *b) + ((s,) if save_conf else ())
+                lines.append(("%g " * len(vals)).rstrip() % vals)
+        if lines:
+            Path(txt_file).parent.mkdir(parents=True, exist_ok=True)
+            with open(txt_file, "a") as f:
+                f.writelines(t + "\n" for t in lines)
+        return str(txt_file)

@@ -377,3 +377,23 @@ def test_check_cfg_types_and_ranges():
     assert soft == dict(epochs=2, save=True, lr0=0.1, time=None) and isinstance(soft["epochs"], int)
     with pytest.raises(KeyError):
         get_cfg(dict(not_an_argument=1))
+
+
+def test_results_text_forms(tmp_path):
+    """engine/results.py: verbose / summary / to_json / save_txt / indexing of a detection result (reference results.py:633-940), on hand-made rows."""
+    import json
+
+    from drone_yolo_amd.engine.results import Results
+
+    rows = torch.tensor([[10.0, 20.0, 110.0, 220.0, 0.9, 1.0], [0.0, 0.0, 50.0, 40.0, 0.6, 0.0], [5.0, 5.0, 25.0, 45.0, 0.3, 1.0]])
+    r = Results(torch.zeros(3, 400, 200), "a.jpg", {0: "person", 1: "car"}, boxes=rows, orig_shape=(400, 200))
+    assert r.verbose() == "1 person, 2 cars, " and len(r) == 3 and len(r[0]) == 1 and len(r[rows[:, 4] > 0.5]) == 2
+    s = r.summary()
+    assert s[0] == {"name": "car", "class": 1, "confidence": 0.9, "box": {"x1": 10.0, "y1": 20.0, "x2": 110.0, "y2": 220.0}}
+    assert r.summary(normalize=True)[0]["box"] == {"x1": 0.05, "y1": 0.05, "x2": 0.55, "y2": 0.55}
+    assert json.loads(r.to_json())[1]["name"] == "person" and r.tojson() == r.to_json()
+    out = r.save_txt(tmp_path / "labels" / "a.txt", save_conf=True)
+    lines = open(out).read().splitlines()
+    assert lines[0] == "1 0.3 0.3 0.5 0.5 0.9" and lines[1] == "0 0.125 0.05 0.25 0.1 0.6" and len(lines) == 3
+    empty = Results(torch.zeros(3, 8, 8), "b.jpg", {0: "x"}, boxes=torch.zeros(0, 6), orig_shape=(8, 8))
+    assert empty.verbose() == "(no detections), " and empty.summary() == [] and isinstance(r.numpy().boxes.data, np.ndarray)
