@@ -393,7 +393,10 @@ int32_t dy_detect_decode(const dy_decode_desc* d, dy_stream_t stream);
  * for (cout = 4*reg_max, cin = c_box) / (cout = nc, cin = c_cls); b_box / b_cls: fp32 bias padded like there.
  * out, nms_workspace, conf_thres, classes_mask: exactly as in dy_decode_desc.
  * Built for reg_max 16, nc <= 128, c_box = 64, c_cls in {64, 96, 128, 160} (16-bit) or {64, 80} (fp32);
- * dy_detect_head_decode_supported() tells (1/0); unsupported shapes return DY_ERR_UNSUPPORTED. */
+ * dy_detect_head_decode_supported() tells (1/0); unsupported shapes return DY_ERR_UNSUPPORTED.
+ * DY_F16X2 (round 5; c_box = 64, c_cls in {64, 96, 128}): x_box / x_cls are split-float16 views; w_box[l] / w_cls[l] hold the float16
+ * DY_WLAYOUT_FRAG1X1 image (k-groups of 32 channels) of the hi halves followed by the image of the lo halves (rows scaled by a power of
+ * two into [2^13, 2^14) first, as for dy_conv2d_nhwc); b_box[l] / b_cls[l] hold the padded bias followed by as many inverse row scales. */
 typedef struct dy_head_decode_desc {
   const void* x_box[DY_MAX_LEVELS];
   const void* x_cls[DY_MAX_LEVELS];
