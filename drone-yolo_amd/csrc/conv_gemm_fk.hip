@@ -92,7 +92,10 @@ __device__ __forceinline__ void fk_store4(unsigned char* sp, const float (&v)[4]
 // offset is (row base + table offset) | (mask bit - 1): an out-of-range offset wherever the tap is padding.
 // STATS (r04; training forward in front of a train-mode BatchNorm): per-channel sum / sum of squares of the STORED outputs of the tile,
 // as in conv_gemm_glds.hip.
-template <typename T, typename OT, int MFR, int NFR, int WM, int WN, bool RES = false, int TABN = 768, bool STATS = false>
+// W32 (ablate build only, DYOLO_FK_W32=1): the same tile and loop on v_mfma_f32_32x32x16 — a wave tile of 64 x 64 is 2 x 2 fragments of 32
+// rows, a 128-byte K-step four 16-deep MFMA steps (lane l: row l % 32, chunk 2 t + l / 32) — for the A/B of the MFMA shape inside a production kernel.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <typename T, typename OT, int MFR, int NFR, int WM, int WN, bool RES = false, int TABN = 768, bool STATS = false, bool W32 = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs p) {
   constexpr bool MX = FkIsFp8<T>::v;
   constexpr bool SP = std::is_same<T, f16x2_t>::value;  // DY_F16X2: split float16 pairs, three MFMAs per staged fragment pair (header)
@@ -237,11 +240,45 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
 #pragma unroll
     for (int i = 0; i < MFR; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  f32x16 acc32[W32 ? NFR / 2 : 1][W32 ? MFR / 2 : 1];
+  if constexpr (W32) {
+    static_assert(!W32 || (!RES && !STATS && sizeof(T) == 2 && sizeof(OT) == 2 && MFR % 2 == 0 && NFR % 2 == 0), "W32: plain 16-bit tiles of whole 32-row fragments");
+#pragma unroll
+    for (int j = 0; j < NFR / 2; ++j)
+#pragma unroll
+      for (int i = 0; i < MFR / 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc32[j][i][e] = 0.f;
+  }
   const int swz = lr >> 1;
   auto compute = [&](int stage) {
+    if constexpr (W32) {
+      const int r32 = lane & 31, kh = lane >> 5, sw32 = (r32 >> 1) & 7;
+      const unsigned char* sa32 = smem + stage * STAGE + (wm * MFR * 16 + r32) * 128;
+      const unsigned char* sb32 = smem + stage * STAGE + A_BYTES + (wn * NFR * 16 + r32) * 128;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int slot = ((2 * t + kh) ^ sw32) * 16;
+        u32x4 a[MFR / 2], b[NFR / 2];
+#pragma unroll
+        for (int j = 0; j < NFR / 2; ++j) b[j] = *reinterpret_cast<const u32x4*>(sb32 + j * 32 * 128 + slot);
+#pragma unroll
+        for (int i = 0; i < MFR / 2; ++i) a[i] = *reinterpret_cast<const u32x4*>(sa32 + i * 32 * 128 + slot);
+#pragma unroll
+        for (int j = 0; j < NFR / 2; ++j)
+#pragma unroll
+          for (int i = 0; i < MFR / 2; ++i) {
+            if constexpr (std::is_same<T, f16_t>::value)
+              acc32[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, b[j]), __builtin_bit_cast(f16x8, a[i]), acc32[j][i], 0, 0, 0);
+            else
+              acc32[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, a[i]), acc32[j][i], 0, 0, 0);
+          }
+      }
+      return;
+    }
     const unsigned char* sa = smem + stage * STAGE + (wm * MFR * 16 + lr) * 128;
     const unsigned char* sb = smem + stage * STAGE + A_BYTES + (wn * NFR * 16 + lr) * 128;
-#ifdef DYOLO_ABLATE
+#ifdef DYOLO_FK_KDBG  // (in-kernel timing probes: `make ABLATE=1 KDBG=1`; they move the accumulators of the MFMA loop through VGPRs — 64 v_accvgpr moves per K-step — so a build that carries them cannot time the loop itself)
     if (p.dbg == 3) {  // no fragment reads: MFMAs on whatever the registers hold
       sa = smem + (lr & 1) * 128;
       sb = smem + (lr & 1) * 128 + 512;
@@ -323,7 +360,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
   for (int s = 0; s < nsteps; ++s) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of step s has landed
     __syncthreads();                                   // publishes stage s & 1; everyone is done with the other one
-#ifdef DYOLO_ABLATE
+#ifdef DYOLO_FK_KDBG
     if (s + 1 < nsteps && p.dbg != 2) issue((s + 1) & 1);
 #else
     if (s + 1 < nsteps) issue((s + 1) & 1);
@@ -350,6 +387,28 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
     const int m0 = tileM * BM + wm * MFR * 16 + h * PXP;
+    if constexpr (W32) {  // D[32 couts][32 pixels]: lane l holds pixel l % 32 and couts 8 j + 4 (l / 32) + e of the fragment, as acc32[..][..][4 j + e]
+      static_assert(!W32 || NH == 1, "W32: one epilogue pass");
+      const int r32 = lane & 31, kh = lane >> 5;
+#pragma unroll
+      for (int jf = 0; jf < NFR / 2; ++jf)
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+          const int cl = jf * 32 + 8 * j4 + 4 * kh, co = n0 + cl;
+          const f32x4 bb = co + 3 < p.cout_pad ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int i = 0; i < MFR / 2; ++i) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc32[jf][i][4 * j4 + e] + bb[e];
+            if (p.act == DY_ACT_SILU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
+            }
+            fk_store4<OT>(escr + (i * 32 + r32) * EP_PITCH + cl * OES, v);
+          }
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < NFR; ++j) {
       const int co = n0 + j * 16 + lq * 4;
@@ -386,6 +445,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
           }
         }
       }
+    }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -460,7 +520,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
         } else {
           val = *reinterpret_cast<const u32x4*>(escr + px * EP_PITCH + cc * 16);
         }
-#ifdef DYOLO_ABLATE
+#ifdef DYOLO_FK_KDBG
         if (p.dbg == 4 && val[0] != 0x7fc07fc1u) continue;
 #endif
         *reinterpret_cast<u32x4*>(yg + (size_t)m * (size_t)p.ldy + (size_t)(n0 + cc * OEPC)) = val;
@@ -560,7 +620,20 @@ static int launch_fk_tiles(const FkArgs& a, hipStream_t st) {
   if (best == 80 && nf > 128) best = 160;
   switch (best) {
     case 160: return launch_fk<T, OT, 4, 5, 2, 2, 768>(a, st, "conv_gemm_fk_kernel<128,160>");
-    case 128: return launch_fk<T, OT, 4, 4, 2, 2, 768>(a, st, "conv_gemm_fk_kernel<128,128>");
+    case 128:
+#ifdef DYOLO_ABLATE
+      if constexpr (sizeof(T) == 2 && std::is_same<T, OT>::value) {
+        const char* v32 = getenv("DYOLO_FK_W32");
+        if (v32 && atoi(v32) && a.res == nullptr && a.stats == nullptr) {
+          FkArgs q = a;
+          q.tilesN = (q.Cout + 127) / 128;
+          q.nblk = ((q.M + 127) / 128) * q.tilesN;
+          hipLaunchKernelGGL((conv_gemm_fk_kernel<T, OT, 4, 4, 2, 2, false, 768, false, true>), dim3((unsigned)q.nblk), dim3(256), 0, st, q);
+          return check_launch("conv_gemm_fk_kernel<128,128,w32>");
+        }
+      }
+#endif
+      return launch_fk<T, OT, 4, 4, 2, 2, 768>(a, st, "conv_gemm_fk_kernel<128,128>");
     case 80: return launch_fk<T, OT, 2, 5, 4, 1, 128>(a, st, "conv_gemm_fk_kernel<128,80>");
     default: return launch_fk<T, OT, 2, 4, 4, 1, 768>(a, st, "conv_gemm_fk_kernel<128,64>");
   }

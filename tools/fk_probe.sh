@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box, ablate build: where does the flat-K kernel's time go?  DYOLO_FK_DBG = 0 full, 1 no MFMAs, 2 no LDS-DMA after step 0, 3 no fragment reads, 4 no stores
+# GPU box, ablate build WITH the in-kernel probes (make ABLATE=1 KDBG=1 OUT=../lib_ablate): where does the flat-K kernel's time go?  DYOLO_FK_DBG = 0 full, 1 no MFMAs, 2 no LDS-DMA after step 0, 3 no fragment reads, 4 no stores
 O=${1:-gpurun_out/fkprobe}
 mkdir -p $O
 S="160,160,3,1,192 320,320,3,1,96 80,80,3,1,384 2560,640,1,1,96 400,160,1,1,384"
