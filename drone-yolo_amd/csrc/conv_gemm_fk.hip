@@ -240,6 +240,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
 #pragma unroll
     for (int i = 0; i < MFR; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // split float16: the x_lo' w_hi products (worth 2^-11 of the others) collect in their own accumulators and join in the epilogue — in the
+  // same accumulator they needed w_hi 2^-11 formed per fragment and K-step (16 v_pk_mul_f16 beside 24 MFMAs)
+  // (+1.6 % on the s-scale pass; tiles of more than 8 fragments per wave keep the one-accumulator form: 80 more registers halved the
+  // 128 x 160 tile's occupancy, -15 % on the x scale)
+  constexpr bool SPL = SP && MFR * NFR <= 8;
+  f32x4 accl[SPL ? NFR : 1][SPL ? MFR : 1];
+  if constexpr (SPL) {
+#pragma unroll
+    for (int j = 0; j < NFR; ++j)
+#pragma unroll
+      for (int i = 0; i < MFR; ++i) accl[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   f32x16 acc32[W32 ? NFR / 2 : 1][W32 ? MFR / 2 : 1];
   if constexpr (W32) {
     static_assert(!W32 || (!RES && !STATS && sizeof(T) == 2 && sizeof(OT) == 2 && MFR % 2 == 0 && NFR % 2 == 0), "W32: plain 16-bit tiles of whole 32-row fragments");
@@ -319,7 +331,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
           acc[j][i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b[j], a[i], acc[j][i], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
         }
     } else if constexpr (SP) {
-      // a 128-byte row = four (hi, lo) chunk pairs of 8 channels: lane quarter lq takes pair lq.  x w = x_hi w_hi + x_hi w_lo + x_lo' (w_hi 2^-11)
+      // a 128-byte row = four (hi, lo) chunk pairs of 8 channels: lane quarter lq takes pair lq.  x w = x_hi w_hi + x_hi w_lo + 2^-11 x_lo' w_hi
       // (x_lo' is stored times 2^11; lo x lo, 2^-22 relative, is dropped): fp32-grade products from three 16-bit MFMAs, and per MFMA
       // two thirds of the LDS reads and DMA bytes of the plain float16 loop
       const int sh = ((2 * lq) ^ swz) * 16, sl = ((2 * lq + 1) ^ swz) * 16;
@@ -329,13 +341,22 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
 #pragma unroll
       for (int j = 0; j < NFR; ++j) {
         const u32x4 bh = *reinterpret_cast<const u32x4*>(sb + j * 16 * 128 + sh), bl = *reinterpret_cast<const u32x4*>(sb + j * 16 * 128 + sl);
-        const f16x8 bsv = __builtin_bit_cast(f16x8, bh) * (f16_t)kSplitInv;  // v_pk_mul_f16 x 4: exact (a power of two), rows are scaled to >= 2^13 at the top
-        const u32x4 bs = __builtin_bit_cast(u32x4, bsv);
+        if constexpr (SPL) {
 #pragma unroll
-        for (int i = 0; i < MFR; ++i) {
-          acc[j][i] = Elem<f16_t>::mma(bh, ah[i], acc[j][i]);
-          acc[j][i] = Elem<f16_t>::mma(bl, ah[i], acc[j][i]);
-          acc[j][i] = Elem<f16_t>::mma(bs, al[i], acc[j][i]);
+          for (int i = 0; i < MFR; ++i) {
+            acc[j][i] = Elem<f16_t>::mma(bh, ah[i], acc[j][i]);
+            acc[j][i] = Elem<f16_t>::mma(bl, ah[i], acc[j][i]);
+            accl[j][i] = Elem<f16_t>::mma(bh, al[i], accl[j][i]);
+          }
+        } else {
+          const f16x8 bsv = __builtin_bit_cast(f16x8, bh) * (f16_t)kSplitInv;  // v_pk_mul_f16 x 4: exact (a power of two), rows are scaled to >= 2^13 at the top
+          const u32x4 bs = __builtin_bit_cast(u32x4, bsv);
+#pragma unroll
+          for (int i = 0; i < MFR; ++i) {
+            acc[j][i] = Elem<f16_t>::mma(bh, ah[i], acc[j][i]);
+            acc[j][i] = Elem<f16_t>::mma(bl, ah[i], acc[j][i]);
+            acc[j][i] = Elem<f16_t>::mma(bs, al[i], acc[j][i]);
+          }
         }
       }
     } else {
@@ -421,7 +442,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
         const int i = h * MPP + ii;
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (MX || SP) ? acc[j][i][e] * sc4[e] + bb[e] : acc[j][i][e] + bb[e];
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (SPL) v[e] = (acc[j][i][e] + accl[j][i][e] * kSplitInv) * sc4[e] + bb[e];
+          else v[e] = (MX || SP) ? acc[j][i][e] * sc4[e] + bb[e] : acc[j][i][e] + bb[e];
+        }
         if (p.act == DY_ACT_SILU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
