@@ -40,6 +40,7 @@ class ConvDesc(C.Structure):
         ("k_pad", _i32), ("cout_pad", _i32), ("up2x", _i32),
         ("x2", _vp), ("ld_x2", _i32), ("cin_split", _i32), ("w_layout", _i32),
         ("w_scale", _vp), ("act_scale", _f32), ("bn_stats", _vp), ("y_dtype1", _i32),
+        ("bnb_z", _vp), ("bnb_ld_z", _i32), ("bnb_act", _i32), ("bnb_mean", _vp), ("bnb_rstd", _vp), ("bnb_gamma", _vp), ("bnb_beta", _vp),
     ]  # fmt: skip
 
 

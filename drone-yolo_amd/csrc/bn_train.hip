@@ -313,7 +313,7 @@ static int bn_prepare(const dy_bn_desc* d, BnArgs* a, const char* who, bool bwd)
   a->running_mean = d->running_mean, a->running_var = d->running_mean ? d->running_var : nullptr;
   a->eps = d->eps, a->momentum = d->momentum, a->dgamma = d->dgamma, a->dbeta = d->dbeta;
   a->acc = reinterpret_cast<double*>(d->workspace);
-  a->partial_slabs = bwd ? 0 : d->partial_slabs;
+  a->partial_slabs = d->partial_slabs;
   DY_REQUIRE(a->partial_slabs >= 0 && a->partial_slabs <= kBnMaxSlabs, DY_ERR_INVALID_ARG, "%s: partial_slabs out of range", who);
   a->nch = d->c / epc;
   a->invn = 1.0 / (double)d->rows;
@@ -357,9 +357,14 @@ template <typename T>
 static int bn_bwd_t(const BnArgs& a, hipStream_t st) {
   const unsigned blocks = (unsigned)((a.rows + a.rows_per_block - 1) / a.rows_per_block);
   const size_t smem = (size_t)2 * a.R * a.c * 4;
-  if (dy_ablate("DYOLO_BN_RUNR") == 8) hipLaunchKernelGGL((bn_reduce_kernel<T, 1, 8>), dim3(blocks), dim3(256), smem, st, a);
-  else hipLaunchKernelGGL((bn_reduce_kernel<T, 1, 4>), dim3(blocks), dim3(256), smem, st, a);
-  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((unsigned)((2 * a.c + 31) / 32), kBnSumY), dim3(256), 0, st, a, (int)blocks);
+  if (a.partial_slabs > 0) {
+    // the input-gradient convolution behind left the slots of du and du * xhat (dy_conv_desc.bnb_z): no pass over dy and z
+  } else if (dy_ablate("DYOLO_BN_RUNR") == 8) {
+    hipLaunchKernelGGL((bn_reduce_kernel<T, 1, 8>), dim3(blocks), dim3(256), smem, st, a);
+  } else {
+    hipLaunchKernelGGL((bn_reduce_kernel<T, 1, 4>), dim3(blocks), dim3(256), smem, st, a);
+  }
+  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((unsigned)((2 * a.c + 31) / 32), kBnSumY), dim3(256), 0, st, a, a.partial_slabs > 0 ? a.partial_slabs : (int)blocks);
   const int unr = dy_ablate("DYOLO_BN_BUNR") ? dy_ablate("DYOLO_BN_BUNR") : 2;
   const int cap = dy_ablate("DYOLO_BN_GRID") ? dy_ablate("DYOLO_BN_GRID") : 2048;
   const unsigned ab = apply_blocks(a, unr, cap);

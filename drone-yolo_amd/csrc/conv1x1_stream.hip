@@ -350,7 +350,7 @@ int conv1x1_stream_dispatch(const dy_conv_desc* d, hipStream_t st) {
   a.act = d->act;
   a.div_hw = make_fastdiv((unsigned)(d->h * d->w_in));
   a.div_w = make_fastdiv((unsigned)d->w_in);
-  a.stats = d->bn_stats;
+  a.stats = d->bnb_z ? nullptr : d->bn_stats;
   if (d->x2) {
     DY_REQUIRE(d->cin_split > 0 && d->cin_split < d->cin && d->cin_split % epc == 0, DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: bad cin_split %d", d->cin_split);
     DY_REQUIRE(aligned16(d->x2) && (d->ld_x2 * es) % 16 == 0, DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: x2 view misaligned");

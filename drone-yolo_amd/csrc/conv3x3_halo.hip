@@ -686,7 +686,7 @@ int conv3x3_halo_dispatch(const dy_conv_desc* d, hipStream_t st) {
   a.ldy = d->ld_y;
   a.ldres = d->ld_res;
   a.act = d->act;
-  a.stats = (d->out_f32 || d->y_dtype1) ? nullptr : d->bn_stats;
+  a.stats = (d->out_f32 || d->y_dtype1 || d->bnb_z) ? nullptr : d->bn_stats;  // (bnb_z: backward sums, conv3x3_hreg only)
   a.nChunks = (d->cin + 4 * epc - 1) / (4 * epc);
   a.x_bytes = (unsigned)((long long)d->batch * d->h * d->w_in * d->ld_x * es);
   {

@@ -43,6 +43,11 @@ struct HregArgs {
   int tilesX, tilesY, tilesN, nSpatial;  // spatial tiles (n, ty, tx) and 64-cout groups
   unsigned x_bytes, y_bytes, r_bytes;
   double* stats;  // optional: a dy_bn_train_fwd workspace; spatial block sb stores its per-channel sum / sum of squares of the STORED outputs in slot sb (dy_conv_desc.bn_stats)
+  const float* bnb_mean;  // BNB (dy_conv_desc.bnb_z, which travels as `res`): the BatchNorm in front of the layer whose gradient this launch computes
+  const float* bnb_rstd;
+  const float* bnb_gamma;
+  const float* bnb_beta;
+  int bnb_act;
   int dbg;  // -DDYOLO_ABLATE builds only (DYOLO_DBG): 1 no output stores, 2 no MFMAs, 4 no DMA after the prologue, 8 no fragment reads
 };
 
@@ -62,10 +67,22 @@ constexpr int kHrStages = 3;
 // workgroup's slot of the BatchNorm workspace (dy_bn_train_fwd adds the slots up as it does for its own reduction pass; atomics on
 // the 2 x Cout totals from ~770 workgroups serialise: +0.7 ms per step, measured) -- instead of a separate pass that reads the whole
 // map again (dy_bn_train_fwd's reduction: 1.4 of 10 ms of BatchNorm per step at B = 64).
-template <typename T, int NCH, bool RES, bool STATS = false>
-__global__ __launch_bounds__(256, NCH <= 2 ? 3 : 2) void conv3x3_hreg_kernel(const HregArgs p) {
+// BNB (r05; training backward, dy_conv_desc.bnb_z): the launch computes the gradient dy that reaches the BatchNorm + activation of the layer
+// in front, and that BatchNorm's backward needs sum(du) and sum(du xhat) over the batch before it can form dz (du = dy act'(u), u = gamma xhat
+// + beta, xhat = (z - mean) rstd) -- a pass of its own over dy and z (dy_bn_train_bwd's reduction: 2.8 of 8.9 ms of BatchNorm per step at
+// B = 64).  Here the tile's z arrives the way a residual does (16 bytes per lane and row pair, requested an item ahead), the epilogue forms du
+// from the STORED dy, and the sums leave through the STATS slots.  A gradient convolution has no activation, so the epilogue's vector issue
+// is free where the forward kernel spends it on SiLU.
+// The four BatchNorm constants per channel (rstd, -mean rstd, gamma rstd, beta - gamma rstd mean) wait in 1 KB of LDS and are read in the
+// epilogue only: in registers they cost the main loop 16 of its 168 (64 channels) / 256 (128 channels) and spilled 38 / 22.
+// BW: workgroups per CU the 64-channel BNB form is compiled for (3: 168 registers, 29 spilled; 2: 198, none).
+template <typename T, int NCH, bool RES, bool STATS = false, bool BNB = false, int BW = 3>
+__global__ __launch_bounds__(256, NCH <= 2 ? (BNB ? BW : 3) : 2) void conv3x3_hreg_kernel(const HregArgs p) {
+  static_assert(!(BNB && (RES || STATS)), "BNB: its own mode");
+  constexpr bool SLOTS = STATS || BNB, RLOAD = RES || BNB;
   constexpr int EPC = Elem<T>::EPC;  // 8
   __shared__ __attribute__((aligned(1024))) unsigned char smem[kHrStages * kHrStage];
+  __shared__ f32x4 bnc[BNB ? 64 : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane >> 4, lr = lane & 15;
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
@@ -78,7 +95,7 @@ __global__ __launch_bounds__(256, NCH <= 2 ? 3 : 2) void conv3x3_hreg_kernel(con
   const int nt = logical % p.tilesN;
   const int sb = logical / p.tilesN, Gs = G / p.tilesN;
   const int myTiles = sb < p.nSpatial ? (p.nSpatial - sb + Gs - 1) / Gs : 0;
-  if constexpr (STATS) {
+  if constexpr (SLOTS) {
     if (blockIdx.x == 0)  // the totals the BatchNorm's partial-sum launch adds into
       for (int i = tid; i < 2 * p.Cout; i += 256) p.stats[i] = 0.0;
     if (myTiles <= 0 && tid < 128) {  // a slot is summed whether its workgroup had tiles or not
@@ -219,6 +236,14 @@ __global__ __launch_bounds__(256, NCH <= 2 ? 3 : 2) void conv3x3_hreg_kernel(con
     for (int o = 0; o < kHrTH; o += 2) lane_out[o / 2] = (unsigned)(((o + (lq & 1)) * p.W + lr) * p.ldy + co16) * (unsigned)sizeof(T);
   }
   float st_sum[4] = {0.f, 0.f, 0.f, 0.f}, st_sq[4] = {0.f, 0.f, 0.f, 0.f};  // STATS: this lane's four channels, all its tiles
+  if constexpr (BNB) {  // (published by the barrier that opens the item pipeline)
+    if (tid < 64) {
+      const int co = nt * 64 + tid;
+      const float mu = p.bnb_mean[co], rs = p.bnb_rstd[co], gr = p.bnb_gamma[co] * rs;
+      bnc[tid] = f32x4{rs, -mu * rs, gr, p.bnb_beta[co] - gr * mu};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   auto epilogue = [&](int tile) {
     const int tx = tile % p.tilesX;
     const int r = tile / p.tilesX;
@@ -256,6 +281,26 @@ __global__ __launch_bounds__(256, NCH <= 2 ? 3 : 2) void conv3x3_hreg_kernel(con
           }
         }
       }
+      if constexpr (BNB) {
+        const auto sx = __builtin_amdgcn_permlane16_swap(rl[o / 2][0], rl[o / 2][2], false, false);  // z of this lane's pixel and channels, as RES reads its residual
+        const auto sy = __builtin_amdgcn_permlane16_swap(rl[o / 2][1], rl[o / 2][3], false, false);
+        const t4 zz = __builtin_bit_cast(t4, u32x2{sx[o & 1], sy[o & 1]});
+        if (whole || (y0 + o < p.H && x0 + lr < p.W)) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const f32x4 k = bnc[wave * 16 + lq * 4 + e];
+            const float zf = Elem<T>::to_f32(zz[e]);
+            const float xh = zf * k[0] + k[1];
+            float du = Elem<T>::to_f32(ov[e]);  // the gradient as the BatchNorm's apply pass will read it back
+            if (p.bnb_act == DY_ACT_SILU) {
+              const float u = zf * k[2] + k[3];
+              const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f));
+              du *= sg * (1.0f + u * (1.0f - sg));  // bn_train.hip: silu_grad
+            }
+            st_sum[e] += du, st_sq[e] += du * xh;
+          }
+        }
+      }
       pk[o] = __builtin_bit_cast(u32x2, ov);
       acc[o] = bias4;
     }
@@ -284,7 +329,7 @@ __global__ __launch_bounds__(256, NCH <= 2 ? 3 : 2) void conv3x3_hreg_kernel(con
   for (int it = 0; it < nItems; it += NCH) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      if constexpr (RES) {
+      if constexpr (RLOAD) {
         if (c == NCH - 1) load_residual(c_tile);
       }
       issue_dma(stage + 2 >= kHrStages ? stage + 2 - kHrStages : stage + 2);
@@ -300,7 +345,7 @@ __global__ __launch_bounds__(256, NCH <= 2 ? 3 : 2) void conv3x3_hreg_kernel(con
       stage = stage + 1 == kHrStages ? 0 : stage + 1;
     }
   }
-  if constexpr (STATS) {
+  if constexpr (SLOTS) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float a = st_sum[e], b = st_sq[e];
@@ -540,6 +585,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_hreg_s2_kernel(const HregArgs 
   }
 }
 
+[[maybe_unused]] constexpr int kBnbWgs = 2;  // measured (tools/bn_behind_ab.sh, B = 64 step): 3 per CU with 29 spills +0.2 ms, 2 per CU without -0.1 ms against the two-pass form
 template <typename T>
 static int launch_hreg(const HregArgs& a, hipStream_t st) {
   HregArgs p = a;
@@ -552,6 +598,23 @@ static int launch_hreg(const HregArgs& a, hipStream_t st) {
   const int q = 8 * p.tilesN;
   grid = (grid + q - 1) / q * q;  // the XCD remap and the fixed cout group per block need G % (8 * tilesN) == 0
   const bool res = p.res != nullptr;
+#ifndef DYOLO_L2E_BUILD
+  if (p.bnb_mean) {  // training backward: z travels as the residual view, the sums as the forward statistics do
+    static const int bw = dy_ablate("DYOLO_BNB_WGS") ? dy_ablate("DYOLO_BNB_WGS") : kBnbWgs;
+    if (nch == 2 && bw == 2) {
+      int g2 = 256 * 2;
+      if (nwork < g2) g2 = (int)nwork;
+      grid = (g2 + q - 1) / q * q;
+      hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 2, false, false, true, 2>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    } else if (nch == 2) {
+      hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 2, false, false, true, 3>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    } else {
+      hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 4, false, false, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    }
+    note_stats(grid / p.tilesN);
+    return check_launch("conv3x3_hreg_kernel<bnb>");
+  }
+#endif
   if (p.stats) {  // conv3x3_hreg_try admits it without a residual only
     if (nch == 1) hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 1, false, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
     else if (nch == 2) hipLaunchKernelGGL((conv3x3_hreg_kernel<T, 2, false, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
@@ -607,7 +670,7 @@ int conv3x3_hreg_try(const dy_conv_desc* d, hipStream_t st) {
     a.tilesN = d->cout / 64;
     a.nSpatial = d->batch * a.tilesY * a.tilesX;
     a.x_bytes = (unsigned)xb2, a.y_bytes = (unsigned)yb2, a.r_bytes = 0;
-    a.stats = d->y_dtype1 ? nullptr : d->bn_stats;
+    a.stats = (d->y_dtype1 || d->bnb_z) ? nullptr : d->bn_stats;
     return d->dtype == DY_BF16 ? launch_hreg_s2<bf16_t>(a, st) : launch_hreg_s2<f16_t>(a, st);
   }
   if (d->stride != 1) return 1;
@@ -632,6 +695,20 @@ int conv3x3_hreg_try(const dy_conv_desc* d, hipStream_t st) {
   a.nSpatial = d->batch * a.tilesY * a.tilesX;
   a.x_bytes = (unsigned)xb, a.y_bytes = (unsigned)yb, a.r_bytes = (unsigned)rb;
   a.stats = d->bn_stats;  // (at most 768 + 8 * tilesN - 1 workgroups: the slot count stays below the workspace's 1024)
+  if (d->bnb_z) {
+    const long long zb = (long long)d->batch * d->ho * d->wo * d->bnb_ld_z * 2;
+#ifdef DYOLO_L2E_BUILD
+    const bool built = false;  // (a gradient convolution carries no activation: it never comes through the scaled-domain build)
+#else
+    const bool built = d->bn_stats && !d->y_dtype1 && d->act == DY_ACT_NONE && d->cin != 32 && zb < (1ll << 32) - 64 && d->bnb_ld_z % 8 == 0 && (reinterpret_cast<uintptr_t>(d->bnb_z) & 15) == 0;
+#endif
+    if (built) {
+      a.res = d->bnb_z, a.ldres = d->bnb_ld_z, a.r_bytes = (unsigned)zb;
+      a.bnb_mean = d->bnb_mean, a.bnb_rstd = d->bnb_rstd, a.bnb_gamma = d->bnb_gamma, a.bnb_beta = d->bnb_beta, a.bnb_act = d->bnb_act;
+    } else {
+      a.stats = nullptr;  // (the caller's BatchNorm backward runs its own reduction: dy_conv_stats_written() stays 0)
+    }
+  }
   a.dbg = dy_ablate("DYOLO_DBG");
   return d->dtype == DY_BF16 ? launch_hreg<bf16_t>(a, st) : launch_hreg<f16_t>(a, st);
 }

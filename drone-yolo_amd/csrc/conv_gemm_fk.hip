@@ -701,7 +701,7 @@ int conv_gemm_fk_try(const dy_conv_desc* d, hipStream_t st) {
   a.dCin = make_fastdiv((unsigned)d->cin);
   if (d->ksize == 3 && ((long long)(2 * d->w_in + 2) * d->ld_x + d->cin) * es >= (1ll << 28)) return 1;  // table words hold a 28-bit byte offset
   a.dbg = dy_ablate("DYOLO_FK_DBG");
-  a.stats = d->y_dtype1 ? nullptr : d->bn_stats;
+  a.stats = (d->y_dtype1 || d->bnb_z) ? nullptr : d->bn_stats;
   a.res_scale = in8 ? d->act_scale : 1.f;
   a.out_scale = out8 ? 1.f / d->act_scale : 1.f;
   if (in8) return out8 ? launch_fk_tiles<fp8_t, fp8_t>(a, st) : launch_fk_tiles<fp8_t, f16_t>(a, st);

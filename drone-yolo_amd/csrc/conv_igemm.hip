@@ -488,7 +488,12 @@ int32_t conv2d_entry(const dy_conv_desc* d, dy_stream_t stream) {
   a.HoWo = ho * wo;
   a.act = d->act;
   a.up2x = d->up2x;  // 0 plain, 1 nearest-upsampled source, 2 zero-dilated source (stride-2 transposed conv)
-  a.stats = (d->out_f32 || d->y_dtype1) ? nullptr : d->bn_stats;  // (kernels without a statistics epilogue ignore it: dy_conv_stats_written() stays 0)
+  a.stats = (d->out_f32 || d->y_dtype1 || d->bnb_z) ? nullptr : d->bn_stats;  // (kernels without a statistics epilogue ignore it: dy_conv_stats_written() stays 0)
+  if (d->bnb_z) {
+    DY_REQUIRE(d->bn_stats && d->bnb_mean && d->bnb_rstd && d->bnb_gamma && d->bnb_beta, DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: bnb_z needs bn_stats and bnb_mean / rstd / gamma / beta");
+    DY_REQUIRE(aligned16(d->bnb_z) && d->bnb_ld_z >= d->cout && (d->bnb_ld_z * es) % 16 == 0 && !d->residual && !d->out_f32, DY_ERR_INVALID_ARG,
+               "dy_conv2d_nhwc: bnb_z view misaligned, pitch below cout, or combined with a residual / out_f32");
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
   if (d->dtype == DY_F16X2) {

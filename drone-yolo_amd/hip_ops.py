@@ -599,6 +599,18 @@ def last_kernel_name() -> str:
     return (lib().dy_last_kernel_name() or b"").decode()
 
 
+class BnBehind:
+    """The train-mode BatchNorm + activation of the layer IN FRONT of a convolution, for that convolution's input gradient
+    (``conv_dgrad(bn_behind=)``, ``dy_conv_desc.bnb_z``): when the gradient kernel has the epilogue, the sums that BatchNorm's
+    backward needs (du, du * xhat per channel) are in ``state``'s workspace afterwards and ``slots`` says how many partial slots —
+    hand it to ``bn_train_bwd(partial_slabs=)``; 0: nothing was written, the backward runs its own reduction.  Only valid when the
+    gradient that convolution computes is the WHOLE gradient of that layer's output (no other consumer)."""
+
+    def __init__(self, z: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, state: "BnState", act: bool):
+        self.z, self.gamma, self.beta, self.state, self.act = z, gamma, beta, state, act
+        self.slots = 0
+
+
 def conv_stats_written() -> int:
     """Partial-sum slots this thread's last ``dy_conv2d_nhwc`` left in ``bn_stats`` (0: the launched kernel has no statistics epilogue)."""
     return int(lib().dy_conv_stats_written())
@@ -606,7 +618,7 @@ def conv_stats_written() -> int:
 
 def conv2d(x: torch.Tensor, pc: PackedConv, out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
            out_f32: bool = False, up2x: bool = False, x2: Optional[torch.Tensor] = None, dil2: bool = False,
-           bn_stats: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+           bn_stats: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, bn_behind: Optional[BnBehind] = None) -> torch.Tensor:
     """act(conv(x) + bias) (+ residual) through ``dy_conv2d_nhwc``.
 
     ``x2``: optional second input whose channels follow x's (Concat folded into the gather);
@@ -651,6 +663,16 @@ def conv2d(x: torch.Tensor, pc: PackedConv, out: Optional[torch.Tensor] = None, 
         if bn_stats.c != pc.cout:
             raise ValueError("conv2d: bn_stats must be the BnState of a BatchNorm over the output channels")
         d.bn_stats = bn_stats.ws.data_ptr()
+    if bn_behind is not None:
+        bb = bn_behind
+        if bn_stats is not None or residual is not None or out_f32 or tuple(bb.z.shape) != tuple(out.shape) or bb.z.dtype != x.dtype or bb.state.c != pc.cout:
+            raise ValueError("conv2d: bn_behind needs the saved z of the layer in front (shape / dtype of the output) and excludes bn_stats / residual / out_f32")
+        if bb.gamma.dtype != torch.float32 or bb.beta.dtype != torch.float32 or not bb.gamma.is_contiguous() or not bb.beta.is_contiguous():
+            raise ValueError("conv2d: bn_behind.gamma / beta must be contiguous fp32")
+        d.bn_stats = bb.state.ws.data_ptr()
+        d.bnb_z, d.bnb_ld_z = view_params(bb.z)
+        d.bnb_act = DY_ACT_SILU if bb.act else DY_ACT_NONE
+        d.bnb_mean, d.bnb_rstd, d.bnb_gamma, d.bnb_beta = bb.state.mean.data_ptr(), bb.state.rstd.data_ptr(), bb.gamma.data_ptr(), bb.beta.data_ptr()
     if residual is not None:
         if tuple(residual.shape) != tuple(out.shape) or residual.dtype != x.dtype:
             raise ValueError("conv2d: residual must match the output shape and the input dtype")
@@ -666,7 +688,9 @@ def conv2d(x: torch.Tensor, pc: PackedConv, out: Optional[torch.Tensor] = None, 
         d.y_dtype1 = dy_dtype(odt) + 1
         if odt == FP8:
             d.act_scale = fp8_act_scale()  # the output quantum (the input is 16-bit: no pack-time scale)
-    _launch(lib().dy_conv2d_nhwc, (C.byref(d),), keep=(d, x, out, residual, x2, pc))
+    _launch(lib().dy_conv2d_nhwc, (C.byref(d),), keep=(d, x, out, residual, x2, pc, bn_behind))
+    if bn_behind is not None:
+        bn_behind.slots = conv_stats_written()
     if _absmax_log is not None and not out_f32:  # activations that WOULD be stored in fp8 (the fp32 head logits are not)
         _absmax_log.append(out.float().abs().amax())
     return out
@@ -1154,8 +1178,10 @@ def bn_train_fwd(z: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, state
 
 
 def bn_train_bwd(dy: torch.Tensor, z: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, state: BnState, act: bool,
-                 dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
-    """(dz, dgamma, dbeta) of y = act(BN_batchstats(z)) given dy, through ``dy_bn_train_bwd`` (state from the forward)."""
+                 dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                 partial_slabs: int = 0):
+    """(dz, dgamma, dbeta) of y = act(BN_batchstats(z)) given dy, through ``dy_bn_train_bwd`` (state from the forward).
+    ``partial_slabs``: > 0 = the workspace already holds that many slots of the sums of du and du * xhat (``BnBehind.slots``): no reduction pass."""
     n, c, h, w = z.shape
     if out is None:
         out = alloc_nhwc(n, c, h, w, z.dtype, z.device)
@@ -1169,6 +1195,7 @@ def bn_train_bwd(dy: torch.Tensor, z: torch.Tensor, gamma: torch.Tensor, beta: t
     d.gamma, d.beta, d.mean, d.rstd = gamma.data_ptr(), beta.data_ptr(), state.mean.data_ptr(), state.rstd.data_ptr()
     d.dgamma, d.dbeta = dgamma.data_ptr(), dbeta.data_ptr()
     d.workspace, d.workspace_bytes = state.ws.data_ptr(), state.ws.numel()
+    d.partial_slabs = int(partial_slabs)
     _launch(lib().dy_bn_train_bwd, (C.byref(d),), keep=(d, z, dy, out, gamma, beta, state, dgamma, dbeta))
     return out, dgamma, dbeta
 
@@ -1329,12 +1356,15 @@ def pack_dgrad(weight: torch.Tensor, stride: int, dtype: torch.dtype, device, no
 
 
 def conv_dgrad(dz: torch.Tensor, pc: PackedConv, stride: int, out: Optional[torch.Tensor] = None,
-               accumulate: Optional[torch.Tensor] = None) -> torch.Tensor:
+               accumulate: Optional[torch.Tensor] = None, bn_behind: Optional[BnBehind] = None) -> torch.Tensor:
     """dx of z = conv2d(x, w, stride, k//2) given dz, with ``pc = pack_dgrad(w, stride, ...)``; ``accumulate``: a gradient
-    already held for x (another consumer's contribution), added in the epilogue."""
+    already held for x (another consumer's contribution), added in the epilogue; ``bn_behind``: see ``BnBehind`` (x is the output of a
+    BatchNorm + activation layer with no other consumer: the sums of its backward come out of this kernel's epilogue where built)."""
     if stride not in (1, 2):
         raise NotImplementedError("conv_dgrad: stride 1 or 2")
-    return conv2d(dz, pc, out=out, residual=accumulate, dil2=(stride == 2))
+    if bn_behind is not None and (accumulate is not None or dz.dtype not in (torch.bfloat16, torch.float16)):
+        bn_behind = None  # (its slots stay 0: the BatchNorm backward reduces by itself)
+    return conv2d(dz, pc, out=out, residual=accumulate, dil2=(stride == 2), bn_behind=bn_behind)
 
 
 # ---- small training-path ops + optimizer --------------------------------------------------------------------------

@@ -124,13 +124,29 @@ def _commits_sink(fn):
     return staticmethod(backward)
 
 
-def conv_bn_bwd(dy, x, z, weight, gamma, beta, st, stride, pad, act, need_dx=True, dx_out=None, dx_accumulate=None):
+# BatchNorm-backward sums from the epilogue of the input-gradient convolution behind (dy_conv_desc.bnb_z): on unless
+# DYOLO_BN_BEHIND=0.  Used where the structure says the intermediate has ONE consumer: cv1 -> cv2 of a Bottleneck inside C2fTrain and of
+# the Detect branches (ConvBnAct2).
+BN_BEHIND = [os.environ.get("DYOLO_BN_BEHIND", "1") != "0"]
+BEHIND_LOG = [None]  # a list: (channels, h, w, slots) per candidate layer of one backward (tests, tools/train_stats_census.py)
+
+
+def bn_behind_of(z, gamma, beta, st, act):
+    """The ``H.BnBehind`` of a layer whose output feeds exactly one convolution, or None when the fusion is off or its operands do not fit."""
+    if not BN_BEHIND[0] or z.dtype not in (torch.bfloat16, torch.float16) or gamma.dtype != torch.float32 or not gamma.is_contiguous() or not beta.is_contiguous():
+        return None
+    return H.BnBehind(z, gamma, beta, st, act)
+
+
+def conv_bn_bwd(dy, x, z, weight, gamma, beta, st, stride, pad, act, need_dx=True, dx_out=None, dx_accumulate=None, behind=None, partial_slabs=0):
     """(dx, dw, dgamma, dbeta) of conv_bn_fwd.  ``dx_accumulate``: a gradient already held for x (another consumer's
     contribution), added in the dgrad epilogue; ``dx_out`` may be that same view (in place: a lane reads what it then overwrites).
-    Parameter gradients that went to the trainer's sink come back as None."""
+    ``behind``: the ``H.BnBehind`` of the layer that produced x when this convolution is its only consumer (its ``slots`` are set by
+    the input-gradient launch); ``partial_slabs``: the slots such a launch left for THIS layer's BatchNorm backward (dy then is exactly
+    what that launch stored).  Parameter gradients that went to the trainer's sink come back as None."""
     cout, cin, k, _ = weight.shape
     sg, sb, sw = grad_sink(gamma), grad_sink(beta), grad_sink(weight)
-    dz, dgamma, dbeta = H.bn_train_bwd(as_nhwc(dy), z, gamma, beta, st, act, dgamma=sg, dbeta=sb)
+    dz, dgamma, dbeta = H.bn_train_bwd(as_nhwc(dy), z, gamma, beta, st, act, dgamma=sg, dbeta=sb, partial_slabs=partial_slabs)
     if sg is not None:
         dgamma = None
     if sb is not None:
@@ -150,7 +166,9 @@ def conv_bn_bwd(dy, x, z, weight, gamma, beta, st, stride, pad, act, need_dx=Tru
         dw = H.conv_wgrad(x, dz, k, stride, pad)[:, :cin]
     dx = None
     if need_dx:
-        dx = H.conv_dgrad(dz, H.pack_dgrad(weight, stride, x.dtype, x.device), stride, out=dx_out, accumulate=dx_accumulate)
+        dx = H.conv_dgrad(dz, H.pack_dgrad(weight, stride, x.dtype, x.device), stride, out=dx_out, accumulate=dx_accumulate, bn_behind=behind)
+        if behind is not None and BEHIND_LOG[0] is not None:
+            BEHIND_LOG[0].append((cin, x.shape[2], x.shape[3], H.last_kernel_name(), behind.slots))
     return dx, dw, dgamma, dbeta
 
 
@@ -169,6 +187,30 @@ class ConvBnAct(torch.autograd.Function):
         x, z, weight, gamma, beta = ctx.saved_tensors
         dx, dw, dgamma, dbeta = conv_bn_bwd(dy, x, z, weight, gamma, beta, ctx.st, ctx.stride, ctx.pad, ctx.act, need_dx=ctx.need_dx)
         return dx, dw, dgamma, dbeta, None, None, None, None, None, None
+
+
+class ConvBnAct2(torch.autograd.Function):
+    """Two Conv modules in a row whose intermediate nobody else reads — cv2[i][0] -> cv2[i][1] and cv3[i][0] -> cv3[i][1] of Detect
+    (head.py:43-57), cv1 -> cv2 of a Bottleneck outside C2fTrain (block.py:337-350) — as ONE node, so that the second layer's
+    input-gradient launch can leave the first layer's BatchNorm-backward sums (``conv_bn_bwd(behind=)``)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, bn1, bn2, geo, need_dx):
+        (s1, p1, a1), (s2, p2, a2) = geo
+        z1, st1, t = conv_bn_fwd(x, w1, g1, b1, bn1, s1, p1, a1)
+        z2, st2, y = conv_bn_fwd(t, w2, g2, b2, bn2, s2, p2, a2)
+        ctx.save_for_backward(x, z1, t, z2, w1, g1, b1, w2, g2, b2)
+        ctx.st, ctx.geo, ctx.need_dx = (st1, st2), geo, need_dx
+        return y
+
+    @_commits_sink
+    def backward(ctx, dy):
+        x, z1, t, z2, w1, g1, b1, w2, g2, b2 = ctx.saved_tensors
+        (s1, p1, a1), (s2, p2, a2) = ctx.geo
+        behind = bn_behind_of(z1, g1, b1, ctx.st[0], a1)
+        dt, dw2, dg2, db2 = conv_bn_bwd(dy, t, z2, w2, g2, b2, ctx.st[1], s2, p2, a2, behind=behind)
+        dx, dw1, dg1, db1 = conv_bn_bwd(dt, x, z1, w1, g1, b1, ctx.st[0], s1, p1, a1, need_dx=ctx.need_dx, partial_slabs=behind.slots if behind is not None else 0)
+        return dx, dw1, dg1, db1, dw2, dg2, db2, None, None, None, None
 
 
 class C2fTrain(torch.autograd.Function):
@@ -226,9 +268,12 @@ class C2fTrain(torch.autograd.Function):
             g, gin = dbuf[:, (2 + i) * c : (3 + i) * c], dbuf[:, (1 + i) * c : (2 + i) * c]
             if ctx.add[i]:
                 H.add_nhwc(gin, g, out=gin)  # the shortcut hands the gradient straight to the Bottleneck's input
-            dt, dw, dg, db = conv_bn_bwd(g, t, zb, *P[2 + 2 * i], S[2 + 2 * i], *geo[2 + 2 * i], True)
+            # t = cv1's output feeds cv2 alone: the sums of cv1's BatchNorm backward come out of cv2's input-gradient launch where built
+            behind = bn_behind_of(za, P[1 + 2 * i][1], P[1 + 2 * i][2], S[1 + 2 * i], True)
+            dt, dw, dg, db = conv_bn_bwd(g, t, zb, *P[2 + 2 * i], S[2 + 2 * i], *geo[2 + 2 * i], True, behind=behind)
             put(2 + 2 * i, dw, dg, db)
-            _, dw, dg, db = conv_bn_bwd(dt, buf[:, (1 + i) * c : (2 + i) * c], za, *P[1 + 2 * i], S[1 + 2 * i], *geo[1 + 2 * i], True, dx_out=gin, dx_accumulate=gin)
+            _, dw, dg, db = conv_bn_bwd(dt, buf[:, (1 + i) * c : (2 + i) * c], za, *P[1 + 2 * i], S[1 + 2 * i], *geo[1 + 2 * i], True, dx_out=gin, dx_accumulate=gin,
+                                        partial_slabs=behind.slots if behind is not None else 0)
             put(1 + 2 * i, dw, dg, db)
         dx, dw, dg, db = conv_bn_bwd(dbuf[:, : 2 * c], x, saved[0], *P[0], S[0], *geo[0], True, need_dx=ctx.needs_input_grad[0])
         put(0, dw, dg, db)

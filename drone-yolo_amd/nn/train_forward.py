@@ -36,8 +36,17 @@ def repvgg_train(m, x):
     return A.RepVGGTrain.apply(x, d.conv.weight, d.bn.weight, d.bn.bias, o.conv.weight, o.bn.weight, o.bn.bias, d.bn, o.bn, m.stride)
 
 
+def conv_pair_train(m1, m2, x):
+    """m2(m1(x)) for two plain Conv modules whose intermediate has no other consumer: one autograd node (A.ConvBnAct2)."""
+    c1, c2 = m1.conv, m2.conv
+    if c1.groups != 1 or c2.groups != 1 or x.shape[1] != c1.weight.shape[1]:
+        return conv_train(m2, conv_train(m1, x))
+    geo = ((c1.stride[0], c1.padding[0], isinstance(m1.act, nn.SiLU)), (c2.stride[0], c2.padding[0], isinstance(m2.act, nn.SiLU)))
+    return A.ConvBnAct2.apply(x, c1.weight, m1.bn.weight, m1.bn.bias, c2.weight, m2.bn.weight, m2.bn.bias, m1.bn, m2.bn, geo, True)
+
+
 def bottleneck_train(m, x):
-    y = conv_train(m.cv2, conv_train(m.cv1, x))
+    y = conv_pair_train(m.cv1, m.cv2, x)
     return A.AddT.apply(x, y) if m.add else y
 
 
@@ -67,8 +76,8 @@ def detect_train(m, xs: List[torch.Tensor]) -> List[torch.Tensor]:
     out = []
     for i, x in enumerate(xs):
         b, c = m.cv2[i], m.cv3[i]
-        xb = conv_train(b[1], conv_train(b[0], x))
-        xc = conv_train(c[1], conv_train(c[0], x))
+        xb = conv_pair_train(b[0], b[1], x)
+        xc = conv_pair_train(c[0], c[1], x)
         out.append(A.HeadTail.apply(xb, xc, b[2].weight, b[2].bias, c[2].weight, c[2].bias))
     return out
 

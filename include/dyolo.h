@@ -159,6 +159,22 @@ typedef struct dy_conv_desc {
    * dy_dtype k - 1.  Built in the flat-K kernel (csrc/conv_gemm_fk.hip, DY_WLAYOUT_ROWS) for DY_FP8 -> DY_F16 and DY_F16 -> DY_FP8
    * (act_scale > 0 then gives the output quantum: y_q = sat_e4m3(y_real / act_scale)); any other pair returns DY_ERR_UNSUPPORTED. */
   int32_t y_dtype1;
+  /* Training backward (r05).  This convolution computes an INPUT gradient whose output IS the gradient dy that reaches the train-mode
+   * BatchNorm + activation of the layer in front (conv.py:49-51 backwards; that layer's output has this convolution as its only consumer,
+   * so nothing is added to dy afterwards).  With bnb_z != NULL a kernel built for it reads that layer's saved pre-BatchNorm map z beside
+   * its own stores and leaves, in bn_stats (= that BatchNorm's dy_bn_desc.workspace), per-channel partial sums of
+   *     du = dy * act'(u)  and  du * xhat,      xhat = (z - mean) * rstd,  u = gamma * xhat + beta,   dy as STORED,
+   * in the slot layout of dy_bn_train_bwd's own reduction pass (totals zeroed): dy_conv_stats_written() > 0 then goes to
+   * dy_bn_desc.partial_slabs of dy_bn_train_bwd, which skips its pass over dy and z.  0 slots: the dispatched kernel has no such epilogue
+   * and touched nothing (built: the register-weight 3x3 kernel, 16-bit, stride 1, 64 or 128 channels in, cout % 64 == 0, no residual).
+   * bnb_z: (n, ho, wo, cout) view of pitch bnb_ld_z and type `dtype`; bnb_act: dy_act of that layer; mean / rstd / gamma / beta: fp32[cout].
+   * With bnb_z set, bn_stats is never used for the forward statistics. */
+  const void* bnb_z;
+  int32_t bnb_ld_z, bnb_act;
+  const float* bnb_mean;
+  const float* bnb_rstd;
+  const float* bnb_gamma;
+  const float* bnb_beta;
 } dy_conv_desc;
 
 /* Quantise a 16-bit / fp32 NHWC view to DY_FP8: dst_q = sat_e4m3(src / act_scale).  c % 16 == 0, views 16-byte aligned.
@@ -555,8 +571,9 @@ typedef struct dy_bn_desc {
   float* dbeta;
   void* workspace;
   int64_t workspace_bytes;
-  /* Forward only: > 0 = the workspace ALREADY holds that many partial-sum slots of z (a convolution epilogue wrote them:
-   * dy_conv_desc.bn_stats / dy_conv_stats_written): the reduction pass over z is skipped.  0: the pass runs. */
+  /* > 0 = the workspace ALREADY holds that many partial-sum slots (a convolution epilogue wrote them: dy_conv_desc.bn_stats /
+   * dy_conv_stats_written) and the reduction pass is skipped — forward: sums of z and z^2 from the convolution in front;
+   * backward: sums of du and du * xhat from the input-gradient convolution behind (dy_conv_desc.bnb_z).  0: the pass runs. */
   int32_t partial_slabs;
 } dy_bn_desc;
 int64_t dy_bn_workspace_bytes(int32_t c);

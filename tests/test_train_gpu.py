@@ -186,6 +186,55 @@ def test_conv_epilogue_batchnorm_statistics(cin, cout, k, b, h, w, s, dtype, dev
         assert H.conv_stats_written() == 0 and torch.equal(before, s1.ws)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("c,c2,b,h,w,act", [(64, 64, 3, 40, 48, True), (64, 64, 2, 17, 23, True), (64, 128, 2, 24, 16, True), (128, 128, 2, 24, 20, True), (128, 128, 1, 9, 33, False),
+                                             (128, 64, 5, 8, 16, True), (64, 64, 16, 80, 80, True)])
+def test_input_gradient_epilogue_leaves_the_batchnorm_backward_sums(c, c2, b, h, w, act, dtype, device):
+    """dy_conv_desc.bnb_z (r05): the input-gradient launch of a 3x3 layer (c2 <- c channels) whose input is the output of a train-mode BatchNorm + SiLU
+    layer with no other consumer leaves that BatchNorm's backward sums (du, du * xhat per channel; ragged tiles masked) in its workspace;
+    dy_bn_train_bwd with partial_slabs then gives what its own reduction pass over dy and z gives, and the gradient itself is unchanged."""
+    g = torch.Generator().manual_seed(c + c2 + h)
+    z = nhwc(quantize(torch.randn(b, c, h, w, generator=g) * 1.5 + 0.3, dtype), dtype, device)
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).to(device), (torch.randn(c, generator=g) * 0.3).to(device)
+    st = H.BnState(c, device)
+    H.bn_train_fwd(z, gamma, beta, st, act)  # mean / rstd of the layer in front
+    wt = quantize(torch.randn(c2, c, 3, 3, generator=g) * 0.06, dtype).to(device)
+    dz2 = nhwc(quantize(torch.randn(b, c2, h, w, generator=g), dtype), dtype, device)
+    pc = H.pack_dgrad(wt.float(), 1, dtype, device)
+    dx_plain = H.conv_dgrad(dz2, pc, 1)
+    plain_kernel = H.last_kernel_name()
+    st.ws.fill_(0xFF)  # whatever the workspace held
+    behind = H.BnBehind(z, gamma, beta, st, act)
+    dx = H.conv_dgrad(dz2, pc, 1, bn_behind=behind)
+    assert behind.slots > 0 and "bnb" in H.last_kernel_name(), (behind.slots, H.last_kernel_name(), plain_kernel)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_plain)
+    # the slots against float64 sums of the stored gradient
+    part = st.ws.view(torch.float64)[2 * c : (1 + behind.slots) * 2 * c].view(behind.slots, 2 * c).sum(0)
+    xh = (z.double() - st.mean.double().view(1, -1, 1, 1)) * st.rstd.double().view(1, -1, 1, 1)
+    du = dx.double()
+    if act:
+        u = gamma.double().view(1, -1, 1, 1) * xh + beta.double().view(1, -1, 1, 1)
+        sg = torch.sigmoid(u)
+        du = du * (sg * (1 + u * (1 - sg)))
+    ref = torch.cat([du.sum((0, 2, 3)), (du * xh).sum((0, 2, 3))])
+    assert float((part - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-6, (part - ref).abs().max()
+    # ... and the backward that uses them against the one that reduces by itself
+    st2 = H.BnState(c, device)
+    st2.mean.copy_(st.mean), st2.rstd.copy_(st.rstd)
+    dz_a, dg_a, db_a = H.bn_train_bwd(dx, z, gamma, beta, st2, act)
+    dz_b, dg_b, db_b = H.bn_train_bwd(dx, z, gamma, beta, st, act, partial_slabs=behind.slots)
+    torch.cuda.synchronize()
+    assert float((dg_a - dg_b).abs().max()) <= 1e-4 * float(dg_a.abs().max()) and float((db_a - db_b).abs().max()) <= 1e-4 * float(db_a.abs().max())
+    assert float((dz_a.float() - dz_b.float()).abs().max()) <= TOL[dtype] * float(dz_a.float().abs().max())
+    # a call the epilogue is not built for (a gradient already held for x is added: that sum is not what this launch stores) says so
+    if c == 64 and b == 3:
+        held = nhwc(quantize(torch.randn(b, c, h, w, generator=g), dtype), dtype, device)
+        other = H.BnBehind(z, gamma, beta, H.BnState(c, device), act)
+        H.conv_dgrad(dz2, H.pack_dgrad(wt.float(), 1, dtype, device), 1, accumulate=held, bn_behind=other)
+        assert other.slots == 0
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("cin,cout,b,h,w", [(32, 64, 2, 40, 40), (64, 128, 2, 21, 27), (128, 256, 1, 10, 10)])
 def test_1x1_stride2_input_gradient_by_scatter(cin, cout, b, h, w, dtype, device):
