@@ -129,8 +129,9 @@ class LaunchPlan:
         self.input_slot: Optional[Tuple[int, int]] = None  # (op index, arg index) of the user input pointer
         self.outputs = None
 
-    def replay(self, stream: int) -> None:
-        for fn, args, _ in self.ops:
+    def replay(self, stream: int, start: int = 0, stop: Optional[int] = None) -> None:
+        """Issue the recorded launches (ops[start:stop]) on ``stream``."""
+        for fn, args, _ in (self.ops if start == 0 and stop is None else self.ops[start:stop]):
             rc = fn(*args, stream)
             if rc:
                 check(rc, fn.__name__)

@@ -33,8 +33,25 @@ def test_replay_graph_and_api(device):
         torch.cuda.synchronize()
         assert cf2 is cf
         assert torch.equal(cf.pred, first[0]) and torch.equal(cf.nms.out, first[1]) and torch.equal(cf.nms.count, first[2])
-        outs.append(first)
+        # r05: another batch at another address (graph: the image launch runs from the caller's address, the rest from the tail graph — no copy
+        # into the static input), then the first batch again from ITS address, then from the graph's own static input
+        x2 = torch.rand(xin.shape, generator=torch.Generator().manual_seed(11)).to(device)
+        pred.forward_device(x2)
+        torch.cuda.synchronize()
+        other = (cf.pred.clone(), cf.nms.out.clone(), cf.nms.count.clone())
+        assert not torch.equal(other[0], first[0])
+        for again in (xin, cf.static_in if graph else xin):
+            if graph and again is cf.static_in:
+                cf.static_in.copy_(xin)
+            cf.pred.zero_(), cf.nms.out.zero_(), cf.nms.count.zero_()
+            pred.forward_device(again)
+            torch.cuda.synchronize()
+            assert torch.equal(cf.pred, first[0]) and torch.equal(cf.nms.out, first[1]) and torch.equal(cf.nms.count, first[2])
+        if graph:
+            assert cf.graph_tail is not None
+        outs.append(first + other)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][3], outs[1][3]) and torch.equal(outs[0][4], outs[1][4]) and torch.equal(outs[0][5], outs[1][5])
     yolo = D.YOLO("yolov8n-p2-repvgg.yaml")
     yolo.model.load_state_dict(sd, strict=False) if yolo.model.yaml["nc"] == m["nc"] else None
     res = yolo.predict(torch.rand(2, 3, 64, 96), device=0, dtype="fp32", conf=0.001)
