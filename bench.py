@@ -580,6 +580,20 @@ def other_scales_record(device_index: int, batch: int = 256, steps: int = 10):
                                  "top_kernels": {k: {"launches": v[0], "us": round(v[1], 1), "TFLOPs": round(v[2] / v[1] * 1e3, 1) if v[1] else None} for k, v in top}}})
         del p, cf
         torch.cuda.empty_cache()
+        # the same model at the precision YOLO.predict picks without arguments (split float16 where the kernels cover the model — r05: the -sf YAML too)
+        p = DetectionPredictor(model, dict(conf=0.25, iou=0.7, max_det=300, device=device_index, graph=True))
+        cf = p.forward_device(x)
+        for _ in range(2):
+            p.forward_device(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(max(steps // 2, 3)):
+            p.forward_device(x)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / max(steps // 2, 3)
+        out[-1]["default_precision"] = {"dtype": str(p.dtype).replace("torch.", "").replace("complex32", "f16x2"), "ms_per_pass": round(dt * 1e3, 3), "img_s": round(batch / dt, 1)}
+        del p, cf
+        torch.cuda.empty_cache()
     return out
 
 

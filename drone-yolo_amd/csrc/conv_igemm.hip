@@ -368,6 +368,84 @@ __global__ __launch_bounds__(256) void conv_smallgroup_kernel(const ConvArgs p) 
   }
 }
 
+// The same for DY_F16X2 (split float16; the -sf YAML at the default precision of YOLO.predict, r05): a thread owns one group of 8 output
+// channels of a pixel — a (hi, lo) chunk pair, 32 bytes — joins the CPG input pairs those channels read to fp32 (exact), multiplies by fp32
+// weights (kept whole in LDS: the layer's rows are handed over in fp32, [cout][taps][CPG]) and splits the result again.  Pitches in elements
+// of 4 bytes, as everywhere for this type.
+#ifndef DYOLO_L2E_BUILD
+template <int CPG>
+__global__ __launch_bounds__(256) void conv_smallgroup_split_kernel(const ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  float* wl = reinterpret_cast<float*>(dyn_smem);  // [ks*ks][CPG][Cout]
+  const int taps = p.ks * p.ks;
+  const float* __restrict__ wg = reinterpret_cast<const float*>(p.w);
+  for (int i = threadIdx.x; i < taps * CPG * p.Cout; i += 256) {
+    const int co = i % p.Cout, t2 = i / p.Cout;
+    const int ci = t2 % CPG, tap = t2 / CPG;
+    wl[i] = wg[(size_t)co * (size_t)(taps * CPG) + tap * CPG + ci];
+  }
+  __syncthreads();
+  const int cg = p.Cout / 8;  // output groups per pixel
+  const long long total = (long long)p.M * cg;
+  const unsigned* __restrict__ xg = reinterpret_cast<const unsigned*>(p.x);
+  unsigned* __restrict__ yg = reinterpret_cast<unsigned*>(p.y);
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int cc = (int)(idx % cg);
+    const int m = (int)(idx / cg);
+    const int n = m / p.HoWo;
+    const int rem = m - n * p.HoWo;
+    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    const int co0 = cc * 8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = p.bias[co0 + e];
+    for (int r = 0; r < p.ks; ++r) {
+      const int hi = ho * p.stride - p.pad + r;
+      if ((unsigned)hi >= (unsigned)p.H) continue;
+      for (int q = 0; q < p.ks; ++q) {
+        const int wi = wo * p.stride - p.pad + q;
+        if ((unsigned)wi >= (unsigned)p.W) continue;
+        const unsigned* xp = xg + (size_t)((n * p.H + hi) * p.W + wi) * (size_t)p.ldx + (size_t)co0 * CPG;  // input channels co * CPG ..: CPG groups of 8
+        const float* wt = wl + (size_t)((r * p.ks + q) * CPG) * p.Cout + co0;
+        float xin[CPG * 8];
+#pragma unroll
+        for (int k = 0; k < CPG; ++k) {
+          float f[8];
+          join8(*reinterpret_cast<const u32x4*>(xp + k * 8), *reinterpret_cast<const u32x4*>(xp + k * 8 + 4), f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xin[k * 8 + e] = f[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+          for (int ci = 0; ci < CPG; ++ci) acc[e] += xin[e * CPG + ci] * wt[(size_t)ci * p.Cout + e];
+      }
+    }
+    if (p.act == DY_ACT_SILU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = silu_f32(acc[e]);
+    }
+    u32x4 oh, ol;
+    split8(acc, oh, ol);
+    unsigned* yp = yg + (size_t)m * (size_t)p.ldy + co0;
+    *reinterpret_cast<u32x4*>(yp) = oh;
+    *reinterpret_cast<u32x4*>(yp + 4) = ol;
+  }
+}
+
+static int launch_smallgroup_split(const ConvArgs& a, int cpg, hipStream_t st) {
+  const long long total = (long long)a.M * (a.Cout / 8);
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  const size_t smem = (size_t)a.ks * a.ks * cpg * a.Cout * 4;
+  switch (cpg) {
+    case 1: hipLaunchKernelGGL((conv_smallgroup_split_kernel<1>), dim3(blocks), dim3(256), smem, st, a); break;
+    case 2: hipLaunchKernelGGL((conv_smallgroup_split_kernel<2>), dim3(blocks), dim3(256), smem, st, a); break;
+    default: hipLaunchKernelGGL((conv_smallgroup_split_kernel<4>), dim3(blocks), dim3(256), smem, st, a); break;
+  }
+  return check_launch("conv_smallgroup_split_kernel");
+}
+#endif
+
 template <typename T>
 static int launch_smallgroup(const ConvArgs& a, int cpg, hipStream_t st) {
   const long long total = (long long)a.M * (a.Cout / Elem<T>::EPC);
@@ -496,6 +574,19 @@ int32_t conv2d_entry(const dy_conv_desc* d, dy_stream_t stream) {
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
+#ifndef DYOLO_L2E_BUILD
+  if (d->dtype == DY_F16X2 && d->groups > 1) {
+    // DWConv of the -sf YAML (conv.py:102-107) in split float16: one output channel per group, 1 / 2 / 4 input channels each; w = fp32 rows
+    const int cpg = d->groups > 0 && d->cin % d->groups == 0 ? d->cin / d->groups : 0;
+    DY_REQUIRE(d->cout == d->groups && (cpg == 1 || cpg == 2 || cpg == 4) && d->cout % 8 == 0 && !d->residual && !d->out_f32 && !d->up2x && !d->x2 && !d->y_dtype1 && !d->bn_stats &&
+                   d->w_layout == DY_WLAYOUT_ROWS, DY_ERR_UNSUPPORTED,
+               "dy_conv2d_nhwc: a grouped DY_F16X2 convolution is built for cout == groups, 1 / 2 / 4 input channels per group, cout %% 8 == 0, plain call");
+    DY_REQUIRE((size_t)d->ksize * d->ksize * cpg * d->cout * 4 <= 48 * 1024, DY_ERR_UNSUPPORTED, "dy_conv2d_nhwc: grouped DY_F16X2 weights exceed 48 KB of LDS");
+    DY_REQUIRE(aligned16(d->x) && aligned16(d->y) && d->ld_x % 4 == 0 && d->ld_y % 4 == 0 && d->ld_x >= d->cin && (reinterpret_cast<uintptr_t>(d->w) & 3) == 0, DY_ERR_INVALID_ARG,
+               "dy_conv2d_nhwc: grouped DY_F16X2 views must be 16-byte aligned with pitches in whole chunks");
+    return launch_smallgroup_split(a, cpg, st);
+  }
+#endif
   if (d->dtype == DY_F16X2) {
     DY_REQUIRE(d->k_pad == dy_conv_k_pad(d->cin, d->ksize, d->dtype) && d->cout_pad == dy_conv_cout_pad(d->cout), DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: k_pad / cout_pad");
     DY_REQUIRE(aligned16(d->w) && aligned16(d->bias), DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: w/bias not 16-byte aligned");

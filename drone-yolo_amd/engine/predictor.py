@@ -44,7 +44,11 @@ def split_supported(model) -> bool:
 
     convs = [m for k, m in model.named_modules() if isinstance(m, nn.Conv2d) and ".dfl" not in k]  # (DFL's fixed 16 -> 1 conv lives inside the decode kernel)
     for c in convs:
-        if c.groups != 1 or c.kernel_size not in ((1, 1), (3, 3)) or c.stride[0] not in (1, 2):
+        if c.groups != 1:  # DWConv of the -sf YAML: the small-group kernel (one output channel per group, 1 / 2 / 4 inputs each)
+            if c.out_channels != c.groups or c.in_channels // c.groups not in (1, 2, 4) or c.out_channels % 8 or c.kernel_size[0] ** 2 * (c.in_channels // c.groups) * c.out_channels * 4 > 48 * 1024:
+                return False
+            continue
+        if c.kernel_size not in ((1, 1), (3, 3)) or c.stride[0] not in (1, 2):
             return False
         if (c.in_channels % 8 and c.in_channels > 3) or (c.out_channels % 8 and c.bias is None):  # (plain biased 1x1 = Detect's fp32 outputs)
             return False

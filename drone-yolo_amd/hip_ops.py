@@ -433,7 +433,14 @@ class PackedConv:
             # smallest normal — and lo = rn_f16(w - hi), UNSCALED: the kernel multiplies x_hi by it directly and forms w_hi 2^-11 for the
             # x_lo term itself.  Row layout: K order (r, q, c), every 8 channels as [hi x 8 | lo x 8]: 4 bytes per element.
             if groups != 1:
-                raise NotImplementedError("split-float16 storage is built for dense convolutions")
+                # DWConv of the -sf YAML: the small-group kernel multiplies joined fp32 inputs by fp32 weights (rows [cout][taps][cin / groups])
+                if cout != groups or cin_g not in (1, 2, 4) or cout % 8:
+                    raise NotImplementedError("split-float16 storage of a grouped convolution: one output channel per group, 1 / 2 / 4 inputs each, cout % 8 == 0")
+                self.w = weight.detach().to(torch.float32).permute(0, 2, 3, 1).reshape(cout, k * k * cin_g).contiguous().to(device)
+                self.b = bias.detach().to(torch.float32).contiguous().to(device)
+                self.k_pad, self.cout_pad = k * k * cin_g, cout
+                self._rows_args = None
+                return
             w = weight.detach().to(torch.float32).permute(0, 2, 3, 1).reshape(cout, k * k, cin_g)
             if cin_g % 8:
                 w = torch.nn.functional.pad(w, (0, 8 - cin_g % 8))

@@ -58,7 +58,9 @@ typedef enum dy_dtype { DY_BF16 = 0, DY_F16 = 1, DY_F32 = 2, DY_FP8 = 3, DY_F16X
  * accumulate; the lo x lo term (2^-22 relative) is dropped.  Weights (DY_WLAYOUT_ROWS only) are packed the same way per (tap, 8
  * channels) after each output-channel row was scaled by a power of two into [2^13, 2^14) (w_lo unscaled); dy_conv_desc.w_scale[co]
  * holds the inverse power and multiplies the accumulator in the epilogue.  Built in dy_conv2d_nhwc (dense 1x1 / 3x3, stride 1 / 2,
- * residual, x2 / up2x, out_f32), dy_nchw_f32_to_nhwc, dy_nhwc_to_nchw_f32, dy_sppf_maxpool3 and the chunk copies; the reference has
+ * residual, x2 / up2x, out_f32; and the GROUPED form of DWConv, conv.py:102-107 — cout == groups, 1 / 2 / 4 input channels per group,
+ * cout % 8 == 0, plain call: there w is fp32 [cout][ksize * ksize * (cin / groups)], unscaled, no w_scale, and the kernel multiplies joined
+ * fp32 inputs by it), dy_nchw_f32_to_nhwc, dy_nhwc_to_nchw_f32, dy_sppf_maxpool3 and the chunk copies; the reference has
  * no counterpart (its CPU path is fp32: this type reproduces it to ~4 fp32 ulps per layer, see tests/test_kernels_gpu.py). */
 /* DY_ACT_SILU_L2E: SiLU in the log2(e)-SCALED activation domain.  The caller packs every bias multiplied by log2(e) (and the weights of a
  * layer that reads unscaled data, e.g. the image, likewise), so the accumulator holds t = log2(e) * z; the epilogue computes

@@ -341,12 +341,13 @@ def test_yolo_profile_reports_every_launching_layer(device):
 
 
 def test_default_precision_follows_what_the_split_kernels_cover(device):
-    """The bar-exact default is split float16 where its kernels cover the model and fp32 storage otherwise (the DWConv of the -sf YAML); half=True is float16."""
+    """The bar-exact default is split float16 where its kernels cover the model — r05: the -sf YAML too, its DWConv on the split small-group kernel —
+    and fp32 storage otherwise (here: a model given a 5x5 convolution); half=True is float16."""
     from drone_yolo_amd import hip_ops as H
     from drone_yolo_amd.engine.predictor import split_supported
 
     x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(4))
-    for yaml_name, want in (("yolov8n-p2-repvgg.yaml", H.F16X2), ("yolov8n-p2-repvgg-sf.yaml", torch.float32), ("yolov8n.yaml", H.F16X2)):
+    for yaml_name, want in (("yolov8n-p2-repvgg.yaml", H.F16X2), ("yolov8n-p2-repvgg-sf.yaml", H.F16X2), ("yolov8n.yaml", H.F16X2)):
         yolo = D.YOLO(yaml_name)
         assert split_supported(yolo.model) == (want == H.F16X2)
         res = yolo.predict(x, device=0, conf=0.001)
@@ -354,4 +355,8 @@ def test_default_precision_follows_what_the_split_kernels_cover(device):
         ref = yolo.predict(x, device=0, conf=0.001, dtype="fp32")  # the two bar-exact precisions agree on the rows
         assert res[0].boxes.data.shape == ref[0].boxes.data.shape
         assert torch.allclose(res[0].boxes.data[:, :4], ref[0].boxes.data[:, :4], atol=2e-2) and torch.equal(res[0].boxes.data[:, 5], ref[0].boxes.data[:, 5])
+    odd = D.YOLO("yolov8n-p2-repvgg.yaml")
+    conv = odd.model.model[0].conv
+    odd.model.model[0].conv = torch.nn.Conv2d(conv.in_channels, conv.out_channels, 5, 2, 2, bias=False)  # not a kernel size the split kernels take
+    assert not split_supported(odd.model)
     assert D.YOLO("yolov8n-p2-repvgg.yaml").predict(x, device=0, half=True) is not None

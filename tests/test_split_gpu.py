@@ -93,6 +93,39 @@ def test_split_conv_matches_float64(case, device):
     assert err <= 4e-6 * scale and err <= 8 * err32 + 1e-6 * scale, (tag, err, err32, scale)
 
 
+@pytest.mark.parametrize("cin,cout,b,h,w,act", [(128, 64, 2, 20, 24, True), (64, 32, 2, 17, 19, True), (32, 16, 3, 40, 40, True), (16, 8, 1, 9, 11, False), (32, 32, 2, 12, 12, True),
+                                                 (64, 16, 1, 14, 10, True)])
+def test_split_grouped_conv_matches_float64(cin, cout, b, h, w, act, device):
+    """DWConv of the -sf YAML (conv.py:102-107: 3x3 stride 2, groups = gcd(c1, c2)) on split-float16 storage: dy_conv2d_nhwc's grouped
+    DY_F16X2 form (fp32 weights, joined inputs) against a float64 CPU convolution, to the tolerance of the dense split kernels;
+    input and output as channel slices of wider buffers (the Concat the layer writes into)."""
+    import math
+
+    groups = math.gcd(cin, cout)
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(b, cin, h, w, generator=g) * 2.0
+    wt = torch.randn(cout, cin // groups, 3, 3, generator=g) * (2.0 / (9 * cin // groups)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.2
+    ref = F.conv2d(x.double(), wt.double(), bias.double(), 2, 1, groups=groups)
+    ref32 = F.conv2d(x, wt, bias, 2, 1, groups=groups)
+    if act:
+        ref, ref32 = F.silu(ref), F.silu(ref32)
+    pc = H.PackedConv(wt, bias, 2, 1, groups, act, X2, device)
+    xin = up(x, device, ld=cin + 16, c_off=8)
+    ho, wo = ref.shape[2:]
+    buf = torch.zeros((b, ho, wo, cout + 24), dtype=torch.float32, device=device).view(X2).permute(0, 3, 1, 2)
+    y = H.conv2d(xin, pc, out=buf[:, 16 : 16 + cout])
+    torch.cuda.synchronize()
+    assert H.last_kernel_name() == "conv_smallgroup_split_kernel"
+    got = down(y).double()
+    scale = float(ref.abs().max())
+    err, err32 = float((got - ref).abs().max()), float((ref32.double() - ref).abs().max())
+    assert err <= 4e-6 * scale and err <= 8 * err32 + 1e-6 * scale, (err, err32, scale)
+    assert float(down(buf[:, :16]).abs().max()) == 0.0 and float(down(buf[:, 16 + cout :]).abs().max()) == 0.0  # the neighbours of the slice are untouched
+    with pytest.raises(NotImplementedError):
+        H.PackedConv(torch.randn(24, 3, 3, 3), torch.zeros(24), 2, 1, 8, True, X2, device)  # 3 inputs per group: not a built form
+
+
 @pytest.mark.parametrize("how", ["residual", "out_f32", "out_f32_cout10", "slice_io", "x2_up2x", "tiny_weights", "huge_activations"])
 def test_split_conv_call_forms(how, device):
     g = torch.Generator().manual_seed(zlib.crc32(how.encode()) % 1000)
@@ -155,7 +188,7 @@ def _build(tag, g):
     return b(tag, g, None)
 
 
-@pytest.mark.parametrize("tag", ["n64", "n128", "v8n320", "s640"])
+@pytest.mark.parametrize("tag", ["n64", "n128", "sf_n64", "v8n320", "s640"])  # sf_n64 (r05): the -sf YAML, its DWConv on the split small-group kernel
 def test_split_end_to_end_is_bar_exact(tag, device):
     """The fp32 branch of tests/test_model_gpu.py::test_end_to_end_against_reference_vectors, on split-float16 storage: kept sets, classes
     and order identical to the REAL reference's rows, IoU >= 0.999, raw outputs to fp32 round-off."""
