@@ -133,7 +133,7 @@ def test_split_float16_type_validates_without_gpu():
     d.ksize, d.stride, d.pad, d.groups, d.dtype, d.k_pad, d.cout_pad = 3, 1, 1, 1, L.DY_F16X2, 576, 64
     assert h.dy_conv2d_nhwc(ctypes.byref(d), None) == -1 and b"w_scale" in h.dy_last_error_string()  # the inverse row scales are part of the type
     d.groups = 2
-    assert h.dy_conv2d_nhwc(ctypes.byref(d), None) == -2 and b"dense" in h.dy_last_error_string()  # DY_ERR_UNSUPPORTED: grouped convolutions are not built for it
+    assert h.dy_conv2d_nhwc(ctypes.byref(d), None) == -2 and b"cout == groups" in h.dy_last_error_string()  # DY_ERR_UNSUPPORTED: of the grouped forms only DWConv's is built (r05)
     d.groups, d.cin, d.k_pad = 1, 12, 128
     assert h.dy_conv2d_nhwc(ctypes.byref(d), None) in (-1, -2)  # channels not in whole groups of 8
     assert h.dy_resize_bilinear_u8_nchw_f32(None, None, 1, 3, 8, 8, 16, 16, None) == -1
