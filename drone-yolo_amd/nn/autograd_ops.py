@@ -295,12 +295,17 @@ class GroupedConvBnAct(torch.autograd.Function):
         ctx.st, ctx.stride, ctx.pad, ctx.groups, ctx.act = st, stride, pad, groups, act
         return y
 
-    @staticmethod
+    @_commits_sink
     def backward(ctx, dy):
         x, z, weight, gamma, beta = ctx.saved_tensors
-        dz, dgamma, dbeta = H.bn_train_bwd(as_nhwc(dy), z, gamma, beta, ctx.st, ctx.act)
+        sg, sb, sw = grad_sink(gamma), grad_sink(beta), grad_sink(weight)
+        dz, dgamma, dbeta = H.bn_train_bwd(as_nhwc(dy), z, gamma, beta, ctx.st, ctx.act, dgamma=sg, dbeta=sb)
         dw, dx = H.conv_grouped_bwd(x, dz, weight.detach().contiguous(), ctx.stride, ctx.pad, ctx.groups)
-        return dx, dw, dgamma, dbeta, None, None, None, None, None
+        if sw is not None:  # r05: into the trainer's sink like every other parameter gradient (slot order (cout, k, k, cin / groups), as the dense layers')
+            cout, cg, k, _ = weight.shape
+            sw.view(cout, k, k, cg).add_(dw.permute(0, 2, 3, 1))
+            dw = None
+        return dx, dw, None if sg is not None else dgamma, None if sb is not None else dbeta, None, None, None, None, None
 
 
 class RepVGGTrain(torch.autograd.Function):

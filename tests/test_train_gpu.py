@@ -485,15 +485,15 @@ def test_model_train_step_gradients_bf16(device):
     assert c_h > 0.9 and c_a > 0.8 and 0.85 < r_a < 1.15, (c_h, c_a, r_a)
 
 
-@pytest.mark.parametrize("opt", ["SGD", "AdamW"])
-def test_trainer_step_matches_oracle(opt, device):
+@pytest.mark.parametrize("opt,tag", [("SGD", "tn64"), ("AdamW", "tn64"), ("SGD", "tsf64")])  # tsf64 (r05): the -sf YAML — DWConv's gradients through the sink too
+def test_trainer_step_matches_oracle(opt, tag, device):
     """DetectionTrainer.step (fp32 storage): forward, loss, backward, clip 10, optimizer (3 groups, warm-up lr), EMA —
     parameters and EMA after TWO steps against oracle/train_oracle.py (torch.optim semantics, checked against torch.optim
     itself in oracle/make_golden.py)."""
     from drone_yolo_amd.engine.trainer import DetectionTrainer
     from oracle import train_oracle as TO
 
-    g, m, d, model, sd, img, labels = _train_case("tn64")
+    g, m, d, model, sd, img, labels = _train_case(tag)
     tr = DetectionTrainer(model, dict(optimizer=opt, lr0=0.01, momentum=0.937, batch=64, dtype="fp32", warmup_epochs=0.0))
     assert tr.accumulate == 1 and abs(tr.weight_decay - 0.0005) < 1e-12
     batch = dict(img=img.to(device), **labels)
@@ -543,7 +543,8 @@ def test_trainer_step_matches_oracle(opt, device):
         off += n
 
 
-def test_graphed_steps_equal_eager_steps(device):
+@pytest.mark.parametrize("tag", ["tn64", "tsf64"])
+def test_graphed_steps_equal_eager_steps(tag, device):
     """DetectionTrainer replays forward + loss + backward as a hipGraph from its third step on (single rank).  Five steps with
     changing labels, graphed against eager: same losses, same parameters, same BatchNorm statistics (both sum wgrad / BN
     partials with fp32 atomics in whatever order the waves arrive: 2e-3 of each tensor's max)."""
@@ -552,7 +553,7 @@ def test_graphed_steps_equal_eager_steps(device):
     from drone_yolo_amd.engine.trainer import DetectionTrainer
     from oracle import loss_oracle as LO
 
-    g, m, d, model, sd, img, labels = _train_case("tn64")
+    g, m, d, model, sd, img, labels = _train_case(tag)
     runs = {}
     for graphed in (False, True):
         mdl = copy.deepcopy(model)
