@@ -70,7 +70,7 @@ def test_loss_class_api_and_empty_labels(device):
     labels = LO.synthetic_labels(2, 3, n_mean=10.0)
     loss, items = crit(_dev_feats(feats, device), labels)
     total, ref_items = LO.v8_detection_loss(feats, labels, STRIDES, 10)
-    assert torch.allclose(items.cpu(), ref_items, rtol=2e-4, atol=1e-5) and abs(float(loss) - float(total)) <= 2e-4 * float(total)
+    assert torch.allclose(items.cpu(), ref_items, rtol=2e-4, atol=1e-5) and abs(float(loss.detach()) - float(total)) <= 2e-4 * float(total)
     empty = {"batch_idx": torch.zeros(0), "cls": torch.zeros(0, 1), "bboxes": torch.zeros(0, 4)}
     loss0, items0 = crit(_dev_feats(feats, device), empty)
     t0, i0 = LO.v8_detection_loss(feats, empty, STRIDES, 10)

@@ -433,9 +433,9 @@ def test_model_train_step_gradients_fp32(tag, device):
     loss, items = model(batch)
     loss.backward()
     torch.cuda.synchronize()
-    assert abs(float(loss) - float(total_ref)) <= 5e-4 * abs(float(total_ref)), (float(loss), float(total_ref))
+    assert abs(float(loss.detach()) - float(total_ref.detach())) <= 5e-4 * abs(float(total_ref.detach())), (float(loss.detach()), float(total_ref.detach()))
     assert torch.allclose(items.cpu(), items_ref, rtol=5e-4, atol=1e-5)
-    assert abs(float(loss) - float(g[f"{tag}__total"])) <= 5e-4 * abs(float(g[f"{tag}__total"]))
+    assert abs(float(loss.detach()) - float(g[f"{tag}__total"])) <= 5e-4 * abs(float(g[f"{tag}__total"]))
     worst, worst_k = 0.0, None
     params = dict(model.named_parameters())
     for k, gr in grads_ref.items():
@@ -466,7 +466,7 @@ def test_model_train_step_gradients_bf16(device):
     loss, items = model(dict(img=img.to(device), **labels))
     loss.backward()
     torch.cuda.synchronize()
-    assert abs(float(loss) - float(total_ref)) <= 3e-2 * abs(float(total_ref))
+    assert abs(float(loss.detach()) - float(total_ref.detach())) <= 3e-2 * abs(float(total_ref.detach()))
     params = dict(model.named_parameters())
     def cos_of(keys):
         a = torch.cat([params[k].grad.flatten().cpu().double() for k in keys])
@@ -516,7 +516,7 @@ def test_trainer_step_matches_oracle(opt, tag, device):
         upd = TO.ema_update(ema, osd, upd)
         loss, _ = tr.step(batch, epoch=0, nb=1000)
         torch.cuda.synchronize()
-        assert abs(float(loss) - float(total)) <= 1e-3 * abs(float(total)), (it, float(loss), float(total))
+        assert abs(float(loss.detach()) - float(total.detach())) <= 1e-3 * abs(float(total.detach())), (it, float(loss.detach()), float(total.detach()))
     own = model.state_dict()
     worst, bad, count = 0.0, 0, 0
     for k, v in osd.items():
@@ -563,7 +563,7 @@ def test_graphed_steps_equal_eager_steps(tag, device):
         for it in range(5):
             lab = LO.synthetic_labels(img.shape[0], 100 + it, n_mean=m["n_mean"] + 3 * it)  # another label count every step
             loss, _ = tr.step(dict(img=img.to(device), **lab), epoch=0, nb=1000)
-            losses.append(float(loss))
+            losses.append(float(loss.detach()))
         torch.cuda.synchronize()
         assert (getattr(tr, "_graph", None) is not None) == graphed
         runs[graphed] = (losses, {k: v.detach().float().cpu().clone() for k, v in mdl.state_dict().items()})
@@ -897,7 +897,7 @@ def test_fp16_training_runs_under_the_grad_scaler(device):
     scale = float(tr.amp_state[0])
     G = tr.flat.G.clone() / scale
     tr.flat.G.zero_()
-    assert abs(float(loss) - float(total_ref)) <= 3e-2 * abs(float(total_ref)), (float(loss), float(total_ref))
+    assert abs(float(loss.detach()) - float(total_ref.detach())) <= 3e-2 * abs(float(total_ref.detach())), (float(loss.detach()), float(total_ref.detach()))
     if bool(torch.isfinite(G).all()):
         def cos_of(keys):
             a = torch.cat([G[tr.flat.offsets[k][0]: tr.flat.offsets[k][0] + tr.flat.offsets[k][1]].cpu().double() for k in keys])
@@ -980,7 +980,7 @@ def test_config3_batch64_graph_and_sink_step(device):
         tr.graph_steps = graphed
         tr.iters = 5 if graphed else 0  # the trainer graphs from its third step on
         loss, items = tr._forward_backward(batch)
-        return float(loss), items.float().cpu().clone(), grads_of(tr)
+        return float(loss.detach()), items.float().cpu().clone(), grads_of(tr)
 
     l32, i32, g32 = fb(batch_of(data), False, torch.float32)
     l16, i16, g16 = fb(batch_of(data), True, torch.bfloat16)
