@@ -132,6 +132,7 @@ class Stem2Desc(C.Structure):
     _fields_ = [
         ("x", _vp), ("w0", _vp), ("b0", _vp), ("w1", _vp), ("b1", _vp), ("y", _vp),
         ("n", _i32), ("h", _i32), ("w", _i32), ("ld_y", _i32), ("act0", _i32), ("act1", _i32), ("dtype", _i32),
+        ("w1_scale", _vp),
     ]  # fmt: skip
 
 

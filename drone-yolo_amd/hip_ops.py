@@ -805,6 +805,13 @@ class PackedStem2:
         self.stem = PackedStem(w0, b0, act0, dtype, device)
         self.dtype = dtype
         self.act1 = _act_code(act1)
+        self.w1_scale = None
+        if dtype == F16X2:  # layer 1 as dy_conv2d_nhwc's split rows (K order (r, q, c), 8-channel groups [hi x 8 | lo x 8]) + inverse row scales
+            self._pc1 = PackedConv(w1.detach().cpu(), b1.detach().cpu(), 2, 1, 1, act1, dtype, device)
+            if self._pc1.cout_pad != 64 or self._pc1.k_pad != 288:
+                raise ValueError("PackedStem2: unexpected split pack geometry")
+            self.w1, self.b1, self.w1_scale = self._pc1.w, self._pc1.b, self._pc1.wscale
+            return
         self.w1 = w1.detach().to(torch.float32).cpu().permute(0, 2, 3, 1).reshape(64, 288).to(dtype).contiguous().to(device)
         self.b1 = b1.detach().to(torch.float32).cpu().contiguous().to(device)
 
@@ -823,7 +830,8 @@ def stem2_fused(src: torch.Tensor, ps: PackedStem2, out: Optional[torch.Tensor] 
         out = alloc_nhwc(n, 64, h // 4, w // 4, ps.dtype, src.device)
     op, ld = view_params(out)
     d = Stem2Desc(x=src.data_ptr(), w0=ps.stem.w.data_ptr(), b0=ps.stem.b.data_ptr(), w1=ps.w1.data_ptr(), b1=ps.b1.data_ptr(), y=op,
-                  n=n, h=h, w=w, ld_y=ld, act0=ps.stem.act, act1=ps.act1, dtype=dy_dtype(ps.dtype))
+                  n=n, h=h, w=w, ld_y=ld, act0=ps.stem.act, act1=ps.act1, dtype=dy_dtype(ps.dtype),
+                  w1_scale=ps.w1_scale.data_ptr() if ps.w1_scale is not None else None)
     _launch(lib().dy_stem2_fused, (C.byref(d),), keep=(d, out, ps))
     if mark_input and _recording is not None:
         _recording.input_slot = (len(_recording.ops) - 1, -1)

@@ -296,7 +296,11 @@ int32_t dy_stem_conv3x3s2_nchw_u8(const uint8_t* x, float divisor, const void* w
  * x: fp32 NCHW (n, 3, h, w) contiguous.  w0/b0: as dy_stem_conv3x3s2_nchw ([32][32], k = c*9 + r*3 + q; fp32[32]).
  * w1: [64][288] of `dtype`, k = (r*3 + q)*32 + c (BatchNorm and branches folded); b1: fp32[64].
  * y: NHWC view (n, h/4, w/4, 64) of `dtype`, pitch ld_y.  Built for DY_BF16 / DY_F16 and h, w multiples of 4
- * (dy_stem2_fused_supported tells); otherwise run dy_stem_conv3x3s2_nchw and dy_conv2d_nhwc. */
+ * (dy_stem2_fused_supported tells); otherwise run dy_stem_conv3x3s2_nchw and dy_conv2d_nhwc.
+ * DY_F16X2 (round 5): w0 = the split stem pack of dy_stem_conv3x3s2_nchw ([32][32] float16 hi halves, as many lo halves, fp32[32] inverse row
+ * scales, one buffer); w1 = the split DY_WLAYOUT_ROWS pack of dy_conv2d_nhwc for a 3x3 32 -> 64 layer ([64][9 taps x 4 groups x (hi x 8 | lo x 8)]
+ * float16) with its inverse row scales in w1_scale (fp32[64]); act0 = act1 = DY_ACT_SILU; y: split-float16 view, ld_y in 4-byte elements and
+ * a multiple of 8.  The intermediate is rounded to (hi, lo) pairs where the layer-by-layer path rounds it. */
 typedef struct dy_stem2_desc {
   const float* x;
   const void* w0;
@@ -305,6 +309,7 @@ typedef struct dy_stem2_desc {
   const float* b1;
   void* y;
   int32_t n, h, w, ld_y, act0, act1, dtype;
+  const float* w1_scale; /* DY_F16X2 only (NULL otherwise) */
 } dy_stem2_desc;
 int32_t dy_stem2_fused_supported(int32_t cin, int32_t c0, int32_t c1, int32_t h, int32_t w, int32_t dtype);
 int32_t dy_stem2_fused(const dy_stem2_desc* d, dy_stream_t stream);

@@ -124,7 +124,12 @@ def test_split_float16_type_validates_without_gpu():
     assert h.dy_conv_k_pad(64, 3, L.DY_F16X2) == 576 and h.dy_conv_k_pad(8, 3, L.DY_F16X2) == 96 and h.dy_conv_k_pad(96, 1, L.DY_F16X2) == 96
     assert h.dy_detect_head_decode_supported(64, 64, 10, 16, L.DY_F16X2) == 1 and h.dy_detect_head_decode_supported(64, 80, 10, 16, L.DY_F16X2) == 0
     assert h.dy_detect_head_decode_supported(128, 64, 10, 16, L.DY_F16X2) == 0
-    assert h.dy_c2f_fused_supported(64, 0, 32, 64, 1, L.DY_F16X2) == 0 and h.dy_stem2_fused_supported(3, 32, 64, 640, 640, L.DY_F16X2) == 0  # fused 16-bit kernels: not for the type
+    assert h.dy_c2f_fused_supported(64, 0, 32, 64, 1, L.DY_F16X2) == 0  # the fused 16-bit C2f kernel: not for the type
+    assert h.dy_stem2_fused_supported(3, 32, 64, 640, 640, L.DY_F16X2) == 1  # r05: the fused image-layer pair is (stem2_split_kernel) ...
+    s2 = L.Stem2Desc()
+    s2.x = s2.w0 = s2.b0 = s2.w1 = s2.b1 = s2.y = ctypes.cast((ctypes.c_float * 64)(), ctypes.c_void_p)
+    s2.n, s2.h, s2.w, s2.ld_y, s2.act0, s2.act1, s2.dtype = 1, 64, 64, 64, 1, 1, L.DY_F16X2
+    assert h.dy_stem2_fused(ctypes.byref(s2), None) == -1 and b"w1_scale" in h.dy_last_error_string()  # ... and needs layer 1's inverse row scales
     buf = (ctypes.c_float * 64)()
     p = ctypes.cast(buf, ctypes.c_void_p)
     d = L.ConvDesc()

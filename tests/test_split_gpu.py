@@ -237,7 +237,7 @@ def test_split_bench_configuration_is_bar_exact(tag, device):
     assert box_err < 2e-2 and cls_err < 1e-4, (box_err, cls_err)
     assert par["counts_equal"] and par["kept_sets_identical"] and par["match_rate"] == 1.0 and par["iou_min"] >= 0.999, par
     names = [fn.__name__ for fn, _, _ in cf.plan.ops]
-    assert "dy_detect_head_decode" in names and "dy_stem_conv3x3s2_nchw" in names  # the type's fused Detect tail (1x1 x 2 + decode + filter) and image stem ran
+    assert "dy_detect_head_decode" in names and "dy_stem2_fused" in names  # the type's fused Detect tail (1x1 x 2 + decode + filter) and fused image stem pair ran
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 64, 64, 32), (1, 3, 50, 70, 16), (3, 3, 640, 640, 32), (1, 1, 32, 36, 64)], ids=["64x64", "odd 50x70 cout 16", "640x640", "cin 1 cout 64"])
@@ -254,6 +254,35 @@ def test_split_stem_matches_float64(shape, device):
     assert H.last_kernel_name() == "conv_stem_split_kernel" and tuple(y.shape) == tuple(ref.shape)
     err = float((down(y).double() - ref).abs().max())
     assert err <= 4e-6 * float(ref.abs().max()), err
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64), (1, 52, 76), (3, 640, 640), (2, 4, 20)], ids=["64x64", "ragged 52x76", "640x640", "one partial tile"])
+def test_split_fused_stem_pair_matches_float64_and_the_layer_path(shape, device):
+    """dy_stem2_fused with DY_F16X2 (r05): fp32 image -> Conv(3, 32, 3, 2) + SiLU -> 3x3 stride-2 32 -> 64 + SiLU in one kernel, the half-resolution map
+    kept in LDS as (hi, lo) halves — against a float64 CPU chain to the dense split kernels' tolerance, and against the two launches it replaces."""
+    b, h, w = shape
+    g = torch.Generator().manual_seed(h + w)
+    x = torch.rand(b, 3, h, w, generator=g)
+    w0, b0 = torch.randn(32, 3, 3, 3, generator=g) * (2.0 / 27) ** 0.5, torch.randn(32, generator=g) * 0.2
+    w1, b1 = torch.randn(64, 32, 3, 3, generator=g) * (2.0 / 288) ** 0.5, torch.randn(64, generator=g) * 0.2
+    ref = F.silu(F.conv2d(F.silu(F.conv2d(x.double(), w0.double(), b0.double(), 2, 1)), w1.double(), b1.double(), 2, 1))
+    assert H.stem2_fused_supported(3, 32, 64, h, w, X2)
+    xd = x.to(device).contiguous()
+    y = H.stem2_fused(xd, H.PackedStem2(w0, b0, True, w1, b1, True, X2, device))
+    torch.cuda.synchronize()
+    assert H.last_kernel_name() == "stem2_split_kernel" and tuple(y.shape) == tuple(ref.shape)
+    got = down(y).double()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 6e-6 * scale, float((got - ref).abs().max()) / scale
+    t = H.stem_conv(xd, H.PackedStem(w0, b0, True, X2, device))
+    y2 = H.conv2d(t, H.PackedConv(w1, b1, 2, 1, 1, True, X2, device))
+    torch.cuda.synchronize()
+    assert float((down(y2).double() - got).abs().max()) <= 2e-6 * scale  # same roundings of the intermediate, another summation order in layer 1
+    # into a channel slice of a wider buffer (a Concat the layer writes into): the neighbours stay untouched
+    buf = torch.zeros((b, h // 4, w // 4, 64 + 24), dtype=torch.float32, device=device).view(X2).permute(0, 3, 1, 2)
+    H.stem2_fused(xd, H.PackedStem2(w0, b0, True, w1, b1, True, X2, device), out=buf[:, 8:72])
+    torch.cuda.synchronize()
+    assert torch.equal(down(buf[:, 8:72]), down(y)) and float(down(buf[:, :8]).abs().max()) == 0.0 and float(down(buf[:, 72:]).abs().max()) == 0.0
 
 
 def test_split_full_size_properties(device):
