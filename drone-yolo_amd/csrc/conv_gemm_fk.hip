@@ -334,7 +334,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_fk_kernel(const FkArgs
       // a 128-byte row = four (hi, lo) chunk pairs of 8 channels: lane quarter lq takes pair lq.  x w = x_hi w_hi + x_hi w_lo + 2^-11 x_lo' w_hi
       // (x_lo' is stored times 2^11; lo x lo, 2^-22 relative, is dropped): fp32-grade products from three 16-bit MFMAs, and per MFMA
       // two thirds of the LDS reads and DMA bytes of the plain float16 loop
-      const int sh = ((2 * lq) ^ swz) * 16, sl = ((2 * lq + 1) ^ swz) * 16;
+      // WHICH pair a lane quarter takes is free (both operands use the same order), and it decides the bank conflicts: a ds_read_b128 is
+      // served in groups of 16 lanes — rows {0..3, 12..15} of quarter q with rows {4..11} of quarter q ^ 1 — whose same-parity rows XOR their
+      // chunk with {0, 1, 6, 7} and {2, 3, 4, 5} (the row swizzle lr >> 1): the two sets of positions are disjoint only when the quarters' chunks
+      // differ by 6, i.e. their pairs by 3.  Pairs 0, 3, 1, 2 for quarters 0 .. 3 (pair = lq for both: every read a 2-way conflict,
+      // SQ_LDS_BANK_CONFLICT 47 % of the LDS cycles, profiles/r05_pmc_split_fk.txt).
+      const int pr = (0x9C >> (2 * lq)) & 3;
+      const int sh = ((2 * pr) ^ swz) * 16, sl = ((2 * pr + 1) ^ swz) * 16;
       u32x4 ah[MFR], al[MFR];
 #pragma unroll
       for (int i = 0; i < MFR; ++i) ah[i] = *reinterpret_cast<const u32x4*>(sa + i * 16 * 128 + sh), al[i] = *reinterpret_cast<const u32x4*>(sa + i * 16 * 128 + sl);
