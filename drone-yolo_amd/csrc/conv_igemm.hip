@@ -519,6 +519,11 @@ extern "C" int32_t dy_conv2d_nhwc(const dy_conv_desc* d, dy_stream_t stream) {
 }
 #endif
 
+#ifndef DYOLO_L2E_BUILD
+namespace dy {
+int conv3x3_hsplit_try(const dy_conv_desc* d, hipStream_t st);  // conv3x3_hsplit.hip: DY_F16X2, 3x3 stride 1, cin 32 / 64
+}
+#endif
 namespace DY_NS {
 int32_t conv2d_entry(const dy_conv_desc* d, dy_stream_t stream) {
   DY_REQUIRE(d != nullptr, DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: null descriptor");
@@ -591,6 +596,12 @@ int32_t conv2d_entry(const dy_conv_desc* d, dy_stream_t stream) {
     DY_REQUIRE(d->k_pad == dy_conv_k_pad(d->cin, d->ksize, d->dtype) && d->cout_pad == dy_conv_cout_pad(d->cout), DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: k_pad / cout_pad");
     DY_REQUIRE(aligned16(d->w) && aligned16(d->bias), DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: w/bias not 16-byte aligned");
     DY_REQUIRE(!d->up2x || (d->h % 2 == 0 && d->w_in % 2 == 0), DY_ERR_INVALID_ARG, "dy_conv2d_nhwc: up2x needs even h, w");
+#ifndef DYOLO_L2E_BUILD
+    {
+      const int rh = ::dy::conv3x3_hsplit_try(d, st);  // narrow 3x3 layers: halo staged once, weights in registers (conv3x3_hsplit.hip)
+      if (rh <= 0) return rh;
+    }
+#endif
     return conv_gemm_fk_split(d, st);
   }
   if (d->dtype == DY_FP8) {

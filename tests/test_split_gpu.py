@@ -61,6 +61,14 @@ CASES = [
     (128, 128, 3, 2, 2, 40, 40, True, "s2 deep"),
     (160, 160, 3, 1, 1, 24, 24, True, "x-scale 160 (tile 160)"),
     (80, 80, 3, 1, 1, 24, 24, True, "x-scale 80 (tile 80)"),
+    # r05: the register-weight kernel of the type (conv3x3_hsplit.hip): cin 32 / 64, cout % 32 == 0, stride 1
+    # (maps of at least 3,200 pixels: smaller ones stay on the flat-K kernel)
+    (32, 32, 3, 1, 2, 64, 56, True, "hsplit 32->32 (two cout fragments, waves split the rows)"),
+    (32, 32, 3, 1, 3, 61, 53, False, "hsplit 32->32 ragged tiles, no act"),
+    (32, 64, 3, 1, 1, 64, 64, True, "hsplit 32->64"),
+    (64, 128, 3, 1, 2, 57, 67, True, "hsplit 64->128 ragged (two cout groups)"),
+    (64, 32, 3, 1, 1, 56, 64, True, "hsplit 64->32"),
+    (64, 64, 3, 1, 16, 80, 80, True, "hsplit 64->64 persistent (more tiles than workgroups)"),
 ]
 
 
@@ -85,7 +93,9 @@ def test_split_conv_matches_float64(case, device):
     pc = H.PackedConv(wt, bias, s, k // 2, 1, act, X2, device)
     y = H.conv2d(up(x, device), pc)
     torch.cuda.synchronize()
-    assert H.last_kernel_name().startswith("conv_gemm_fk_kernel<split") and tuple(y.shape) == tuple(ref.shape)
+    want_h = k == 3 and s == 1 and cin in (32, 64) and cout % 32 == 0 and h * w >= 3200
+    assert (H.last_kernel_name() == "conv3x3_hsplit_kernel" if want_h else H.last_kernel_name().startswith("conv_gemm_fk_kernel<split")), H.last_kernel_name()
+    assert tuple(y.shape) == tuple(ref.shape)
     got = down(y).double()
     scale = float(ref.abs().max())
     err, err32 = float((got - ref).abs().max()), float((ref32.double() - ref).abs().max())
@@ -126,11 +136,18 @@ def test_split_grouped_conv_matches_float64(cin, cout, b, h, w, act, device):
         H.PackedConv(torch.randn(24, 3, 3, 3), torch.zeros(24), 2, 1, 8, True, X2, device)  # 3 inputs per group: not a built form
 
 
-@pytest.mark.parametrize("how", ["residual", "out_f32", "out_f32_cout10", "slice_io", "x2_up2x", "tiny_weights", "huge_activations"])
+@pytest.mark.parametrize("how", ["residual", "out_f32", "out_f32_cout10", "slice_io", "x2_up2x", "tiny_weights", "huge_activations",
+                                 "residual_big", "residual_big_c32", "slice_io_big"])  # *_big (r05): maps the register-weight kernel takes (conv3x3_hsplit.hip)
 def test_split_conv_call_forms(how, device):
     g = torch.Generator().manual_seed(zlib.crc32(how.encode()) % 1000)
     b, cin, cout, h, w = 2, 64, 64, 24, 20
     k, act, kw = 3, True, {}
+    big = "_big" in how
+    if big:
+        h, w = 70, 52
+        if how.endswith("c32"):
+            cin = cout = 32
+        how = how.split("_big")[0]
     if how in ("out_f32", "out_f32_cout10"):
         k, act, cout = 1, False, (10 if how.endswith("10") else 64)
     if how == "x2_up2x":
@@ -160,6 +177,7 @@ def test_split_conv_call_forms(how, device):
     pc = H.PackedConv(wt, bias, 1, k // 2, 1, act, X2, device, for_out_f32=how.startswith("out_f32"))
     y = H.conv2d(xin, pc, **kw)
     torch.cuda.synchronize()
+    assert (H.last_kernel_name() == "conv3x3_hsplit_kernel") == (big and not (how == "residual" and cin == 64)), H.last_kernel_name()  # (64 channels with a residual: flat-K)
     got = (y.float().cpu() if how.startswith("out_f32") else down(y)).double()
     scale = float(ref.abs().max())
     assert float((got - ref).abs().max()) <= 4e-6 * scale, (how, float((got - ref).abs().max()), scale)
