@@ -331,3 +331,23 @@ def test_split_full_size_properties(device):
         assert bool((sc[:-1] >= sc[1:]).all()) and float(sc.min()) > 0.25
         assert float(out[i, :c, :4].min()) >= 0 and float(out[i, :c, :4].max()) <= 640
         assert len(set(idx[i, :c].tolist())) == c
+
+
+def test_split_batch_of_256_equals_batches_of_8(device):
+    """BASELINE config 2's batch (256 images of 640 x 640, bench.py's weights) on split-float16 storage: the P2 maps of the batch are 3.4 GB views, the
+    reach of the register-weight kernel's 32-bit buffer offsets (conv3x3_hsplit.hip) — images at the start, the middle and the end of the batch come out
+    bit for bit as in a batch of 8."""
+    import bench
+
+    model = D.DetectionModel("yolov8s-p2-repvgg.yaml", nc=10, verbose=False)
+    model.load_state_dict(bench.synthetic_state_dict(model, seed=0))
+    pred = D.engine.predictor.DetectionPredictor(model, dict(conf=0.25, iou=0.7, max_det=300, device=0, graph=True))
+    assert pred.dtype == X2
+    x = torch.rand(256, 3, 640, 640, generator=torch.Generator().manual_seed(7)).to(device)
+    cf = pred.forward_device(x)
+    torch.cuda.synchronize()
+    y, out, cnt = cf.pred.clone(), cf.nms.out.clone(), cf.nms.count.clone()
+    for lo in (0, 120, 248):
+        cs = pred.forward_device(x[lo : lo + 8].contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(cs.pred, y[lo : lo + 8]) and torch.equal(cs.nms.out, out[lo : lo + 8]) and torch.equal(cs.nms.count, cnt[lo : lo + 8]), lo
