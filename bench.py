@@ -536,6 +536,18 @@ def predict_api_record(model_yaml: str, sd, device_index: int, batch: int = 256,
                      .replace("complex32", "f16x2 (split float16, carried as complex32)"), "hipgraph": bool(yolo.predictor.args["graph"]), "batch": batch,
                      "ms_per_call": round(dt * 1e3, 3), "img_s": round(batch / dt, 1), "detections": int(sum(len(r) for r in res)),
                      "per_image_ms": {k: round(v, 4) for k, v in sp.items()}})
+        if kw:  # the same call over a source of four batches, streamed (the device a batch ahead of the host: engine/predictor.py::stream_batches)
+            xs = x.repeat(4, 1, 1, 1) if batch <= 256 else x
+            for r in yolo.predict(xs, device=device_index, batch=batch, stream=True, **kw):
+                pass
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_img = sum(1 for _ in yolo.predict(xs, device=device_index, batch=batch, stream=True, **kw))
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - t0
+            rows.append({"call": f"YOLO(yaml).predict(x4, half=True, batch={batch}, stream=True)", "dtype": "float16", "hipgraph": True, "batch": batch, "images": n_img,
+                         "ms_per_call": round(dts * 1e3 / (n_img / batch), 3), "img_s": round(n_img / dts, 1)})
+            del xs
         yolo.predictor = None
         torch.cuda.empty_cache()
     return rows

@@ -13,6 +13,7 @@ postprocess = NMS + scale_boxes + Results).  MI355X-first differences:
 """
 from __future__ import annotations
 
+import time
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -90,7 +91,7 @@ class DetectionPredictor:
 
     def __init__(self, model, overrides: Optional[dict] = None):
         a = dict(conf=0.25, iou=0.7, max_det=300, classes=None, agnostic_nms=False, half=False, dtype=None, device="",
-                 verbose=False, graph=True, max_nms=30000, max_wh=7680, imgsz=640, fp8_layers=None)
+                 verbose=False, graph=True, max_nms=30000, max_wh=7680, imgsz=640, fp8_layers=None, batch=None)
         a.update(overrides or {})
         self.args = a
         self.device = select_device(a["device"])
@@ -321,7 +322,62 @@ class DetectionPredictor:
                                orig_shape=(one[0], one[1]) if one else im.shape[2:]))
         return out
 
+    # ---- a source larger than one batch (reference predictor.py:221-298, stream_inference: `for self.batch in self.dataset`) -------------------
+    def _chunks(self, source, batch: int):
+        """``source`` cut into pieces of ``batch`` images: a BCHW float tensor, a uint8 (N, H, W, 3) tensor, or a list of HWC frames."""
+        n = len(source)
+        for lo in range(0, n, batch):
+            yield lo, source[lo : lo + batch]
+
+    def stream_batches(self, source, batch: int):
+        """Generator over the images of ``source``, run ``batch`` at a time, one ``Results`` per image in order.  The device works one batch
+        ahead of the host: batch k + 1 is preprocessed and enqueued (its launches, a device copy of batch k's output rows in front of them, an
+        asynchronous copy of the kept counts to pinned memory) before batch k's ``Results`` are built, so the host side of postprocess — the
+        one synchronisation and a Python object per image — runs under the next batch's kernels.  What the reference's loop does batch by batch
+        (predictor.py:246-298), without its per-batch device synchronisations."""
+        names = self.model.names
+        pending = None
+
+        def finish(item):
+            lo, im, rows, counts_host, ev, info, t_pre, t_inf = item
+            t0 = time.perf_counter()
+            ev.synchronize()
+            counts = counts_host.tolist()
+            out = []
+            for i, k in enumerate(counts):
+                one = (info[i] if isinstance(info, list) else info) if info else None
+                r = Results(im[i], f"image{lo + i}.jpg", names, boxes=rows[i, :k], orig_shape=(one[0], one[1]) if one else im.shape[2:])
+                out.append(r)
+            dt = (time.perf_counter() - t0) * 1e3 / max(len(out), 1)
+            for r in out:  # host-side times per image (the device runs ahead: no synchronisation is placed around the stages)
+                r.speed = {"preprocess": t_pre, "inference": t_inf, "postprocess": dt}
+            return out
+
+        for lo, piece in self._chunks(source, batch):
+            t0 = time.perf_counter()
+            im = self.preprocess(piece)
+            t1 = time.perf_counter()
+            cf = self.forward_device(im)
+            rows = cf.nms.out.clone()  # stream-ordered behind this batch's launches, in front of the next batch's (which overwrite the buffer)
+            counts_host = torch.empty(cf.nms.count.shape, dtype=cf.nms.count.dtype, pin_memory=True)
+            counts_host.copy_(cf.nms.count, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            t2 = time.perf_counter()
+            n = max(im.shape[0], 1)
+            item = (lo, im, rows, counts_host, ev, getattr(self, "letterbox_info", None), (t1 - t0) * 1e3 / n, (t2 - t1) * 1e3 / n)
+            if pending is not None:
+                yield from finish(pending)
+            pending = item
+        if pending is not None:
+            yield from finish(pending)
+
     def __call__(self, source, stream: bool = False):
+        batch = self.args.get("batch")
+        many = (isinstance(source, (list, tuple)) and len(source) > 0 and getattr(source[0], "ndim", 0) == 3) or (isinstance(source, torch.Tensor) and source.dim() == 4)
+        if batch and many and len(source) > int(batch):  # more images than one batch: the reference's dataset loop
+            gen = self.stream_batches(source, int(batch))
+            return gen if stream else list(gen)
         prof = [ops.Profile(device=self.device) for _ in range(3)]
         with prof[0]:
             im = self.preprocess(source)

@@ -360,3 +360,33 @@ def test_default_precision_follows_what_the_split_kernels_cover(device):
     odd.model.model[0].conv = torch.nn.Conv2d(conv.in_channels, conv.out_channels, 5, 2, 2, bias=False)  # not a kernel size the split kernels take
     assert not split_supported(odd.model)
     assert D.YOLO("yolov8n-p2-repvgg.yaml").predict(x, device=0, half=True) is not None
+
+
+def test_a_source_larger_than_one_batch_is_streamed_batch_by_batch(device):
+    """`predict(source, batch=B)` with more images than B (reference stream_inference, predictor.py:221-298: `for self.batch in self.dataset`): the
+    images run B at a time — a ragged last batch included — one `Results` per image in order, `stream=True` as a generator; the device works a batch
+    ahead of the host, and the rows are those of the same images run as ONE batch (batch independence), for a float tensor and for uint8 frames."""
+    import types
+
+    g = golden("e2e.npz")
+    m, d, sd, model, x = _build("n128", g, device)
+    yolo = D.YOLO("yolov8n-p2-repvgg.yaml")
+    yolo.model = model
+    gen = torch.Generator().manual_seed(21)
+    xs = torch.rand(10, 3, 128, 128, generator=gen)
+    whole = yolo.predict(xs, device=0, conf=0.05)
+    assert len(whole) == 10
+    for stream in (False, True):
+        got = yolo.predict(xs, device=0, conf=0.05, batch=4, stream=stream)
+        assert isinstance(got, types.GeneratorType) == stream
+        got = list(got)
+        assert len(got) == 10 and all(set(r.speed) == {"preprocess", "inference", "postprocess"} for r in got)
+        for a, b in zip(got, whole):
+            assert torch.equal(a.boxes.data, b.boxes.data) and a.orig_shape == b.orig_shape
+        assert [r.path for r in got] == [f"image{i}.jpg" for i in range(10)]
+    frames = [np.ascontiguousarray((torch.rand(96, 120, 3, generator=gen) * 255).to(torch.uint8).numpy()) for _ in range(7)]
+    whole = yolo.predict(frames, device=0, conf=0.05)
+    got = list(yolo.predict(frames, device=0, conf=0.05, batch=3, stream=True))
+    assert len(got) == 7
+    for a, b in zip(got, whole):
+        assert torch.equal(a.boxes.data, b.boxes.data) and a.orig_shape == (96, 120)
