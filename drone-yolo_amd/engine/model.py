@@ -122,6 +122,37 @@ class Model(nn.Module):
         self.predictor = None
         return out
 
+    def val(self, validator=None, **kwargs) -> dict:
+        """Reference engine/model.py:620-656 (``Model.val``): the model's own weights scored on a dataset by the task's validator
+        (models/yolo/detect/val.py; engine/validator.py here: the model pass and the ``multi_label`` NMS at conf 0.001 on the device, matching and
+        AP on the host).  ``data``: a tensor dataset — a dict / ``.pt`` in the training layout, its ``"val"`` split when it has one — or
+        ``"synthetic[:N]"`` (engine/trainer.py::load_dataset; image folders and dataset YAMLs are outside the accelerated path);
+        ``batch``, ``imgsz``, ``conf``, ``iou``, ``max_det``, ``half`` / ``dtype``, ``device`` as the reference's arguments.  Returns the
+        reference's ``results_dict`` (metrics/precision(B) ... metrics/mAP50-95(B), fitness) with the validation losses; kept in ``self.metrics``."""
+        from .predictor import resolve_dtype
+        from .trainer import TensorLoader, load_dataset
+        from .validator import DetectionValidator
+        from ..utils.torch_utils import select_device
+
+        args = {**{k: v for k, v in self.overrides.items() if k not in ("task", "mode")}, **kwargs}
+        if args.get("data") is None:
+            raise ValueError("val(): 'data' is missing (a tensor dataset: dict / .pt, or 'synthetic[:N]')")
+        device = select_device(args.get("device", ""))
+        data = load_dataset(args["data"], int(args.get("imgsz", 640)), self.model.yaml["nc"], int(args.get("seed", 0)))
+        data = data.get("val") or data
+        dtype = resolve_dtype(args.get("dtype"), bool(args.get("half", False)), self.model)
+        if dtype not in (torch.float32, torch.float16, torch.bfloat16):
+            dtype = torch.float32  # (the validator's pass returns the raw maps for the loss: the storage types of the training path)
+        was_training = self.model.training
+        model = self.model.to(device)
+        loader = TensorLoader({k: data[k] for k in ("img", "batch_idx", "cls", "bboxes")}, int(args.get("batch") or 16), 0, 1, shuffle=False)
+        try:
+            self.metrics = (validator or DetectionValidator)(args)(model, loader, device, dtype)
+        finally:
+            model.train(was_training)
+        self.predictor = None  # (the pass may have re-packed weights for another storage type)
+        return self.metrics
+
     def fuse(self):
         self.model.fuse()
         return self

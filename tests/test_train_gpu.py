@@ -1159,6 +1159,11 @@ def test_validator_scores_a_model_against_its_own_detections(device):
     assert out["metrics/mAP50(B)"] >= 0.95 and out["metrics/mAP50-95(B)"] >= 0.9 and out["metrics/recall(B)"] >= 0.9, out
     assert abs(out["fitness"] - (0.1 * out["metrics/mAP50(B)"] + 0.9 * out["metrics/mAP50-95(B)"])) < 1e-4
     assert out["val/box_loss"] > 0 and out["val/cls_loss"] > 0 and out["val/dfl_loss"] > 0
+    # the public entry (reference Model.val, engine/model.py:620-656): the same numbers through YOLO(...).val(data=...)
+    yolo = D.YOLO("yolov8n-p2-repvgg.yaml")
+    yolo.model = model
+    api = yolo.val(data=data, batch=4, dtype="fp32", iou=0.7, device=0)
+    assert api == out and yolo.metrics is api
     moved = dict(data, bboxes=data["bboxes"] + torch.tensor([0.5, 0.5, 0.0, 0.0]) * data["bboxes"][:, 2:].repeat(1, 2))
     out2 = DetectionValidator(dict(iou=0.7, max_det=300))(model, TensorLoader(moved, 4, 0, 1, shuffle=False), torch.device(device), torch.float32)
     assert out2["metrics/mAP50-95(B)"] < 0.3 * out["metrics/mAP50-95(B)"], (out, out2)
