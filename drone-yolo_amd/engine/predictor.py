@@ -322,14 +322,69 @@ class DetectionPredictor:
                                orig_shape=(one[0], one[1]) if one else im.shape[2:]))
         return out
 
+    # ---- image files and PIL images as sources (reference data/build.py:160-200 check_source / load_inference_source, data/loaders.py:284-420
+    # LoadImagesAndVideos, :451-500 LoadPilAndNumpy).  Decoding is host glue in front of the path: PIL here (cv2 is not in the image), so a lossless
+    # file (png, bmp, tif) gives the reference's pixels and a jpeg whatever PIL's libjpeg decodes; videos, streams and URLs are not built. ----------
+    IMG_FORMATS = {"bmp", "jpeg", "jpg", "mpo", "png", "tif", "tiff", "webp"}
+
+    @classmethod
+    def list_image_files(cls, source) -> List[str]:
+        """A file, a directory (its `*.*`, sorted), a glob pattern, a `.txt` list of such, or a list of them -> the image files, in the reference's order."""
+        import glob
+        import os
+        from pathlib import Path
+
+        parent = None
+        if isinstance(source, (str, Path)) and Path(str(source)).suffix == ".txt":
+            parent = Path(str(source)).parent
+            source = Path(str(source)).read_text().splitlines()
+        files = []
+        for q in (sorted(str(v) for v in source) if isinstance(source, (list, tuple)) else [str(source)]):
+            a = str(Path(q).absolute())
+            if "*" in a:
+                files.extend(sorted(glob.glob(a, recursive=True)))
+            elif os.path.isdir(a):
+                files.extend(sorted(glob.glob(os.path.join(a, "*.*"))))
+            elif os.path.isfile(a):
+                files.append(a)
+            elif parent is not None and (parent / q).is_file():
+                files.append(str((parent / q).absolute()))
+            else:
+                raise FileNotFoundError(f"{q} does not exist")
+        images = [f for f in files if f.rpartition(".")[-1].lower() in cls.IMG_FORMATS]
+        if len(images) != len(files):
+            other = sorted({f.rpartition(".")[-1].lower() for f in files} - cls.IMG_FORMATS)
+            if not images:
+                raise NotImplementedError(f"no image files in the source (found suffixes {other}); videos / streams are outside the accelerated path")
+            LOGGER.warning(f"WARNING skipping {len(files) - len(images)} non-image file(s) ({other}): videos / streams are outside the accelerated path")
+        return images
+
+    @staticmethod
+    def decode_image(im):
+        """A file path or a PIL image -> contiguous HWC BGR uint8 (loaders.py:488-500: RGB, then channels reversed)."""
+        import numpy as np
+        from PIL import Image
+
+        if not isinstance(im, Image.Image):
+            with Image.open(im) as f:
+                im = f.convert("RGB")
+        elif im.mode != "RGB":
+            im = im.convert("RGB")
+        return np.ascontiguousarray(np.asarray(im)[:, :, ::-1])
+
+    def _file_pieces(self, files: List[str], batch: int):
+        for lo in range(0, len(files), batch):
+            names = files[lo : lo + batch]
+            yield lo, [self.decode_image(f) for f in names], names
+
     # ---- a source larger than one batch (reference predictor.py:221-298, stream_inference: `for self.batch in self.dataset`) -------------------
     def _chunks(self, source, batch: int):
         """``source`` cut into pieces of ``batch`` images: a BCHW float tensor, a uint8 (N, H, W, 3) tensor, or a list of HWC frames."""
         n = len(source)
         for lo in range(0, n, batch):
-            yield lo, source[lo : lo + batch]
+            yield lo, source[lo : lo + batch], None
 
-    def stream_batches(self, source, batch: int):
+    def stream_batches(self, source, batch: int, pieces=None):
         """Generator over the images of ``source``, run ``batch`` at a time, one ``Results`` per image in order.  The device works one batch
         ahead of the host: batch k + 1 is preprocessed and enqueued (its launches, a device copy of batch k's output rows in front of them, an
         asynchronous copy of the kept counts to pinned memory) before batch k's ``Results`` are built, so the host side of postprocess — the
@@ -339,21 +394,22 @@ class DetectionPredictor:
         pending = None
 
         def finish(item):
-            lo, im, rows, counts_host, ev, info, t_pre, t_inf = item
+            lo, im, rows, counts_host, ev, info, t_pre, t_inf, paths, frames = item
             t0 = time.perf_counter()
             ev.synchronize()
             counts = counts_host.tolist()
             out = []
             for i, k in enumerate(counts):
                 one = (info[i] if isinstance(info, list) else info) if info else None
-                r = Results(im[i], f"image{lo + i}.jpg", names, boxes=rows[i, :k], orig_shape=(one[0], one[1]) if one else im.shape[2:])
+                r = Results(frames[i] if frames is not None else im[i], paths[i] if paths else f"image{lo + i}.jpg", names, boxes=rows[i, :k],
+                            orig_shape=(one[0], one[1]) if one else im.shape[2:])
                 out.append(r)
             dt = (time.perf_counter() - t0) * 1e3 / max(len(out), 1)
             for r in out:  # host-side times per image (the device runs ahead: no synchronisation is placed around the stages)
                 r.speed = {"preprocess": t_pre, "inference": t_inf, "postprocess": dt}
             return out
 
-        for lo, piece in self._chunks(source, batch):
+        for lo, piece, paths in (pieces if pieces is not None else self._chunks(source, batch)):
             t0 = time.perf_counter()
             im = self.preprocess(piece)
             t1 = time.perf_counter()
@@ -365,7 +421,8 @@ class DetectionPredictor:
             ev.record()
             t2 = time.perf_counter()
             n = max(im.shape[0], 1)
-            item = (lo, im, rows, counts_host, ev, getattr(self, "letterbox_info", None), (t1 - t0) * 1e3 / n, (t2 - t1) * 1e3 / n)
+            item = (lo, im, rows, counts_host, ev, getattr(self, "letterbox_info", None), (t1 - t0) * 1e3 / n, (t2 - t1) * 1e3 / n, paths,
+                    piece if paths is not None else None)  # (file sources keep the decoded frame as the result's orig_img)
             if pending is not None:
                 yield from finish(pending)
             pending = item
@@ -373,6 +430,19 @@ class DetectionPredictor:
             yield from finish(pending)
 
     def __call__(self, source, stream: bool = False):
+        from pathlib import Path
+
+        is_path = lambda v: isinstance(v, (str, Path))  # noqa: E731
+        if is_path(source) or (isinstance(source, (list, tuple)) and len(source) > 0 and all(is_path(v) for v in source)):
+            # image files: the reference's loader hands over `batch` files at a time (default 1: every image letterboxed to ITS minimum rectangle)
+            files = self.list_image_files(source)
+            gen = self.stream_batches(None, 0, pieces=self._file_pieces(files, int(self.args.get("batch") or 1)))
+            return gen if stream else list(gen)
+        if type(source).__module__.startswith("PIL.") or (isinstance(source, (list, tuple)) and len(source) > 0 and type(source[0]).__module__.startswith("PIL.")):
+            ims = list(source) if isinstance(source, (list, tuple)) else [source]  # LoadPilAndNumpy: ONE batch of all of them
+            paths = [getattr(im, "filename", "") or f"image{i}.jpg" for i, im in enumerate(ims)]
+            gen = self.stream_batches(None, 0, pieces=iter([(0, [self.decode_image(im) for im in ims], paths)]))
+            return gen if stream else list(gen)
         batch = self.args.get("batch")
         many = (isinstance(source, (list, tuple)) and len(source) > 0 and getattr(source[0], "ndim", 0) == 3) or (isinstance(source, torch.Tensor) and source.dim() == 4)
         if batch and many and len(source) > int(batch):  # more images than one batch: the reference's dataset loop

@@ -397,3 +397,36 @@ def test_results_text_forms(tmp_path):
     assert lines[0] == "1 0.3 0.3 0.5 0.5 0.9" and lines[1] == "0 0.125 0.05 0.25 0.1 0.6" and len(lines) == 3
     empty = Results(torch.zeros(3, 8, 8), "b.jpg", {0: "x"}, boxes=torch.zeros(0, 6), orig_shape=(8, 8))
     assert empty.verbose() == "(no detections), " and empty.summary() == [] and isinstance(r.numpy().boxes.data, np.ndarray)
+
+
+def test_image_file_sources_are_listed_and_decoded_like_the_reference_loader(tmp_path):
+    """Host glue in front of the path (reference data/loaders.py:284-420 LoadImagesAndVideos, :451-500 LoadPilAndNumpy): a file, a directory, a glob, a
+    .txt list or a list of them -> the image files in sorted order; decoding -> contiguous HWC BGR uint8 (RGB reversed), greyscale / RGBA converted."""
+    import numpy as np
+    from PIL import Image
+
+    from drone_yolo_amd.engine.predictor import DetectionPredictor as P
+
+    rng = np.random.default_rng(0)
+    arrs = {}
+    for i, (h, w) in enumerate(((40, 50), (33, 47), (64, 64))):
+        arrs[f"b{i}.png"] = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        Image.fromarray(arrs[f"b{i}.png"]).save(tmp_path / f"b{i}.png")
+    Image.fromarray(rng.integers(0, 256, (20, 30), dtype=np.uint8)).save(tmp_path / "grey.bmp")
+    (tmp_path / "notes.md").write_text("not an image")
+    (tmp_path / "list.txt").write_text("b2.png\nb0.png\n")
+    base = lambda fs: [f.rsplit("/", 1)[-1] for f in fs]  # noqa: E731
+    assert base(P.list_image_files(str(tmp_path))) == ["b0.png", "b1.png", "b2.png", "grey.bmp"]  # the directory's *.*, sorted; the .md / .txt skipped
+    assert base(P.list_image_files(str(tmp_path / "*.png"))) == ["b0.png", "b1.png", "b2.png"]
+    assert base(P.list_image_files(str(tmp_path / "list.txt"))) == ["b0.png", "b2.png"]  # relative to the list's directory, sorted as the reference sorts
+    assert base(P.list_image_files([tmp_path / "b1.png", str(tmp_path / "b0.png")])) == ["b0.png", "b1.png"]
+    with pytest.raises(FileNotFoundError):
+        P.list_image_files(str(tmp_path / "nothing.png"))
+    with pytest.raises(NotImplementedError):
+        P.list_image_files(str(tmp_path / "notes.md"))
+    a = P.decode_image(str(tmp_path / "b1.png"))
+    assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"] and np.array_equal(a, arrs["b1.png"][:, :, ::-1])  # BGR
+    gimg = P.decode_image(str(tmp_path / "grey.bmp"))
+    assert gimg.shape == (20, 30, 3) and np.array_equal(gimg[..., 0], gimg[..., 2])
+    rgba = Image.fromarray(rng.integers(0, 256, (8, 9, 4), dtype=np.uint8), "RGBA")
+    assert P.decode_image(rgba).shape == (8, 9, 3)

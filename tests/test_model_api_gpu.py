@@ -390,3 +390,36 @@ def test_a_source_larger_than_one_batch_is_streamed_batch_by_batch(device):
     assert len(got) == 7
     for a, b in zip(got, whole):
         assert torch.equal(a.boxes.data, b.boxes.data) and a.orig_shape == (96, 120)
+
+
+def test_image_files_and_pil_images_as_sources(device, tmp_path):
+    """`predict("dir")` / `predict(["a.png", ...])` / `predict(PIL image)` (reference check_source -> LoadImagesAndVideos / LoadPilAndNumpy): files are
+    decoded on the host and run `batch` at a time — by default one by one, each letterboxed to its own minimum rectangle, as the reference's loader
+    does — and give what the decoded frames give; `Results.path` / `orig_img` / `orig_shape` are the file's."""
+    from PIL import Image
+
+    g = golden("e2e.npz")
+    m, d, sd, model, x = _build("n128", g, device)
+    yolo = D.YOLO("yolov8n-p2-repvgg.yaml")
+    yolo.model = model
+    gen = torch.Generator().manual_seed(31)
+    frames = []
+    for i, (h, w) in enumerate(((96, 120), (128, 128), (70, 100), (96, 120))):
+        f = np.ascontiguousarray((torch.rand(h, w, 3, generator=gen) * 255).to(torch.uint8).numpy())
+        frames.append(f)
+        Image.fromarray(f[:, :, ::-1].copy()).save(tmp_path / f"img{i}.png")  # (files hold RGB; frames are BGR)
+    res = yolo.predict(str(tmp_path), device=0, conf=0.05)
+    assert [r.path.rsplit("/", 1)[-1] for r in res] == [f"img{i}.png" for i in range(4)]
+    for i, r in enumerate(res):
+        one = yolo.predict([frames[i]], device=0, conf=0.05)[0]  # the same image as an array source: a batch of its own
+        assert torch.equal(r.boxes.data, one.boxes.data) and r.orig_shape == frames[i].shape[:2] and np.array_equal(r.orig_img, frames[i])
+    # `batch=3`: three files at a time (different shapes in one batch: each letterboxed to the full size), then the ragged rest
+    got = list(yolo.predict([str(tmp_path / f"img{i}.png") for i in range(4)], device=0, conf=0.05, batch=3, stream=True))
+    ref = yolo.predict(frames[:3], device=0, conf=0.05) + yolo.predict(frames[3:], device=0, conf=0.05)
+    assert len(got) == 4 and all(torch.equal(a.boxes.data, b.boxes.data) for a, b in zip(got, ref))
+    # PIL images (LoadPilAndNumpy): one batch of all of them, names from `filename`
+    with Image.open(tmp_path / "img0.png") as a, Image.open(tmp_path / "img3.png") as b:
+        pres = yolo.predict([a, b], device=0, conf=0.05)
+        assert pres[0].path.endswith("img0.png")
+    ref = yolo.predict([frames[0], frames[3]], device=0, conf=0.05)
+    assert all(torch.equal(a.boxes.data, b.boxes.data) for a, b in zip(pres, ref))
