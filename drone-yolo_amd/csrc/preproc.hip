@@ -197,6 +197,45 @@ __global__ __launch_bounds__(256) void resize_bilinear_u8_kernel(const uint8_t* 
 }
 }  // namespace dy
 
+// scale_img (utils/torch_utils.py:436-445) for test-time augmentation (DetectionModel._predict_augment, nn/tasks.py:347-383): the fp32 NCHW batch —
+// read mirrored left-right when asked — resized bilinearly to (hs, ws) with the rule above and padded right / bottom with `pad` up to (ho, wo).
+namespace dy {
+__global__ __launch_bounds__(256) void scale_img_kernel(const float* __restrict__ src, float* __restrict__ dst, int planes, int h, int w, int hs, int ws, int ho, int wo,
+                                                        float sy, float sx, int flip_lr, float pad) {
+  const long long total = (long long)planes * ho * wo;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % wo);
+    long long t = i / wo;
+    const int y = (int)(t % ho);
+    const int pl = (int)(t / ho);
+    if (y >= hs || x >= ws) {
+      dst[i] = pad;
+      continue;
+    }
+    float fy = __fmaf_rn((float)y + 0.5f, sy, -0.5f), fx = __fmaf_rn((float)x + 0.5f, sx, -0.5f);
+    fy = fy < 0.f ? 0.f : fy, fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float* s = src + (size_t)pl * h * w;
+    const int c0 = flip_lr ? w - 1 - x0 : x0, c1 = flip_lr ? w - 1 - x1 : x1;  // column k of the mirrored image is column w - 1 - k of the source
+    const float v00 = s[(size_t)y0 * w + c0], v01 = s[(size_t)y0 * w + c1], v10 = s[(size_t)y1 * w + c0], v11 = s[(size_t)y1 * w + c1];
+    dst[i] = __fadd_rn(__fmul_rn(hy, __fadd_rn(__fmul_rn(hx, v00), __fmul_rn(lx, v01))), __fmul_rn(ly, __fadd_rn(__fmul_rn(hx, v10), __fmul_rn(lx, v11))));
+  }
+}
+}  // namespace dy
+
+extern "C" int32_t dy_scale_img_nchw_f32(const float* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t hs, int32_t ws, int32_t ho, int32_t wo,
+                                         int32_t flip_lr, float pad, dy_stream_t stream) {
+  DY_REQUIRE(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && hs > 0 && ws > 0 && ho >= hs && wo >= ws, DY_ERR_INVALID_ARG, "dy_scale_img_nchw_f32: bad arguments");
+  const long long total = (long long)n * c * ho * wo;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(dy::scale_img_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, n * c, h, w, hs, ws, ho, wo,
+                     (float)h / (float)hs, (float)w / (float)ws, flip_lr ? 1 : 0, pad);
+  return dy::check_launch("dy_scale_img_nchw_f32");
+}
+
 extern "C" int32_t dy_resize_bilinear_u8_nchw_f32(const uint8_t* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t ho, int32_t wo, dy_stream_t stream) {
   DY_REQUIRE(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && ho > 0 && wo > 0, DY_ERR_INVALID_ARG, "dy_resize_bilinear_u8_nchw_f32: bad arguments");
   const long long total = (long long)n * c * ho * wo;

@@ -91,7 +91,7 @@ class DetectionPredictor:
 
     def __init__(self, model, overrides: Optional[dict] = None):
         a = dict(conf=0.25, iou=0.7, max_det=300, classes=None, agnostic_nms=False, half=False, dtype=None, device="",
-                 verbose=False, graph=True, max_nms=30000, max_wh=7680, imgsz=640, fp8_layers=None, batch=None)
+                 verbose=False, graph=True, max_nms=30000, max_wh=7680, imgsz=640, fp8_layers=None, batch=None, augment=False)
         a.update(overrides or {})
         self.args = a
         self.device = select_device(a["device"])
@@ -217,8 +217,27 @@ class DetectionPredictor:
             rows.append([gain, float(round((wn - w0 * gain) / 2 - 0.1)), float(round((hn - h0 * gain) / 2 - 0.1)), float(w0), float(h0)])
         return rows
 
+    def _forward_augment(self, im: torch.Tensor) -> CompiledForward:
+        """``augment=True`` (reference predictor.py:306: ``self.model(im, augment=...)`` -> DetectionModel._predict_augment): three passes of the path over
+        the image pyramid, merged along the anchors, then the NMS over the merged candidates.  Launched as it comes — nothing recorded or replayed."""
+        a = self.args
+        if self.dtype == H.FP8 or self.mixed8:
+            raise NotImplementedError("augment=True is built for the 16-bit, split-float16 and fp32 storage types")
+        cf = CompiledForward()
+        y, _ = self.model._predict_augment(im, image_dtype=self.dtype)
+        cf.pred = y
+        cf.nms = H.nms(y, float(a["conf"]), float(a["iou"]), max_det=int(a["max_det"]), max_nms=int(a["max_nms"]), max_wh=float(a["max_wh"]),
+                       agnostic=bool(a["agnostic_nms"]), nc=self.model.yaml["nc"], classes_mask=self._classes_mask)
+        n, _, h, w = im.shape
+        params = torch.tensor(self._box_params(h, w, n), dtype=torch.float32, device=self.device)
+        H.scale_boxes_(cf.nms, params)
+        cf.box_params = params
+        return cf
+
     def forward_device(self, im: torch.Tensor) -> CompiledForward:
         """Run one batch; outputs stay on the device in the returned object's ``nms`` buffers."""
+        if self.args.get("augment"):
+            return self._forward_augment(im)
         key = (tuple(im.shape), self.dtype)
         cf = self._compiled.get(key)
         sig = self.model.weights_signature()

@@ -1499,6 +1499,24 @@ def resize_bilinear_u8(img: torch.Tensor, size) -> torch.Tensor:
     return out
 
 
+def scale_img(img: torch.Tensor, ratio: float, gs: int = 32, flip_lr: bool = False) -> torch.Tensor:
+    """``scale_img(img.flip(3) if flip_lr else img, ratio, gs=gs)`` of the reference (utils/torch_utils.py:436-445) in one kernel: bilinear resize to
+    (int(h r), int(w r)), padded right / bottom with 0.447 to the next multiples of ``gs`` of (h r, w r) — the image pyramid of test-time augmentation."""
+    import math
+
+    require_device(img, "image batch")
+    if img.dtype != torch.float32 or img.dim() != 4 or not img.is_contiguous():
+        raise ValueError("scale_img expects a contiguous fp32 (N, C, H, W) device tensor")
+    n, c, h, w = img.shape
+    if ratio == 1.0 and not flip_lr:
+        return img
+    hs, ws = (int(h * ratio), int(w * ratio)) if ratio != 1.0 else (h, w)
+    ho, wo = ((math.ceil(h * ratio / gs) * gs, math.ceil(w * ratio / gs) * gs) if ratio != 1.0 else (h, w))
+    out = torch.empty((n, c, ho, wo), dtype=torch.float32, device=img.device)
+    _launch(lib().dy_scale_img_nchw_f32, (img.data_ptr(), out.data_ptr(), n, c, h, w, hs, ws, ho, wo, int(flip_lr), 0.447), keep=(img, out))
+    return out
+
+
 # ---- fused C2f block ------------------------------------------------------------------------------------------------------
 
 

@@ -147,9 +147,37 @@ class BaseModel(nn.Module):
         return self.predict(x, *args, **kwargs)
 
     def predict(self, x, profile=False, visualize=False, augment=False, embed=None):
-        if profile or visualize or augment or embed:
-            raise NotImplementedError("profile/visualize/augment/embed are outside the accelerated path")
+        if profile or visualize or embed:
+            raise NotImplementedError("profile/visualize/embed are outside the accelerated path")
+        if augment:
+            return self._predict_augment(x)
         return self._predict_once(x)
+
+    def _predict_augment(self, x, image_dtype=None):
+        """Test-time augmentation — reference DetectionModel._predict_augment / _descale_pred / _clip_augmented (nn/tasks.py:347-383): the batch at
+        scales 1, 0.83 (mirrored left-right) and 0.67 (``dy_scale_img_nchw_f32``: resize + pad in one kernel), three passes of the path, every pass's
+        boxes scaled and mirrored back into the input's frame, the coarsest level of the first pass and the finest level of the last one dropped, all
+        anchors side by side: ((B, 4 + nc, A_total), None).  Eval mode, Detect returning its decoded output."""
+        if self.training or not isinstance(self.model[-1], Detect):
+            raise NotImplementedError("augment=True is built for the Detect models in eval mode")
+        x = x.float().contiguous()
+        img_size = x.shape[-2:]
+        gs = int(self.stride.max())
+        ys = []
+        for si, fi in zip((1, 0.83, 0.67), (None, 3, None)):
+            xi = H.scale_img(x, si, gs=gs, flip_lr=(fi == 3))
+            yi = self._predict_once(xi, image_dtype=image_dtype)[0].clone()  # (the pass's output buffer belongs to its recorded / cached plan)
+            yi[:, :4] /= si  # de-scale
+            if fi == 3:
+                yi[:, 0] = img_size[1] - yi[:, 0]  # de-flip lr
+            ys.append(yi)
+        nl = self.model[-1].nl
+        g = sum(4 ** k for k in range(nl))  # grid points of the level pyramid relative to its coarsest level
+        i = ys[0].shape[-1] // g  # large: without its coarsest level (the tail of the anchor axis)
+        ys[0] = ys[0][..., :-i]
+        i = (ys[-1].shape[-1] // g) * 4 ** (nl - 1)  # small: without its finest level (the head)
+        ys[-1] = ys[-1][..., i:]
+        return torch.cat(ys, -1), None
 
     # ---- graph planning ---------------------------------------------------------------------------
     def _plan_graph(self) -> None:

@@ -330,6 +330,11 @@ int32_t dy_letterbox_u8_to_nchw_f32(const uint8_t* src, float* dst, int32_t n, i
 /* multi_scale of DetectionTrainer.preprocess_batch (models/yolo/detect/train.py:60-73): a uint8 NCHW batch -> fp32 NCHW (n, c, ho, wo) holding
  * nn.functional.interpolate(src.float() / 255, size=(ho, wo), mode="bilinear", align_corners=False) — torch's coordinate rule and blend order. */
 int32_t dy_resize_bilinear_u8_nchw_f32(const uint8_t* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t ho, int32_t wo, dy_stream_t stream);
+/* scale_img of test-time augmentation (utils/torch_utils.py:436-445, called by DetectionModel._predict_augment, nn/tasks.py:347-383): the fp32 NCHW batch
+ * (n, c, h, w) — read mirrored left-right when flip_lr — resized bilinearly (align_corners = False, torch's coordinate rule) to (hs, ws) in the top-left
+ * corner of dst (n, c, ho, wo), the rest filled with `pad` (the reference pads with 0.447 to multiples of the model's largest stride). */
+int32_t dy_scale_img_nchw_f32(const float* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t hs, int32_t ws, int32_t ho, int32_t wo,
+                              int32_t flip_lr, float pad, dy_stream_t stream);
 
 /* ---- tiled inference on large frames -----------------------------------------------------------------
  * The reference slices through third-party packages that are not vendored (mix6.py:84-89 `sv.InferenceSlicer`,

@@ -398,6 +398,44 @@ def predict(d: dict, sd: SD, im: Tensor, conf=0.25, iou=0.7, max_det=300, classe
     return [torch.cat((scale_boxes(im.shape[2:], p[:, :4].clone(), im.shape[2:]), p[:, 4:]), 1) if len(p) else p for p in preds]
 
 
+# ---- test-time augmentation (predict(augment=True)) -------------------------------------------------------------
+
+
+def scale_img(img: Tensor, ratio: float = 1.0, gs: int = 32) -> Tensor:
+    """utils/torch_utils.py:436-445: bilinear resize to (int(h r), int(w r)), then padded right / bottom with 0.447 up to the next multiples of ``gs`` of (h r, w r)."""
+    if ratio == 1.0:
+        return img
+    h, w = img.shape[2:]
+    s = (int(h * ratio), int(w * ratio))
+    img = F.interpolate(img, size=s, mode="bilinear", align_corners=False)
+    h2, w2 = (math.ceil(v * ratio / gs) * gs for v in (h, w))
+    return F.pad(img, [0, w2 - s[1], 0, h2 - s[0]], value=0.447)
+
+
+def predict_augment(d: dict, sd: SD, x: Tensor, fused: bool = True) -> Tensor:
+    """DetectionModel._predict_augment (nn/tasks.py:347-383): the image at scales 1, 0.83 (mirrored left-right) and 0.67, every pass's boxes scaled back
+    (and mirrored back) into the input's frame (_descale_pred), the coarsest level of the first pass and the finest level of the last one dropped
+    (_clip_augmented), all anchors side by side: (B, 4 + nc, A_total)."""
+    img_size = x.shape[-2:]
+    layers = resolve_layers(d, x.shape[1])
+    gs = int(max(model_strides(layers)))
+    ys = []
+    for si, fi in zip((1, 0.83, 0.67), (None, 3, None)):
+        xi = scale_img(x.flip(fi) if fi else x, si, gs=gs)
+        yi = forward(d, sd, xi, fused=fused)[0].clone()
+        yi[:, :4] /= si  # de-scale
+        if fi == 3:
+            yi[:, 0] = img_size[1] - yi[:, 0]  # de-flip lr
+        ys.append(yi)
+    nl = len(model_strides(layers))  # detection levels
+    g = sum(4 ** k for k in range(nl))
+    i = (ys[0].shape[-1] // g) * 1
+    ys[0] = ys[0][..., :-i]  # large: without its coarsest level
+    i = (ys[-1].shape[-1] // g) * 4 ** (nl - 1)
+    ys[-1] = ys[-1][..., i:]  # small: without its finest level
+    return torch.cat(ys, -1)
+
+
 # ---- deterministic weights shared by both sides ---------------------------------------------------------------
 
 

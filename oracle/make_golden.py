@@ -487,6 +487,41 @@ def e2e(R):
     np.savez_compressed(OUT / "e2e.npz", **out)
 
 
+def aug_vectors(R):
+    """predict(augment=True) of the REAL reference (DetectionModel._predict_augment, nn/tasks.py:347-383) on the e2e fixture n128: the merged
+    (B, 4 + nc, A_total) output and the rows non_max_suppression keeps from it, with the oracle's restatement checked against both."""
+    e2e_g = np.load(OUT / "e2e.npz", allow_pickle=True)
+    out = {}
+    for tag in ("n128", "n64"):
+        meta = eval(str(e2e_g[f"{tag}__meta"]))  # noqa: S307 - our own fixture
+        b, h, w = meta["shape"]
+        model, _ = build_reference_model(R, meta["yaml"], meta["scale"], meta["nc"])
+        d = our_yaml(meta["yaml"], meta["scale"], meta["nc"])
+        template = {k: v for k, v in model.state_dict().items()}
+        sd = O.seeded_state_dict(template, meta["seed"], cls_bias=meta["cls_bias"])
+        model.load_state_dict(sd)
+        R.tu.initialize_weights(model)
+        model.eval()
+        x = torch.rand(b, 3, h, w, generator=torch.Generator().manual_seed(meta["seed"]))
+        with torch.no_grad():
+            model.fuse(verbose=False)
+            y, _ = model.predict(x, augment=True)
+            oy = O.predict_augment(d, sd, x, fused=True)
+        assert tuple(oy.shape) == tuple(y.shape), (oy.shape, y.shape)
+        rel_tol_check(f"{tag} augmented y", oy, y, tol=5e-5)
+        ref_det = R.ops.non_max_suppression(y.clone(), 0.25, 0.7, max_det=300, nc=meta["nc"])
+        our_det, our_idx = O.non_max_suppression(oy.clone(), 0.25, 0.7, max_det=300, nc=meta["nc"], return_index=True)
+        for a_, b_ in zip(our_det, ref_det):
+            assert a_.shape == b_.shape and torch.allclose(a_, b_, rtol=1e-4, atol=1e-3), f"{tag}: augmented rows differ from the reference's"
+        _, ref_idx = O.non_max_suppression(y.clone(), 0.25, 0.7, max_det=300, nc=meta["nc"], return_index=True)
+        print(f"[aug {tag}] A_total={y.shape[2]} kept {[len(r) for r in ref_det]}")
+        out[f"{tag}__y"] = tnp(y)
+        out[f"{tag}__n"] = np.array([len(r) for r in ref_det])
+        out[f"{tag}__det"] = np.concatenate([tnp(r) for r in ref_det], 0)
+        out[f"{tag}__det_idx"] = np.concatenate([tnp(r) for r in ref_idx], 0)
+    np.savez_compressed(OUT / "aug.npz", **out)
+
+
 import math  # noqa: E402
 
 
@@ -823,6 +858,8 @@ if __name__ == "__main__":
         val_metric_vectors(R)
     elif "--train-only" in sys.argv:
         train_vectors(R)
+    elif "--aug-only" in sys.argv:
+        aug_vectors(R)
     elif "--loss-only" in sys.argv:
         loss_vectors(R)
     elif "--big-only" in sys.argv:
@@ -839,5 +876,6 @@ if __name__ == "__main__":
         train_vectors(R)
         checkpoint_fixture(R)
         big_vectors(R)
+        aug_vectors(R)
     for f in sorted(OUT.glob("*.npz")):
         print(f"wrote {f.relative_to(ROOT)}  {f.stat().st_size / 1024:.1f} KiB")

@@ -11,7 +11,7 @@ import torch
 import drone_yolo_amd as D
 from drone_yolo_amd.nn import modules as M
 from oracle import drone_yolo_oracle as O
-from tests._util import box_iou_pairs, golden, load_yaml
+from tests._util import box_iou_pairs, golden, load_yaml, split_rows
 from tests.test_model_gpu import _build, _report
 
 pytestmark = pytest.mark.gpu
@@ -423,3 +423,36 @@ def test_image_files_and_pil_images_as_sources(device, tmp_path):
         assert pres[0].path.endswith("img0.png")
     ref = yolo.predict([frames[0], frames[3]], device=0, conf=0.05)
     assert all(torch.equal(a.boxes.data, b.boxes.data) for a, b in zip(pres, ref))
+
+
+@pytest.mark.parametrize("tag", ["n128", "n64"])
+def test_augmented_inference_matches_the_reference_rows(tag, device):
+    """`predict(x, augment=True)` (reference DetectionModel._predict_augment, nn/tasks.py:347-383) on the device in fp32 storage: the image pyramid from
+    `dy_scale_img_nchw_f32`, three passes of the path, de-scaled / de-mirrored / clipped / merged — the merged output to fp32 round-off of the REAL
+    reference's (tests/golden/aug.npz) and the rows its NMS keeps: the same anchors, classes and order."""
+    g = golden("aug.npz")
+    m, d, sd, model, x = _build(tag, golden("e2e.npz"), device)
+    pred = D.engine.predictor.DetectionPredictor(model, dict(conf=0.25, iou=0.7, max_det=300, dtype="fp32", device=0, augment=True))
+    cf = pred.forward_device(pred.preprocess(x))
+    torch.cuda.synchronize()
+    yref = torch.from_numpy(g[f"{tag}__y"])
+    y = cf.pred.cpu()
+    assert tuple(y.shape) == tuple(yref.shape)
+    assert float((y[:, :4] - yref[:, :4]).abs().max()) < 2e-2 and float((y[:, 4:] - yref[:, 4:]).abs().max()) < 1e-4
+    counts = cf.nms.count.cpu().tolist()
+    assert counts == [int(v) for v in g[f"{tag}__n"]]
+    exp_idx = split_rows(g[f"{tag}__det_idx"], g[f"{tag}__n"])
+    exp_rows = split_rows(g[f"{tag}__det"], g[f"{tag}__n"])
+    for i, c in enumerate(counts):
+        got_idx = cf.nms.index[i, :c].cpu().numpy()
+        assert sorted(got_idx.tolist()) == sorted(exp_idx[i].tolist())
+        score_of = {int(a): float(s) for a, s in zip(exp_idx[i], exp_rows[i][:, 4])}
+        for k in np.nonzero(got_idx != exp_idx[i])[0]:  # two detections whose scores differ by fp32 round-off may swap places
+            assert abs(score_of[int(got_idx[k])] - float(exp_rows[i][k, 4])) < 2e-6
+    # the public call, at the default precision as well
+    yolo = D.YOLO("yolov8n-p2-repvgg.yaml")
+    yolo.model = model
+    res = yolo.predict(x, device=0, augment=True)
+    assert [len(r) for r in res] == counts
+    with pytest.raises(NotImplementedError):
+        yolo.predict(x, device=0, augment=True, dtype="fp8")

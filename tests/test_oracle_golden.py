@@ -3,6 +3,7 @@
 import ast
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import drone_yolo_oracle as O
@@ -148,6 +149,31 @@ def test_e2e_vectors():
         assert [len(r) for r in det] == list(g[f"{tag}__n"]), tag
         assert np.array_equal(np.concatenate([i.numpy() for i in idx]), g[f"{tag}__det_idx"]), tag
         assert np.allclose(np.concatenate([r.numpy() for r in det]), g[f"{tag}__det"], atol=2e-3), tag
+
+
+def test_augmented_inference_vectors():
+    """predict(augment=True) of the REAL reference (DetectionModel._predict_augment, nn/tasks.py:347-383; tests/golden/aug.npz, oracle/make_golden.py::aug_vectors):
+    the oracle's restatement — image pyramid 1 / 0.83 mirrored / 0.67, boxes scaled and mirrored back, the two clipped tails — gives the merged output and the rows."""
+    import drone_yolo_amd as D
+
+    g, ge = golden("aug.npz"), golden("e2e.npz")
+    for tag in ("n128", "n64"):
+        m = meta(ge, tag)
+        d = load_yaml(m["yaml"], m["scale"], m["nc"])
+        sd = O.seeded_state_dict(D.DetectionModel(dict(d), nc=m["nc"], verbose=False).state_dict(), m["seed"], cls_bias=m["cls_bias"])
+        b, h, w = m["shape"]
+        x = torch.rand(b, 3, h, w, generator=torch.Generator().manual_seed(m["seed"]))
+        y = O.predict_augment(d, sd, x, fused=True)
+        yref = torch.from_numpy(g[f"{tag}__y"])
+        assert tuple(y.shape) == tuple(yref.shape)
+        assert float((y - yref).abs().max()) <= 5e-5 * float(yref.abs().max())
+        dets, idx = O.non_max_suppression(y, 0.25, 0.7, max_det=300, nc=m["nc"], return_index=True)
+        assert [len(r) for r in dets] == [int(v) for v in g[f"{tag}__n"]]
+        assert np.allclose(torch.cat(dets).numpy(), g[f"{tag}__det"], rtol=1e-4, atol=2e-3)
+        assert np.array_equal(torch.cat(idx).numpy(), g[f"{tag}__det_idx"])
+    # scale_img: the padded size follows ceil(h r / gs) gs, the pad value is 0.447
+    z = O.scale_img(torch.zeros(1, 3, 128, 96), 0.67, gs=32)
+    assert tuple(z.shape) == (1, 3, 96, 96) and float(z[0, 0, 90, 90]) == pytest.approx(0.447) and float(z[0, 0, 10, 10]) == 0.0
 
 
 def test_bench_configuration_vectors():
